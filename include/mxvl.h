@@ -1,0 +1,166 @@
+/*
+ * mxvl.h -- C-ABI of libmxvl.so, the MI355X (gfx950) native hot path of
+ * MambaXray-VL (Event-AHU/Medical_Image_Analysis).
+ *
+ * Every entry point takes plain device pointers + sizes + element strides and a
+ * hipStream_t passed as void*.  No torch / C++ types cross this boundary.  All
+ * functions return MXVL_OK (0) or a negative mxvl_status; they never throw and
+ * never allocate: the caller owns every buffer.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference checkout, R2GenCSR/VMamba/kernels/selective_scan = KSS):
+ *
+ *   mxvl_scan_fwd        selective_scan_fwd   KSS/csrc/selective_scan/cus/selective_scan.cpp:157-239
+ *                        (oflex twin          KSS/csrc/selective_scan/cusoflex/selective_scan_oflex.cpp:144-232)
+ *                        = mamba_ssm selective_scan_fn forward as called at
+ *                        CXPMRG_Bench_MambaXray_VL/arm/Finetuning/mamba_simple.py:693-704
+ *   mxvl_scan_bwd        selective_scan_bwd   KSS/csrc/selective_scan/cus/selective_scan.cpp:241-349
+ *   mxvl_conv1d_fwd/bwd  causal_conv1d_fn     call site mamba_simple.py:676-681, definition = the in-repo
+ *                        fallback act(conv1d(x)[..., :L]) at mamba_simple.py:672-673
+ *   mxvl_conv1d_update   causal_conv1d_update call site mamba_simple.py:732-738, fallback :724-730
+ *   mxvl_state_update    selective_state_update call site mamba_simple.py:757-759, fallback :748-755
+ *
+ * Tensor conventions (identical to the reference op boundary):
+ *   u, delta, z, out : (batch, dim, seqlen)   seqlen stride 1
+ *   A                : (dim, dstate) fp32     (= -exp(A_log))
+ *   B, C             : (batch, n_groups, dstate, seqlen)  seqlen stride 1
+ *   D, delta_bias    : (dim) fp32
+ * "io" tensors (u, delta, z, out, B, C and their gradients) share one dtype
+ * (fp32 / bf16 / fp16); weights, state and accumulators are always fp32.
+ */
+#ifndef MXVL_H_
+#define MXVL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXVL_ABI_VERSION 1
+
+typedef enum mxvl_status {
+  MXVL_OK = 0,
+  MXVL_ERR_NULL = -1,        /* required pointer is NULL                        */
+  MXVL_ERR_DTYPE = -2,       /* io dtype not in {f32,bf16,f16}                  */
+  MXVL_ERR_SHAPE = -3,       /* non-positive size, dim % n_groups != 0, ...     */
+  MXVL_ERR_DSTATE = -4,      /* dstate > MXVL_MAX_DSTATE                        */
+  MXVL_ERR_STRIDE = -5,      /* a stride that would alias / is negative         */
+  MXVL_ERR_LAUNCH = -6,      /* hipLaunchKernel failed (see mxvl_last_hip_error)*/
+  MXVL_ERR_UNSUPPORTED = -7, /* valid request this build has no kernel for      */
+  MXVL_ERR_CHECKPOINT = -8   /* seqlen > one chunk but no checkpoint buffer     */
+} mxvl_status;
+
+typedef enum mxvl_dtype { MXVL_F32 = 0, MXVL_BF16 = 1, MXVL_F16 = 2 } mxvl_dtype;
+
+#define MXVL_MAX_DSTATE 256
+
+/* flag bits of mxvl_scan_desc.flags */
+#define MXVL_SCAN_DELTA_SOFTPLUS 1u
+
+/*
+ * Forward selective scan.
+ *   delta' = softplus?(delta + delta_bias)
+ *   h_t    = exp(delta'_t * A) * h_{t-1} + delta'_t * B_t * u_t        (h in R^{dim x dstate}, fp32)
+ *   y_t    = <C_t, h_t> + D * u_t ;  out_t = y_t * silu(z_t)  (if z)
+ * Mirrors SSMParamsBase (KSS/csrc/selective_scan/selective_scan.h:26-61): sizes, element strides,
+ * raw pointers.  Optional pointers may be NULL: D, delta_bias, z, last_state, ckpt.
+ *
+ * ckpt: (batch, dim, n_chunks, dstate) fp32, state entering each chunk of mxvl_scan_chunk_len()
+ * time steps -- the analogue of the reference's `x` buffer (selective_scan.cpp:217-219); it is
+ * what mxvl_scan_bwd restarts its recomputation from.  last_state: (batch, dim, dstate) fp32 = h_L.
+ */
+typedef struct mxvl_scan_desc {
+  int32_t batch, dim, seqlen, dstate, n_groups;
+  int32_t io_dtype; /* mxvl_dtype */
+  uint32_t flags;
+  int32_t reserved0;
+  /* element strides; the seqlen stride of every io tensor is 1 */
+  int64_t u_bs, u_ds;
+  int64_t delta_bs, delta_ds;
+  int64_t z_bs, z_ds;
+  int64_t out_bs, out_ds;
+  int64_t B_bs, B_gs, B_ns;
+  int64_t C_bs, C_gs, C_ns;
+  int64_t A_ds, A_ns;
+  const void *u, *delta, *A, *B, *C;
+  const void *D, *delta_bias, *z; /* optional */
+  void *out;
+  void *last_state; /* optional */
+  void *ckpt;       /* optional (required by bwd when n_chunks > 1) */
+} mxvl_scan_desc;
+
+/*
+ * Backward selective scan (same math as selective_scan_bwd, selective_scan.cpp:241-349).
+ * Gradients du, ddelta, dz (io dtype) are fully written.  dA (dim,dstate), dD (dim),
+ * ddelta_bias (dim), dB, dC (batch,n_groups,dstate,seqlen) are fp32 and ACCUMULATED into:
+ * the caller zero-fills them first (reference contract: selective_scan.cpp:321-327).
+ * `fwd` carries the forward inputs (fwd.out may be NULL; fwd.ckpt must be the buffer
+ * the forward call filled, or NULL when seqlen fits one chunk).
+ */
+typedef struct mxvl_scan_bwd_desc {
+  mxvl_scan_desc fwd;
+  int64_t dout_bs, dout_ds;
+  int64_t du_bs, du_ds;
+  int64_t ddelta_bs, ddelta_ds;
+  int64_t dz_bs, dz_ds;
+  int64_t dB_bs, dB_gs, dB_ns;
+  int64_t dC_bs, dC_gs, dC_ns;
+  const void *dout;
+  void *du, *ddelta, *dz;   /* dz required iff fwd.z */
+  void *dA, *dB, *dC;       /* fp32 accumulate */
+  void *dD, *ddelta_bias;   /* fp32 accumulate; optional like their forward twins */
+} mxvl_scan_bwd_desc;
+
+/* depthwise causal conv1d (+ optional SiLU): y[b,d,t] = act(bias[d] + sum_k w[d,k] * x[b,d,t-W+1+k]) */
+typedef struct mxvl_conv1d_desc {
+  int32_t batch, dim, seqlen, width;
+  int32_t io_dtype; /* dtype of x / y (and dx, dy) */
+  int32_t silu;     /* 1: SiLU activation, 0: identity */
+  int64_t x_bs, x_ds;
+  int64_t y_bs, y_ds;
+  const void *x;
+  const void *weight; /* (dim, width) fp32, row stride = width */
+  const void *bias;   /* (dim) fp32, optional */
+  void *y;
+} mxvl_conv1d_desc;
+
+typedef struct mxvl_conv1d_bwd_desc {
+  mxvl_conv1d_desc fwd; /* fwd.y unused */
+  int64_t dy_bs, dy_ds;
+  int64_t dx_bs, dx_ds;
+  const void *dy;
+  void *dx;      /* io dtype, fully written */
+  void *dweight; /* (dim,width) fp32, accumulated into */
+  void *dbias;   /* (dim) fp32, accumulated into, optional */
+} mxvl_conv1d_bwd_desc;
+
+int mxvl_abi_version(void);
+/* time steps covered by one checkpoint chunk for a sequence of `seqlen` steps and `dstate` states */
+int mxvl_scan_chunk_len(int seqlen, int dstate);
+int mxvl_scan_n_chunks(int seqlen, int dstate);
+
+int mxvl_scan_fwd(const mxvl_scan_desc *desc, void *hip_stream);
+int mxvl_scan_bwd(const mxvl_scan_bwd_desc *desc, void *hip_stream);
+
+int mxvl_conv1d_fwd(const mxvl_conv1d_desc *desc, void *hip_stream);
+int mxvl_conv1d_bwd(const mxvl_conv1d_bwd_desc *desc, void *hip_stream);
+/* single-token decode step: conv_state (batch,dim,width) io dtype is rolled in place; x,y: (batch,dim) */
+int mxvl_conv1d_update(const void *x, void *conv_state, const void *weight, const void *bias, void *y,
+                       int batch, int dim, int width, int io_dtype, int silu, void *hip_stream);
+/* single-token SSM step (selective_state_update): state (batch,dim,dstate) fp32 updated in place */
+int mxvl_state_update(void *state, const void *x, const void *dt, const void *A, const void *B,
+                      const void *C, const void *D, const void *z, const void *dt_bias, void *out,
+                      int batch, int dim, int dstate, int io_dtype, int dt_softplus, void *hip_stream);
+
+/* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
+int mxvl_last_hip_error(void);
+/* kernel-variant override for A/B measurements (bench.py only); 0 = automatic */
+void mxvl_set_scan_variant(int variant);
+/* name of the kernel the last mxvl_scan_fwd on this thread dispatched to (static string) */
+const char *mxvl_last_scan_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXVL_H_ */

@@ -1,0 +1,147 @@
+"""ctypes binding of the C-ABI declared in include/mxvl.h (libmxvl.so).
+
+This is the only place Python touches the native library.  Tensors cross the boundary as raw
+device pointers + element strides; the stream is torch's current HIP stream (the reference
+enqueues on at::cuda::getCurrentCUDAStream(), selective_scan.cpp:232-233).  Loading fails loudly:
+there is no fallback implementation anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmxvl.so")
+ABI_VERSION = 1
+
+MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
+SCAN_DELTA_SOFTPLUS = 1
+
+STATUS = {
+    0: "MXVL_OK", -1: "MXVL_ERR_NULL", -2: "MXVL_ERR_DTYPE", -3: "MXVL_ERR_SHAPE", -4: "MXVL_ERR_DSTATE",
+    -5: "MXVL_ERR_STRIDE", -6: "MXVL_ERR_LAUNCH", -7: "MXVL_ERR_UNSUPPORTED", -8: "MXVL_ERR_CHECKPOINT",
+}
+
+# every symbol include/mxvl.h declares (tests/test_abi.py checks the .so exports all of them)
+SYMBOLS = [
+    "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fwd", "mxvl_scan_bwd",
+    "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
+    "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel",
+]
+
+
+class ScanDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("dstate", c_int32), ("n_groups", c_int32),
+        ("io_dtype", c_int32), ("flags", c_uint32), ("reserved0", c_int32),
+        ("u_bs", c_int64), ("u_ds", c_int64), ("delta_bs", c_int64), ("delta_ds", c_int64),
+        ("z_bs", c_int64), ("z_ds", c_int64), ("out_bs", c_int64), ("out_ds", c_int64),
+        ("B_bs", c_int64), ("B_gs", c_int64), ("B_ns", c_int64),
+        ("C_bs", c_int64), ("C_gs", c_int64), ("C_ns", c_int64),
+        ("A_ds", c_int64), ("A_ns", c_int64),
+        ("u", c_void_p), ("delta", c_void_p), ("A", c_void_p), ("B", c_void_p), ("C", c_void_p),
+        ("D", c_void_p), ("delta_bias", c_void_p), ("z", c_void_p),
+        ("out", c_void_p), ("last_state", c_void_p), ("ckpt", c_void_p),
+    ]
+
+
+class ScanBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("fwd", ScanDesc),
+        ("dout_bs", c_int64), ("dout_ds", c_int64), ("du_bs", c_int64), ("du_ds", c_int64),
+        ("ddelta_bs", c_int64), ("ddelta_ds", c_int64), ("dz_bs", c_int64), ("dz_ds", c_int64),
+        ("dB_bs", c_int64), ("dB_gs", c_int64), ("dB_ns", c_int64),
+        ("dC_bs", c_int64), ("dC_gs", c_int64), ("dC_ns", c_int64),
+        ("dout", c_void_p), ("du", c_void_p), ("ddelta", c_void_p), ("dz", c_void_p),
+        ("dA", c_void_p), ("dB", c_void_p), ("dC", c_void_p), ("dD", c_void_p), ("ddelta_bias", c_void_p),
+    ]
+
+
+class Conv1dDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("width", c_int32),
+        ("io_dtype", c_int32), ("silu", c_int32),
+        ("x_bs", c_int64), ("x_ds", c_int64), ("y_bs", c_int64), ("y_ds", c_int64),
+        ("x", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("y", c_void_p),
+    ]
+
+
+class Conv1dBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("fwd", Conv1dDesc),
+        ("dy_bs", c_int64), ("dy_ds", c_int64), ("dx_bs", c_int64), ("dx_ds", c_int64),
+        ("dy", c_void_p), ("dx", c_void_p), ("dweight", c_void_p), ("dbias", c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libmxvl.so; raises (never falls back) when it is absent or its ABI is stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m medical_image_analysis_amd.build` "
+            "(hipcc, gfx950). medical_image_analysis_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mxvl_abi_version.restype = c_int
+    if lib.mxvl_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmxvl.so ABI {lib.mxvl_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
+    for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    lib.mxvl_conv1d_update.restype = c_int
+    lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
+    lib.mxvl_state_update.restype = c_int
+    lib.mxvl_state_update.argtypes = [c_void_p] * 10 + [c_int] * 5 + [c_void_p]
+    lib.mxvl_scan_chunk_len.restype = c_int
+    lib.mxvl_scan_n_chunks.restype = c_int
+    lib.mxvl_set_scan_variant.argtypes = [c_int]
+    _lib = lib
+    return lib
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MXVL_F32
+    if dt == torch.bfloat16:
+        return MXVL_BF16
+    if dt == torch.float16:
+        return MXVL_F16
+    raise RuntimeError(f"mxvl: io dtype must be float32/bfloat16/float16, got {dt}")  # selective_scan.cpp:167
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(*tensors) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mxvl: expected a HIP device tensor (no CPU path exists); got a CPU tensor")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("mxvl: tensors live on different devices")
+    return dev
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        hip = lib.mxvl_last_hip_error()
+        raise RuntimeError(f"{what} failed: {STATUS.get(rc, rc)} (hipError {hip})")

@@ -1,0 +1,181 @@
+"""Drop-in for `mamba_ssm.ops.selective_scan_interface` (the names the reference imports at
+CXPMRG_Bench_MambaXray_VL/arm/Finetuning/mamba_simple.py:20-23) over libmxvl.so.
+
+    selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False)                                   (call site :693-704)
+    mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, B=None, C=None, D=None, delta_bias=None, ...)  (call site :650-664)
+    mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                   A, B=None, C=None, D=None, delta_bias=None, ...)                 (call sites :450-511)
+
+Argument checks and conversions follow the reference's wrappers and host code: contiguous() when the
+last stride is not 1 (KSS/test_selective_scan.py:24-35), D / delta_bias up-cast to fp32 (:42-47),
+3-D B/C treated as one group (:36-41), dtype / shape TORCH_CHECKs of
+csrc/selective_scan/cus/selective_scan.cpp:165-215 raised as RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _abi
+
+
+def _last_contig(t):
+    return t if (t is None or t.stride(-1) == 1 or t.size(-1) == 1) else t.contiguous()
+
+
+def _prep(u, delta, A, B, C, D, z, delta_bias):
+    dev = _abi.require_gpu(u, delta, A, B, C, D, z, delta_bias)
+    if u.dim() != 3:
+        raise RuntimeError("selective_scan: u must be (batch, dim, seqlen)")
+    if A.dtype != torch.float32:
+        raise RuntimeError("selective_scan: A must be float32 (selective_scan.cpp:168)")
+    if A.is_complex():
+        raise RuntimeError("selective_scan: complex A is not supported")
+    for name, t in (("delta", delta), ("B", B), ("C", C)) + ((("z", z),) if z is not None else ()):
+        if t.dtype != u.dtype:
+            raise RuntimeError(f"selective_scan: {name}.dtype {t.dtype} != u.dtype {u.dtype} (selective_scan.cpp:170-172)")
+    u, delta, B, C, z = (_last_contig(t) for t in (u, delta, B, C, z))
+    if B.dim() == 3:
+        B = B.unsqueeze(1)
+    if C.dim() == 3:
+        C = C.unsqueeze(1)
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    G = B.shape[1]
+    if tuple(delta.shape) != (batch, dim, L):
+        raise RuntimeError("selective_scan: delta must have the shape of u")
+    if tuple(A.shape) != (dim, N):
+        raise RuntimeError("selective_scan: A must be (dim, dstate)")
+    if dim % G != 0:
+        raise RuntimeError("selective_scan: dims should be dividable by n_groups (selective_scan.cpp:188)")
+    if tuple(B.shape) != (batch, G, N, L) or tuple(C.shape) != (batch, G, N, L):
+        raise RuntimeError("selective_scan: B and C must be (batch, n_groups, dstate, seqlen)")
+    if N > 256:
+        raise RuntimeError("selective_scan only supports state dimension <= 256 (selective_scan.cpp:189)")
+    if z is not None and tuple(z.shape) != (batch, dim, L):
+        raise RuntimeError("selective_scan: z must have the shape of u")
+    if D is not None:
+        D = D.float().contiguous()
+        if tuple(D.shape) != (dim,):
+            raise RuntimeError("selective_scan: D must be (dim,)")
+    if delta_bias is not None:
+        delta_bias = delta_bias.float().contiguous()
+        if tuple(delta_bias.shape) != (dim,):
+            raise RuntimeError("selective_scan: delta_bias must be (dim,)")
+    return dev, u, delta, A, B, C, D, z, delta_bias
+
+
+def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last_state, ckpt):
+    batch, dim, L = u.shape
+    desc.batch, desc.dim, desc.seqlen, desc.dstate, desc.n_groups = batch, dim, L, A.shape[1], B.shape[1]
+    desc.io_dtype = _abi.dtype_code(u.dtype)
+    desc.flags = _abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0
+    desc.u_bs, desc.u_ds = u.stride(0), u.stride(1)
+    desc.delta_bs, desc.delta_ds = delta.stride(0), delta.stride(1)
+    if z is not None:
+        desc.z_bs, desc.z_ds = z.stride(0), z.stride(1)
+    if out is not None:
+        desc.out_bs, desc.out_ds = out.stride(0), out.stride(1)
+    desc.B_bs, desc.B_gs, desc.B_ns = B.stride(0), B.stride(1), B.stride(2)
+    desc.C_bs, desc.C_gs, desc.C_ns = C.stride(0), C.stride(1), C.stride(2)
+    desc.A_ds, desc.A_ns = A.stride(0), A.stride(1)
+    desc.u, desc.delta, desc.A, desc.B, desc.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    desc.D, desc.delta_bias, desc.z = _abi.ptr(D), _abi.ptr(delta_bias), _abi.ptr(z)
+    desc.out, desc.last_state, desc.ckpt = _abi.ptr(out), _abi.ptr(last_state), _abi.ptr(ckpt)
+
+
+def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                 want_last_state=False, want_ckpt=False):
+    """One mxvl_scan_fwd call on already-validated tensors; returns (out, last_state|None, ckpt|None)."""
+    lib = _abi.load()
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    out = torch.empty((batch, dim, L), dtype=u.dtype, device=u.device)
+    last = torch.empty((batch, dim, N), dtype=torch.float32, device=u.device) if want_last_state else None
+    ckpt = None
+    if want_ckpt:
+        n_chunks = lib.mxvl_scan_n_chunks(L, N)
+        if n_chunks > 1:
+            ckpt = torch.empty((batch, dim, n_chunks, N), dtype=torch.float32, device=u.device)
+    desc = _abi.ScanDesc()
+    _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt)
+    with torch.cuda.device(u.device):
+        rc = lib.mxvl_scan_fwd(ctypes.byref(desc), _abi.stream_ptr(u.device))
+    _abi.check(rc, "mxvl_scan_fwd")
+    return out, last, ckpt
+
+
+def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout):
+    """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C)."""
+    lib = _abi.load()
+    batch, dim, L = u.shape
+    dout = _last_contig(dout)
+    du = torch.empty_like(u)
+    ddelta = torch.empty_like(delta)
+    dz = torch.empty_like(z) if z is not None else None
+    # accumulated-into buffers start at zero (reference contract, selective_scan.cpp:321-327)
+    dA = torch.zeros_like(A)
+    dB = torch.zeros(B.shape, dtype=torch.float32, device=u.device)
+    dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
+    dD = torch.zeros_like(D) if D is not None else None
+    dbias = torch.zeros_like(delta_bias) if delta_bias is not None else None
+    desc = _abi.ScanBwdDesc()
+    _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt)
+    desc.dout_bs, desc.dout_ds = dout.stride(0), dout.stride(1)
+    desc.du_bs, desc.du_ds = du.stride(0), du.stride(1)
+    desc.ddelta_bs, desc.ddelta_ds = ddelta.stride(0), ddelta.stride(1)
+    if dz is not None:
+        desc.dz_bs, desc.dz_ds = dz.stride(0), dz.stride(1)
+    desc.dB_bs, desc.dB_gs, desc.dB_ns = dB.stride(0), dB.stride(1), dB.stride(2)
+    desc.dC_bs, desc.dC_gs, desc.dC_ns = dC.stride(0), dC.stride(1), dC.stride(2)
+    desc.dout, desc.du, desc.ddelta, desc.dz = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), _abi.ptr(dz)
+    desc.dA, desc.dB, desc.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    desc.dD, desc.ddelta_bias = _abi.ptr(dD), _abi.ptr(dbias)
+    with torch.cuda.device(u.device):
+        rc = lib.mxvl_scan_bwd(ctypes.byref(desc), _abi.stream_ptr(u.device))
+    _abi.check(rc, "mxvl_scan_bwd")
+    return du, ddelta, dA, dB, dC, dD, dz, dbias
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    """Autograd node over mxvl_scan_fwd / mxvl_scan_bwd (the reference's twin: VMB/vmamba.py:294-312)."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state):
+        B_was_3d, C_was_3d = B.dim() == 3, C.dim() == 3
+        dev, u, delta, A, B, C, D, z, delta_bias = _prep(u, delta, A, B, C, D, z, delta_bias)
+        needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        out, last, ckpt = scan_fwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus,
+                                       want_last_state=return_last_state, want_ckpt=needs_grad)
+        ctx.delta_softplus = delta_softplus
+        ctx.flags = (B_was_3d, C_was_3d, D is not None, z is not None, delta_bias is not None)
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, ckpt)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        u, delta, A, B, C, D, z, delta_bias, ckpt = ctx.saved_tensors
+        B_was_3d, C_was_3d, has_D, has_z, has_bias = ctx.flags
+        du, ddelta, dA, dB, dC, dD, dz, dbias = scan_bwd_raw(
+            u, delta, A, B, C, D, z, delta_bias, ctx.delta_softplus, ckpt, dout.to(u.dtype))
+        dB = dB.to(B.dtype)  # accumulated in fp32, cast back (selective_scan.cpp:347)
+        dC = dC.to(C.dtype)
+        if B_was_3d:
+            dB = dB.squeeze(1)
+        if C_was_3d:
+            dC = dC.squeeze(1)
+        return (du, ddelta, dA, dB, dC, dD if has_D else None, dz if has_z else None,
+                dbias if has_bias else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """out = selective scan of u (B,D,L); with z the output is gated by silu(z).
+    Returns out, or (out, last_state (B,D,N) fp32) when return_last_state."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)

@@ -1,0 +1,78 @@
+"""CPU: pins the oracle (oracle/mxvl_oracle.c, oracle/oracle.py) against the golden vectors that
+tests/golden/make_golden.py captured from the reference's own Python (selective_scan_ref,
+nn.Conv1d fallback, Mamba slow path).  fp32 tolerances; both sides are CPU fp32 so only
+re-association noise is allowed."""
+import pytest
+import torch
+
+from conftest import assert_close, golden_names, load_golden
+from oracle import oracle as orc
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+def test_scan_fwd_bwd_matches_reference(name):
+    g = load_golden(name)
+    sp = bool(g["delta_softplus"])
+    out, last = orc.selective_scan_ref(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                                       g.get("delta_bias"), sp, return_last_state=True)
+    # |out| reaches 2.6e2 on this distribution: 1e-4 absolute holds for unit-scale outputs, so the
+    # bound is 1e-4 * max(1, max|ref|/32) (still >= 4x tighter than the reference's own fp32 atol 2e-3)
+    atol = 1e-4 * max(1.0, float(g["out"].abs().max()) / 32)
+    assert_close(out, g["out"], atol, 1e-5, "out")
+    assert_close(last, g["last_state"], atol, 1e-5, "last_state")
+    gr = orc.selective_scan_ref_bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                                    g.get("delta_bias"), sp, g["dout"])
+    for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias"):
+        if k in g:
+            scale = float(g[k].abs().max())
+            assert_close(gr[k], g[k], 2e-5 * max(scale, 1.0), 1e-4, k)
+
+
+@pytest.mark.parametrize("name", golden_names("conv1d_"))
+def test_conv1d_matches_reference(name):
+    g = load_golden(name)
+    y = orc.causal_conv1d_ref(g["x"], g["weight"], g["bias"], "silu")
+    assert_close(y, g["y"], 1e-5, 1e-5, "y")
+    y0 = orc.causal_conv1d_ref(g["x"], g["weight"], g["bias"], None)
+    assert_close(y0, g["y_noact"], 1e-5, 1e-5, "y_noact")
+    gr = orc.causal_conv1d_ref_bwd(g["x"], g["weight"], g["bias"], "silu", g["dy"])
+    assert_close(gr["dx"], g["dx"], 1e-5, 1e-4, "dx")
+    assert_close(gr["dweight"], g["dweight"], 1e-4, 1e-4, "dweight")
+    assert_close(gr["dbias"], g["dbias"], 1e-4, 1e-4, "dbias")
+
+
+@pytest.mark.parametrize("name", golden_names("mamba_slow_"))
+def test_mamba_inner_restatement_equals_reference_slow_path(name):
+    """The fused mamba_inner_fn is third-party; its restatement must equal the reference's own
+    slow path (mamba_simple.py:665-709) from xz to the module output."""
+    g = load_golden(name)
+    A = -torch.exp(g["p_A_log"])
+    out = orc.mamba_inner_ref(g["xz"], g["p_conv1d.weight"], g["p_conv1d.bias"], g["p_x_proj.weight"],
+                              g["p_dt_proj.weight"], g["p_out_proj.weight"], None, A, None, None, g["p_D"],
+                              delta_bias=g["p_dt_proj.bias"], delta_softplus=True)
+    assert_close(out, g["out"], 1e-5, 1e-4, "out")
+
+
+def test_decode_step_matches_reference():
+    g = load_golden("mamba_step")
+    T = g["xs"].shape[1]
+    A = -torch.exp(g["p_A_log"])
+    Bz, d = g["xs"].shape[0], g["xs"].shape[2]
+    N = A.shape[1]
+    R = g["p_dt_proj.weight"].shape[1]
+    conv_state = torch.zeros(Bz, d, g["p_conv1d.weight"].shape[-1])
+    ssm_state = torch.zeros(Bz, d, N)
+    for t in range(T):
+        xz = g["xs"][:, t] @ g["p_in_proj.weight"].t()
+        x, z = xz.chunk(2, dim=-1)
+        x = orc.causal_conv1d_update_ref(x.contiguous(), conv_state, g["p_conv1d.weight"], g["p_conv1d.bias"], "silu")
+        x_db = x @ g["p_x_proj.weight"].t()
+        dt, Bm, Cm = torch.split(x_db, [R, N, N], dim=-1)
+        dt = dt @ g["p_dt_proj.weight"].t()
+        y = orc.selective_state_update_ref(ssm_state, x, dt, A, Bm.contiguous(), Cm.contiguous(), g["p_D"],
+                                           z=z.contiguous(), dt_bias=g["p_dt_proj.bias"], dt_softplus=True)
+        out = y @ g["p_out_proj.weight"].t()
+        assert_close(out, g["outs"][:, t], 1e-5, 1e-4, f"out[{t}]")
+        assert_close(conv_state, g["conv_states"][t], 1e-6, 1e-6, f"conv_state[{t}]")
+        assert_close(ssm_state, g["ssm_states"][t], 1e-5, 1e-4, f"ssm_state[{t}]")
+    assert_close(g["outs"], g["full"], 1e-4, 1e-4, "recurrent == parallel (reference self-consistency)")
