@@ -7,17 +7,18 @@
 // kernel gives one 32..128-thread block to ONE (b,d) row, re-reads the B/C rows for every row and
 // leans on cub BlockLoad/BlockScan.  Here:
 //
-//   * a workgroup owns DT = NWAVES*64/LPR rows (consecutive d of one batch element) and walks the
-//     sequence in chunks of CH = LPR*T steps.  The B/C tile [N][CH] of the chunk is staged in LDS
-//     ONCE and shared by all DT rows (B/C are common to every d of a batch row);
+//   * a workgroup owns DT = NWAVES*64/LPR rows (consecutive d inside one B/C group of one batch
+//     element) and walks the sequence in chunks of CH = LPR*T steps.  The B/C tile [N][CH] of the
+//     chunk is staged in LDS ONCE and shared by all DT rows;
 //   * each row is spread over LPR lanes, every lane owning T CONSECUTIVE time steps, so the
 //     recurrence h_t = a_t h_{t-1} + b_t is: a serial fold over T steps in registers, a
-//     log2(LPR)-step wave prefix scan of the per-lane affine maps (a,b) with DPP row shifts
-//     (no LDS, no shuffles), and a second serial pass that applies the incoming state and
-//     accumulates y_t += C_t h_t.  The per-lane product of the a's is exp2(A * sum(delta)) -- one
-//     v_exp instead of T multiplies;
+//     log2(LPR)-step prefix scan of the per-lane affine maps (P,h) done with DPP row shifts fused
+//     into v_fmac/v_mul (no LDS, no shuffles), and a second serial pass that applies the incoming
+//     state and accumulates y_t += C_t h_t.  The per-lane product of the a's is
+//     exp2(A * sum(delta)) -- one v_exp instead of T multiplies;
 //   * u/delta/z/out travel HBM <-> LDS fully coalesced (wave-private rows, no barrier) whatever the
-//     alignment of L (L = 197 / 4097 with the cls token is never a multiple of 4);
+//     alignment of L (L = 197 / 4097 with the cls token is never a multiple of 4); 16-byte
+//     accesses are used when every row start is 16-byte aligned;
 //   * state, A, D, bias and every accumulator are fp32; io tensors fp32 / bf16 / fp16.
 //
 // Algorithmic HBM bytes per launch: elt*(4*B*D*L + 2*B*G*N*L) + 4*(D*N + 2*D).
@@ -29,7 +30,7 @@ constexpr int kCkptLen = 128;  // checkpoint spacing in time steps (mxvl_scan_ch
 
 struct ScanArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus;
+  int softplus, vec_ok;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, o_bs, o_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
   const void *u, *delta, *B, *C, *z;
@@ -38,34 +39,126 @@ struct ScanArgs {
   float *last_state, *ckpt;
 };
 
-template <typename io_t, int T, int LPR, int NWAVES, int NU>
-__global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p) {
-  constexpr int RPW = 64 / LPR;   // rows per wave
+// ---- 4-wide global access (row starts 16-byte aligned for fp32, 8-byte for 16-bit types) --------
+template <typename io_t> __device__ inline float4 ld4(const io_t* p);
+template <> __device__ inline float4 ld4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ inline float4 ld4<bf16_t>(const bf16_t* p) {
+  const uint2 r = *(const uint2*)p;
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+template <> __device__ inline float4 ld4<f16_t>(const f16_t* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 r = *(const h4*)p;
+  return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
+}
+template <typename io_t> __device__ inline void st4(io_t* p, float4 v);
+template <> __device__ inline void st4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ inline void st4<bf16_t>(bf16_t* p, float4 v) {
+  bf16_t t[4];
+  Io<bf16_t>::st(&t[0], v.x); Io<bf16_t>::st(&t[1], v.y); Io<bf16_t>::st(&t[2], v.z); Io<bf16_t>::st(&t[3], v.w);
+  *(uint2*)p = make_uint2((uint32_t)t[0].v | ((uint32_t)t[1].v << 16), (uint32_t)t[2].v | ((uint32_t)t[3].v << 16));
+}
+template <> __device__ inline void st4<f16_t>(f16_t* p, float4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  *(h4*)p = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+
+// ---- inclusive scan of the affine maps (P,h) over the 16 lanes of a DPP row, then the exclusive
+// shift.  x enters holding the state that precedes lane 0 (the carry) and leaves holding the
+// state that precedes each lane.  Lanes without a source lane are disabled by DPP bound_ctrl=0,
+// which is exactly the identity element.  VALU-write -> DPP-read needs 2 wait states: the two
+// interleaved chains provide them.
+__device__ inline void scan16_x2(float& h0, float& P0, float& x0, float& h1, float& P1, float& x1) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mov_b32_dpp %5, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(h0), "+v"(P0), "+v"(x0), "+v"(h1), "+v"(P1), "+v"(x1));
+}
+__device__ inline void scan16_x1(float& h0, float& P0, float& x0) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(h0), "+v"(P0), "+v"(x0));
+}
+// generic form for rows spread over 32 / 64 lanes (few-row problems); not on the headline path
+template <int LPR>
+__device__ inline void scan_generic(float& hl, float& P, float& x, int j) {
+  float pb, pa;
+  pb = dpp<DPP_ROW_SHR(1)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(1)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
+  pb = dpp<DPP_ROW_SHR(2)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(2)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
+  pb = dpp<DPP_ROW_SHR(4)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(4)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
+  pb = dpp<DPP_ROW_SHR(8)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(8)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
+  if constexpr (LPR >= 32) {
+    pb = dpp<DPP_ROW_BCAST15, 0xa>(0.0f, hl); pa = dpp<DPP_ROW_BCAST15, 0xa>(1.0f, P);
+    hl = fmaf(P, pb, hl); P *= pa;
+  }
+  if constexpr (LPR >= 64) {
+    pb = dpp<DPP_ROW_BCAST31, 0xc>(0.0f, hl); pa = dpp<DPP_ROW_BCAST31, 0xc>(1.0f, P);
+    hl = fmaf(P, pb, hl); P *= pa;
+  }
+  const float car = x;
+  x = dpp<DPP_WAVE_SHR1>(car, hl);
+  x = (j == 0) ? car : x;
+}
+
+template <typename io_t, int T, int LPR, int NWAVES, int NU, int MINW = 1>
+__global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanArgs p) {
+  constexpr int RPW = 64 / LPR;     // rows per wave
   constexpr int DT = NWAVES * RPW;  // rows per workgroup
   constexpr int CH = LPR * T;       // time steps per chunk
   constexpr int NT = NWAVES * 64;
-  static_assert(CH % 64 == 0, "chunk must be a multiple of the wave width");
-  static_assert(T % 4 == 0, "T must keep 16-byte LDS reads aligned");
+  static_assert(CH % 64 == 0 && T % 4 == 0, "tile shape");
+  static_assert(NT % CH == 0 || CH % NT == 0, "B/C staging shape");
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = p.N, L = p.L;
   float* sB = smem;
   float* sC = sB + N * CH;
-  float* sU = sC + N * CH;   // u tile, later the out tile
-  float* sD = sU + DT * CH;  // delta tile
-  float* sZ = sD + DT * CH;  // z tile
-  float* sA = sZ + DT * CH;  // A * log2(e), [DT][N]
-  float* sCar = sA + DT * N; // running state h, [DT][N]
+  float* sU = sC + N * CH;    // u tile, later the out tile
+  float* sD = sU + DT * CH;   // delta tile
+  float* sZ = sD + DT * CH;   // z tile
+  float2* sAC = (float2*)(sZ + DT * CH);  // [DT][N] {A*log2(e), running state h}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane / LPR, j = lane % LPR;
   const int row = wave * RPW + r;
   const int b = blockIdx.y;
-  const int d0 = blockIdx.x * DT;
+  const int dpg = p.dim / p.G;
+  const int tiles = (dpg + DT - 1) / DT;
+  const int g = blockIdx.x / tiles;
+  const int d0 = g * dpg + (blockIdx.x - g * tiles) * DT;
+  const int d_end = (g + 1) * dpg;  // rows of this tile stay inside the B/C group
   const int d = d0 + row;
-  const bool row_ok = d < p.dim;
-  const int g = d0 / (p.dim / p.G);
+  const bool row_ok = d < d_end;
 
   const io_t* __restrict__ up = (const io_t*)p.u + (int64_t)b * p.u_bs;
   const io_t* __restrict__ dp = (const io_t*)p.delta + (int64_t)b * p.dl_bs;
@@ -74,12 +167,12 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
   const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
   const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
   const bool has_z = zp != nullptr;
+  const bool vec_ok = p.vec_ok != 0;
 
   for (int i = tid; i < DT * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
-    sA[i] = dd < p.dim ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f;
-    sCar[i] = 0.0f;
+    sAC[i] = make_float2(dd < d_end ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
   }
   const float bias = (p.bias && row_ok) ? p.bias[d] : 0.0f;
   const float Dv = (p.D && row_ok) ? p.D[d] : 0.0f;
@@ -87,29 +180,65 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
   const int nchunks = (L + CH - 1) / CH;
   for (int c = 0; c < nchunks; ++c) {
     const int t0 = c * CH;
-    __syncthreads();  // every wave is done with the previous B/C tile (first pass: sA/sCar visible)
-    for (int i = tid; i < N * CH; i += NT) {
-      const int n = i / CH, e = i - n * CH;
-      const int t = t0 + e;
-      float bv = 0.0f, cv = 0.0f;
-      if (t < L) {
-        bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
-        cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
+    const bool full = t0 + CH <= L;
+    __syncthreads();  // every wave is done with the previous B/C tile (first pass: sAC visible)
+    // ---- stage the shared B/C tile -------------------------------------------------------------
+    if (vec_ok && full) {
+      constexpr int CQ = CH / 4;                 // float4 columns per row
+      constexpr int RSTEP = NT / CQ;             // rows covered per pass
+      const int e4 = (tid % CQ) * 4;
+      const io_t* pb = Bp + t0 + e4 + (int64_t)(tid / CQ) * p.B_ns;
+      const io_t* pc = Cp + t0 + e4 + (int64_t)(tid / CQ) * p.C_ns;
+      for (int n = tid / CQ; n < N; n += RSTEP) {
+        *(float4*)(sB + n * CH + e4) = ld4<io_t>(pb);
+        *(float4*)(sC + n * CH + e4) = ld4<io_t>(pc);
+        pb += (int64_t)RSTEP * p.B_ns;
+        pc += (int64_t)RSTEP * p.C_ns;
       }
-      sB[i] = bv;
-      sC[i] = cv;
+    } else {
+      constexpr int RSTEP = (NT >= CH) ? NT / CH : 1;
+      constexpr int CSTEP = (NT >= CH) ? CH : NT;
+      for (int e = tid % CSTEP; e < CH; e += CSTEP) {
+        const bool ok = t0 + e < L;
+        const io_t* pb = Bp + t0 + e + (int64_t)(tid / CSTEP) * p.B_ns;
+        const io_t* pc = Cp + t0 + e + (int64_t)(tid / CSTEP) * p.C_ns;
+        for (int n = tid / CSTEP; n < N; n += RSTEP) {
+          sB[n * CH + e] = ok ? io::ld(pb) : 0.0f;
+          sC[n * CH + e] = ok ? io::ld(pc) : 0.0f;
+          pb += (int64_t)RSTEP * p.B_ns;
+          pc += (int64_t)RSTEP * p.C_ns;
+        }
+      }
     }
+    // ---- stage this wave's own rows of u / delta / z -------------------------------------------
+    if (vec_ok && full) {
+      constexpr int CQ = CH / 4;  // float4 columns per row; a wave owns RPW*CQ = 16*T of them
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int wrow = wave * RPW + rr;
-      const int dd = d0 + wrow;
+      for (int q = lane; q < RPW * CQ; q += 64) {
+        const int rr = q / CQ, e4 = (q % CQ) * 4;
+        const int wrow = wave * RPW + rr;
+        const int dd = d0 + wrow;
+        if (dd < d_end) {
+          *(float4*)(sU + wrow * CH + e4) = ld4<io_t>(up + (int64_t)dd * p.u_ds + t0 + e4);
+          *(float4*)(sD + wrow * CH + e4) = ld4<io_t>(dp + (int64_t)dd * p.dl_ds + t0 + e4);
+          if (has_z) *(float4*)(sZ + wrow * CH + e4) = ld4<io_t>(zp + (int64_t)dd * p.z_ds + t0 + e4);
+        }
+      }
+    } else {
 #pragma unroll
-      for (int e = lane; e < CH; e += 64) {
-        const int t = t0 + e;
-        const bool ok = dd < p.dim && t < L;
-        sU[wrow * CH + e] = ok ? io::ld(up + (int64_t)dd * p.u_ds + t) : 0.0f;
-        sD[wrow * CH + e] = ok ? io::ld(dp + (int64_t)dd * p.dl_ds + t) : 0.0f;
-        if (has_z) sZ[wrow * CH + e] = ok ? io::ld(zp + (int64_t)dd * p.z_ds + t) : 0.0f;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int wrow = wave * RPW + rr;
+        const int dd = d0 + wrow;
+        const io_t* pu = up + (int64_t)dd * p.u_ds + t0;
+        const io_t* pd = dp + (int64_t)dd * p.dl_ds + t0;
+        const io_t* pz = has_z ? zp + (int64_t)dd * p.z_ds + t0 : nullptr;
+#pragma unroll
+        for (int e = lane; e < CH; e += 64) {
+          const bool ok = dd < d_end && t0 + e < L;
+          sU[wrow * CH + e] = ok ? io::ld(pu + e) : 0.0f;
+          sD[wrow * CH + e] = ok ? io::ld(pd + e) : 0.0f;
+          if (has_z) sZ[wrow * CH + e] = ok ? io::ld(pz + e) : 0.0f;
+        }
       }
     }
     __syncthreads();
@@ -128,7 +257,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
           const int i = q * 4 + k;
           float x = dv[k] + bias;
           if (p.softplus) x = softplus(x);
-          x = (t0 + j * T + i < L) ? x : 0.0f;  // padding steps are the identity map (a=1, b=0)
+          if (!full) x = (t0 + j * T + i < L) ? x : 0.0f;  // padding steps are the identity map
           dl[i] = x;
           du[i] = x * uv[k];
           y[i] = Dv * uv[k];
@@ -141,66 +270,54 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
 
     const bool ckpt_here = p.ckpt != nullptr && row_ok && ((t0 + j * T) % kCkptLen == 0) && (t0 + j * T < L);
     float* ckpt_row = p.ckpt ? p.ckpt + (((int64_t)b * p.dim + d) * p.n_ckpt + (t0 + j * T) / kCkptLen) * N : nullptr;
+    float2* ac = sAC + row * N;
 
     for (int n0 = 0; n0 < N; n0 += NU) {
+      float a[NU][T], bb[NU][T], cv[NU][T], hl[NU], P[NU], x[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         const int n = n0 + k;
-        const float A2 = sA[row * N + n];
-        const float car = sCar[row * N + n];
-        float a[T], bb[T], cv[T];
-        {
-          const float4* sb4 = (const float4*)(sB + n * CH + j * T);
-          const float4* sc4 = (const float4*)(sC + n * CH + j * T);
+        const float2 A2c = ac[n];
+        const float4* sb4 = (const float4*)(sB + n * CH + j * T);
+        const float4* sc4 = (const float4*)(sC + n * CH + j * T);
 #pragma unroll
-          for (int q = 0; q < T / 4; ++q) {
-            const float4 b4 = sb4[q], c4 = sc4[q];
-            bb[q * 4 + 0] = b4.x; bb[q * 4 + 1] = b4.y; bb[q * 4 + 2] = b4.z; bb[q * 4 + 3] = b4.w;
-            cv[q * 4 + 0] = c4.x; cv[q * 4 + 1] = c4.y; cv[q * 4 + 2] = c4.z; cv[q * 4 + 3] = c4.w;
-          }
+        for (int q = 0; q < T / 4; ++q) {
+          const float4 b4 = sb4[q], c4 = sc4[q];
+          bb[k][q * 4 + 0] = b4.x; bb[k][q * 4 + 1] = b4.y; bb[k][q * 4 + 2] = b4.z; bb[k][q * 4 + 3] = b4.w;
+          cv[k][q * 4 + 0] = c4.x; cv[k][q * 4 + 1] = c4.y; cv[k][q * 4 + 2] = c4.z; cv[k][q * 4 + 3] = c4.w;
         }
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-          a[i] = fast_exp2(dl[i] * A2);
-          bb[i] = du[i] * bb[i];
+          a[k][i] = fast_exp2(dl[i] * A2c.x);
+          bb[k][i] = du[i] * bb[k][i];
         }
         // pass 1: the lane's affine map h_out = P * h_in + hl
-        float hl = bb[0];
+        float h = bb[k][0];
 #pragma unroll
-        for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, bb[i]);
-        float P = fast_exp2(A2 * dsum);
-        hl = fmaf(P, (j == 0) ? car : 0.0f, hl);  // lane 0 absorbs the state entering the chunk
-        // inclusive prefix scan of (P, hl) over the LPR lanes of the row
-        {
-          float pb, pa;
-          pb = dpp<DPP_ROW_SHR(1)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(1)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
-          pb = dpp<DPP_ROW_SHR(2)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(2)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
-          pb = dpp<DPP_ROW_SHR(4)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(4)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
-          pb = dpp<DPP_ROW_SHR(8)>(0.0f, hl); pa = dpp<DPP_ROW_SHR(8)>(1.0f, P); hl = fmaf(P, pb, hl); P *= pa;
-          if constexpr (LPR >= 32) {
-            pb = dpp<DPP_ROW_BCAST15, 0xa>(0.0f, hl); pa = dpp<DPP_ROW_BCAST15, 0xa>(1.0f, P);
-            hl = fmaf(P, pb, hl); P *= pa;
-          }
-          if constexpr (LPR >= 64) {
-            pb = dpp<DPP_ROW_BCAST31, 0xc>(0.0f, hl); pa = dpp<DPP_ROW_BCAST31, 0xc>(1.0f, P);
-            hl = fmaf(P, pb, hl); P *= pa;
-          }
-        }
-        // state entering this lane's steps = inclusive value of the previous lane (lane 0: carry)
-        float h;
-        if constexpr (LPR == 16) {
-          h = dpp<DPP_ROW_SHR(1)>(car, hl);
-        } else {
-          h = dpp<DPP_WAVE_SHR1>(car, hl);
-          h = (j == 0) ? car : h;
-        }
-        if (j == LPR - 1) sCar[row * N + n] = hl;  // state leaving the chunk
-        if (ckpt_here) ckpt_row[n] = h;
-        // pass 2
+        for (int i = 1; i < T; ++i) h = fmaf(a[k][i], h, bb[k][i]);
+        P[k] = fast_exp2(A2c.x * dsum);
+        x[k] = A2c.y;                                       // state entering the chunk
+        hl[k] = fmaf(P[k], (j == 0) ? A2c.y : 0.0f, h);     // lane 0 absorbs it
+      }
+      if constexpr (LPR == 16 && NU == 2) {
+        scan16_x2(hl[0], P[0], x[0], hl[1], P[1], x[1]);
+      } else if constexpr (LPR == 16) {
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-          h = fmaf(a[i], h, bb[i]);
-          y[i] = fmaf(cv[i], h, y[i]);
+        for (int k = 0; k < NU; ++k) scan16_x1(hl[k], P[k], x[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) scan_generic<LPR>(hl[k], P[k], x[k], j);
+      }
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        const int n = n0 + k;
+        if (j == LPR - 1) ac[n].y = hl[k];  // state leaving the chunk
+        if (ckpt_here) ckpt_row[n] = x[k];
+        float h = x[k];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {  // pass 2
+          h = fmaf(a[k][i], h, bb[k][i]);
+          y[i] = fmaf(cv[k][i], h, y[i]);
         }
       }
     }
@@ -223,14 +340,24 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (vec_ok && full) {
+      constexpr int CQ = CH / 4;
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int wrow = wave * RPW + rr;
-      const int dd = d0 + wrow;
+      for (int q = lane; q < RPW * CQ; q += 64) {
+        const int rr = q / CQ, e4 = (q % CQ) * 4;
+        const int wrow = wave * RPW + rr;
+        const int dd = d0 + wrow;
+        if (dd < d_end) st4<io_t>(op + (int64_t)dd * p.o_ds + t0 + e4, *(const float4*)(sU + wrow * CH + e4));
+      }
+    } else {
 #pragma unroll
-      for (int e = lane; e < CH; e += 64) {
-        const int t = t0 + e;
-        if (dd < p.dim && t < L) io::st(op + (int64_t)dd * p.o_ds + t, sU[wrow * CH + e]);
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int wrow = wave * RPW + rr;
+        const int dd = d0 + wrow;
+        io_t* po = op + (int64_t)dd * p.o_ds + t0;
+#pragma unroll
+        for (int e = lane; e < CH; e += 64)
+          if (dd < d_end && t0 + e < L) io::st(po + e, sU[wrow * CH + e]);
       }
     }
   }
@@ -242,7 +369,7 @@ __global__ __launch_bounds__(NWAVES * 64) void scan_fwd_kernel(const ScanArgs p)
     for (int i = lane; i < RPW * N; i += 64) {
       const int rr = i / N, n = i - rr * N;
       const int dd = d0 + wave * RPW + rr;
-      if (dd < p.dim) p.last_state[((int64_t)b * p.dim + dd) * N + n] = sCar[(wave * RPW + rr) * N + n];
+      if (dd < d_end) p.last_state[((int64_t)b * p.dim + dd) * N + n] = sAC[(wave * RPW + rr) * N + n].y;
     }
   }
 }
@@ -252,17 +379,18 @@ static thread_local int g_last_hip_error = 0;
 static thread_local const char* g_last_kernel = "none";
 static int g_variant = 0;
 
-template <typename io_t, int T, int LPR, int NWAVES, int NU>
+template <typename io_t, int T, int LPR, int NWAVES, int NU, int MINW = 1>
 static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   constexpr int RPW = 64 / LPR, DT = NWAVES * RPW, CH = LPR * T;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)3 * DT * CH + (size_t)2 * DT * a.N);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_fwd_kernel<io_t, T, LPR, NWAVES, NU>;
+  auto kern = scan_fwd_kernel<io_t, T, LPR, NWAVES, NU, MINW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
   }
-  dim3 grid((a.dim + DT - 1) / DT, a.batch), block(NWAVES * 64);
+  const int dpg = a.dim / a.G;
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   g_last_kernel = name;
@@ -272,35 +400,33 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
 
 #define MXVL_FWD_CASE(T, LPR, NW, NU) \
   launch_fwd<io_t, T, LPR, NW, NU>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ">")
+#define MXVL_FWD_CASE_OCC(T, LPR, NW, NU, MW) \
+  launch_fwd<io_t, T, LPR, NW, NU, MW>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ",occ" #MW ">")
 
 template <typename io_t>
 static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
-  const int dpg = a.dim / a.G;  // rows sharing one B/C group
   const bool even = (a.N % 2) == 0;
+  const int64_t rows = (int64_t)a.batch * a.dim;
   int v = g_variant;
-  if (v == 0) v = (a.L <= 128) ? 1 : 2;
-  // a workgroup's DT rows must sit in one group: fall back to fewer rows per workgroup otherwise
-  auto rows_ok = [&](int dt) { return dpg % dt == 0; };
+  if (v == 0) {
+    // rows over 16 lanes needs rows/4 waves: switch to wider rows when that cannot fill 1024 SIMDs
+    if (rows >= 8192 || a.L <= 128) v = 1;
+    else if (rows >= 2048 || a.L <= 256) v = 3;
+    else v = 4;
+  }
   switch (v) {
-    case 1:  // CH=128, 16 rows per workgroup
-      if (rows_ok(16)) return even ? MXVL_FWD_CASE(8, 16, 4, 2) : MXVL_FWD_CASE(8, 16, 4, 1);
-      break;
-    case 2:  // CH=256, 16 rows per workgroup
-      if (rows_ok(16)) return even ? MXVL_FWD_CASE(16, 16, 4, 2) : MXVL_FWD_CASE(16, 16, 4, 1);
-      break;
-    case 3:  // CH=256, 8 rows per workgroup
-      if (rows_ok(8)) return even ? MXVL_FWD_CASE(8, 32, 4, 2) : MXVL_FWD_CASE(8, 32, 4, 1);
-      break;
-    case 4:  // CH=512, 4 rows per workgroup
-      if (rows_ok(4)) return even ? MXVL_FWD_CASE(8, 64, 4, 2) : MXVL_FWD_CASE(8, 64, 4, 1);
-      break;
-    case 5:  // CH=128, 8 rows per workgroup (2 waves)
-      if (rows_ok(8)) return even ? MXVL_FWD_CASE(8, 16, 2, 2) : MXVL_FWD_CASE(8, 16, 2, 1);
-      break;
+    case 1: return even ? MXVL_FWD_CASE(8, 16, 4, 2) : MXVL_FWD_CASE(8, 16, 4, 1);   // CH=128, 16 rows
+    case 2: return even ? MXVL_FWD_CASE(8, 16, 4, 1) : MXVL_FWD_CASE(8, 16, 4, 1);   // same, one state at a time
+    case 3: return even ? MXVL_FWD_CASE(8, 32, 4, 2) : MXVL_FWD_CASE(8, 32, 4, 1);   // CH=256, 8 rows
+    case 4: return even ? MXVL_FWD_CASE(8, 64, 4, 2) : MXVL_FWD_CASE(8, 64, 4, 1);   // CH=512, 4 rows
+    case 5: return even ? MXVL_FWD_CASE(8, 16, 2, 2) : MXVL_FWD_CASE(8, 16, 2, 1);   // CH=128, 8 rows
+    case 6: return even ? MXVL_FWD_CASE(8, 16, 8, 2) : MXVL_FWD_CASE(8, 16, 8, 1);   // CH=128, 32 rows
+    case 8: return MXVL_FWD_CASE_OCC(8, 16, 4, 1, 4);                                  // <=128 VGPR
+    case 9: return even ? MXVL_FWD_CASE_OCC(8, 16, 4, 2, 3) : MXVL_FWD_CASE_OCC(8, 16, 4, 1, 4);
+    case 7: return even ? MXVL_FWD_CASE(16, 16, 4, 2) : MXVL_FWD_CASE(16, 16, 4, 1); // CH=256, 16 rows
     default: break;
   }
-  // any dim / group shape: one row per wave, one wave per workgroup
-  return even ? MXVL_FWD_CASE(8, 64, 1, 2) : MXVL_FWD_CASE(8, 64, 1, 1);
+  return even ? MXVL_FWD_CASE(8, 16, 1, 2) : MXVL_FWD_CASE(8, 16, 1, 1);
 }
 
 }  // namespace mxvl
@@ -346,6 +472,18 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.u = d->u; a.delta = d->delta; a.B = d->B; a.C = d->C; a.z = d->z;
   a.A = (const float*)d->A; a.D = (const float*)d->D; a.bias = (const float*)d->delta_bias;
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
+  // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
+  {
+    const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2;
+    const int64_t strides[] = {d->u_bs, d->u_ds, d->delta_bs, d->delta_ds, d->out_bs, d->out_ds,
+                               d->B_bs, d->B_gs, d->B_ns, d->C_bs, d->C_gs, d->C_ns,
+                               d->z ? d->z_bs : 0, d->z ? d->z_ds : 0};
+    bool ok = true;
+    for (int64_t s : strides) ok = ok && (s % 4 == 0);
+    const void* ptrs[] = {d->u, d->delta, d->out, d->B, d->C, d->z};
+    for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
+    a.vec_ok = ok ? 1 : 0;
+  }
   hipStream_t stream = (hipStream_t)hip_stream;
   switch (d->io_dtype) {
     case MXVL_F32: return dispatch_fwd<float>(a, stream);

@@ -6,7 +6,7 @@ import torch
 from medical_image_analysis_amd import _abi
 from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
-def run(B, D, L, N, dtype, variants=(1, 2, 3, 4, 5), iters=20):
+def run(B, D, L, N, dtype, variants=(1, 2, 6, 7, 8, 9), iters=20):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
