@@ -30,7 +30,7 @@ constexpr int kCkptLen = 128;  // checkpoint spacing in time steps (mxvl_scan_ch
 
 struct ScanArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok;
+  int softplus, vec_ok, ablate;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, o_bs, o_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
   const void *u, *delta, *B, *C, *z;
@@ -183,7 +183,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     const bool full = t0 + CH <= L;
     __syncthreads();  // every wave is done with the previous B/C tile (first pass: sAC visible)
     // ---- stage the shared B/C tile -------------------------------------------------------------
-    if (vec_ok && full) {
+    if (p.ablate & 2) {
+    } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;                 // float4 columns per row
       constexpr int RSTEP = NT / CQ;             // rows covered per pass
       const int e4 = (tid % CQ) * 4;
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
       }
     }
     // ---- stage this wave's own rows of u / delta / z -------------------------------------------
-    if (vec_ok && full) {
+    if (p.ablate & 4) {
+    } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;  // float4 columns per row; a wave owns RPW*CQ = 16*T of them
 #pragma unroll
       for (int q = lane; q < RPW * CQ; q += 64) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     float* ckpt_row = p.ckpt ? p.ckpt + (((int64_t)b * p.dim + d) * p.n_ckpt + (t0 + j * T) / kCkptLen) * N : nullptr;
     float2* ac = sAC + row * N;
 
-    for (int n0 = 0; n0 < N; n0 += NU) {
+    for (int n0 = 0; n0 < ((p.ablate & 1) ? 0 : N); n0 += NU) {
       float a[NU][T], bb[NU][T], cv[NU][T], hl[NU], P[NU], x[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (vec_ok && full) {
+    if (p.ablate & 8) {
+    } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;
 #pragma unroll
       for (int q = lane; q < RPW * CQ; q += 64) {
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
   }
 }
 
+}  // namespace mxvl
+#include "scan_fwd_stream.h"
+namespace mxvl {
+
 // ---------------------------------------------------------------------------------------------
 static thread_local int g_last_hip_error = 0;
 static thread_local const char* g_last_kernel = "none";
@@ -398,6 +405,23 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   return MXVL_OK;
 }
 
+template <typename io_t, int NWAVES, bool VEC, int MINW>
+static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name) {
+  constexpr int DT = NWAVES * 4, CH = 128;
+  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * DT * a.N);
+  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW>;
+  const int dpg = a.dim / a.G;
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  hipError_t e = hipGetLastError();
+  g_last_kernel = name;
+  if (e != hipSuccess) { g_last_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+#define MXVL_STREAM_CASE(NW, MW) \
+  (a.vec_ok ? launch_stream<io_t, NW, true, MW>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ">") \
+            : launch_stream<io_t, NW, false, MW>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ">"))
+
 #define MXVL_FWD_CASE(T, LPR, NW, NU) \
   launch_fwd<io_t, T, LPR, NW, NU>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ">")
 #define MXVL_FWD_CASE_OCC(T, LPR, NW, NU, MW) \
@@ -407,12 +431,22 @@ template <typename io_t>
 static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
   const bool even = (a.N % 2) == 0;
   const int64_t rows = (int64_t)a.batch * a.dim;
-  int v = g_variant;
+  int v = g_variant & 0xff;
   if (v == 0) {
-    // rows over 16 lanes needs rows/4 waves: switch to wider rows when that cannot fill 1024 SIMDs
-    if (rows >= 8192 || a.L <= 128) v = 1;
-    else if (rows >= 2048 || a.L <= 256) v = 3;
+    // 16 lanes per row needs rows/4 waves: use wider rows when that cannot fill the 1024 SIMDs
+    if (rows >= 4096 || a.L <= 128) v = (a.N <= 16) ? 10 : 1;
+    else if (rows >= 1024 || a.L <= 256) v = 3;
     else v = 4;
+  }
+  if (a.N <= 16) {
+    switch (v) {
+      case 10: return MXVL_STREAM_CASE(4, 3);
+      case 11: return MXVL_STREAM_CASE(4, 4);
+      case 12: return MXVL_STREAM_CASE(8, 3);
+      case 13: return MXVL_STREAM_CASE(2, 3);
+      case 14: return MXVL_STREAM_CASE(4, 2);
+      default: break;
+    }
   }
   switch (v) {
     case 1: return even ? MXVL_FWD_CASE(8, 16, 4, 2) : MXVL_FWD_CASE(8, 16, 4, 1);   // CH=128, 16 rows
@@ -472,6 +506,7 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.u = d->u; a.delta = d->delta; a.B = d->B; a.C = d->C; a.z = d->z;
   a.A = (const float*)d->A; a.D = (const float*)d->D; a.bias = (const float*)d->delta_bias;
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
+  a.ablate = (g_variant >> 8) & 0xff;  // measurement-only knobs (tools/scan_bench.py); 0 in production
   // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
   {
     const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2;

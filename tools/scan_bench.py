@@ -6,7 +6,7 @@ import torch
 from medical_image_analysis_amd import _abi
 from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
-def run(B, D, L, N, dtype, variants=(1, 2, 6, 7, 8, 9), iters=20):
+def run(B, D, L, N, dtype, variants=(9, 10, 11, 12, 13, 14), iters=20):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
@@ -33,7 +33,11 @@ def run(B, D, L, N, dtype, variants=(1, 2, 6, 7, 8, 9), iters=20):
     lib.mxvl_set_scan_variant(0)
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+        for ab in (0, 1, 2, 4, 8, 6, 14, 15, 1 | 8):
+            print("ablate bits", ab, "(1=no n-loop 2=no B/C staging 4=no u/d/z staging 8=no out store)")
+            run(8, 1536, 4096, 16, torch.float32, variants=[9 | (ab << 8)])
+    elif len(sys.argv) > 1:
         B, D, L, N = map(int, sys.argv[1:5]); dt = getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32
         run(B, D, L, N, dt)
     else:
