@@ -15,7 +15,9 @@
 
 namespace mxvl {
 
-template <typename io_t, int NWAVES, bool VEC, int MINW>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename io_t, int NWAVES, bool VEC, int MINW, int NU = 1>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NMAX = 16;
   constexpr int BCV = (NMAX * CH / 4 + NT - 1) / NT;  // float4 per thread per array (VEC)
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const int N = p.N, L = p.L;
   float* sBC = smem;                          // [2 buffers][B|C][N][CH]
   float* sO = sBC + 4 * N * CH;               // [DT][CH] out tile (unaligned rows / ragged tail)
-  float2* sAC = (float2*)(sO + DT * CH);      // [DT][N] {A*log2(e), running state h}
+  float2* sAC = (float2*)(sO + DT * CH);      // [DT + 1][N] {A*log2(e), running state h}; row DT stays zero
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane >> 4, j = lane & 15;
@@ -50,10 +52,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
   const bool has_z = pz != nullptr;
 
-  for (int i = tid; i < DT * N; i += NT) {
+  for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
-    sAC[i] = make_float2(dd < d_end ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    sAC[i] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
   }
   const float bias = p.bias ? p.bias[dc] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       const int e4 = (tid % CQ) * 4;
 #pragma unroll
       for (int k = 0; k < BCV; ++k) {
-        const int n = tid / CQ + k * RSTEP;
+        // NU == 2: a thread fetches rows (2m, 2m+1) so the commit can interleave the state pair
+        const int n = (NU == 2 && BCV == 2) ? 2 * (tid / CQ) + k : tid / CQ + k * RSTEP;
         bq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         cq[k] = bq[k];
         if (n < N) {
@@ -111,12 +114,27 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     if constexpr (VEC) {
       constexpr int CQ = CH / 4, RSTEP = NT / CQ;
       const int e4 = (tid % CQ) * 4;
+      if constexpr (NU == 2) {
+        static_assert(BCV == 2, "packed layout needs two rows per thread");
+        const int m = tid / CQ;  // state pair
+        if (2 * m < N) {         // layout [N/2][CH][2]
+          float4* qB = (float4*)(dB + (m * CH + e4) * 2);
+          float4* qC = (float4*)(dC + (m * CH + e4) * 2);
+          qB[0] = make_float4(bq[0].x, bq[1].x, bq[0].y, bq[1].y);
+          qB[1] = make_float4(bq[0].z, bq[1].z, bq[0].w, bq[1].w);
+          qC[0] = make_float4(cq[0].x, cq[1].x, cq[0].y, cq[1].y);
+          qC[1] = make_float4(cq[0].z, cq[1].z, cq[0].w, cq[1].w);
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < BCV; ++k) {
-        const int n = tid / CQ + k * RSTEP;
-        if (n < N) {
-          *(float4*)(dB + n * CH + e4) = bq[k];
-          *(float4*)(dC + n * CH + e4) = cq[k];
+        for (int k = 0; k < BCV; ++k) {
+          const int n = tid / CQ + k * RSTEP;
+          // lane-major halves: [half][16 lanes][4] so a 16-lane ds_read_b128 touches 16 distinct slots
+          const int pos = ((e4 >> 2) & 1) * 64 + (e4 >> 3) * 4;
+          if (n < N) {
+            *(float4*)(dB + n * CH + pos) = bq[k];
+            *(float4*)(dC + n * CH + pos) = cq[k];
+          }
         }
       }
     } else {
@@ -126,8 +144,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int k = 0; k < BCS; ++k) {
         const int n = tid / CH + k * RSTEP;
         if (n < N) {
-          dB[n * CH + e] = bs[k];
-          dC[n * CH + e] = cs[k];
+          const int o = (NU == 2) ? ((n >> 1) * CH + e) * 2 + (n & 1)
+                                  : n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
+          dB[o] = bs[k];
+          dC[o] = cs[k];
         }
       }
     }
@@ -183,18 +203,68 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
     for (int i = 0; i < T; ++i) dsum += dl[i];
 
-    const bool ckpt_here = p.ckpt != nullptr && row_ok && (j == 0);  // CH == kCkptLen: lane 0 holds the entry state
-    float* ckpt_row = p.ckpt ? p.ckpt + (((int64_t)b * p.dim + dc) * p.n_ckpt + c) * N : nullptr;
+    if (p.ckpt != nullptr) {
+      // checkpoint = state entering the chunk = the running state this wave left in LDS (CH == kCkptLen)
+      for (int i = lane; i < RPW * N; i += 64) {
+        const int rr = i / N, n = i - rr * N;
+        const int dd = d0 + wave * RPW + rr;
+        if (dd < d_end) p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n] = sAC[(wave * RPW + rr) * N + n].y;
+      }
+    }
     float2* ac = sAC + row * N;
-    const float* cB = sBC + (c & 1) * 2 * N * CH + j * T;
+    const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;  // only lane 0 sees the state entering the chunk
+    const float* cB = sBC + (c & 1) * 2 * N * CH + j * 4;
     const float* cC = cB + N * CH;
 
+    if constexpr (NU == 2) {
+      // two states per iteration on packed fp32 (v_pk_mul/v_pk_fma): B/C tile is [N/2][CH][2]
+      const float* cB2 = sBC + (c & 1) * 2 * N * CH + j * T * 2;
+      const float* cC2 = cB2 + N * CH;
+      for (int m = 0; m < ((p.ablate & 1) ? 0 : N / 2); ++m) {
+        const float4 ac4 = *(const float4*)(ac + 2 * m);   // {A2_n, h_n, A2_n+1, h_n+1}
+        const f2 A2 = f2{ac4.x, ac4.z};
+        f2 a[T], bb[T], cv[T];
+#pragma unroll
+        for (int q = 0; q < T / 2; ++q) {
+          const float4 b4 = *(const float4*)(cB2 + m * CH * 2 + q * 4);
+          const float4 c4 = *(const float4*)(cC2 + m * CH * 2 + q * 4);
+          bb[2 * q] = f2{b4.x, b4.y}; bb[2 * q + 1] = f2{b4.z, b4.w};
+          cv[2 * q] = f2{c4.x, c4.y}; cv[2 * q + 1] = f2{c4.z, c4.w};
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const f2 e = dl[i] * A2;
+          a[i] = f2{fast_exp2(e.x), fast_exp2(e.y)};
+          bb[i] = du[i] * bb[i];
+        }
+        f2 h = bb[0];
+#pragma unroll
+        for (int i = 1; i < T; ++i) h = a[i] * h + bb[i];   // pass 1
+        const f2 pe = dsum * A2;
+        float P0 = fast_exp2(pe.x), P1 = fast_exp2(pe.y);
+        float x0 = ac4.y, x1 = ac4.w;                        // states entering the chunk
+        float h0 = fmaf(P0, (j == 0) ? x0 : 0.0f, h.x);
+        float h1 = fmaf(P1, (j == 0) ? x1 : 0.0f, h.y);
+        scan16_x2(h0, P0, x0, h1, P1, x1);
+        if (j == LPR - 1) { ac[2 * m].y = h0; ac[2 * m + 1].y = h1; }
+        h = f2{x0, x1};
+        f2 y2[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {                        // pass 2
+          h = a[i] * h + bb[i];
+          y2[i] = cv[i] * h;
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) y[i] += y2[i].x + y2[i].y;
+      }
+    } else
+#pragma unroll 4
     for (int n = 0; n < ((p.ablate & 1) ? 0 : N); ++n) {
-      const float2 A2c = ac[n];
+      const float2 A2c = make_float2(ac[n].x, ac_in[n].y);
       float a[T], bb[T], cv[T];
       {
-        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 4);
-        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 4);
+        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 64);
+        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 64);
         bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
         cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
       }
@@ -208,10 +278,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int i = 1; i < T; ++i) h = fmaf(a[i], h, bb[i]);   // pass 1: lane map h_out = P*h_in + h
       float P = fast_exp2(A2c.x * dsum);
       float x = A2c.y;                                        // state entering the chunk
-      float hl = fmaf(P, (j == 0) ? A2c.y : 0.0f, h);         // lane 0 absorbs it
+      float hl = fmaf(P, A2c.y, h);                           // lane 0 absorbs it (others read 0)
       scan16_x1(hl, P, x);
       if (j == LPR - 1) ac[n].y = hl;                         // state leaving the chunk
-      if (ckpt_here) ckpt_row[n] = x;
       h = x;
 #pragma unroll
       for (int i = 0; i < T; ++i) {                           // pass 2

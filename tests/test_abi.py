@@ -1,0 +1,66 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mxvl.h declares, the ctypes structs
+match the header's field order, and argument validation rejects bad descriptors without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from medical_image_analysis_amd import _abi
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "mxvl.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load()
+    declared = set(re.findall(r"\b(mxvl_[a-z0-9_]+)\s*\(", _header()))
+    assert declared, "no declarations parsed"
+    assert declared == set(_abi.SYMBOLS), declared ^ set(_abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), f"libmxvl.so does not export {name}"
+    assert lib.mxvl_abi_version() == _abi.ABI_VERSION
+
+
+@pytest.mark.parametrize("cstruct,pystruct", [("mxvl_scan_desc", _abi.ScanDesc), ("mxvl_scan_bwd_desc", _abi.ScanBwdDesc),
+                                              ("mxvl_conv1d_desc", _abi.Conv1dDesc), ("mxvl_conv1d_bwd_desc", _abi.Conv1dBwdDesc)])
+def test_ctypes_struct_mirrors_header(cstruct, pystruct):
+    m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|mxvl_scan_desc|mxvl_conv1d_desc)\s*", "", decl)
+        names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
+    assert names == [f[0] for f in pystruct._fields_]
+
+
+def test_scan_descriptor_validation_without_gpu():
+    lib = _abi.load()
+    d = _abi.ScanDesc()
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -1  # MXVL_ERR_NULL
+    d.u = d.delta = d.A = d.B = d.C = d.out = 64            # fake non-null pointers, never dereferenced
+    d.io_dtype = 7
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -2  # MXVL_ERR_DTYPE
+    d.io_dtype = 0
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -3  # MXVL_ERR_SHAPE (zero sizes)
+    d.batch, d.dim, d.seqlen, d.dstate, d.n_groups = 1, 6, 8, 4, 4
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -3  # dim % n_groups
+    d.n_groups, d.dstate = 2, 300
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -4  # MXVL_ERR_DSTATE
+    d.dstate, d.u_ds = 4, -1
+    assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -5  # MXVL_ERR_STRIDE
+    assert lib.mxvl_scan_chunk_len(4096, 16) > 0
+    assert lib.mxvl_scan_n_chunks(4097, 16) == -(-4097 // lib.mxvl_scan_chunk_len(4097, 16))
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    u = torch.randn(1, 4, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        selective_scan_fn(u, u, torch.randn(4, 2), torch.randn(1, 2, 8), torch.randn(1, 2, 8))

@@ -6,7 +6,7 @@ import torch
 from medical_image_analysis_amd import _abi
 from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
-def run(B, D, L, N, dtype, variants=(9, 10, 11, 12, 13, 14), iters=20):
+def run(B, D, L, N, dtype, variants=(10, 14, 11), iters=10, rounds=5):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
@@ -17,19 +17,26 @@ def run(B, D, L, N, dtype, variants=(9, 10, 11, 12, 13, 14), iters=20):
     elt = u.element_size()
     bytes_ = elt * (4 * B * D * L + 2 * B * N * L) + 4 * (D * N + 2 * D)
     lib = _abi.load()
+    import statistics
+    times = {v: [] for v in variants}
+    names = {}
+    for rnd in range(rounds):          # interleaved rounds: DVFS / box noise hits every variant alike
+        for v in variants:
+            lib.mxvl_set_scan_variant(v)
+            for _ in range(2):
+                scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True)
+            e1.record(); torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / iters * 1e3)
+            names[v] = lib.mxvl_last_scan_kernel().decode()
     for v in variants:
-        lib.mxvl_set_scan_variant(v)
-        for _ in range(3):
-            scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / iters * 1e3
-        print(f"B={B} D={D} L={L} N={N} {str(dtype)[6:]:8s} variant {v} {lib.mxvl_last_scan_kernel().decode():32s} "
-              f"{us:9.1f} us  {bytes_ / us * 1e-6:7.3f} TB/s  ({bytes_ / us * 1e-6 / 8 * 100:5.1f}% of 8 TB/s)")
+        us, med = min(times[v]), statistics.median(times[v])
+        print(f"B={B} D={D} L={L} N={N} {str(dtype)[6:]:8s} variant {v:5d} {names[v]:36s} "
+              f"min {us:8.1f} us  med {med:8.1f} us  {bytes_ / us * 1e-6:6.3f} TB/s  ({bytes_ / us * 1e-6 / 8 * 100:5.1f}% of 8 TB/s)")
     lib.mxvl_set_scan_variant(0)
 
 if __name__ == "__main__":
