@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 [os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))]
                 + [os.path.getmtime(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h"))]):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -1,0 +1,448 @@
+// scan_bwd.hip -- selective-scan backward for gfx950 (MI355X, CDNA4, wave64).
+//
+// Replaces the reference's CUDA selective_scan_bwd_kernel
+// (R2GenCSR/VMamba/kernels/selective_scan/csrc/selective_scan/cus/selective_scan_bwd_kernel.cuh:66-273,
+// host selective_scan.cpp:241-349).  Same lane mapping as the forward streaming kernel (workgroup = 16
+// rows of one batch element, a row over the 16 lanes of a DPP row, 8 consecutive steps per lane, 128-step
+// chunks) walked from the LAST chunk to the first:
+//   * the forward states of the chunk are recomputed from the checkpoint the forward pass wrote (state
+//     entering every 128-step chunk) -- fold, forward DPP scan, second pass keeping h_t in registers;
+//   * the adjoint recurrence g_t = C_t dy_t + a_{t+1} g_{t+1} is the mirror image: a Horner fold from the
+//     lane's last step, a REVERSE prefix scan over the lanes (DPP row_shl fused into v_fmac/v_mul), and a
+//     second pass that produces every gradient contribution of the step;
+//   * dB/dC (summed over the rows of a B/C group) are reduced over the workgroup's 16 rows in an LDS
+//     tile with ds_add_f32 and leave as ONE fp32 global atomic per (n,t) per workgroup -- the CUDA kernel
+//     issues one global atomic per (row,n,t) (bwd_kernel.cuh:215-221);
+//   * dA, dD, ddelta_bias are reduced over lanes with DPP and over chunks in LDS/registers: one global
+//     atomic per (row,n) / row per workgroup.
+// du, ddelta, dz are fully written; dA, dB, dC, dD, ddelta_bias are accumulated into caller-zeroed fp32.
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+constexpr int kCkptLenB = 128;
+
+struct ScanBwdArgs {
+  int batch, dim, L, N, G, n_ckpt;
+  int softplus, vec_ok;
+  int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, do_bs, do_ds;
+  int64_t du_bs, du_ds, dd_bs, dd_ds, dz_bs, dz_ds;
+  int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
+  int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
+  const void *u, *delta, *B, *C, *z, *dout;
+  const float *A, *D, *bias, *ckpt;
+  void *du, *ddelta, *dz;
+  float *dA, *dB, *dC, *dD, *dbias;
+};
+
+template <typename io_t> __device__ inline float4 ld4b(const io_t* p);
+template <> __device__ inline float4 ld4b<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ inline float4 ld4b<bf16_t>(const bf16_t* p) {
+  const uint2 r = *(const uint2*)p;
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+template <> __device__ inline float4 ld4b<f16_t>(const f16_t* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 r = *(const h4*)p;
+  return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
+}
+template <typename io_t> __device__ inline void st4b(io_t* p, float4 v);
+template <> __device__ inline void st4b<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ inline void st4b<bf16_t>(bf16_t* p, float4 v) {
+  bf16_t t[4];
+  Io<bf16_t>::st(&t[0], v.x); Io<bf16_t>::st(&t[1], v.y); Io<bf16_t>::st(&t[2], v.z); Io<bf16_t>::st(&t[3], v.w);
+  *(uint2*)p = make_uint2((uint32_t)t[0].v | ((uint32_t)t[1].v << 16), (uint32_t)t[2].v | ((uint32_t)t[3].v << 16));
+}
+template <> __device__ inline void st4b<f16_t>(f16_t* p, float4 v) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  *(h4*)p = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+
+// forward inclusive scan + exclusive shift over a 16-lane DPP row (see scan_fwd.hip)
+__device__ inline void scan16_fwd(float& h0, float& P0, float& x0) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(h0), "+v"(P0), "+v"(x0));
+}
+// mirror image: lane j combines with lanes j+1.. (row_shl); x leaves holding the value entering from the right
+__device__ inline void scan16_rev(float& q0, float& P0, float& x0) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_mov_b32_dpp %2, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(q0), "+v"(P0), "+v"(x0));
+}
+// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
+__device__ inline float row_sum_to_lane15(float v) {
+  v += dpp<DPP_ROW_SHR(1)>(0.0f, v);
+  v += dpp<DPP_ROW_SHR(2)>(0.0f, v);
+  v += dpp<DPP_ROW_SHR(4)>(0.0f, v);
+  v += dpp<DPP_ROW_SHR(8)>(0.0f, v);
+  return v;
+}
+
+template <typename io_t, int NWAVES, bool VEC>
+__global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
+  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
+  static_assert(CH == kCkptLenB, "one checkpoint per chunk");
+  using io = Io<io_t>;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = p.N, L = p.L;
+  float* sB = smem;                        // [N][CH]  lane-major halves (see scan_fwd_stream.h)
+  float* sC = sB + N * CH;                 // [N][CH]
+  float* sdB = sC + N * CH;                // [N][CH]  natural order, fp32 accumulators of this chunk
+  float* sdC = sdB + N * CH;               // [N][CH]
+  float* sO = sdC + N * CH;                // [DT][CH] store transpose tile (unaligned rows)
+  float2* sAC = (float2*)(sO + DT * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
+  float* sG = (float*)(sAC + (DT + 1) * N);  // [DT+1][N] adjoint entering the chunk from the right; row DT = 0
+  float* sdA = sG + (DT + 1) * N;          // [DT][N] dA accumulated over the chunks
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane >> 4, j = lane & 15;
+  const int row = wave * RPW + r;
+  const int b = blockIdx.y;
+  const int dpg = p.dim / p.G;
+  const int tiles = (dpg + DT - 1) / DT;
+  const int g = blockIdx.x / tiles;
+  const int d0 = g * dpg + (blockIdx.x - g * tiles) * DT;
+  const int d_end = (g + 1) * dpg;
+  const int d = d0 + row;
+  const bool row_ok = d < d_end;
+  const int dc = row_ok ? d : d_end - 1;
+
+  const io_t* __restrict__ pu = (const io_t*)p.u + (int64_t)b * p.u_bs + (int64_t)dc * p.u_ds + j * T;
+  const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dc * p.dl_ds + j * T;
+  const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
+  const io_t* __restrict__ pg = (const io_t*)p.dout + (int64_t)b * p.do_bs + (int64_t)dc * p.do_ds + j * T;
+  io_t* __restrict__ qdu = (io_t*)p.du + (int64_t)b * p.du_bs + (int64_t)dc * p.du_ds + j * T;
+  io_t* __restrict__ qdd = (io_t*)p.ddelta + (int64_t)b * p.dd_bs + (int64_t)dc * p.dd_ds + j * T;
+  io_t* __restrict__ qdz = p.dz ? (io_t*)p.dz + (int64_t)b * p.dz_bs + (int64_t)dc * p.dz_ds + j * T : nullptr;
+  const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
+  const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
+  float* __restrict__ dBp = p.dB + (int64_t)b * p.dB_bs + (int64_t)g * p.dB_gs;
+  float* __restrict__ dCp = p.dC + (int64_t)b * p.dC_bs + (int64_t)g * p.dC_gs;
+  const bool has_z = pz != nullptr;
+
+  for (int i = tid; i < (DT + 1) * N; i += NT) {
+    const int rr = i / N, n = i - rr * N;
+    const int dd = d0 + rr;
+    sAC[i] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    sG[i] = 0.0f;
+    if (rr < DT) sdA[i] = 0.0f;
+  }
+  const float bias = p.bias ? p.bias[dc] : 0.0f;
+  const float Dv = p.D ? p.D[dc] : 0.0f;
+  float dD_acc = 0.0f, dbias_acc = 0.0f;
+
+  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
+    if (t0 + CH <= L) {
+      if constexpr (VEC) {
+        const float4 a0 = ld4b<io_t>(q + t0), a1 = ld4b<io_t>(q + t0 + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
+    }
+  };
+  auto row_store = [&](io_t* q, const void* base, int64_t bs, int64_t ds, int t0, const float (&v)[T]) {
+    if (VEC && t0 + CH <= L) {
+      if (row_ok) {
+        st4b<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
+        st4b<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
+      }
+    } else {
+      float4* so4 = (float4*)(sO + row * CH + j * T);
+      so4[0] = make_float4(v[0], v[1], v[2], v[3]);
+      so4[1] = make_float4(v[4], v[5], v[6], v[7]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int wrow = wave * RPW + rr;
+        const int dd = d0 + wrow;
+        io_t* w = (io_t*)base + (int64_t)b * bs + (int64_t)dd * ds + t0;
+#pragma unroll
+        for (int e = lane; e < CH; e += 64)
+          if (dd < d_end && t0 + e < L) io::st(w + e, sO[wrow * CH + e]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+
+  const int nchunks = (L + CH - 1) / CH;
+  for (int c = nchunks - 1; c >= 0; --c) {
+    const int t0 = c * CH;
+    const bool full = t0 + CH <= L;
+    __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible)
+    // ---- B/C tile of this chunk + zero the dB/dC accumulators + state entering the chunk ----------
+    for (int i = tid; i < N * CH; i += NT) {
+      const int n = i / CH, e = i - n * CH;
+      const int t = t0 + e;
+      float bv = 0.0f, cv = 0.0f;
+      if (t < L) {
+        bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
+        cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
+      }
+      const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
+      sB[pos] = bv;
+      sC[pos] = cv;
+      sdB[i] = 0.0f;
+      sdC[i] = 0.0f;
+    }
+    for (int i = lane; i < RPW * N; i += 64) {
+      const int rr = i / N, n = i - rr * N;
+      const int dd = d0 + wave * RPW + rr;
+      float h0 = 0.0f;
+      if (c > 0 && dd < d_end) h0 = p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n];
+      sAC[(wave * RPW + rr) * N + n].y = h0;
+    }
+    float uu[T], dl[T], zz[T], go[T];
+    row_fetch(pu, t0, uu);
+    row_fetch(pd, t0, dl);
+    row_fetch(pg, t0, go);
+    if (has_z) row_fetch(pz, t0, zz);
+    __syncthreads();
+
+    float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      float x = dl[i] + bias;
+      float ds = 1.0f;
+      if (p.softplus) {
+        ds = (x > 20.0f) ? 1.0f : sigmoid(x);  // d softplus / dx
+        x = softplus(x);
+      }
+      if (!full && !(t0 + j * T + i < L)) { x = 0.0f; ds = 0.0f; }
+      dl[i] = x;
+      dsp[i] = ds;
+      du[i] = x * uu[i];
+      y[i] = Dv * uu[i];
+      if (!row_ok) go[i] = 0.0f;  // clamped duplicate rows must not add into the shared dB/dC tile
+      dy[i] = has_z ? go[i] * silu(zz[i]) : go[i];
+      sgB[i] = 0.0f;
+      sAh[i] = 0.0f;
+    }
+    float dsum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < T; ++i) dsum += dl[i];
+
+    float2* ac = sAC + row * N;
+    const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;
+    float* gq = sG + row * N;
+    const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * N;
+    const float* cB = sB + j * 4;
+    const float* cC = sC + j * 4;
+    float* aB = sdB + j * T;
+    float* aC = sdC + j * T;
+
+    for (int n = 0; n < N; ++n) {
+      const float A2 = ac[n].x;
+      const float hin = ac_in[n].y;
+      float a[T], bb[T], cv[T], h[T];
+      {
+        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 64);
+        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 64);
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+      }
+      // ---- forward recompute -----------------------------------------------------------------------
+      float hl;
+      {
+#pragma unroll
+        for (int i = 0; i < T; ++i) a[i] = fast_exp2(dl[i] * A2);
+        hl = du[0] * bb[0];
+#pragma unroll
+        for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, du[i] * bb[i]);
+      }
+      const float P = fast_exp2(A2 * dsum);
+      float Pf = P, x = hin;
+      hl = fmaf(P, hin, hl);
+      scan16_fwd(hl, Pf, x);           // x = state entering this lane's steps
+      {
+        float hh = x;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          hh = fmaf(a[i], hh, du[i] * bb[i]);
+          h[i] = hh;
+          y[i] = fmaf(cv[i], hh, y[i]);
+        }
+      }
+      // ---- adjoint: g_i = C_i dy_i + a_{i+1} g_{i+1} ---------------------------------------------------
+      float ql = cv[T - 1] * dy[T - 1];
+#pragma unroll
+      for (int i = T - 2; i >= 0; --i) ql = fmaf(a[i + 1], ql, cv[i] * dy[i]);
+      ql *= a[0];                      // what this lane hands to its left neighbour for gamma_in = 0
+      const float gin = gq_in[n];      // only lane 15 sees the adjoint entering from chunk c+1
+      float Pr = P, gx = gin;
+      ql = fmaf(P, gin, ql);
+      scan16_rev(ql, Pr, gx);          // gx = a_{next} g_{next} entering this lane from the right
+      if (j == 0) gq[n] = ql;          // leaves the chunk towards chunk c-1
+      float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
+      float dA_part = 0.0f;
+#pragma unroll
+      for (int i = T - 1; i >= 0; --i) {
+        const float gi = fmaf(cv[i], dy[i], gg);          // g_i
+        const float hprev = (i == 0) ? x : h[i - 1];
+        const float ga = gi * a[i];                       // a_i g_i
+        const float gha = ga * hprev;                     // g_i h_{i-1} a_i
+        atomicAdd(aC + n * CH + i, dy[i] * h[i]);         // LDS: dC_{n,t} over the 16 rows
+        atomicAdd(aB + n * CH + i, gi * du[i]);           // LDS: dB_{n,t}
+        sgB[i] = fmaf(gi, bb[i], sgB[i]);
+        sAh[i] = fmaf(gha, A2, sAh[i]);
+        dA_part = fmaf(gha, dl[i], dA_part);
+        gg = ga;
+      }
+      dA_part = row_sum_to_lane15(dA_part);
+      if (j == LPR - 1) sdA[row * N + n] += dA_part;
+    }
+
+    // ---- per-step outputs --------------------------------------------------------------------------------
+    float o_du[T], o_dd[T], o_dz[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      o_du[i] = fmaf(dl[i], sgB[i], dy[i] * Dv);
+      const float dd = fmaf(uu[i], sgB[i], sAh[i] * 0.6931471805599453f) * dsp[i];  // A = A2 * ln2
+      o_dd[i] = dd;
+      dD_acc = fmaf(dy[i], uu[i], dD_acc);
+      dbias_acc += dd;
+      if (has_z) {
+        const float s = sigmoid(zz[i]);
+        o_dz[i] = go[i] * y[i] * s * fmaf(zz[i], 1.0f - s, 1.0f);
+      }
+    }
+    row_store(qdu, p.du, p.du_bs, p.du_ds, t0, o_du);
+    row_store(qdd, p.ddelta, p.dd_bs, p.dd_ds, t0, o_dd);
+    if (has_z) row_store(qdz, p.dz, p.dz_bs, p.dz_ds, t0, o_dz);
+
+    __syncthreads();  // every row of the workgroup has added into the dB/dC tile
+    for (int i = tid; i < N * CH; i += NT) {
+      const int n = i / CH, e = i - n * CH;
+      if (t0 + e < L) {
+        unsafeAtomicAdd(dBp + (int64_t)n * p.dB_ns + t0 + e, sdB[i]);
+        unsafeAtomicAdd(dCp + (int64_t)n * p.dC_ns + t0 + e, sdC[i]);
+      }
+    }
+  }
+
+  // ---- per-row reductions: dA (LDS, lane 15 wrote), dD, ddelta_bias (registers -> row sum) -----------------
+  dD_acc = row_sum_to_lane15(dD_acc);
+  dbias_acc = row_sum_to_lane15(dbias_acc);
+  if (j == LPR - 1 && row_ok) {
+    if (p.dD) unsafeAtomicAdd(p.dD + d, dD_acc);
+    if (p.dbias) unsafeAtomicAdd(p.dbias + d, dbias_acc);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = lane; i < RPW * N; i += 64) {
+    const int rr = i / N, n = i - rr * N;
+    const int dd = d0 + wave * RPW + rr;
+    // d a / d A = delta * a and A2 = A*log2e only rescales the exponent argument: sdA already holds dA
+    if (dd < d_end) unsafeAtomicAdd(p.dA + (int64_t)dd * N + n, sdA[(wave * RPW + rr) * N + n]);
+  }
+}
+
+static thread_local int g_bwd_hip_error = 0;
+
+template <typename io_t, int NWAVES, bool VEC>
+static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  constexpr int DT = NWAVES * 4, CH = 128;
+  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
+  if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  }
+  const int dpg = a.dim / a.G;
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
+  hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
+template <typename io_t>
+static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  return a.vec_ok ? launch_bwd<io_t, 4, true>(a, stream) : launch_bwd<io_t, 4, false>(a, stream);
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" int mxvl_scan_check(const mxvl_scan_desc* d);
+
+extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
+  if (!d) return MXVL_ERR_NULL;
+  const mxvl_scan_desc* f = &d->fwd;
+  int rc = mxvl_scan_check(f);
+  if (rc != MXVL_OK) return rc;
+  if (!d->dout || !d->du || !d->ddelta || !d->dA || !d->dB || !d->dC) return MXVL_ERR_NULL;
+  if (f->z && !d->dz) return MXVL_ERR_NULL;
+  if (f->D && !d->dD) return MXVL_ERR_NULL;
+  if (f->delta_bias && !d->ddelta_bias) return MXVL_ERR_NULL;
+  const int n_ckpt = (f->seqlen + kCkptLenB - 1) / kCkptLenB;
+  if (n_ckpt > 1 && !f->ckpt) return MXVL_ERR_CHECKPOINT;
+  ScanBwdArgs a;
+  a.batch = f->batch; a.dim = f->dim; a.L = f->seqlen; a.N = f->dstate; a.G = f->n_groups; a.n_ckpt = n_ckpt;
+  a.softplus = (f->flags & MXVL_SCAN_DELTA_SOFTPLUS) ? 1 : 0;
+  a.u_bs = f->u_bs; a.u_ds = f->u_ds; a.dl_bs = f->delta_bs; a.dl_ds = f->delta_ds; a.z_bs = f->z_bs; a.z_ds = f->z_ds;
+  a.do_bs = d->dout_bs; a.do_ds = d->dout_ds; a.du_bs = d->du_bs; a.du_ds = d->du_ds;
+  a.dd_bs = d->ddelta_bs; a.dd_ds = d->ddelta_ds; a.dz_bs = d->dz_bs; a.dz_ds = d->dz_ds;
+  a.B_bs = f->B_bs; a.B_gs = f->B_gs; a.B_ns = f->B_ns; a.C_bs = f->C_bs; a.C_gs = f->C_gs; a.C_ns = f->C_ns;
+  a.A_ds = f->A_ds; a.A_ns = f->A_ns;
+  a.dB_bs = d->dB_bs; a.dB_gs = d->dB_gs; a.dB_ns = d->dB_ns; a.dC_bs = d->dC_bs; a.dC_gs = d->dC_gs; a.dC_ns = d->dC_ns;
+  a.u = f->u; a.delta = f->delta; a.B = f->B; a.C = f->C; a.z = f->z; a.dout = d->dout;
+  a.A = (const float*)f->A; a.D = (const float*)f->D; a.bias = (const float*)f->delta_bias; a.ckpt = (const float*)f->ckpt;
+  a.du = d->du; a.ddelta = d->ddelta; a.dz = d->dz;
+  a.dA = (float*)d->dA; a.dB = (float*)d->dB; a.dC = (float*)d->dC; a.dD = (float*)d->dD; a.dbias = (float*)d->ddelta_bias;
+  if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
+  {
+    const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
+    const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,
+                               d->dout_bs, d->dout_ds, d->du_bs, d->du_ds, d->ddelta_bs, d->ddelta_ds,
+                               f->z ? d->dz_bs : 0, f->z ? d->dz_ds : 0};
+    bool ok = true;
+    for (int64_t s : strides) ok = ok && (s % 4 == 0);
+    const void* ptrs[] = {f->u, f->delta, f->z, d->dout, d->du, d->ddelta, d->dz};
+    for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
+    a.vec_ok = ok ? 1 : 0;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  switch (f->io_dtype) {
+    case MXVL_F32: return dispatch_bwd<float>(a, stream);
+    case MXVL_BF16: return dispatch_bwd<bf16_t>(a, stream);
+    default: return dispatch_bwd<f16_t>(a, stream);
+  }
+}

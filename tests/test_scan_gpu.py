@@ -145,3 +145,75 @@ def test_scan_strided_inputs_match_contiguous():
     a = selective_scan_fn(u_v, x["delta"], x["A"], x["B"], x["C"], x["D"], z=z_v, delta_bias=x["delta_bias"], delta_softplus=True)
     b = selective_scan_fn(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], z=x["z"], delta_bias=x["delta_bias"], delta_softplus=True)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward (mxvl_scan_bwd through torch.autograd)
+# ---------------------------------------------------------------------------------------------------
+def _grads_via_autograd(x, sp, dout):
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    leaves = {k: (v.clone().requires_grad_(True) if v is not None else None) for k, v in x.items()}
+    out = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                            z=leaves["z"], delta_bias=leaves["delta_bias"], delta_softplus=sp)
+    out.backward(dout)
+    torch.cuda.synchronize()
+    names = dict(u="du", delta="ddelta", A="dA", B="dB", C="dC", D="dD", z="dz", delta_bias="ddelta_bias")
+    return {names[k]: v.grad for k, v in leaves.items() if v is not None}
+
+
+def _check_grads(got, ref, what=""):
+    for k, r in ref.items():
+        if r is None:
+            continue
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(got[k], r, 2e-5 * scale, 1e-4, f"{what}{k}")
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+def test_scan_bwd_golden(name):
+    g = load_golden(name)
+    dev = _dev()
+    x = _to({k: g.get(k) for k in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias")}, dev)
+    got = _grads_via_autograd(x, bool(g["delta_softplus"]), g["dout"].to(dev))
+    ref = {k: g.get(k) for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")}
+    _check_grads(got, ref, name + ":")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_scan_bwd_vs_oracle(case):
+    from oracle import oracle as orc
+    B, D, L, N, G, hz, hD, hb, sp = case
+    cpu = scan_inputs(B, D, L, N, G, hz, hD, hb, seed=5)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(6))
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], sp, dout)
+    got = _grads_via_autograd(_to(cpu, _dev()), sp, dout.to(_dev()))
+    _check_grads(got, ref)
+
+
+def test_scan_bwd_half_io():
+    from oracle import oracle as orc
+    dtype = torch.bfloat16
+    cpu = scan_inputs(2, 64, 300, 16, 1, True, True, True, seed=7, dtype=dtype)
+    dout = torch.randn(2, 64, 300, generator=torch.Generator().manual_seed(8)).to(dtype)
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], True, dout)
+    got = _grads_via_autograd(_to(cpu, _dev()), True, dout.to(_dev()))
+    for k, r in ref.items():  # reference bf16 tolerances (test_selective_scan.py:403-404, x2..x10 on grads)
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(got[k], r, 5e-2 * scale * 0.2, 6e-2, k)
+
+
+def test_scan_bwd_linearity_full_size():
+    """Size-independent property at BASELINE configs[1] full size: the gradient is linear in dout."""
+    dev = _dev()
+    x = _to(scan_inputs(32, 768, 196, 16, 1, True, True, True, seed=9), dev)
+    g1 = torch.randn(32, 768, 196, device=dev)
+    g2 = torch.randn(32, 768, 196, device=dev)
+    a = _grads_via_autograd(x, True, g1)
+    b = _grads_via_autograd(x, True, g2)
+    c = _grads_via_autograd(x, True, g1 + 2.0 * g2)
+    for k in a:
+        ref = a[k].float() + 2.0 * b[k].float()
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close(c[k], ref, 5e-5 * scale, 1e-4, k)
