@@ -1,0 +1,321 @@
+// conv1d.hip -- depthwise causal conv1d (+SiLU) forward/backward, and the two single-token decode
+// steps of the Mamba mixer, for gfx950.
+//
+// Replaces (reference paths relative to CXPMRG_Bench_MambaXray_VL/arm/Finetuning/):
+//   mxvl_conv1d_fwd/bwd   causal_conv1d_fn (third-party wheel, call site mamba_simple.py:676-681); semantics =
+//                         the in-repo fallback act(conv1d(x)[..., :L]) with nn.Conv1d(D, D, W, groups=D,
+//                         padding=W-1) (mamba_simple.py:78-86, 672-673)
+//   mxvl_conv1d_update    causal_conv1d_update (call site :732-738), fallback roll + dot (:724-730)
+//   mxvl_state_update     selective_state_update (call site :757-759), fallback :748-755
+// All are HBM-bound streaming kernels: algorithmic bytes = 2*elt*B*D*L (fwd), 3*elt*B*D*L (bwd).
+// (B,D,L) rows are L-contiguous and usually NOT 16-byte aligned (L = 197), so a thread owns 4 consecutive
+// steps of one row and reads its 3-step halo through L1; consecutive threads cover consecutive steps.
+#include <algorithm>
+
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+constexpr int kMaxW = 8;
+
+struct ConvArgs {
+  int batch, dim, L, W, silu;
+  int64_t x_bs, x_ds, y_bs, y_ds, dy_bs, dy_ds, dx_bs, dx_ds;
+  const void *x, *dy;
+  const float *w, *bias;
+  void *y, *dx;
+  float *dw, *dbias;
+};
+
+// runtime-indexed register arrays would go to scratch: select chain instead (generic-width path only)
+__device__ inline float pick(const float (&w)[kMaxW], int idx) {
+  float v = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxW; ++k) v = (k == idx) ? w[k] : v;
+  return v;
+}
+
+// WT = compile-time tap count (4 is Mamba's d_conv); WT = 0 reads the width at run time (<= kMaxW)
+template <typename io_t, int WT>
+__global__ __launch_bounds__(256) void conv1d_fwd_kernel(const ConvArgs p) {
+  using io = Io<io_t>;
+  const int nq = (p.L + 3) / 4;
+  const int64_t total = (int64_t)p.batch * p.dim * nq;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % nq);
+    const int64_t rowi = idx / nq;
+    const int d = (int)(rowi % p.dim), b = (int)(rowi / p.dim);
+    const io_t* xr = (const io_t*)p.x + (int64_t)b * p.x_bs + (int64_t)d * p.x_ds;
+    io_t* yr = (io_t*)p.y + (int64_t)b * p.y_bs + (int64_t)d * p.y_ds;
+    const int t0 = q * 4, W = WT ? WT : p.W;
+    float w[kMaxW];
+#pragma unroll
+    for (int k = 0; k < kMaxW; ++k) w[k] = k < W ? p.w[(int64_t)d * W + k] : 0.0f;
+    const float bias = p.bias ? p.bias[d] : 0.0f;
+    float xv[kMaxW + 3];  // x[t0-(W-1) .. t0+3]
+#pragma unroll
+    for (int k = 0; k < kMaxW + 3; ++k) {
+      const int t = t0 - (W - 1) + k;
+      xv[k] = (k < W + 3 && t >= 0 && t < p.L) ? io::ld(xr + t) : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (t0 + i < p.L) {
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < kMaxW; ++k)
+          if (k < W) acc = fmaf(w[k], xv[i + k], acc);
+        io::st(yr + t0 + i, p.silu ? silu(acc) : acc);
+      }
+    }
+  }
+}
+
+// one workgroup per (d, batch slice): dx written per element, dw/dbias reduced in the block then atomically
+template <typename io_t, int WT>
+__global__ __launch_bounds__(256) void conv1d_bwd_kernel(const ConvArgs p, int b_per_block) {
+  using io = Io<io_t>;
+  const int d = blockIdx.x, W = WT ? WT : p.W, L = p.L;
+  const int b_lo = blockIdx.y * b_per_block;
+  const int b_hi = min(p.batch, b_lo + b_per_block);
+  float w[kMaxW];
+#pragma unroll
+  for (int k = 0; k < kMaxW; ++k) w[k] = k < W ? p.w[(int64_t)d * W + k] : 0.0f;
+  const float bias = p.bias ? p.bias[d] : 0.0f;
+  float dw_acc[kMaxW], db_acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxW; ++k) dw_acc[k] = 0.0f;
+
+  const int per_b = L;
+  const int total = (b_hi - b_lo) * per_b;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int b = b_lo + idx / per_b;
+    const int s = idx - (idx / per_b) * per_b;
+    const io_t* xr = (const io_t*)p.x + (int64_t)b * p.x_bs + (int64_t)d * p.x_ds;
+    const io_t* gr = (const io_t*)p.dy + (int64_t)b * p.dy_bs + (int64_t)d * p.dy_ds;
+    io_t* dxr = (io_t*)p.dx + (int64_t)b * p.dx_bs + (int64_t)d * p.dx_ds;
+    // x[s-(W-1) .. s+(W-1)] covers the pre-activations of steps s .. s+W-1
+    float xv[2 * kMaxW - 1];
+#pragma unroll
+    for (int k = 0; k < 2 * kMaxW - 1; ++k) {
+      const int t = s - (W - 1) + k;
+      xv[k] = (k < 2 * W - 1 && t >= 0 && t < L) ? io::ld(xr + t) : 0.0f;
+    }
+    float dxs = 0.0f;
+#pragma unroll
+    for (int m = 0; m < kMaxW; ++m) {  // step t = s + m uses x[s] with tap k = W-1-m
+      if (m < W && s + m < L) {
+        float g = io::ld(gr + s + m);
+        if (p.silu) {
+          float pre = bias;
+#pragma unroll
+          for (int k = 0; k < kMaxW; ++k)
+            if (k < W) pre = fmaf(w[k], xv[m + k], pre);
+          const float sg = sigmoid(pre);
+          g *= sg * fmaf(pre, 1.0f - sg, 1.0f);
+        }
+        float wr;  // tap that multiplies x[s] inside pre[s+m]
+        if constexpr (WT > 0) wr = w[(WT - 1 - m) & (kMaxW - 1)];  // static after unrolling (m < WT here)
+        else wr = pick(w, W - 1 - m);
+        dxs = fmaf(wr, g, dxs);
+        if (m == 0) {  // this thread owns step s for the weight / bias sums
+          db_acc += g;
+#pragma unroll
+          for (int k = 0; k < kMaxW; ++k)
+            if (k < W) dw_acc[k] = fmaf(g, xv[k], dw_acc[k]);
+        }
+      }
+    }
+    io::st(dxr + s, dxs);
+  }
+  // block reduction: wave shuffle then LDS
+  __shared__ float red[4][kMaxW + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k <= kMaxW; ++k) {
+    float v = (k < kMaxW) ? dw_acc[k] : db_acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x <= kMaxW) {
+    const int k = threadIdx.x;
+    const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    if (k < W) unsafeAtomicAdd(p.dw + (int64_t)d * W + k, v);
+    if (k == kMaxW && p.dbias) unsafeAtomicAdd(p.dbias + d, v);
+  }
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void conv1d_update_kernel(const io_t* x, io_t* state, const float* w,
+                                                            const float* bias, io_t* y, int batch, int dim,
+                                                            int W, int silu_on) {
+  using io = Io<io_t>;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * dim) return;
+  const int d = (int)(idx % dim);
+  io_t* st = state + idx * W;
+  float acc = bias ? bias[d] : 0.0f;
+  for (int k = 0; k + 1 < W; ++k) {
+    const float v = io::ld(st + k + 1);
+    io::st(st + k, v);
+    acc = fmaf(v, w[(int64_t)d * W + k], acc);
+  }
+  const float xn = io::ld(x + idx);
+  io::st(st + W - 1, xn);
+  acc = fmaf(xn, w[(int64_t)d * W + W - 1], acc);
+  io::st(y + idx, silu_on ? silu(acc) : acc);
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void state_update_kernel(float* state, const io_t* x, const io_t* dt, const float* A,
+                                                           const io_t* B, const io_t* C, const float* D, const io_t* z,
+                                                           const float* dt_bias, io_t* out, int batch, int dim, int N,
+                                                           int softplus_on) {
+  using io = Io<io_t>;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)batch * dim) return;
+  const int d = (int)(idx % dim), b = (int)(idx / dim);
+  float dtv = io::ld(dt + idx) + (dt_bias ? dt_bias[d] : 0.0f);
+  if (softplus_on) dtv = softplus(dtv);
+  const float xv = io::ld(x + idx);
+  float* st = state + idx * N;
+  float y = 0.0f;
+  for (int n = 0; n < N; ++n) {
+    const float h = fmaf(st[n], fast_exp(dtv * A[(int64_t)d * N + n]), xv * dtv * io::ld(B + (int64_t)b * N + n));
+    st[n] = h;
+    y = fmaf(h, io::ld(C + (int64_t)b * N + n), y);
+  }
+  if (D) y = fmaf(D[d], xv, y);
+  if (z) y *= silu(io::ld(z + idx));
+  io::st(out + idx, y);
+}
+
+static int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+static int conv_check(const mxvl_conv1d_desc* d) {
+  if (!d || !d->x || !d->weight) return MXVL_ERR_NULL;
+  if (d->io_dtype != MXVL_F32 && d->io_dtype != MXVL_BF16 && d->io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  if (d->batch <= 0 || d->dim <= 0 || d->seqlen <= 0 || d->width <= 0) return MXVL_ERR_SHAPE;
+  if (d->width > kMaxW) return MXVL_ERR_UNSUPPORTED;
+  if (d->x_bs < 0 || d->x_ds < 0) return MXVL_ERR_STRIDE;
+  return MXVL_OK;
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" {
+
+int mxvl_conv1d_fwd(const mxvl_conv1d_desc* d, void* hip_stream) {
+  int rc = conv_check(d);
+  if (rc != MXVL_OK) return rc;
+  if (!d->y) return MXVL_ERR_NULL;
+  ConvArgs a{};
+  a.batch = d->batch; a.dim = d->dim; a.L = d->seqlen; a.W = d->width; a.silu = d->silu;
+  a.x_bs = d->x_bs; a.x_ds = d->x_ds; a.y_bs = d->y_bs; a.y_ds = d->y_ds;
+  a.x = d->x; a.w = (const float*)d->weight; a.bias = (const float*)d->bias; a.y = d->y;
+  const int64_t total = (int64_t)a.batch * a.dim * ((a.L + 3) / 4);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+  hipStream_t s = (hipStream_t)hip_stream;
+#define MXVL_CONV_FWD(T) \
+  do { \
+    if (a.W == 4) hipLaunchKernelGGL((conv1d_fwd_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((conv1d_fwd_kernel<T, 0>), dim3(blocks), dim3(256), 0, s, a); \
+  } while (0)
+  switch (d->io_dtype) {
+    case MXVL_F32: MXVL_CONV_FWD(float); break;
+    case MXVL_BF16: MXVL_CONV_FWD(bf16_t); break;
+    default: MXVL_CONV_FWD(f16_t); break;
+  }
+  return check_launch();
+}
+
+int mxvl_conv1d_bwd(const mxvl_conv1d_bwd_desc* d, void* hip_stream) {
+  if (!d) return MXVL_ERR_NULL;
+  int rc = conv_check(&d->fwd);
+  if (rc != MXVL_OK) return rc;
+  if (!d->dy || !d->dx || !d->dweight) return MXVL_ERR_NULL;
+  if (d->fwd.bias && !d->dbias) return MXVL_ERR_NULL;
+  ConvArgs a{};
+  a.batch = d->fwd.batch; a.dim = d->fwd.dim; a.L = d->fwd.seqlen; a.W = d->fwd.width; a.silu = d->fwd.silu;
+  a.x_bs = d->fwd.x_bs; a.x_ds = d->fwd.x_ds; a.dy_bs = d->dy_bs; a.dy_ds = d->dy_ds; a.dx_bs = d->dx_bs; a.dx_ds = d->dx_ds;
+  a.x = d->fwd.x; a.w = (const float*)d->fwd.weight; a.bias = (const float*)d->fwd.bias;
+  a.dy = d->dy; a.dx = d->dx; a.dw = (float*)d->dweight; a.dbias = (float*)d->dbias;
+  // enough workgroups to fill the chip: split the batch when dim alone is short of ~4 blocks per CU
+  int bsplit = 1;
+  while (a.dim * bsplit < 1024 && bsplit < a.batch) bsplit *= 2;
+  const int b_per_block = (a.batch + bsplit - 1) / bsplit;
+  dim3 grid(a.dim, (a.batch + b_per_block - 1) / b_per_block);
+  hipStream_t s = (hipStream_t)hip_stream;
+#define MXVL_CONV_BWD(T) \
+  do { \
+    if (a.W == 4) hipLaunchKernelGGL((conv1d_bwd_kernel<T, 4>), grid, dim3(256), 0, s, a, b_per_block); \
+    else hipLaunchKernelGGL((conv1d_bwd_kernel<T, 0>), grid, dim3(256), 0, s, a, b_per_block); \
+  } while (0)
+  switch (d->fwd.io_dtype) {
+    case MXVL_F32: MXVL_CONV_BWD(float); break;
+    case MXVL_BF16: MXVL_CONV_BWD(bf16_t); break;
+    default: MXVL_CONV_BWD(f16_t); break;
+  }
+  return check_launch();
+}
+
+int mxvl_conv1d_update(const void* x, void* conv_state, const void* weight, const void* bias, void* y, int batch,
+                       int dim, int width, int io_dtype, int silu_on, void* hip_stream) {
+  if (!x || !conv_state || !weight || !y) return MXVL_ERR_NULL;
+  if (batch <= 0 || dim <= 0 || width <= 0) return MXVL_ERR_SHAPE;
+  const int blocks = (int)(((int64_t)batch * dim + 255) / 256);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32:
+      hipLaunchKernelGGL(conv1d_update_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)conv_state,
+                         (const float*)weight, (const float*)bias, (float*)y, batch, dim, width, silu_on);
+      break;
+    case MXVL_BF16:
+      hipLaunchKernelGGL(conv1d_update_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)conv_state,
+                         (const float*)weight, (const float*)bias, (bf16_t*)y, batch, dim, width, silu_on);
+      break;
+    case MXVL_F16:
+      hipLaunchKernelGGL(conv1d_update_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (const f16_t*)x, (f16_t*)conv_state,
+                         (const float*)weight, (const float*)bias, (f16_t*)y, batch, dim, width, silu_on);
+      break;
+    default: return MXVL_ERR_DTYPE;
+  }
+  return check_launch();
+}
+
+int mxvl_state_update(void* state, const void* x, const void* dt, const void* A, const void* B, const void* C,
+                      const void* D, const void* z, const void* dt_bias, void* out, int batch, int dim, int dstate,
+                      int io_dtype, int dt_softplus, void* hip_stream) {
+  if (!state || !x || !dt || !A || !B || !C || !out) return MXVL_ERR_NULL;
+  if (batch <= 0 || dim <= 0 || dstate <= 0) return MXVL_ERR_SHAPE;
+  const int blocks = (int)(((int64_t)batch * dim + 255) / 256);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32:
+      hipLaunchKernelGGL(state_update_kernel<float>, dim3(blocks), dim3(256), 0, s, (float*)state, (const float*)x,
+                         (const float*)dt, (const float*)A, (const float*)B, (const float*)C, (const float*)D,
+                         (const float*)z, (const float*)dt_bias, (float*)out, batch, dim, dstate, dt_softplus);
+      break;
+    case MXVL_BF16:
+      hipLaunchKernelGGL(state_update_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (float*)state, (const bf16_t*)x,
+                         (const bf16_t*)dt, (const float*)A, (const bf16_t*)B, (const bf16_t*)C, (const float*)D,
+                         (const bf16_t*)z, (const float*)dt_bias, (bf16_t*)out, batch, dim, dstate, dt_softplus);
+      break;
+    case MXVL_F16:
+      hipLaunchKernelGGL(state_update_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (float*)state, (const f16_t*)x,
+                         (const f16_t*)dt, (const float*)A, (const f16_t*)B, (const f16_t*)C, (const float*)D,
+                         (const f16_t*)z, (const float*)dt_bias, (f16_t*)out, batch, dim, dstate, dt_softplus);
+      break;
+    default: return MXVL_ERR_DTYPE;
+  }
+  return check_launch();
+}
+
+}  // extern "C"

@@ -179,3 +179,53 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     """out = selective scan of u (B,D,L); with z the output is gated by silu(z).
     Returns out, or (out, last_state (B,D,N) fp32) when return_last_state."""
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fused mixer functions.  THIRD-PARTY in the reference (a patched mamba_ssm it neither vendors nor pins,
+# SURVEY.md 8-c): semantics restated from the reference's own slow path, mamba_simple.py:665-709 --
+#   x, z = xz.chunk(2, 1) -> causal conv1d + SiLU -> x_proj -> split (R, N, N) -> dt_proj (no bias)
+#   -> selective scan(x, dt, A, B, C, D, z, delta_bias, softplus) [-> out_proj].
+# Composition of the HIP conv1d and scan autograd nodes with hipBLASLt GEMMs for the three skinny
+# projections (plain library GEMMs); u and z are consumed as strided halves of xz, B and C as strided
+# slices of x_dbl -- no chunk/contiguous copies.
+# ---------------------------------------------------------------------------------------------------
+def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
+                               D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    from .causal_conv1d import causal_conv1d_fn
+    if B is not None or C is not None:
+        raise NotImplementedError("mamba_inner_fn: only input-dependent B and C (the reference passes None, mamba_simple.py:456-457)")
+    if xz.dim() != 3 or xz.shape[1] % 2 != 0:
+        raise RuntimeError("mamba_inner_fn: xz must be (batch, 2*d_inner, seqlen)")
+    batch, two_d, L = xz.shape
+    d_inner = two_d // 2
+    N = A.shape[1]
+    R = delta_proj_weight.shape[1]
+    x, z = xz[:, :d_inner], xz[:, d_inner:]                       # views: strided rows, L contiguous
+    xc = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")  # (b, d, l)
+    # every projection is applied as W @ X on the (b, d, l) layout (the reference's own trick for in_proj,
+    # mamba_simple.py:408-412): results come out L-contiguous, no transposes or copies
+    x_dbl = torch.matmul(x_proj_weight.to(xc.dtype), xc)            # (b, R+2N, l)   skinny GEMM, K = d_inner
+    dt = torch.matmul(delta_proj_weight.to(xc.dtype), x_dbl[:, :R])  # (b, d, l)
+    Bm = x_dbl[:, R:R + N]                                          # (b, N, l) views, l-stride 1
+    Cm = x_dbl[:, R + N:R + 2 * N]
+    if B_proj_bias is not None:
+        Bm = Bm + B_proj_bias.to(Bm.dtype)[None, :, None]
+    if C_proj_bias is not None:
+        Cm = Cm + C_proj_bias.to(Cm.dtype)[None, :, None]
+    io = xc.dtype
+    return selective_scan_fn(xc, dt.to(io), A, Bm.to(io), Cm.to(io), D, z=z.to(io), delta_bias=delta_bias,
+                             delta_softplus=delta_softplus)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                   A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    y = mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D,
+                                   delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+    return torch.nn.functional.linear(y.transpose(1, 2), out_proj_weight.to(y.dtype),
+                                      None if out_proj_bias is None else out_proj_bias.to(y.dtype))
+
+
+def bimamba_inner_fn(*args, **kwargs):
+    raise NotImplementedError("bimamba_inner_fn (bimamba_type='v1') is not used by any shipped factory "
+                              "(models_mamba.py:398-436 build 'v3'); not built")

@@ -1,0 +1,98 @@
+"""GPU parity of conv1d / decode-step kernels and the fused mixer functions (all through the C-ABI)
+against the reference goldens (tests/golden/conv1d_*, mamba_slow_*, mamba_step) and the CPU oracle."""
+import pytest
+import torch
+
+from conftest import assert_close, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", golden_names("conv1d_"))
+def test_conv1d_fwd_bwd_golden(name):
+    from medical_image_analysis_amd.causal_conv1d import causal_conv1d_fn
+    g = load_golden(name)
+    x = g["x"].to(DEV).requires_grad_(True)
+    w = g["weight"].to(DEV).requires_grad_(True)   # nn.Conv1d layout (D, 1, W)
+    b = g["bias"].to(DEV).requires_grad_(True)
+    y = causal_conv1d_fn(x, w, b, "silu")
+    assert_close(y, g["y"], 1e-5, 1e-5, "y")
+    y.backward(g["dy"].to(DEV))
+    assert_close(x.grad, g["dx"], 1e-5, 1e-4, "dx")
+    assert_close(w.grad, g["dweight"], 1e-4, 1e-4, "dweight")
+    assert_close(b.grad, g["dbias"], 1e-4, 1e-4, "dbias")
+    y0 = causal_conv1d_fn(g["x"].to(DEV), g["weight"].to(DEV).squeeze(1), g["bias"].to(DEV), None)
+    assert_close(y0, g["y_noact"], 1e-5, 1e-5, "y_noact")
+
+
+@pytest.mark.parametrize("shape", [(2, 768, 197, 4, torch.float32), (3, 100, 50, 3, torch.float32),
+                                   (2, 64, 1024, 4, torch.bfloat16), (1, 8, 2, 4, torch.float32)])
+def test_conv1d_vs_oracle(shape):
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.causal_conv1d import causal_conv1d_fn
+    B, D, L, W, dtype = shape
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(B, D, L, generator=gen).to(dtype)
+    w, b = torch.randn(D, W, generator=gen), torch.randn(D, generator=gen)
+    dy = torch.randn(B, D, L, generator=gen).to(dtype)
+    ref = orc.causal_conv1d_ref(x, w, b, "silu")
+    rg = orc.causal_conv1d_ref_bwd(x, w, b, "silu", dy)
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = causal_conv1d_fn(xd, wd, bd, "silu")
+    y.backward(dy.to(DEV))
+    tol = (1e-5, 1e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    assert_close(y, ref, *tol, "y")
+    assert_close(xd.grad, rg["dx"], tol[0] * 4, tol[1] * 4, "dx")
+    scale = max(1.0, float(rg["dweight"].abs().max()))
+    assert_close(wd.grad, rg["dweight"], (1e-5 if dtype == torch.float32 else 2e-2) * scale, 1e-3, "dweight")
+    assert_close(bd.grad, rg["dbias"], (1e-5 if dtype == torch.float32 else 2e-2) * scale, 1e-3, "dbias")
+
+
+@pytest.mark.parametrize("name", golden_names("mamba_slow_"))
+def test_mamba_inner_fn_equals_reference_slow_path(name):
+    """xz -> out and every parameter gradient of the reference Mamba mixer (slow path goldens)."""
+    from medical_image_analysis_amd.selective_scan_interface import mamba_inner_fn
+    g = load_golden(name)
+    P = {k[2:]: v.to(DEV).requires_grad_(True) for k, v in g.items() if k.startswith("p_")}
+    hidden = g["hidden"].to(DEV).requires_grad_(True)
+    xz = torch.matmul(P["in_proj.weight"], hidden.transpose(1, 2))    # (b, 2d, l), as mamba_simple.py:408-412
+    A = -torch.exp(P["A_log"].float())
+    out = mamba_inner_fn(xz, P["conv1d.weight"], P["conv1d.bias"], P["x_proj.weight"], P["dt_proj.weight"],
+                         P["out_proj.weight"], None, A, None, None, P["D"].float(),
+                         delta_bias=P["dt_proj.bias"].float(), delta_softplus=True)
+    assert_close(out, g["out"], 2e-5, 1e-4, "out")
+    out.backward(g["dout"].to(DEV))
+    assert_close(hidden.grad, g["dhidden"], 2e-5, 1e-3, "dhidden")
+    for k in ("in_proj.weight", "conv1d.weight", "conv1d.bias", "x_proj.weight", "dt_proj.weight", "dt_proj.bias",
+              "A_log", "D", "out_proj.weight"):
+        ref = g["g_" + k]
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close(P[k].grad, ref, 5e-5 * scale, 1e-3, "grad " + k)
+
+
+def test_decode_step_kernels_golden():
+    """conv1d_update + selective_state_update reproduce the reference Mamba.step recurrence."""
+    from medical_image_analysis_amd.causal_conv1d import causal_conv1d_update
+    from medical_image_analysis_amd.selective_state_update import selective_state_update
+    g = {k: v.to(DEV) for k, v in load_golden("mamba_step").items()}
+    T = g["xs"].shape[1]
+    A = -torch.exp(g["p_A_log"])
+    Bz, d = g["xs"].shape[0], g["xs"].shape[2]
+    N, R = A.shape[1], g["p_dt_proj.weight"].shape[1]
+    conv_state = torch.zeros(Bz, d, g["p_conv1d.weight"].shape[-1], device=DEV)
+    ssm_state = torch.zeros(Bz, d, N, device=DEV)
+    for t in range(T):
+        xz = g["xs"][:, t] @ g["p_in_proj.weight"].t()
+        x, z = xz.chunk(2, dim=-1)
+        x = causal_conv1d_update(x.contiguous(), conv_state, g["p_conv1d.weight"], g["p_conv1d.bias"], "silu")
+        x_db = x @ g["p_x_proj.weight"].t()
+        dt, Bm, Cm = torch.split(x_db, [R, N, N], dim=-1)
+        dt = dt @ g["p_dt_proj.weight"].t()
+        y = selective_state_update(ssm_state, x, dt, A, Bm, Cm, g["p_D"], z=z.contiguous(),
+                                   dt_bias=g["p_dt_proj.bias"], dt_softplus=True)
+        out = y @ g["p_out_proj.weight"].t()
+        assert_close(out, g["outs"][:, t], 2e-5, 1e-4, f"out[{t}]")
+        assert_close(conv_state, g["conv_states"][t], 1e-6, 1e-6, f"conv_state[{t}]")
+        assert_close(ssm_state, g["ssm_states"][t], 1e-5, 1e-4, f"ssm_state[{t}]")
