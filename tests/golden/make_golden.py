@@ -70,7 +70,7 @@ def install_mamba_stubs(scan_ref):
 
 
 def np_(t):
-    return None if t is None else t.detach().cpu().float().numpy()
+    return None if t is None else t.detach().cpu().float().numpy().copy()
 
 
 def save(name, **arrs):
@@ -180,6 +180,134 @@ def gen_mamba_step(mamba_mod):
          ssm_states=np_(torch.stack(ssms)), full=np_(full), **sd)
 
 
+def install_timm_stubs():
+    """timm is absent: stub the few names models_mamba.py / models_pretrain.py import.
+    Initialisers only affect random init; every golden stores the reference module's state_dict."""
+    import math
+    import torch.nn as nn
+    for name in ["timm", "timm.models", "timm.models.vision_transformer", "timm.models.registry", "timm.models.layers"]:
+        sys.modules[name] = types.ModuleType(name)
+    vt = sys.modules["timm.models.vision_transformer"]
+    vt.VisionTransformer = object
+    vt._cfg = lambda **kw: {}
+    vt._load_weights = None
+    sys.modules["timm.models.registry"].register_model = lambda f: f
+    lay = sys.modules["timm.models.layers"]
+    lay.trunc_normal_ = lambda t, std=0.02: nn.init.trunc_normal_(t, std=std, a=-2.0, b=2.0)
+    def lecun_normal_(t):
+        fan_in = nn.init._calculate_fan_in_and_fan_out(t)[0]
+        std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+        return nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+    lay.lecun_normal_ = lecun_normal_
+    lay.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+        def forward(self, x):
+            assert not self.training or self.p == 0.0
+            return x
+    lay.DropPath = DropPath
+
+
+def make_inner_stub(scan_ref):
+    """The fused `mamba_inner_fn[_no_out_proj]` is third-party (not in the reference tree).  This stub restates it
+    from the reference's own slow path (mamba_simple.py:665-709): split -> conv1d+SiLU -> x_proj -> split (R,N,N)
+    -> dt_proj (no bias) -> selective_scan_ref with z, D, delta_bias, softplus.  'parity unpinned' boundary."""
+    import torch.nn.functional as F
+    from einops import rearrange
+
+    def no_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, B=None, C=None, D=None, delta_bias=None,
+                    delta_softplus=True):
+        assert B is None and C is None
+        L = xz.shape[-1]
+        R, N = dt_proj_w.shape[1], A.shape[1]
+        x, z = xz.chunk(2, dim=1)
+        x = F.silu(F.conv1d(x, conv_w, conv_b, padding=conv_w.shape[-1] - 1, groups=x.shape[1])[..., :L])
+        x_dbl = F.linear(rearrange(x, "b d l -> (b l) d"), x_proj_w)
+        dt, Bm, Cm = torch.split(x_dbl, [R, N, N], dim=-1)
+        dt = rearrange(dt_proj_w @ dt.t(), "d (b l) -> b d l", l=L)
+        Bm = rearrange(Bm, "(b l) n -> b n l", l=L).contiguous()
+        Cm = rearrange(Cm, "(b l) n -> b n l", l=L).contiguous()
+        return scan_ref(x, dt, A, Bm, Cm, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+
+    def with_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_w, out_b, A, B=None, C=None, D=None,
+                      delta_bias=None, delta_softplus=True):
+        y = no_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, B, C, D, delta_bias, delta_softplus)
+        return F.linear(rearrange(y, "b d l -> b l d"), out_w, out_b)
+
+    return no_out_proj, with_out_proj
+
+
+def _randomize(m):
+    """Move every parameter off its (often trivial: zeros / ones / identical rows) initial value."""
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("A_log") or "A_" in n and n.endswith("_log"):
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 1 or n in ("cls_token", "pos_embed", "ar_token"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.add_(0.02 * torch.randn(p.shape, generator=g))
+
+
+def gen_mamba_v3(mamba_mod):
+    """Reference 4-direction mixer (fast path :447-532 over the restated inner fn) incl. the middle-cls transpose."""
+    for name, Bz, L, d_model in [("mamba_v3_L10", 2, 10, 32), ("mamba_v3_L197", 2, 197, 32)]:
+        torch.manual_seed(0)
+        m = mamba_mod.Mamba(d_model=d_model, expand=1, bimamba_type="v3", if_devide_out=True)
+        _randomize(m)
+        hidden = torch.randn(Bz, L, d_model, requires_grad=True)
+        out = m(hidden)
+        g = torch.randn_like(out)
+        out.backward(g)
+        sd = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+        grads = {("g_" + k): np_(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+        save(name, hidden=np_(hidden), out=np_(out), dout=np_(g), dhidden=np_(hidden.grad), **sd, **grads)
+
+
+def gen_arm(models_mamba):
+    """Reference ARM encoder (models_mamba.py:215-394), depth 2, 48x48 / patch 16 -> 3x3 patches + middle cls."""
+    torch.manual_seed(0)
+    m = models_mamba.ARM(img_size=48, patch_size=16, depth=2, embed_dim=64, if_cls_token=True, if_abs_pos_embed=True,
+                         bimamba_type="v3", use_middle_cls_token=True, if_devide_out=True, drop_path_rate=0.0)
+    _randomize(m)
+    m.eval()
+    img = torch.randn(2, 3, 48, 48, requires_grad=True)
+    out = m(img)
+    g = torch.randn_like(out)
+    out.backward(g)
+    sd = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+    pick = ["pos_embed", "cls_token", "patch_embed.proj.weight", "layers.0.mixer.in_proj.weight",
+            "layers.1.mixer.A_c_b_log", "layers.1.mlp.w3.weight", "norm_f.weight"]
+    grads = {("g_" + k): np_(dict(m.named_parameters())[k].grad) for k in pick}
+    save("arm_d2_48", img=np_(img), out=np_(out), dout=np_(g), dimg=np_(img.grad), **sd, **grads)
+
+
+def gen_pretrain(models_pretrain):
+    """Reference stage-1 VisionMamba (models_pretrain.py:285-515): 128x128 / patch 16 -> 8x8 patches,
+    (2x2 - 1) = 3 clusters of 16 tokens (depth must be 12: `self.skip` only exists for 12/24, :319-322)."""
+    torch.manual_seed(0)
+    m = models_pretrain.VisionMamba(img_size=128, patch_size=16, depth=12, embed_dim=64, dec_embed_dim=64,
+                                    if_abs_pos_embed=True, bimamba_type="None", drop_path_rate=0.0)
+    sincos = dict(sincos_pos_embed=np_(m.pos_embed), sincos_dec_pos_embed=np_(m.dec_pos_embed))
+    _randomize(m)
+    m.eval()
+    img = torch.randn(2, 3, 128, 128)
+    loss = m(img)
+    loss.mean().backward()
+    feats = m.forward_features(img)
+    pred = m.forward_decoder(feats, m.dec_pos_embed)
+    sd = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+    named = dict(m.named_parameters())
+    pick = ["ar_token", "enc2dec.weight", "dec_block.0.attn2.kv.weight", "dec_block.3.mlp.fc2.weight", "ar_pred.weight",
+            "layers.0.mixer.in_proj.weight", "layers.11.mixer.A_log", "patch_embed.proj.weight", "norm_4.weight"]
+    grads = {("g_" + k): np_(named[k].grad) for k in pick}
+    save("pretrain_d12_128", img=np_(img), loss=np_(loss), features=np_(feats), pred=np_(pred),
+         patchify=np_(m.patchify(img)), **sincos, **sd, **grads)
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -191,6 +319,25 @@ def main():
     gen_conv1d(mamba_mod)
     gen_mamba_slow(mamba_mod)
     gen_mamba_step(mamba_mod)
+    # ---- fast paths: inject the restated fused functions, then the reference's own modules run on CPU
+    no_out, with_out = make_inner_stub(scan_ref)
+    mamba_mod.mamba_inner_fn_no_out_proj = no_out
+    mamba_mod.mamba_inner_fn = with_out
+    gen_mamba_v3(mamba_mod)
+    install_timm_stubs()
+    models_mamba = _load(os.path.join(ft_dir, "models_mamba.py"), "models_mamba_ref")
+    gen_arm(models_mamba)
+    # stage-1 pre-training model lives next to its own (uni-directional) mamba_simple.py
+    pt_dir = os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/pretrain")
+    sys.path.remove(ft_dir)
+    sys.path.insert(0, pt_dir)
+    for k in ("mamba_simple", "utils", "utils.pos_embed"):
+        sys.modules.pop(k, None)
+    pt_mamba = _load(os.path.join(pt_dir, "mamba_simple.py"), "mamba_simple")
+    pt_mamba.mamba_inner_fn_no_out_proj = no_out
+    pt_mamba.mamba_inner_fn = with_out
+    models_pretrain = _load(os.path.join(pt_dir, "models_pretrain.py"), "models_pretrain_ref")
+    gen_pretrain(models_pretrain)
 
 
 if __name__ == "__main__":
