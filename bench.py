@@ -13,6 +13,9 @@ Rank 0 prints ONE JSON line (contract in the task statement): whole-job images/s
                   selective_scan_ref) timed on this box's host cores on a bounded sample (rank 0, N=1).
 
 Workloads (BASELINE.json configs):
+  arm_pretrain_large_1024  configs[2]: MambaXray-VL-Large stage-1 pre-training step (forward + backward + clip +
+                   AdamW) on 1024x1024 synthetic X-rays, bf16 autocast, DDP over RCCL; images/sec
+  arm_pretrain_base_192    the reference factory arm_base_pz16 (192x192, L=128) -- quick variant
   scan_fwd_cfg2    configs[1]: MambaXray-VL-Base selective-scan forward, B=32 L=196 D=768 N=16 fp32
   scan_fwd_target  north_star roofline shape: B=8 L=4096 D=1536 N=16 fp32 (one 1024x1024 X-ray = 4096 tokens)
   scan_fwd_target_bf16  same with bf16 io
@@ -42,6 +45,14 @@ WORKLOADS = {
                         "north_star roofline shape: selective-scan forward B=8 L=4096 D=1536 N=16 (z, D, delta_bias, softplus)"),
     "scan_fwd_target_bf16": (8, 1536, 4096, 16, "bfloat16",
                              "north_star roofline shape with bf16 io: B=8 L=4096 D=1536 N=16"),
+}
+PRETRAIN_WORKLOADS = {
+    # name: (img, patch, embed_dim, depth, dec_dim, per-GPU batch, description)
+    "arm_pretrain_large_1024": (1024, 16, 1024, 24, 512, 8,
+                                "configs[2]: MambaXray-VL-Large (VisionMamba 1024x24, dec 512x4) stage-1 ARM pre-training "
+                                "step, 1024x1024 synthetic X-rays (4096 patches, 4080-token scan), bf16 autocast"),
+    "arm_pretrain_base_192": (192, 16, 768, 12, 512, 64,
+                              "reference factory arm_base_pz16 (192x192, 128-token scan) stage-1 pre-training step, bf16 autocast"),
 }
 DEFAULT_WORKLOAD = "scan_fwd_target"
 
@@ -103,12 +114,84 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
     }
 
 
+def run_pretrain(args, rank, world, dev, dist):
+    """Stage-1 pre-training step: VisionMamba forward+backward+clip+AdamW, bf16 autocast, DDP gradient all-reduce."""
+    import medical_image_analysis_amd.selective_scan_interface as ssi
+    from medical_image_analysis_amd.models_pretrain import VisionMamba
+    from medical_image_analysis_amd.pretrain_engine import PretrainEngine
+    img, patch, embed, depth, dec, B, desc = PRETRAIN_WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcasts rank 0's anyway)
+    model = VisionMamba(img_size=img, patch_size=patch, stride=patch, embed_dim=embed, depth=depth, dec_embed_dim=dec,
+                        rms_norm=True, residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True,
+                        bimamba_type="None").to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    eng = PretrainEngine(model, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    batches = [torch.randn(B, 3, img, img, generator=g).to(dev) for _ in range(2)]
+    steps, warmup = args.steps, args.warmup
+    for i in range(warmup):
+        eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ssi.KERNEL_TIMERS = timers = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ssi.KERNEL_TIMERS = None
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    if rank != 0:
+        return
+    stats = {}
+    for kind, e0, e1, nbytes in timers:
+        d = stats.setdefault(kind, [0.0, 0, 0])
+        d[0] += e0.elapsed_time(e1)
+        d[1] += 1
+        d[2] += nbytes
+    # dominant hand-written kernel of the step = the one with the largest total time
+    kind = max(stats, key=lambda k: stats[k][0])
+    tot_ms, calls, tot_bytes = stats[kind]
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    L = (img // patch) ** 2 - 16
+    out = {
+        "metric": "pre-training images/sec (forward + backward + grad-clip + AdamW)",
+        "value": B * world * steps / wall, "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
+        "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world,
+                   "seq_len": L, "params": n_params, "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)",
+                   "final_loss": float(loss)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kind,
+                     "kernel_ms": tot_ms / calls, "launches_timed": calls,
+                     "algorithmic_bytes_per_launch": tot_bytes // calls,
+                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        D = embed
+        out["cpu_baseline"] = cpu_baseline_scan(min(B, 2), D, L, 16, budget_s=10.0)
+        out["cpu_baseline"]["sample"] += " -- the scan of ONE encoder layer only (the full reference step does not run without its CUDA wheels)"
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,6 +212,12 @@ def main():
 
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
+
+    if args.workload in PRETRAIN_WORKLOADS:
+        run_pretrain(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     B, D, L, N, dtname, desc = WORKLOADS[args.workload]
     dtype = getattr(torch, dtname)

@@ -16,6 +16,8 @@
 //   * dA, dD, ddelta_bias are reduced over lanes with DPP and over chunks in LDS/registers: one global
 //     atomic per (row,n) / row per workgroup.
 // du, ddelta, dz are fully written; dA, dB, dC, dD, ddelta_bias are accumulated into caller-zeroed fp32.
+#include <stdlib.h>
+
 #include "mxvl_common.h"
 
 namespace mxvl {
@@ -24,7 +26,7 @@ constexpr int kCkptLenB = 128;
 
 struct ScanBwdArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok;
+  int softplus, vec_ok, ablate;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, do_bs, do_ds;
   int64_t du_bs, du_ds, dd_bs, dd_ds, dz_bs, dz_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
@@ -106,7 +108,7 @@ __device__ inline float row_sum_to_lane15(float v) {
 
 template <typename io_t, int NWAVES, bool VEC>
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
-  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
+  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NG = 2;
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
   using io = Io<io_t>;
 
@@ -114,9 +116,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   const int N = p.N, L = p.L;
   float* sB = smem;                        // [N][CH]  lane-major halves (see scan_fwd_stream.h)
   float* sC = sB + N * CH;                 // [N][CH]
-  float* sdB = sC + N * CH;                // [N][CH]  natural order, fp32 accumulators of this chunk
-  float* sdC = sdB + N * CH;               // [N][CH]
-  float* sO = sdC + N * CH;                // [DT][CH] store transpose tile (unaligned rows)
+  // dB/dC contributions of the current group of NG states, one PRIVATE tile per row of the workgroup:
+  // plain 16-byte LDS stores, then a tree-less 16-way sum at the group flush.  (ds_add_f32 measured 7x the
+  // whole rest of the kernel, with or without same-address conflicts: LDS float atomics are not usable here.)
+  float* sAcc = sC + N * CH;               // [DT][2 (dB,dC)][NG][CH]
+  float* sO = sAcc + DT * 2 * NG * CH;     // [DT][CH] store transpose tile (unaligned rows)
   float2* sAC = (float2*)(sO + DT * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
   float* sG = (float*)(sAC + (DT + 1) * N);  // [DT+1][N] adjoint entering the chunk from the right; row DT = 0
   float* sdA = sG + (DT + 1) * N;          // [DT][N] dA accumulated over the chunks
@@ -216,8 +220,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
       sB[pos] = bv;
       sC[pos] = cv;
-      sdB[i] = 0.0f;
-      sdC[i] = 0.0f;
     }
     for (int i = lane; i < RPW * N; i += 64) {
       const int rr = i / N, n = i - rr * N;
@@ -262,10 +264,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * N;
     const float* cB = sB + j * 4;
     const float* cC = sC + j * 4;
-    float* aB = sdB + j * T;
-    float* aC = sdC + j * T;
+    float* aB = sAcc + (row * 2 + 0) * NG * CH + j * T;
+    float* aC = sAcc + (row * 2 + 1) * NG * CH + j * T;
 
-    for (int n = 0; n < N; ++n) {
+    for (int n = 0; n < ((p.ablate & 4) ? 0 : N); ++n) {
       const float A2 = ac[n].x;
       const float hin = ac_in[n].y;
       float a[T], bb[T], cv[T], h[T];
@@ -309,21 +311,46 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       if (j == 0) gq[n] = ql;          // leaves the chunk towards chunk c-1
       float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
       float dA_part = 0.0f;
+      float vB[T], vC[T];
 #pragma unroll
       for (int i = T - 1; i >= 0; --i) {
         const float gi = fmaf(cv[i], dy[i], gg);          // g_i
         const float hprev = (i == 0) ? x : h[i - 1];
         const float ga = gi * a[i];                       // a_i g_i
         const float gha = ga * hprev;                     // g_i h_{i-1} a_i
-        atomicAdd(aC + n * CH + i, dy[i] * h[i]);         // LDS: dC_{n,t} over the 16 rows
-        atomicAdd(aB + n * CH + i, gi * du[i]);           // LDS: dB_{n,t}
+        vC[i] = dy[i] * h[i];   // dC_{n,t} share of this row
+        vB[i] = gi * du[i];     // dB_{n,t} share of this row
         sgB[i] = fmaf(gi, bb[i], sgB[i]);
         sAh[i] = fmaf(gha, A2, sAh[i]);
         dA_part = fmaf(gha, dl[i], dA_part);
         gg = ga;
       }
+      if (!(p.ablate & 1)) {
+        float4* wB = (float4*)(aB + (n % NG) * CH);
+        float4* wC = (float4*)(aC + (n % NG) * CH);
+        wB[0] = make_float4(vB[0], vB[1], vB[2], vB[3]); wB[1] = make_float4(vB[4], vB[5], vB[6], vB[7]);
+        wC[0] = make_float4(vC[0], vC[1], vC[2], vC[3]); wC[1] = make_float4(vC[4], vC[5], vC[6], vC[7]);
+      }
       dA_part = row_sum_to_lane15(dA_part);
       if (j == LPR - 1) sdA[row * N + n] += dA_part;
+
+      if ((n % NG) == NG - 1 || n == N - 1) {
+        // flush the group: every row of the workgroup has added its share of states n0..n
+        const int n0 = n - (n % NG);
+        __syncthreads();
+        for (int i = tid; i < 2 * NG * CH; i += NT) {
+          const int which = i / (NG * CH), rem = i - which * (NG * CH);
+          const int nn = rem / CH, e = rem - nn * CH;
+          float v = 0.0f;
+#pragma unroll
+          for (int rr = 0; rr < DT; ++rr) v += sAcc[(rr * 2 + which) * NG * CH + rem];
+          if (n0 + nn <= n && t0 + e < L && !(p.ablate & 2)) {
+            float* dst = which ? dCp + (int64_t)(n0 + nn) * p.dC_ns : dBp + (int64_t)(n0 + nn) * p.dB_ns;
+            unsafeAtomicAdd(dst + t0 + e, v);
+          }
+        }
+        __syncthreads();
+      }
     }
 
     // ---- per-step outputs --------------------------------------------------------------------------------
@@ -344,14 +371,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     row_store(qdd, p.ddelta, p.dd_bs, p.dd_ds, t0, o_dd);
     if (has_z) row_store(qdz, p.dz, p.dz_bs, p.dz_ds, t0, o_dz);
 
-    __syncthreads();  // every row of the workgroup has added into the dB/dC tile
-    for (int i = tid; i < N * CH; i += NT) {
-      const int n = i / CH, e = i - n * CH;
-      if (t0 + e < L) {
-        unsafeAtomicAdd(dBp + (int64_t)n * p.dB_ns + t0 + e, sdB[i]);
-        unsafeAtomicAdd(dCp + (int64_t)n * p.dC_ns + t0 + e, sdC[i]);
-      }
-    }
   }
 
   // ---- per-row reductions: dA (LDS, lane 15 wrote), dD, ddelta_bias (registers -> row sum) -----------------
@@ -377,7 +396,7 @@ static thread_local int g_bwd_hip_error = 0;
 template <typename io_t, int NWAVES, bool VEC>
 static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128;
-  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)DT * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
   auto kern = scan_bwd_kernel<io_t, NWAVES, VEC>;
   if (lds > 64 * 1024) {
@@ -428,6 +447,7 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.du = d->du; a.ddelta = d->ddelta; a.dz = d->dz;
   a.dA = (float*)d->dA; a.dB = (float*)d->dB; a.dC = (float*)d->dC; a.dD = (float*)d->dD; a.dbias = (float*)d->ddelta_bias;
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
+  { const char* e = getenv("MXVL_BWD_ABLATE"); a.ablate = e ? atoi(e) : 0; }  // measurement only
   {
     const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
     const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,

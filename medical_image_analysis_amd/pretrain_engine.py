@@ -1,0 +1,90 @@
+"""Stage-1 pre-training step of MambaXray-VL on MI355X (one process per GPU, RCCL gradient all-reduce).
+
+Host-side mirror of the reference's hand-rolled loop:
+  CXPMRG_Bench_MambaXray_VL/pretrain/main_pretrain.py:150-173  model -> DDP -> AdamW(betas=(0.9, 0.95)) with timm's
+                                                               add_weight_decay grouping (no decay on 1-D params)
+  CXPMRG_Bench_MambaXray_VL/pretrain/engine_pretrain.py:37-62  autocast(bf16) forward -> loss.mean() -> backward ->
+                                                               clip_grad_norm_(3.0) -> step -> all_reduce_mean(loss)
+  CXPMRG_Bench_MambaXray_VL/pretrain/utils/misc.py:211-233     env:// NCCL(=RCCL) init
+bf16 autocast needs no loss scaling, so the reference's GradScaler (misc.py:236-256) is an identity here and is
+not instantiated; gradients stay fp32 (params are fp32 under autocast) exactly as in the reference.
+Gradient exchange: torch DDP over RCCL with 256 MiB buckets (ARM-large = 1.16 GiB of fp32 grads -> 5 large
+reduce-scatter+all-gather rounds that use all 7 xGMI links per GPU, overlapped with backward) and
+gradient_as_bucket_view (no extra copy).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def init_distributed(backend: str | None = None):
+    """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK from torchrun), as misc.init_distributed_mode."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def param_groups_weight_decay(model: nn.Module, weight_decay: float = 0.05, skip=()):
+    """timm.optim.optim_factory.add_weight_decay: 1-D tensors, biases and `skip` names get no decay."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or name.endswith(".bias") or name in skip) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class PretrainEngine:
+    """model(imgs) -> per-token loss; one call of step() = forward + backward + clip + AdamW step."""
+
+    def __init__(self, model: nn.Module, lr: float = 1.5e-4, weight_decay: float = 0.05, clip_grad: float | None = 3.0,
+                 amp_dtype: torch.dtype | None = torch.bfloat16, bucket_cap_mb: int = 256, device=None):
+        self.device = device
+        self.amp_dtype = amp_dtype
+        self.clip_grad = clip_grad
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.raw_model = model
+        skip = model.no_weight_decay() if hasattr(model, "no_weight_decay") else ()
+        self.optimizer = torch.optim.AdamW(param_groups_weight_decay(model, weight_decay, skip), lr=lr, betas=(0.9, 0.95),
+                                           fused=bool(device is not None and torch.device(device).type == "cuda"))
+        if self.world > 1:
+            ids = [torch.device(device).index] if (device is not None and torch.device(device).type == "cuda") else None
+            self.model = nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
+                                                             gradient_as_bucket_view=True, broadcast_buffers=False)
+        else:
+            self.model = model
+
+    def step(self, imgs: torch.Tensor) -> torch.Tensor:
+        dev_type = imgs.device.type
+        with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            loss = self.model(imgs)
+        loss = loss.mean()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.clip_grad is not None:
+            nn.utils.clip_grad_norm_(self.raw_model.parameters(), self.clip_grad)
+        self.optimizer.step()
+        return loss.detach()
+
+    def reduced_loss(self, loss: torch.Tensor) -> float:
+        """misc.all_reduce_mean (engine_pretrain.py:62): the only per-step collective besides the gradients."""
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss)
+            loss /= self.world
+        return float(loss)

@@ -22,6 +22,23 @@ import torch
 from . import _abi
 
 
+# bench.py sets this to a list to collect (kind, start_event, end_event, algorithmic_bytes) per kernel launch;
+# None (the default) adds nothing to the launch path.
+KERNEL_TIMERS = None
+
+
+def scan_algorithmic_bytes(batch, dim, L, N, G, elt, has_z, backward=False, n_ckpt=0):
+    """SURVEY.md 8-d.  fwd: elt*((3|4)*B*D*L + 2*B*G*N*L) + 4*(D*N + 2*D) (+ checkpoints 4*B*D*n_ckpt*N);
+    bwd: elt*(reads u,delta,z?,dout + writes du,ddelta,dz?) + elt*2*B*G*N*L + 2*4*B*G*N*L (dB,dC fp32) + checkpoints."""
+    rows = batch * dim * L
+    bc = batch * G * N * L
+    w = 4 * (dim * N + 2 * dim)
+    ck = 4 * batch * dim * n_ckpt * N
+    if not backward:
+        return elt * ((4 if has_z else 3) * rows + 2 * bc) + w + ck
+    return elt * ((7 if has_z else 5) * rows + 2 * bc) + 8 * bc + 2 * w + ck
+
+
 def _last_contig(t):
     return t if (t is None or t.stride(-1) == 1 or t.size(-1) == 1) else t.contiguous()
 
@@ -102,8 +119,17 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
             ckpt = torch.empty((batch, dim, n_chunks, N), dtype=torch.float32, device=u.device)
     desc = _abi.ScanDesc()
     _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt)
+    timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = lib.mxvl_scan_fwd(ctypes.byref(desc), _abi.stream_ptr(u.device))
+        if timers is not None:
+            e1.record()
+            timers.append(("scan_fwd", e0, e1, scan_algorithmic_bytes(
+                batch, dim, L, N, B.shape[1], u.element_size(), z is not None, False,
+                ckpt.shape[2] if ckpt is not None else 0)))
     _abi.check(rc, "mxvl_scan_fwd")
     return out, last, ckpt
 
@@ -134,8 +160,17 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     desc.dout, desc.du, desc.ddelta, desc.dz = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), _abi.ptr(dz)
     desc.dA, desc.dB, desc.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     desc.dD, desc.ddelta_bias = _abi.ptr(dD), _abi.ptr(dbias)
+    timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = lib.mxvl_scan_bwd(ctypes.byref(desc), _abi.stream_ptr(u.device))
+        if timers is not None:
+            e1.record()
+            timers.append(("scan_bwd", e0, e1, scan_algorithmic_bytes(
+                batch, dim, L, A.shape[1], B.shape[1], u.element_size(), z is not None, True,
+                ckpt.shape[2] if ckpt is not None else 0)))
     _abi.check(rc, "mxvl_scan_bwd")
     return du, ddelta, dA, dB, dC, dD, dz, dbias
 
