@@ -35,7 +35,7 @@ def _w2(weight):
 def conv1d_fwd_raw(x, w32, b32, silu):
     lib = _abi.load()
     batch, dim, L = x.shape
-    y = torch.empty((batch, dim, L), dtype=x.dtype, device=x.device)
+    y = torch.empty_like(x)  # follows x's memory layout (channel-major inside the mixer)
     d = _abi.Conv1dDesc()
     d.batch, d.dim, d.seqlen, d.width = batch, dim, L, w32.shape[1]
     d.io_dtype, d.silu = _abi.dtype_code(x.dtype), silu
@@ -51,7 +51,7 @@ def conv1d_bwd_raw(x, w32, b32, silu, dy):
     batch, dim, L = x.shape
     if dy.stride(-1) != 1:
         dy = dy.contiguous()
-    dx = torch.empty((batch, dim, L), dtype=x.dtype, device=x.device)
+    dx = torch.empty_like(x)
     dw = torch.zeros_like(w32)
     db = torch.zeros_like(b32) if b32 is not None else None
     d = _abi.Conv1dBwdDesc()

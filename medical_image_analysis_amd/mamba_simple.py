@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from .selective_scan_interface import mamba_inner_fn, selective_scan_fn
+from .selective_scan_interface import mamba_inner_fn, proj_in, selective_scan_fn
 from .selective_state_update import selective_state_update
 
 _SUFFIXES = {"v2": ["_b"], "v3": ["_b", "_c", "_c_b"], "v4": ["_b", "_c", "_c_b", "_d", "_d_b"]}
@@ -183,15 +183,11 @@ class Mamba(nn.Module):
             if inference_params.seqlen_offset > 0:
                 out, _, _ = self.step(hidden_states, conv_state, ssm_state)
                 return out
-        # in_proj as W @ x^T: the result is already (B, 2D, L) with L contiguous (:408-412)
-        xz = torch.matmul(self.in_proj.weight, hidden_states.transpose(1, 2))
-        if self.in_proj.bias is not None:
-            xz = xz + self.in_proj.bias.to(xz.dtype)[None, :, None]
+        # in_proj as ONE GEMM W @ x^T: the result is (B, 2D, L) with L contiguous, stored channel-major (:408-412)
+        xz = proj_in(hidden_states, self.in_proj.weight, self.in_proj.bias)
         xd = None
         if segmenttation_features is not None:
-            xd = torch.matmul(self.in_proj.weight, segmenttation_features.transpose(1, 2))
-            if self.in_proj.bias is not None:
-                xd = xd + self.in_proj.bias.to(xd.dtype)[None, :, None]
+            xd = proj_in(segmenttation_features, self.in_proj.weight, self.in_proj.bias)
 
         if self.bimamba_type in ("v3", "v4") and inference_params is None:
             if self.bimamba_type == "v4" and xd is None:

@@ -68,6 +68,14 @@ class PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         assert H == self.img_size[0] and W == self.img_size[1], \
             f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        ph, pw = self.patch_size
+        if self.proj.stride == self.proj.kernel_size and self.proj.padding == (0, 0) and self.flatten:
+            # kernel == stride: the convolution IS a GEMM over non-overlapping patches.  (MIOpen falls back to a
+            # naive direct conv for 16x16/s16 bf16 on gfx950: 45 ms fwd + 27 ms wgrad per 8x1024^2 batch, measured.)
+            gh, gw = self.grid_size
+            cols = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+            x = torch.nn.functional.linear(cols, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+            return self.norm(x)
         x = self.proj(x)
         if self.flatten:
             x = x.flatten(2).transpose(1, 2)

@@ -110,7 +110,7 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
     lib = _abi.load()
     batch, dim, L = u.shape
     N = A.shape[1]
-    out = torch.empty((batch, dim, L), dtype=u.dtype, device=u.device)
+    out = torch.empty_like(u)  # keeps a channel-major (D, B, L) memory layout when u has one
     last = torch.empty((batch, dim, N), dtype=torch.float32, device=u.device) if want_last_state else None
     ckpt = None
     if want_ckpt:
@@ -217,6 +217,94 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
 
 
 # ---------------------------------------------------------------------------------------------------
+# Channel-major activations.  Inside the mixer every activation is logically (B, D, L) but is STORED as
+# (D, B, L): then each of the four projections is ONE plain 2-D GEMM on a free view (W @ X with X = (D, B*L)),
+# the HIP kernels read it through their batch/row strides, and no transpose or contiguous() copy exists
+# between the token-major (B, L, d_model) residual stream and the scan.  (The reference gets the same
+# effect for in_proj only: `W @ rearrange(h, "b l d -> d (b l)")`, mamba_simple.py:408-412.)
+# ---------------------------------------------------------------------------------------------------
+def _dmajor_2d(t):
+    """(B, D, L) -> its (D, B*L) matrix; a free view when t is stored channel-major, one copy otherwise."""
+    B, D, L = t.shape
+    if B == 1 or t.stride() == (L, B * L, 1):
+        return t.permute(1, 0, 2).reshape(D, B * L)
+    return t.permute(1, 0, 2).contiguous().view(D, B * L)
+
+
+def _from_2d(m, B, L):
+    """(D, B*L) contiguous -> (B, D, L) channel-major view."""
+    return m.view(m.shape[0], B, L).permute(1, 0, 2)
+
+
+def _compute_dtype(x):
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return x.dtype
+
+
+class _ProjIn(torch.autograd.Function):
+    """tokens (B, L, K) -> (B, M, L) channel-major: Y2 = W @ X2^T, one GEMM; backward dX2 = dY2^T @ W."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        Bz, L, K = x.shape
+        cd = _compute_dtype(x)
+        x2 = x.reshape(Bz * L, K).to(cd)
+        w = weight.to(cd)
+        y2 = torch.matmul(w, x2.t())
+        if bias is not None:
+            y2 = y2 + bias.to(cd)[:, None]
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (Bz, L, K, x.dtype, weight.dtype, bias is not None, None if bias is None else bias.dtype)
+        return _from_2d(y2, Bz, L)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        Bz, L, K, xdt, wdt, has_b, bdt = ctx.meta
+        dy2 = _dmajor_2d(dy.to(w.dtype))
+        dx = torch.matmul(dy2.t(), w).view(Bz, L, K).to(xdt)
+        dw = torch.matmul(dy2, x2).to(wdt)
+        db = dy2.float().sum(1).to(bdt) if has_b else None
+        return dx, dw, db
+
+
+class _ProjOut(torch.autograd.Function):
+    """(B, D, L) channel-major -> tokens (B, L, M): O2 = Y2^T @ W^T, one GEMM; backward dY2 = W^T @ dO2^T."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias):
+        Bz, D, L = y.shape
+        cd = _compute_dtype(y)
+        y2 = _dmajor_2d(y.to(cd))
+        w = weight.to(cd)
+        o2 = torch.matmul(y2.t(), w.t())
+        if bias is not None:
+            o2 = o2 + bias.to(cd)
+        ctx.save_for_backward(y2, w)
+        ctx.meta = (Bz, D, L, y.dtype, weight.dtype, bias is not None, None if bias is None else bias.dtype)
+        return o2.view(Bz, L, -1)
+
+    @staticmethod
+    def backward(ctx, do):
+        y2, w = ctx.saved_tensors
+        Bz, D, L, ydt, wdt, has_b, bdt = ctx.meta
+        d2 = do.reshape(Bz * L, -1).to(w.dtype)
+        dy = _from_2d(torch.matmul(w.t(), d2.t()), Bz, L).to(ydt)
+        dw = torch.matmul(d2.t(), y2.t()).to(wdt)
+        db = d2.float().sum(0).to(bdt) if has_b else None
+        return dy, dw, db
+
+
+def proj_in(x, weight, bias=None):
+    return _ProjIn.apply(x, weight, bias)
+
+
+def proj_out(y, weight, bias=None):
+    return _ProjOut.apply(y, weight, bias)
+
+
+# ---------------------------------------------------------------------------------------------------
 # Fused mixer functions.  THIRD-PARTY in the reference (a patched mamba_ssm it neither vendors nor pins,
 # SURVEY.md 8-c): semantics restated from the reference's own slow path, mamba_simple.py:665-709 --
 #   x, z = xz.chunk(2, 1) -> causal conv1d + SiLU -> x_proj -> split (R, N, N) -> dt_proj (no bias)
@@ -238,12 +326,12 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
     R = delta_proj_weight.shape[1]
     x, z = xz[:, :d_inner], xz[:, d_inner:]                       # views: strided rows, L contiguous
     xc = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")  # (b, d, l)
-    # every projection is applied as W @ X on the (b, d, l) layout (the reference's own trick for in_proj,
-    # mamba_simple.py:408-412): results come out L-contiguous, no transposes or copies
-    x_dbl = torch.matmul(x_proj_weight.to(xc.dtype), xc)            # (b, R+2N, l)   skinny GEMM, K = d_inner
-    dt = torch.matmul(delta_proj_weight.to(xc.dtype), x_dbl[:, :R])  # (b, d, l)
-    Bm = x_dbl[:, R:R + N]                                          # (b, N, l) views, l-stride 1
-    Cm = x_dbl[:, R + N:R + 2 * N]
+    # x_proj / dt_proj as single 2-D GEMMs on the channel-major matrix (D, B*L); B and C are row blocks of x_dbl
+    xc2 = _dmajor_2d(xc)
+    x_dbl = torch.matmul(x_proj_weight.to(xc.dtype), xc2)                    # (R+2N, B*L)
+    dt = _from_2d(torch.matmul(delta_proj_weight.to(xc.dtype), x_dbl[:R]), batch, L)   # (b, d, l)
+    Bm = _from_2d(x_dbl[R:R + N], batch, L)                                  # (b, N, l), l-stride 1
+    Cm = _from_2d(x_dbl[R + N:R + 2 * N], batch, L)
     if B_proj_bias is not None:
         Bm = Bm + B_proj_bias.to(Bm.dtype)[None, :, None]
     if C_proj_bias is not None:
@@ -257,8 +345,7 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
                    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     y = mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C, D,
                                    delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
-    return torch.nn.functional.linear(y.transpose(1, 2), out_proj_weight.to(y.dtype),
-                                      None if out_proj_bias is None else out_proj_bias.to(y.dtype))
+    return proj_out(y, out_proj_weight, out_proj_bias)
 
 
 def bimamba_inner_fn(*args, **kwargs):
