@@ -308,6 +308,58 @@ def gen_pretrain(models_pretrain):
          patchify=np_(m.patchify(img)), **sincos, **sd, **grads)
 
 
+def gen_vit_mae():
+    """HD_Xray_Pretrain_MAE: the standalone ViT (finetune/DP/models/vit.py) and the ViT-MAE model
+    (pretrain/models/mae.py).  mae.py imports timm's Block/PatchEmbed (absent): stubbed with the in-repo vit.py
+    Block, which has the same arithmetic.  The reference hard-codes SmallPatchEmbed(1,1024,1024)
+    (67 MB of conv weights); the golden swaps in the reference's own SmallPatchEmbed class at (1, 64, 32) so the
+    fixture stays small.  Images are regenerated from the stored seed (1280x1280 is 6.5 MB as data)."""
+    mae_root = os.path.join(REF, "HD_Xray_Pretrain_MAE")
+    vit = _load(os.path.join(mae_root, "finetune/DP/models/vit.py"), "vit_ref")
+    torch.manual_seed(0)
+    m = vit.ViT(img_size=32, patch_size=16, stride_size=16, in_chans=1, num_classes=0, embed_dim=64, depth=3,
+                num_heads=4, mlp_ratio=4.0, qkv_bias=True)
+    _randomize(m)
+    m.eval()
+    x = torch.randn(2, 1, 32, 32)
+    save("vit_d3_32", img=np_(x), out=np_(m(x)), **{("p_" + k): np_(v) for k, v in m.state_dict().items()})
+
+    vt = sys.modules["timm.models.vision_transformer"]
+    vt.Block = vit.Block
+    vt.PatchEmbed = vit.PatchEmbed
+    pdir = os.path.join(mae_root, "pretrain")
+    sys.path.insert(0, pdir)
+    for k in ("pos_embed", "patch_embed"):
+        sys.modules.pop(k, None)
+    mae = _load(os.path.join(pdir, "models/mae.py"), "mae_ref")
+    import math as _math
+    mae.math = _math  # mae.py uses math.sqrt without importing math (:190)
+    from patch_embed import SmallPatchEmbed
+    torch.manual_seed(0)
+    m = mae.MaskedAutoencoderViT(embed_dim=64, depth=2, num_heads=4, decoder_embed_dim=64, decoder_depth=1,
+                                 decoder_num_heads=4, norm_pix_loss=True)
+    sincos = dict(sincos_pos_embed=np_(m.pos_embed), sincos_dec_pos_embed=np_(m.decoder_pos_embed))
+    m.patch_embed = SmallPatchEmbed(1, 64, 32)
+    _randomize(m)
+    m.eval()
+    img_seed = 77
+    img = torch.randn(1, 1, 1280, 1280, generator=torch.Generator().manual_seed(img_seed))
+    out = {}
+    for tag, mt, ro, ri, seed in [("rand", 0, 0.75, 0.0, 5), ("yiliao", 1, 0.85, 0.95, 6)]:
+        torch.manual_seed(seed)
+        loss, mask = m(img, mt, ro, ri)
+        torch.manual_seed(seed)
+        latent, mask2, ids = m.forward_encoder(img, mt, ro, ri)
+        pred, _ = m.forward_decoder(latent, ids)
+        assert torch.equal(mask, mask2)
+        out.update({f"{tag}_loss": np_(loss), f"{tag}_mask": np_(mask), f"{tag}_ids_restore": ids.numpy().copy(),
+                    f"{tag}_latent": np_(latent), f"{tag}_pred_sub": np_(pred[:, :, ::64]),
+                    f"{tag}_args": np.array([mt, ro, ri, seed], dtype=np.float64)})
+    save("mae_d2_1280", img_seed=np.array(img_seed), img_checksum=np_(img.double().sum().float()),
+         patchify_sub=np_(m.patchify(img)[:, ::37, ::61]), **sincos, **out,
+         **{("p_" + k): np_(v) for k, v in m.state_dict().items()})
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -338,6 +390,8 @@ def main():
     pt_mamba.mamba_inner_fn = with_out
     models_pretrain = _load(os.path.join(pt_dir, "models_pretrain.py"), "models_pretrain_ref")
     gen_pretrain(models_pretrain)
+    sys.path.remove(pt_dir)
+    gen_vit_mae()
 
 
 if __name__ == "__main__":
