@@ -360,6 +360,92 @@ def gen_vit_mae():
          **{("p_" + k): np_(v) for k, v in m.state_dict().items()})
 
 
+def gen_hybrid_decoder():
+    """EMRRG/models/hybrid_decoder_layer.py under transformers 5.x: SimpleNamespace config + a registered 'default'
+    RoPE init.  The reference's full layer forward needs flash_attn (absent): goldens are captured
+    at the two cross-attention functions, at the eager Qwen2Attention forward, and for a layer forward that is the
+    reference's own statement sequence (:780-931, :1424-1470) with SDPA standing in for _flash_attention_forward."""
+    from types import SimpleNamespace
+    import torch.nn.functional as F
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)  # transformers probes timm with find_spec; a spec-less stub module breaks that probe
+    hdl = _load(os.path.join(REF, "EMRRG/models/hybrid_decoder_layer.py"), "hdl_ref")
+
+    def default_rope(config=None, device=None, seq_len=None, **kw):
+        dim = config.hidden_size // config.num_attention_heads
+        inv = 1.0 / (config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+        return inv, 1.0
+    hdl.ROPE_INIT_FUNCTIONS["default"] = default_rope
+    cfg = SimpleNamespace(hidden_size=64, num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128,
+                          rope_theta=10000.0, attention_dropout=0.0, rope_scaling=None, intermediate_size=96,
+                          hidden_act="silu", rms_norm_eps=1e-6, _attn_implementation="flash_attention_2",
+                          sliding_window=None, use_sliding_window=False, max_window_layers=0)
+    out = {}
+    for impl, tag in [("vanilla", "all"), ("text-only-vanilla", "txt")]:
+        torch.manual_seed(0)
+        att = hdl.Qwen2HybridFlashAttention2(True, "whole-dynamic-tanh-warmup", impl, config=cfg, layer_idx=0)
+        _randomize(att)
+        with torch.no_grad():
+            att.cross_attn_warm_up_gate.fill_(0.7)
+        att.eval()
+        B, T, Lv, H, D = 2, 9, 5, 4, 16
+        state = torch.randn(B, T, 64)
+        query = torch.randn(B, T, H, D)
+        vis = torch.randn(B, Lv, 64)
+        cmask = torch.ones(B, Lv, dtype=torch.bool)
+        cmask[1, 3:] = False
+        has_img = torch.tensor([True, False])
+        token_type = torch.tensor([[1, 1, 3, 3, 2, 2, 2, 4, 2], [2, 2, 2, 1, 4, 4, 2, 2, 1]])
+        with torch.no_grad():
+            if tag == "all":
+                y = att.all2media_cross_attn(state.permute(1, 0, 2), query.permute(1, 0, 2, 3), vis, cmask, has_img).permute(1, 0, 2)
+            else:
+                y = att.onlytext2media_cross_attn(state, query, vis, token_type, cmask, has_img)
+        out.update({f"{tag}_out": np_(y), **{f"{tag}_p_{k}": np_(v) for k, v in att.state_dict().items()}})
+    out.update(state=np_(state), query=np_(query), vis=np_(vis), cmask=cmask.numpy().copy(), has_img=has_img.numpy().copy(),
+               token_type=token_type.numpy().copy())
+    # eager self-attention of the same file (:392-457) as the self-attention oracle
+    torch.manual_seed(1)
+    sa = hdl.Qwen2Attention(cfg, layer_idx=0)
+    _randomize(sa)
+    sa.eval()
+    hs = torch.randn(2, 9, 64)
+    pos = torch.arange(9)[None].expand(2, -1)
+    causal = torch.full((9, 9), float("-inf")).triu(1)[None, None].expand(2, 1, -1, -1)
+    with torch.no_grad():
+        so = sa(hs, attention_mask=causal, position_ids=pos)[0]
+    out.update(sa_hidden=np_(hs), sa_out=np_(so), **{f"sa_p_{k}": np_(v) for k, v in sa.state_dict().items()})
+    # layer forward = the reference statement sequence with SDPA in place of flash attention
+    torch.manual_seed(2)
+    lay_att = hdl.Qwen2HybridFlashAttention2(True, "whole-dynamic-tanh-warmup", "vanilla", config=cfg, layer_idx=0)
+    mlp, ln1, ln2 = hdl.Qwen2MLP(cfg), hdl.Qwen2RMSNorm(64, 1e-6), hdl.Qwen2RMSNorm(64, 1e-6)
+    for mod in (lay_att, mlp, ln1, ln2):
+        _randomize(mod)
+    with torch.no_grad():
+        lay_att.cross_attn_warm_up_gate.fill_(0.7)
+        x = torch.randn(2, 9, 64)
+        vis_x = torch.randn(2, 5, 64)
+        h = ln1(x)
+        vt = ln1(vis_x)
+        q = lay_att.q_proj(h).view(2, 9, 4, 16).transpose(1, 2)
+        k = lay_att.k_proj(h).view(2, 9, 2, 16).transpose(1, 2)
+        v = lay_att.v_proj(h).view(2, 9, 2, 16).transpose(1, 2)
+        cos, sin = lay_att.rotary_emb(v, pos)
+        q, k = hdl.apply_rotary_pos_emb(q, k, cos, sin)
+        a = F.scaled_dot_product_attention(q, hdl.repeat_kv(k, 2), hdl.repeat_kv(v, 2), is_causal=True)
+        a = a.transpose(1, 2).reshape(2, 9, 64)
+        tt = torch.tensor([[3, 3, 1, 1, 2, 2, 2, 2, 2], [1, 1, 1, 2, 2, 2, 2, 2, 2]])
+        a = lay_att.all2media_cross_attn(a.permute(1, 0, 2), q.transpose(1, 2).permute(1, 0, 2, 3), vt, cmask,
+                                         (tt == 3).sum(-1).bool()).permute(1, 0, 2)
+        y = x + lay_att.o_proj(a)
+        y = y + mlp(ln2(y))
+    sd = {**{f"lay_p_self_attn.{k}": np_(v) for k, v in lay_att.state_dict().items()},
+          **{f"lay_p_mlp.{k}": np_(v) for k, v in mlp.state_dict().items()},
+          "lay_p_input_layernorm.weight": np_(ln1.weight), "lay_p_post_attention_layernorm.weight": np_(ln2.weight)}
+    out.update(lay_x=np_(x), lay_vis=np_(vis_x), lay_token_type=tt.numpy().copy(), lay_out=np_(y), **sd)
+    save("hybrid_decoder", **out)
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -392,6 +478,7 @@ def main():
     gen_pretrain(models_pretrain)
     sys.path.remove(pt_dir)
     gen_vit_mae()
+    gen_hybrid_decoder()
 
 
 if __name__ == "__main__":
