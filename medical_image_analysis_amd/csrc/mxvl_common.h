@@ -34,6 +34,14 @@ template <> struct Io<bf16_t> {
     p->v = (uint16_t)(u >> 16);
   }
 };
+// two fp32 -> packed bf16x2 (lo = a, hi = b), round-to-nearest-even, in ONE VALU op (gfx950 v_cvt_pk_bf16_f32;
+// no compiler builtin exists for it)
+__device__ inline uint32_t cvt_pk_bf16(float a, float b) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <> struct Io<f16_t> {
   static constexpr int dtype = MXVL_F16;
   __device__ static inline float ld(const f16_t* p) { return (float)p->v; }

@@ -55,9 +55,7 @@ template <> __device__ inline float4 ld4<f16_t>(const f16_t* p) {
 template <typename io_t> __device__ inline void st4(io_t* p, float4 v);
 template <> __device__ inline void st4<float>(float* p, float4 v) { *(float4*)p = v; }
 template <> __device__ inline void st4<bf16_t>(bf16_t* p, float4 v) {
-  bf16_t t[4];
-  Io<bf16_t>::st(&t[0], v.x); Io<bf16_t>::st(&t[1], v.y); Io<bf16_t>::st(&t[2], v.z); Io<bf16_t>::st(&t[3], v.w);
-  *(uint2*)p = make_uint2((uint32_t)t[0].v | ((uint32_t)t[1].v << 16), (uint32_t)t[2].v | ((uint32_t)t[3].v << 16));
+  *(uint2*)p = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
 }
 template <> __device__ inline void st4<f16_t>(f16_t* p, float4 v) {
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
