@@ -403,11 +403,11 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   return MXVL_OK;
 }
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int NU = 1>
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
 static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name) {
-  constexpr int DT = NWAVES * 4, CH = 128;
+  constexpr int CH = 128, DT = NWAVES * (64 / (CH / T));
   const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * a.N);
-  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, NU>;
+  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T>;
   const int dpg = a.dim / a.G;
   dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
@@ -420,9 +420,9 @@ static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name
   (a.vec_ok ? launch_stream<io_t, NW, true, MW>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ">") \
             : launch_stream<io_t, NW, false, MW>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ">"))
 
-#define MXVL_STREAM2_CASE(NW, MW) \
-  (a.vec_ok ? launch_stream<io_t, NW, true, MW, 2>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ",pk2>") \
-            : launch_stream<io_t, NW, false, MW, 2>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ",pk2>"))
+#define MXVL_STREAM16_CASE(NW, MW) \
+  (a.vec_ok ? launch_stream<io_t, NW, true, MW, 16>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ",T16>") \
+            : launch_stream<io_t, NW, false, MW, 16>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ",T16>"))
 
 #define MXVL_FWD_CASE(T, LPR, NW, NU) \
   launch_fwd<io_t, T, LPR, NW, NU>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ">")
@@ -447,8 +447,9 @@ static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
       case 12: return MXVL_STREAM_CASE(8, 3);
       case 13: return MXVL_STREAM_CASE(2, 3);
       case 14: return MXVL_STREAM_CASE(4, 2);
-      case 15: if (even) return MXVL_STREAM2_CASE(4, 3); break;
-      case 16: if (even) return MXVL_STREAM2_CASE(4, 2); break;
+      case 15: return MXVL_STREAM16_CASE(4, 2);
+      case 16: return MXVL_STREAM16_CASE(4, 3);
+      case 17: return MXVL_STREAM16_CASE(2, 2);
       default: break;
     }
   }

@@ -1,28 +1,47 @@
 // scan_fwd_stream.h -- the streaming selective-scan forward kernel (headline path, dstate <= 16).
 //
-// Same math and lane mapping as scan_fwd_kernel (scan_fwd.hip: 16 lanes per row, 8 consecutive steps
-// per lane, fused-DPP prefix scan) but organised so HBM traffic overlaps the VALU work:
-//   * u / delta of chunk c+1 are loaded straight into registers (each lane owns 32 contiguous bytes
-//     per row: two 16-byte loads when rows are 16-byte aligned, eight dword loads otherwise) while
-//     chunk c is being scanned; z of chunk c is requested before the state loop and consumed after it;
-//   * the B/C tile of chunk c+1 is fetched by the whole workgroup during chunk c and written into
-//     the other half of a double-buffered LDS tile after the state loop: one barrier per chunk;
-//   * out leaves as two 16-byte stores per lane (aligned rows) or through a wave-private LDS tile
-//     that turns the lane-strided layout back into coalesced dword stores (unaligned rows).
-// LDS per workgroup: 2 * 2*N*128*4 B (B/C) + DT*128*4 B (out tile) + DT*N*8 B  -> 40.5 KiB at N=16.
+// Same math as scan_fwd_kernel (scan_fwd.hip) but organised so HBM traffic overlaps the VALU work.  A row is spread
+// over LPR lanes of a DPP row, every lane owns T = 128/LPR consecutive steps; (T, LPR) = (8, 16) or (16, 8):
+//   * u / delta of chunk c+1 are loaded straight into registers (each lane owns T contiguous elements per row:
+//     16-byte loads when rows are 16-byte aligned, dword loads otherwise) while chunk c is being scanned; z of
+//     chunk c is requested before the state loop and consumed after it;
+//   * the B/C tile of chunk c+1 is fetched by the whole workgroup during chunk c and written into the other half
+//     of a double-buffered LDS tile after the state loop: one barrier per chunk.  The tile is stored
+//     "quarter-major" ([T/4][LPR][4] per row) so the per-lane 16-byte reads of a DPP row are conflict-free;
+//   * the prefix scan over the LPR lanes is fused-DPP (v_fmac/v_mul with row_shr).  For LPR = 8 two rows share a
+//     16-lane DPP row: the first lane of every row scans with P = 0 (after absorbing the incoming state), which
+//     cuts every contribution that would cross the row boundary -- no exec masking needed;
+//   * out leaves as 16-byte stores (aligned rows) or through a wave-private LDS tile that turns the lane-strided
+//     layout back into coalesced dword stores (unaligned rows).
 #pragma once
 #include "mxvl_common.h"
 
 namespace mxvl {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+// 3-step scan for rows of 8 lanes (two rows per DPP row); x leaves holding the inclusive value of the lane to the left
+__device__ inline void scan8_x1(float& h0, float& P0, float& x0) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 1\n"
+      "v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(h0), "+v"(P0), "+v"(x0));
+}
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int NU = 1>
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {
-  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NMAX = 16;
+  constexpr int CH = 128, LPR = CH / T, RPW = 64 / LPR, DT = NWAVES * RPW, NT = NWAVES * 64, NMAX = 16;
+  constexpr int TQ = T / 4;                           // 16-byte quarters per lane
   constexpr int BCV = (NMAX * CH / 4 + NT - 1) / NT;  // float4 per thread per array (VEC)
   constexpr int BCS = (NMAX * CH + NT - 1) / NT;      // floats per thread per array (scalar)
-  static_assert(NT >= CH / 4 && (NT % (CH / 4)) == 0 && (NT % CH == 0 || CH % NT == 0), "staging shape");
+  static_assert(T == 8 || T == 16, "lane span");
+  static_assert(NT >= CH && NT % CH == 0 && NT % (CH / 4) == 0, "staging shape");
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -32,7 +51,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   float2* sAC = (float2*)(sO + DT * CH);      // [DT + 1][N] {A*log2(e), running state h}; row DT stays zero
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane >> 4, j = lane & 15;
+  const int r = lane / LPR, j = lane % LPR;
   const int row = wave * RPW + r;
   const int b = blockIdx.y;
   const int dpg = p.dim / p.G;
@@ -60,6 +79,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const float bias = p.bias ? p.bias[dc] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
 
+  // element e = jj*T + i of a tile row lives at quarter-major position (i/4)*(LPR*4) + jj*4 + i%4
+  auto qpos = [](int e) { return ((e % T) >> 2) * (LPR * 4) + (e / T) * 4 + (e & 3); };
+
   // ---- B/C tile fetch (global -> registers) and commit (registers -> LDS buffer) ------------------
   float4 bq[VEC ? BCV : 1], cq[VEC ? BCV : 1];
   float bs[VEC ? 1 : BCS], cs[VEC ? 1 : BCS];
@@ -70,8 +92,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       const int e4 = (tid % CQ) * 4;
 #pragma unroll
       for (int k = 0; k < BCV; ++k) {
-        // NU == 2: a thread fetches rows (2m, 2m+1) so the commit can interleave the state pair
-        const int n = (NU == 2 && BCV == 2) ? 2 * (tid / CQ) + k : tid / CQ + k * RSTEP;
+        const int n = tid / CQ + k * RSTEP;
         bq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         cq[k] = bq[k];
         if (n < N) {
@@ -92,13 +113,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
         }
       }
     } else {
-      constexpr int RSTEP = (NT >= CH) ? NT / CH : 1, CSTEP = (NT >= CH) ? CH : NT;
-      static_assert(NT >= CH, "scalar staging assumes one column per thread");
-      const int e = tid % CSTEP;
+      constexpr int RSTEP = NT / CH;
+      const int e = tid % CH;
       const bool ok = t0 + e < L;
 #pragma unroll
       for (int k = 0; k < BCS; ++k) {
-        const int n = tid / CSTEP + k * RSTEP;
+        const int n = tid / CH + k * RSTEP;
         bs[k] = 0.f;
         cs[k] = 0.f;
         if (n < N && ok) {
@@ -113,51 +133,37 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     float* dC = dB + N * CH;
     if constexpr (VEC) {
       constexpr int CQ = CH / 4, RSTEP = NT / CQ;
-      const int e4 = (tid % CQ) * 4;
-      if constexpr (NU == 2) {
-        static_assert(BCV == 2, "packed layout needs two rows per thread");
-        const int m = tid / CQ;  // state pair
-        if (2 * m < N) {         // layout [N/2][CH][2]
-          float4* qB = (float4*)(dB + (m * CH + e4) * 2);
-          float4* qC = (float4*)(dC + (m * CH + e4) * 2);
-          qB[0] = make_float4(bq[0].x, bq[1].x, bq[0].y, bq[1].y);
-          qB[1] = make_float4(bq[0].z, bq[1].z, bq[0].w, bq[1].w);
-          qC[0] = make_float4(cq[0].x, cq[1].x, cq[0].y, cq[1].y);
-          qC[1] = make_float4(cq[0].z, cq[1].z, cq[0].w, cq[1].w);
-        }
-      } else {
+      const int pos = qpos((tid % CQ) * 4);
 #pragma unroll
-        for (int k = 0; k < BCV; ++k) {
-          const int n = tid / CQ + k * RSTEP;
-          // lane-major halves: [half][16 lanes][4] so a 16-lane ds_read_b128 touches 16 distinct slots
-          const int pos = ((e4 >> 2) & 1) * 64 + (e4 >> 3) * 4;
-          if (n < N) {
-            *(float4*)(dB + n * CH + pos) = bq[k];
-            *(float4*)(dC + n * CH + pos) = cq[k];
-          }
+      for (int k = 0; k < BCV; ++k) {
+        const int n = tid / CQ + k * RSTEP;
+        if (n < N) {
+          *(float4*)(dB + n * CH + pos) = bq[k];
+          *(float4*)(dC + n * CH + pos) = cq[k];
         }
       }
     } else {
       constexpr int RSTEP = NT / CH;
-      const int e = tid % CH;
+      const int pos = qpos(tid % CH);
 #pragma unroll
       for (int k = 0; k < BCS; ++k) {
         const int n = tid / CH + k * RSTEP;
         if (n < N) {
-          const int o = (NU == 2) ? ((n >> 1) * CH + e) * 2 + (n & 1)
-                                  : n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
-          dB[o] = bs[k];
-          dC[o] = cs[k];
+          dB[n * CH + pos] = bs[k];
+          dC[n * CH + pos] = cs[k];
         }
       }
     }
   };
-  // ---- a lane's 8 consecutive elements of one row ----------------------------------------------------
+  // ---- a lane's T consecutive elements of one row ----------------------------------------------------
   auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
     if (t0 + CH <= L) {
       if constexpr (VEC) {
-        const float4 a0 = ld4<io_t>(q + t0), a1 = ld4<io_t>(q + t0 + 4);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+#pragma unroll
+        for (int k = 0; k < TQ; ++k) {
+          const float4 a = ld4<io_t>(q + t0 + 4 * k);
+          v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
@@ -216,70 +222,36 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     const float* cB = sBC + (c & 1) * 2 * N * CH + j * 4;
     const float* cC = cB + N * CH;
 
-    if constexpr (NU == 2) {
-      // two states per iteration on packed fp32 (v_pk_mul/v_pk_fma): B/C tile is [N/2][CH][2]
-      const float* cB2 = sBC + (c & 1) * 2 * N * CH + j * T * 2;
-      const float* cC2 = cB2 + N * CH;
-      for (int m = 0; m < ((p.ablate & 1) ? 0 : N / 2); ++m) {
-        const float4 ac4 = *(const float4*)(ac + 2 * m);   // {A2_n, h_n, A2_n+1, h_n+1}
-        const f2 A2 = f2{ac4.x, ac4.z};
-        f2 a[T], bb[T], cv[T];
-#pragma unroll
-        for (int q = 0; q < T / 2; ++q) {
-          const float4 b4 = *(const float4*)(cB2 + m * CH * 2 + q * 4);
-          const float4 c4 = *(const float4*)(cC2 + m * CH * 2 + q * 4);
-          bb[2 * q] = f2{b4.x, b4.y}; bb[2 * q + 1] = f2{b4.z, b4.w};
-          cv[2 * q] = f2{c4.x, c4.y}; cv[2 * q + 1] = f2{c4.z, c4.w};
-        }
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-          const f2 e = dl[i] * A2;
-          a[i] = f2{fast_exp2(e.x), fast_exp2(e.y)};
-          bb[i] = du[i] * bb[i];
-        }
-        f2 h = bb[0];
-#pragma unroll
-        for (int i = 1; i < T; ++i) h = a[i] * h + bb[i];   // pass 1
-        const f2 pe = dsum * A2;
-        float P0 = fast_exp2(pe.x), P1 = fast_exp2(pe.y);
-        float x0 = ac4.y, x1 = ac4.w;                        // states entering the chunk
-        float h0 = fmaf(P0, (j == 0) ? x0 : 0.0f, h.x);
-        float h1 = fmaf(P1, (j == 0) ? x1 : 0.0f, h.y);
-        scan16_x2(h0, P0, x0, h1, P1, x1);
-        if (j == LPR - 1) { ac[2 * m].y = h0; ac[2 * m + 1].y = h1; }
-        h = f2{x0, x1};
-        f2 y2[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) {                        // pass 2
-          h = a[i] * h + bb[i];
-          y2[i] = cv[i] * h;
-        }
-#pragma unroll
-        for (int i = 0; i < T; ++i) y[i] += y2[i].x + y2[i].y;
-      }
-    } else
 #pragma unroll 4
     for (int n = 0; n < ((p.ablate & 1) ? 0 : N); ++n) {
-      const float2 A2c = make_float2(ac[n].x, ac_in[n].y);
+      const float A2 = ac[n].x;
+      const float car = ac_in[n].y;                           // state entering the chunk (lane 0), 0 elsewhere
       float a[T], bb[T], cv[T];
-      {
-        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 64);
-        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 64);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) {
+        const float4 b4 = *(const float4*)(cB + n * CH + k * (LPR * 4));
+        const float4 c4 = *(const float4*)(cC + n * CH + k * (LPR * 4));
+        bb[4 * k] = b4.x; bb[4 * k + 1] = b4.y; bb[4 * k + 2] = b4.z; bb[4 * k + 3] = b4.w;
+        cv[4 * k] = c4.x; cv[4 * k + 1] = c4.y; cv[4 * k + 2] = c4.z; cv[4 * k + 3] = c4.w;
       }
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        a[i] = fast_exp2(dl[i] * A2c.x);
+        a[i] = fast_exp2(dl[i] * A2);
         bb[i] = du[i] * bb[i];
       }
       float h = bb[0];
 #pragma unroll
       for (int i = 1; i < T; ++i) h = fmaf(a[i], h, bb[i]);   // pass 1: lane map h_out = P*h_in + h
-      float P = fast_exp2(A2c.x * dsum);
-      float x = A2c.y;                                        // state entering the chunk
-      float hl = fmaf(P, A2c.y, h);                           // lane 0 absorbs it (others read 0)
-      scan16_x1(hl, P, x);
+      float P = fast_exp2(A2 * dsum);
+      float x = car;
+      float hl = fmaf(P, car, h);                             // lane 0 absorbs the incoming state
+      if constexpr (LPR == 16) {
+        scan16_x1(hl, P, x);
+      } else {
+        P = (j == 0) ? 0.0f : P;                              // nothing may flow in from the neighbouring row
+        scan8_x1(hl, P, x);
+        x = (j == 0) ? car : x;
+      }
       if (j == LPR - 1) ac[n].y = hl;                         // state leaving the chunk
       h = x;
 #pragma unroll
@@ -297,13 +269,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     if (p.ablate & 8) continue;
     if (VEC && full) {
       if (row_ok) {
-        st4<io_t>(po + t0, make_float4(y[0], y[1], y[2], y[3]));
-        st4<io_t>(po + t0 + 4, make_float4(y[4], y[5], y[6], y[7]));
+#pragma unroll
+        for (int k = 0; k < TQ; ++k)
+          st4<io_t>(po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]));
       }
     } else {
       float4* so4 = (float4*)(sO + row * CH + j * T);
-      so4[0] = make_float4(y[0], y[1], y[2], y[3]);
-      so4[1] = make_float4(y[4], y[5], y[6], y[7]);
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) so4[k] = make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -35,7 +35,7 @@ def _to(d, dev, dtype=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 10, 12, 13, 15, 16, 99])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 10, 12, 13, 15, 17, 99])
 @pytest.mark.parametrize("name", golden_names("scan_"))
 def test_scan_fwd_golden(name, variant):
     from medical_image_analysis_amd import _abi

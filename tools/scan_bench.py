@@ -6,7 +6,7 @@ import torch
 from medical_image_analysis_amd import _abi
 from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
-def run(B, D, L, N, dtype, variants=(10, 14, 11), iters=10, rounds=5):
+def run(B, D, L, N, dtype, variants=(10, 15, 16), iters=10, rounds=5):
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
