@@ -54,7 +54,7 @@ PRETRAIN_WORKLOADS = {
     "arm_pretrain_base_192": (192, 16, 768, 12, 512, 64,
                               "reference factory arm_base_pz16 (192x192, 128-token scan) stage-1 pre-training step, bf16 autocast"),
 }
-DEFAULT_WORKLOAD = "scan_fwd_target"
+DEFAULT_WORKLOAD = "arm_pretrain_large_1024"
 
 
 def scan_bytes(B, D, L, N, G, elt, has_z=True):
@@ -112,6 +112,38 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
                   f"of the same (D={D}, L={L}, N={N}) fp32 scan, OpenMP over rows, {elapsed:.1f} s of CPU work",
         "cpu": cpu_model,
     }
+
+
+def cpu_baseline_pretrain(model, img, patch, depth, budget_s=25.0):
+    """FORWARD pass of the same model on the host: oracle/models_ref.py (functional restatement of the reference's
+    VisionMamba.forward over the C scan/conv oracles), fp32, all cores.  The reference's own training step cannot
+    run without its CUDA wheels; forward-only is what the CPU oracle offers, and the sample says so."""
+    from oracle import models_ref
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0))
+    n, elapsed = 0, 0.0
+    while elapsed < budget_s and n < 8:
+        t0 = time.perf_counter()
+        models_ref.visionmamba_forward_ref(sd, x, patch=patch, depth=depth)
+        elapsed += time.perf_counter() - t0
+        n += 1
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n / elapsed, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model,
+            "sample": f"{n} x forward+loss of the same model on one {img}x{img} image (oracle/models_ref.py over "
+                      f"oracle/mxvl_oracle.c, fp32, torch intra-op + OpenMP threads = {cores}); FORWARD ONLY -- the GPU "
+                      f"value is forward+backward+optimizer, {elapsed:.1f} s of CPU work"}
 
 
 def run_pretrain(args, rank, world, dev, dist):
@@ -179,17 +211,15 @@ def run_pretrain(args, rank, world, dev, dist):
                      "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}},
     }
     if world == 1 and not args.no_cpu_baseline:
-        D = embed
-        out["cpu_baseline"] = cpu_baseline_scan(min(B, 2), D, L, 16, budget_s=10.0)
-        out["cpu_baseline"]["sample"] += " -- the scan of ONE encoder layer only (the full reference step does not run without its CUDA wheels)"
+        out["cpu_baseline"] = cpu_baseline_pretrain(model, img, patch, depth)
     print(json.dumps(out))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0, help="0 = workload default (20 training steps / 200 kernel launches)")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1 = workload default (3 / 20)")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,7 +243,12 @@ def main():
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
-    if args.workload in PRETRAIN_WORKLOADS:
+    pre = args.workload in PRETRAIN_WORKLOADS
+    if args.steps <= 0:
+        args.steps = 20 if pre else 200
+    if args.warmup < 0:
+        args.warmup = 3 if pre else 20
+    if pre:
         run_pretrain(args, rank, world, dev, dist)
         if dist is not None:
             dist.destroy_process_group()

@@ -76,3 +76,15 @@ def test_decode_step_matches_reference():
         assert_close(conv_state, g["conv_states"][t], 1e-6, 1e-6, f"conv_state[{t}]")
         assert_close(ssm_state, g["ssm_states"][t], 1e-5, 1e-4, f"ssm_state[{t}]")
     assert_close(g["outs"], g["full"], 1e-4, 1e-4, "recurrent == parallel (reference self-consistency)")
+
+
+def test_model_level_oracle_matches_reference_visionmamba():
+    """oracle/models_ref.py (functional CPU restatement of the stage-1 forward) against the golden captured from
+    the reference's own VisionMamba: features, prediction and loss."""
+    from oracle import models_ref
+    g = load_golden("pretrain_d12_128")
+    sd = {k[2:]: v for k, v in g.items() if k.startswith("p_")}
+    loss, feats, pred = models_ref.visionmamba_forward_ref(sd, g["img"], patch=16)
+    assert_close(feats, g["features"], 2e-5, 1e-4, "features")
+    assert_close(pred, g["pred"], 5e-5, 1e-4, "pred")
+    assert_close(loss, g["loss"], 2e-5, 1e-4, "loss")
