@@ -1,0 +1,252 @@
+"""Report decoder: decoder-only LM built from the hybrid decoder layers + the autoregressive generation loop.
+
+Replaces, for the MambaXray-VL report path, what the reference delegates to HF transformers:
+  CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301, 389-398
+      self.llama_model.generate(inputs_embeds=[bos, prompt, img(197), prompt], num_beams=beam_size(3), do_sample=False,
+                                min_new_tokens=80, max_new_tokens=120, repetition_penalty=2.0, length_penalty=2.0, ...)
+`ReportDecoder` has HF Llama-2 / Qwen2 parameter names (`model.embed_tokens`, `model.layers.{i}.self_attn.{q,k,v,o}_proj`,
+`mlp.{gate,up,down}_proj`, `input_layernorm`, `post_attention_layernorm`, `model.norm`, `lm_head`), so an HF
+state_dict loads directly (absent q/k/v biases = 0, i.e. Llama).  Layers listed in `hybrid_layers` are
+`Qwen2HybridDecoderLayer`s with the gated image cross-attention enabled (EMRRG installer,
+MambaXrayVL_DownStream.py:176-208); `condition_vis_x` / `clear_vis_x` fan out to them.
+
+`generate` restates the beam search of the transformers release installed next to the reference
+(GenerationMixin._beam_search, vectorised top-K formulation): K = 2*num_beams candidates per step,
+length-penalised finished-hypothesis pool, the early-stop heuristic of `early_stopping=False`,
+RepetitionPenalty and MinNewTokens processors applied to log-probabilities, prompt given as embeddings (so the
+penalties see generated tokens only).  The third-party implementation is not vendored in the reference ->
+parity is pinned by token streams generated here with tiny random Llama configs (tests/golden/decode_*.npz).
+KV cache: one (k, v) pair per layer, re-ordered by beam index after every step; the prompt is prefilled ONCE per
+sample and its cache replicated over the beams (HF prefills batch*beams identical rows).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from .hybrid_decoder_layer import Qwen2HybridDecoderLayer, Qwen2RMSNorm, Qwen2RotaryEmbedding
+
+
+class KVCache:
+    """Minimal per-layer key/value store with the `update` signature the attention module expects."""
+
+    def __init__(self):
+        self.k, self.v = {}, {}
+
+    def get_seq_length(self, layer_idx=0):
+        return 0 if layer_idx not in self.k else self.k[layer_idx].shape[-2]
+
+    def update(self, k, v, layer_idx, cache_kwargs=None):
+        if layer_idx in self.k:
+            k = torch.cat([self.k[layer_idx], k], dim=-2)
+            v = torch.cat([self.v[layer_idx], v], dim=-2)
+        self.k[layer_idx], self.v[layer_idx] = k, v
+        return k, v
+
+    def reorder(self, beam_idx):
+        for i in self.k:
+            self.k[i] = self.k[i].index_select(0, beam_idx)
+            self.v[i] = self.v[i].index_select(0, beam_idx)
+
+    def expand(self, n):
+        for i in self.k:
+            self.k[i] = self.k[i].repeat_interleave(n, dim=0)
+            self.v[i] = self.v[i].repeat_interleave(n, dim=0)
+
+
+class _Stack(nn.Module):
+    def __init__(self, cfg, hybrid_layers, impl, gating):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([
+            Qwen2HybridDecoderLayer(cfg, i, is_hyper_enabled=(i in hybrid_layers), cross_attn_implementation=impl,
+                                    cross_attn_gating_type=gating) for i in range(cfg.num_hidden_layers)])
+        self.norm = Qwen2RMSNorm(cfg.hidden_size, eps=cfg.rms_norm_eps)
+        self.rotary_emb = Qwen2RotaryEmbedding(config=cfg)
+
+
+class ReportDecoder(nn.Module):
+    def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads,
+                 num_key_value_heads=None, rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096,
+                 hybrid_layers: Iterable[int] = (), cross_attn_implementation="vanilla",
+                 cross_attn_gating_type="whole-dynamic-tanh-warmup"):
+        super().__init__()
+        self.config = SimpleNamespace(
+            vocab_size=vocab_size, hidden_size=hidden_size, intermediate_size=intermediate_size,
+            num_hidden_layers=num_hidden_layers, num_attention_heads=num_attention_heads,
+            num_key_value_heads=num_key_value_heads or num_attention_heads, rms_norm_eps=rms_norm_eps,
+            rope_theta=rope_theta, max_position_embeddings=max_position_embeddings, attention_dropout=0.0,
+            rope_scaling=None, hidden_act="silu", _attn_implementation="sdpa")
+        self.hybrid_layers = tuple(hybrid_layers)
+        self.model = _Stack(self.config, set(self.hybrid_layers), cross_attn_implementation, cross_attn_gating_type)
+        self.lm_head = nn.Linear(hidden_size, vocab_size, bias=False)
+
+    # ---- weights -------------------------------------------------------------------------------------------
+    def load_hf_state_dict(self, sd):
+        """HF LlamaForCausalLM / Qwen2ForCausalLM state_dict; Llama has no q/k/v biases -> zero them."""
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        with torch.no_grad():
+            for name in missing:
+                if name.endswith(("q_proj.bias", "k_proj.bias", "v_proj.bias")):
+                    self.get_parameter(name).zero_()
+        bad = [m for m in missing if not (m.endswith("_proj.bias") or "cross_attn" in m)]
+        if bad or unexpected:
+            raise RuntimeError(f"state_dict mismatch: missing {bad}, unexpected {list(unexpected)}")
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def condition_vis_x(self, vis_x, cross_attn_mask=None, token_type=None):
+        for i in self.hybrid_layers:
+            self.model.layers[i].condition_vis_x(vis_x, cross_attn_mask, token_type)
+
+    def clear_vis_x(self):
+        for i in self.hybrid_layers:
+            self.model.layers[i].clear_vis_x()
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def forward(self, inputs_embeds, attention_mask=None, position_ids=None, past_key_values: Optional[KVCache] = None):
+        """inputs_embeds (B, T, hidden); attention_mask (B, past+T) 1 = real token.  Returns logits (B, T, vocab)."""
+        B, T, _ = inputs_embeds.shape
+        past = past_key_values.get_seq_length() if past_key_values is not None else 0
+        if position_ids is None:
+            if attention_mask is not None:   # HF: positions count real tokens (left padding gets position 0..)
+                position_ids = (attention_mask.long().cumsum(-1) - 1).clamp(min=0)[:, past:past + T]
+            else:
+                position_ids = torch.arange(past, past + T, device=inputs_embeds.device)[None].expand(B, -1)
+        pos_emb = self.model.rotary_emb(inputs_embeds, position_ids)
+        h = inputs_embeds
+        for layer in self.model.layers:
+            h = layer(h, attention_mask=attention_mask, position_ids=position_ids, past_key_value=past_key_values,
+                      use_cache=past_key_values is not None, position_embeddings=pos_emb)[0]
+        return self.lm_head(self.model.norm(h))
+
+    # ---- generation ------------------------------------------------------------------------------------------
+    def _greedy(self, logits, cache, attn, dtype, eos_t, fill, min_new, max_new, rep_pen):
+        """num_beams = 1 (HF `_sample` with do_sample=False): the processors act on the raw LOGITS here (on
+        log-probabilities in beam search), finished rows keep emitting the pad token."""
+        B, dev = logits.shape[0], logits.device
+        seq = torch.empty(B, 0, dtype=torch.long, device=dev)
+        alive = torch.ones(B, dtype=torch.bool, device=dev)
+        has_eos = eos_t.numel() > 0
+        while True:
+            sc = logits.float().clone()
+            if rep_pen != 1.0 and seq.shape[1] > 0:
+                g = torch.gather(sc, 1, seq)
+                sc = sc.scatter(1, seq, torch.where(g < 0, g * rep_pen, g / rep_pen))
+            if has_eos and seq.shape[1] < min_new:
+                sc[:, eos_t] = -float("inf")
+            tok = sc.argmax(-1)
+            if has_eos:
+                tok = torch.where(alive, tok, torch.full_like(tok, fill))
+            seq = torch.cat([seq, tok[:, None]], dim=1)
+            if has_eos:
+                alive = alive & ~torch.isin(tok, eos_t)
+            if seq.shape[1] >= max_new or not bool(alive.any()):
+                return seq
+            attn = torch.cat([attn, torch.ones(B, 1, dtype=attn.dtype, device=dev)], dim=1)
+            emb = self.model.embed_tokens(tok)[:, None, :].to(dtype)
+            logits = self.forward(emb, attention_mask=attn, past_key_values=cache)[:, -1]
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds, attention_mask=None, num_beams=1, do_sample=False, min_new_tokens=0,
+                 max_new_tokens=20, repetition_penalty=1.0, length_penalty=1.0, eos_token_id=None, pad_token_id=None,
+                 early_stopping=False, temperature=None):
+        """Greedy (num_beams=1) / beam search over a prompt given as embeddings.  Returns (B, <= max_new_tokens) ids."""
+        if do_sample:
+            raise NotImplementedError("the reference decodes with do_sample=False")
+        dev = inputs_embeds.device
+        B = inputs_embeds.shape[0]
+        nb = num_beams
+        eos = [] if eos_token_id is None else ([eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id))
+        eos_t = torch.tensor(eos, device=dev, dtype=torch.long)
+        # beam search pads with `pad_token_id or eos[0]` in HF (a falsy pad id 0 falls through to EOS); greedy pads with pad
+        fill = (pad_token_id or (eos[0] if eos else -1)) if nb > 1 else (pad_token_id if pad_token_id is not None else (eos[0] if eos else -1))
+        keep = max(2, 1 + len(eos)) * nb
+        top_mask = torch.zeros(keep, dtype=torch.bool, device=dev)
+        top_mask[:nb] = True
+        if attention_mask is None:
+            attention_mask = torch.ones(inputs_embeds.shape[:2], dtype=torch.long, device=dev)
+
+        cache = KVCache()
+        logits = self.forward(inputs_embeds, attention_mask=attention_mask, past_key_values=cache)[:, -1]   # (B, V)
+        if nb == 1:
+            return self._greedy(logits, cache, attention_mask, inputs_embeds.dtype, eos_t, fill, min_new_tokens,
+                                max_new_tokens, repetition_penalty)
+        cache.expand(nb)
+        attn = attention_mask.repeat_interleave(nb, dim=0)
+        vocab = logits.shape[-1]
+        logits = logits.repeat_interleave(nb, dim=0)
+
+        run_seq = torch.full((B, nb, max_new_tokens), fill, dtype=torch.long, device=dev)
+        fin_seq = run_seq.clone()
+        run_score = torch.zeros(B, nb, device=dev)
+        run_score[:, 1:] = -1e9
+        fin_score = torch.full((B, nb), -1e9, device=dev)
+        fin_done = torch.zeros(B, nb, dtype=torch.bool, device=dev)
+        heur_open = torch.ones(B, 1, dtype=torch.bool, device=dev)
+        cur = 0
+        while True:
+            logp = torch.log_softmax(logits.float(), dim=-1)                       # (B*nb, V)
+            flat_seq = run_seq.view(B * nb, -1)[:, :cur]
+            if repetition_penalty != 1.0 and cur > 0:                              # RepetitionPenaltyLogitsProcessor
+                sc = torch.gather(logp, 1, flat_seq)
+                sc = torch.where(sc < 0, sc * repetition_penalty, sc / repetition_penalty)
+                logp = logp.scatter(1, flat_seq, sc)
+            if eos and cur < min_new_tokens:                                       # MinNewTokensLengthLogitsProcessor
+                logp[:, eos_t] = -float("inf")
+            acc = (logp.view(B, nb, vocab) + run_score[:, :, None]).view(B, nb * vocab)
+            top_lp, top_ix = torch.topk(acc, k=keep)
+            src_beam = top_ix // vocab
+            top_seq = torch.take_along_dim(run_seq, src_beam[:, :, None], dim=1)
+            top_seq[:, :, cur] = top_ix % vocab
+            hits = torch.full((B, keep), cur + 1 >= max_new_tokens, dtype=torch.bool, device=dev)   # MaxLengthCriteria
+            if eos:
+                hits |= torch.isin(top_seq[:, :, cur], eos_t)                       # EosTokenCriteria
+            # live beams for the next step: best nb candidates that did not stop
+            live_lp = top_lp + hits.float() * -1e9
+            nxt = torch.topk(live_lp, k=nb)[1]
+            run_seq = torch.take_along_dim(top_seq, nxt[:, :, None], dim=1)
+            run_score = torch.take_along_dim(live_lp, nxt, dim=1)
+            beam_src = torch.take_along_dim(src_beam, nxt, dim=1) + torch.arange(B, device=dev)[:, None] * nb
+            # finished pool: candidates among the top nb that just stopped, scored with the length penalty
+            just = hits & top_mask[None, :]
+            cand = top_lp / ((cur + 1) ** length_penalty)
+            cand = cand + (fin_done.all(-1, keepdim=True) & (early_stopping is True)).float() * -1e9
+            cand = cand + (~heur_open).float() * -1e9 + (~just).float() * -1e9
+            m_seq = torch.cat([fin_seq, top_seq], dim=1)
+            m_score = torch.cat([fin_score, cand], dim=1)
+            m_done = torch.cat([fin_done, just], dim=1)
+            best = torch.topk(m_score, k=nb)[1]
+            fin_seq = torch.take_along_dim(m_seq, best[:, :, None], dim=1)
+            fin_score = torch.take_along_dim(m_score, best, dim=1)
+            fin_done = torch.take_along_dim(m_done, best, dim=1)
+            cache.reorder(beam_src.view(-1))
+            cur += 1
+            # early-stop heuristic of early_stopping=False: best live score at the CURRENT length vs worst finished
+            hyp_len = (max_new_tokens if (early_stopping == "never" and length_penalty > 0.0) else cur)
+            best_live = run_score[:, :1] / (hyp_len ** length_penalty)
+            worst_fin = torch.where(fin_done, fin_score.min(dim=1, keepdim=True)[0], torch.full_like(fin_score, -1e9))
+            heur_open = heur_open & (best_live > worst_fin).any(dim=-1, keepdim=True)
+            unfinished = heur_open.any() & ~(fin_done.all() & (early_stopping is True)) & ~hits.all()
+            if not bool(unfinished):
+                break
+            tok = run_seq[:, :, cur - 1].reshape(B * nb)
+            attn = torch.cat([attn, torch.ones(B * nb, 1, dtype=attn.dtype, device=dev)], dim=1)
+            emb = self.model.embed_tokens(tok)[:, None, :]
+            logits = self.forward(emb.to(inputs_embeds.dtype), attention_mask=attn, past_key_values=cache)[:, -1]
+        out = fin_seq[:, 0]
+        # trim to the longest returned hypothesis (HF trims by the recorded beam indices)
+        lens = []
+        for b in range(B):
+            row = out[b]
+            n = max_new_tokens
+            if eos:
+                e = torch.isin(row, eos_t).nonzero()
+                if len(e):
+                    n = int(e[0]) + 1
+            lens.append(n)
+        return out[:, :max(lens)]

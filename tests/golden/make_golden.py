@@ -446,6 +446,39 @@ def gen_hybrid_decoder():
     save("hybrid_decoder", **out)
 
 
+def gen_decode():
+    """Report decoding oracle: HF transformers (the library the reference calls, MambaXrayVL_DownStream.py:292-301)
+    with a tiny random LlamaForCausalLM: greedy and beam-3 token streams for a prompt given as embeddings, with the
+    reference's generation arguments scaled down (min_new 8 / max_new 12 instead of 80 / 120)."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=48, hidden_size=64, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1,
+                      eos_token_id=2, pad_token_id=0, attention_bias=False, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.mul_(3.0)  # sharper distributions: EOS actually shows up inside 12 tokens
+    out = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(3, 7, 64, generator=g)
+    att = torch.ones(3, 7, dtype=torch.long)
+    att[1, :2] = 0  # left padding, as the tokenizer pads prompts
+    common = dict(inputs_embeds=emb, attention_mask=att, do_sample=False, repetition_penalty=2.0, length_penalty=2.0,
+                  pad_token_id=0, eos_token_id=2)
+    with torch.no_grad():
+        out["greedy"] = m.generate(num_beams=1, min_new_tokens=2, max_new_tokens=12, **common).numpy().copy()
+        out["beam3"] = m.generate(num_beams=3, min_new_tokens=8, max_new_tokens=12, **common).numpy().copy()
+        out["beam3_short"] = m.generate(num_beams=3, min_new_tokens=1, max_new_tokens=12, **common).numpy().copy()
+        out["beam4_nopen"] = m.generate(num_beams=4, min_new_tokens=0, max_new_tokens=10, inputs_embeds=emb,
+                                        attention_mask=att, do_sample=False, pad_token_id=0, eos_token_id=2).numpy().copy()
+        out["logits_prompt"] = np_(m(inputs_embeds=emb, attention_mask=att).logits)
+    print({k: v.tolist() for k, v in out.items() if not k.startswith("p_") and k != "logits_prompt"})
+    save("decode_tiny_llama", inputs_embeds=np_(emb), attention_mask=att.numpy().copy(), **out)
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -479,6 +512,7 @@ def main():
     sys.path.remove(pt_dir)
     gen_vit_mae()
     gen_hybrid_decoder()
+    gen_decode()
 
 
 if __name__ == "__main__":

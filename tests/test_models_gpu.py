@@ -100,3 +100,35 @@ def test_reference_style_import_through_dropin():
     for got, k in zip(grads, ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"]):
         scale = max(1.0, float(rg[k].abs().max()))
         assert_close(got, rg[k], 2e-5 * scale, 1e-4, "oflex.bwd " + k)
+
+
+def test_lora_x_adapter_patches_every_mixer():
+    """EMRRG lora_X (MambaXrayVL_DownStream.py:33-46, 272-306): zero-init up-projection => identity at start;
+    afterwards out[..., :d/2] += s_X * up(down(x)); the reference's late-binding closure is reproduced on request."""
+    from medical_image_analysis_amd.lora_x import apply_lora_X
+    from medical_image_analysis_amd.models_mamba import ARM
+    torch.manual_seed(0)
+    mk = lambda: ARM(img_size=48, patch_size=16, depth=2, embed_dim=64, if_cls_token=True, if_abs_pos_embed=True,
+                     bimamba_type="v3", use_middle_cls_token=True, if_devide_out=True, drop_path_rate=0.0).to(DEV).eval()
+    base = mk()
+    img = torch.randn(2, 3, 48, 48, device=DEV)
+    ref = base(img)
+    names = apply_lora_X(base, dim_X=16, s_X=0.5)
+    assert names == ["layers.0.mixer", "layers.1.mixer"]
+    assert torch.allclose(base(img), ref, atol=1e-6), "zero-initialised adapter_up: identity"
+    with torch.no_grad():
+        for m in (base.layers[0].mixer, base.layers[1].mixer):
+            m.lora_X.adapter_up.weight.normal_(std=0.1)
+    x = torch.randn(2, 10, 64, device=DEV)
+    mix = base.layers[0].mixer
+    plain = type(mix).forward(mix, x)                       # the un-patched class forward
+    want = plain.clone()
+    want[..., :32] += 0.5 * mix.lora_X(x)
+    assert_close(mix(x), want, 1e-6, 1e-6, "patched mixer")
+    # reference late binding: every patched mixer runs the LAST mixer's original forward
+    torch.manual_seed(0)
+    lb = mk()
+    lb.load_state_dict({k: v for k, v in base.state_dict().items() if "lora_X" not in k})
+    apply_lora_X(lb, dim_X=16, s_X=0.5, reference_late_binding=True)
+    m0, m1 = lb.layers[0].mixer, lb.layers[1].mixer
+    assert_close(m0(x), type(m1).forward(m1, x), 1e-6, 1e-6, "layer 0 calls layer 1's forward (zero adapter)")
