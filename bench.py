@@ -54,6 +54,12 @@ PRETRAIN_WORKLOADS = {
     "arm_pretrain_base_192": (192, 16, 768, 12, 512, 64,
                               "reference factory arm_base_pz16 (192x192, 128-token scan) stage-1 pre-training step, bf16 autocast"),
 }
+DECODE_WORKLOADS = {
+    # name: (vocab, hidden, inter, layers, heads, kv_heads, prompt_len, new_tokens, beams, batch, description)
+    "decode_llama7b_128": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 1,
+                           "configs[3]: report generation with a Llama-2-7B-shaped decoder (random-init bf16 weights), 230-embedding "
+                           "prompt [bos, prompt, 197 image tokens, prompt], beam 3, 128 new tokens (min = max = 128), repetition/length penalty 2.0"),
+}
 DEFAULT_WORKLOAD = "arm_pretrain_large_1024"
 
 
@@ -112,6 +118,55 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
                   f"of the same (D={D}, L={L}, N={N}) fp32 scan, OpenMP over rows, {elapsed:.1f} s of CPU work",
         "cpu": cpu_model,
     }
+
+
+def run_decode(args, rank, world, dev, dist):
+    """Autoregressive report decoding: one 'step' = one full generate() of `new_tokens` tokens per sample.
+    Replicas only across GPUs (the reference decodes on a single device, MambaXrayVL_DownStream.py:407)."""
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    vocab, hidden, inter, layers, heads, kvh, plen, new, beams, B, desc = DECODE_WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    with torch.device(dev):
+        m = ReportDecoder(vocab, hidden, inter, layers, heads, kvh).to(torch.bfloat16).eval()
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    emb = (0.02 * torch.randn(B, plen, hidden, generator=g)).to(dev, torch.bfloat16)
+    steps = args.steps if args.steps > 0 else 3
+    warmup = args.warmup if args.warmup >= 0 else 1
+    kw = dict(num_beams=beams, min_new_tokens=new, max_new_tokens=new, repetition_penalty=2.0, length_penalty=2.0,
+              eos_token_id=2, pad_token_id=0)
+    for _ in range(warmup):
+        m.generate(emb, **kw)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = m.generate(emb, **kw)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    if rank != 0:
+        return
+    n_params = sum(p.numel() for p in m.parameters())
+    tokens = B * world * steps * out.shape[1]
+    wbytes = 2 * n_params                                   # every decode step streams the bf16 weights once
+    step_s = wall / (steps * out.shape[1])                  # per generated token (beam batch of `beams` rows)
+    achieved = wbytes / step_s / 1e9
+    print(json.dumps({
+        "metric": "report-generation decode tokens/sec (returned tokens; each step advances all beams)",
+        "value": tokens / wall, "unit": "tokens/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic prompt embeddings (seed 1000+rank), random-init weights (seed 0)",
+        "config": {"workload": f"{args.workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
+                   "new_tokens": int(out.shape[1]), "parallelism": f"replicas x{world} (no collective)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step (weight streaming; library GEMV + SDPA)",
+                     "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}))
 
 
 def cpu_baseline_pretrain(model, img, patch, depth, budget_s=25.0):
@@ -220,7 +275,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="0 = workload default (20 training steps / 200 kernel launches)")
     ap.add_argument("--warmup", type=int, default=-1, help="-1 = workload default (3 / 20)")
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD,
+                    choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -243,6 +299,11 @@ def main():
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
+    if args.workload in DECODE_WORKLOADS:
+        run_decode(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     pre = args.workload in PRETRAIN_WORKLOADS
     if args.steps <= 0:
         args.steps = 20 if pre else 200

@@ -37,9 +37,9 @@ class Qwen2RMSNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, hidden_states):
+        # one fused kernel; same arithmetic as the reference (:193-198): fp32 statistics, result cast back, then * weight
         dt = hidden_states.dtype
-        h = hidden_states.to(torch.float32)
-        h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+        h = F.rms_norm(hidden_states.to(torch.float32), (hidden_states.shape[-1],), None, self.variance_epsilon)
         return self.weight * h.to(dt)
 
     def extra_repr(self):

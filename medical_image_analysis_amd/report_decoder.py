@@ -57,6 +57,100 @@ class KVCache:
             self.v[i] = self.v[i].repeat_interleave(n, dim=0)
 
 
+class StaticKVCache:
+    """Pre-allocated (rows, Hkv, max_len, D) buffers per layer, written in place at `cache_position` -- fixed
+    addresses and shapes, which is what lets one decode step be captured in a hipGraph and replayed."""
+
+    def __init__(self, n_layers, rows, kv_heads, max_len, head_dim, dtype, device):
+        self.k = [torch.zeros(rows, kv_heads, max_len, head_dim, dtype=dtype, device=device) for _ in range(n_layers)]
+        self.v = [torch.zeros(rows, kv_heads, max_len, head_dim, dtype=dtype, device=device) for _ in range(n_layers)]
+        self.filled = 0
+
+    def get_seq_length(self, layer_idx=0):
+        return self.filled
+
+    def load_prefix(self, dyn: "KVCache", repeat):
+        for i in range(len(self.k)):
+            n = dyn.k[i].shape[-2]
+            self.k[i][:, :, :n] = dyn.k[i].repeat_interleave(repeat, dim=0)
+            self.v[i][:, :, :n] = dyn.v[i].repeat_interleave(repeat, dim=0)
+        self.filled = dyn.get_seq_length()
+
+    def update(self, k, v, layer_idx, cache_kwargs=None):
+        pos = cache_kwargs["cache_position"]
+        self.k[layer_idx].index_copy_(2, pos, k)
+        self.v[layer_idx].index_copy_(2, pos, v)
+        return self.k[layer_idx], self.v[layer_idx]
+
+    def reorder_(self, beam_idx):
+        for i in range(len(self.k)):
+            self.k[i].copy_(self.k[i].index_select(0, beam_idx))
+            self.v[i].copy_(self.v[i].index_select(0, beam_idx))
+
+
+class _GraphStepper:
+    """One decode step (beam re-order of the cache + one-token forward) captured ONCE in a hipGraph and replayed per
+    token: a 32-layer decoder is ~1400 kernel launches per token in eager mode -- launch-bound at batch 1-3."""
+
+    def __init__(self, model: "ReportDecoder", rows, prompt_mask, dyn_cache, max_new, dtype):
+        dev = prompt_mask.device
+        cfg = model.config
+        self.model = model
+        P = prompt_mask.shape[1]
+        self.P = P
+        self.max_len = P + max_new
+        self.cache = StaticKVCache(cfg.num_hidden_layers, rows, cfg.num_key_value_heads, self.max_len,
+                                   cfg.hidden_size // cfg.num_attention_heads, dtype, dev)
+        self.cache.load_prefix(dyn_cache, rows // prompt_mask.shape[0])
+        self.mask = torch.zeros(rows, self.max_len, dtype=torch.long, device=dev)
+        self.mask[:, :P] = prompt_mask.repeat_interleave(rows // prompt_mask.shape[0], dim=0)
+        self.n_real = self.mask[:, :P].sum(-1, keepdim=True)            # RoPE position of the first new token
+        self.tok = torch.zeros(rows, dtype=torch.long, device=dev)
+        self.beam = torch.arange(rows, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.long, device=dev)          # cache slot of the token being fed
+        self.step_no = torch.zeros(1, dtype=torch.long, device=dev)
+        self.logits = None
+        self.graph = None
+        self.dtype = dtype
+
+    def reset(self, prompt_mask, dyn_cache):
+        rep = self.mask.shape[0] // prompt_mask.shape[0]
+        self.cache.load_prefix(dyn_cache, rep)
+        self.mask.zero_()
+        self.mask[:, :self.P] = prompt_mask.repeat_interleave(rep, dim=0)
+        self.n_real.copy_(self.mask[:, :self.P].sum(-1, keepdim=True))
+
+    def _body(self):
+        self.cache.reorder_(self.beam)
+        self.mask.index_fill_(1, self.pos, 1)
+        emb = self.model.model.embed_tokens(self.tok)[:, None, :].to(self.dtype)
+        position_ids = self.n_real + self.step_no
+        pos_emb = self.model.model.rotary_emb(emb, position_ids)
+        h = emb
+        for layer in self.model.model.layers:
+            h = layer(h, attention_mask=self.mask, position_ids=position_ids, past_key_value=self.cache, use_cache=True,
+                      cache_position=self.pos, position_embeddings=pos_emb)[0]
+        return self.model.lm_head(self.model.model.norm(h))[:, -1]
+
+    def step(self, tok, beam_idx, k):
+        """k-th new token (k >= 0): feed `tok` (rows,), re-order the cache by `beam_idx`, return next logits."""
+        self.tok.copy_(tok)
+        self.beam.copy_(beam_idx)
+        self.pos.fill_(self.P + k)
+        self.step_no.fill_(k)
+        if self.graph is None:
+            # first token: run eagerly (this is also the warm-up capture needs), then record the same body once;
+            # recording executes nothing, so the state (cache, mask) is advanced exactly once per token
+            out = self._body().clone()
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logits = self._body()
+            return out
+        self.graph.replay()
+        return self.logits
+
+
 class _Stack(nn.Module):
     def __init__(self, cfg, hybrid_layers, impl, gating):
         super().__init__()
@@ -125,7 +219,7 @@ class ReportDecoder(nn.Module):
         return self.lm_head(self.model.norm(h))
 
     # ---- generation ------------------------------------------------------------------------------------------
-    def _greedy(self, logits, cache, attn, dtype, eos_t, fill, min_new, max_new, rep_pen):
+    def _greedy(self, logits, cache, attn, dtype, eos_t, fill, min_new, max_new, rep_pen, stepper=None):
         """num_beams = 1 (HF `_sample` with do_sample=False): the processors act on the raw LOGITS here (on
         log-probabilities in beam search), finished rows keep emitting the pad token."""
         B, dev = logits.shape[0], logits.device
@@ -147,6 +241,9 @@ class ReportDecoder(nn.Module):
                 alive = alive & ~torch.isin(tok, eos_t)
             if seq.shape[1] >= max_new or not bool(alive.any()):
                 return seq
+            if stepper is not None:
+                logits = stepper.step(tok, torch.arange(B, device=dev), seq.shape[1] - 1)
+                continue
             attn = torch.cat([attn, torch.ones(B, 1, dtype=attn.dtype, device=dev)], dim=1)
             emb = self.model.embed_tokens(tok)[:, None, :].to(dtype)
             logits = self.forward(emb, attention_mask=attn, past_key_values=cache)[:, -1]
@@ -154,8 +251,9 @@ class ReportDecoder(nn.Module):
     @torch.no_grad()
     def generate(self, inputs_embeds, attention_mask=None, num_beams=1, do_sample=False, min_new_tokens=0,
                  max_new_tokens=20, repetition_penalty=1.0, length_penalty=1.0, eos_token_id=None, pad_token_id=None,
-                 early_stopping=False, temperature=None):
-        """Greedy (num_beams=1) / beam search over a prompt given as embeddings.  Returns (B, <= max_new_tokens) ids."""
+                 early_stopping=False, temperature=None, use_graph=None):
+        """Greedy (num_beams=1) / beam search over a prompt given as embeddings.  Returns (B, <= max_new_tokens) ids.
+        use_graph (default: on for HIP devices): static KV cache + one hipGraph replay per generated token."""
         if do_sample:
             raise NotImplementedError("the reference decodes with do_sample=False")
         dev = inputs_embeds.device
@@ -173,10 +271,23 @@ class ReportDecoder(nn.Module):
 
         cache = KVCache()
         logits = self.forward(inputs_embeds, attention_mask=attention_mask, past_key_values=cache)[:, -1]   # (B, V)
+        if use_graph is None:
+            use_graph = inputs_embeds.is_cuda
+        stepper = None
+        if use_graph:
+            # the captured graph is reused by later calls with the same shapes (capture costs ~a hundred ms for 32 layers)
+            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev))
+            stepper = getattr(self, "_steppers", {}).get(key)
+            if stepper is None:
+                stepper = _GraphStepper(self, B * nb, attention_mask, cache, max_new_tokens, inputs_embeds.dtype)
+                self.__dict__.setdefault("_steppers", {})[key] = stepper
+            else:
+                stepper.reset(attention_mask, cache)
         if nb == 1:
             return self._greedy(logits, cache, attention_mask, inputs_embeds.dtype, eos_t, fill, min_new_tokens,
-                                max_new_tokens, repetition_penalty)
-        cache.expand(nb)
+                                max_new_tokens, repetition_penalty, stepper)
+        if stepper is None:
+            cache.expand(nb)
         attn = attention_mask.repeat_interleave(nb, dim=0)
         vocab = logits.shape[-1]
         logits = logits.repeat_interleave(nb, dim=0)
@@ -224,7 +335,8 @@ class ReportDecoder(nn.Module):
             fin_seq = torch.take_along_dim(m_seq, best[:, :, None], dim=1)
             fin_score = torch.take_along_dim(m_score, best, dim=1)
             fin_done = torch.take_along_dim(m_done, best, dim=1)
-            cache.reorder(beam_src.view(-1))
+            if stepper is None:
+                cache.reorder(beam_src.view(-1))
             cur += 1
             # early-stop heuristic of early_stopping=False: best live score at the CURRENT length vs worst finished
             hyp_len = (max_new_tokens if (early_stopping == "never" and length_penalty > 0.0) else cur)
@@ -235,6 +347,9 @@ class ReportDecoder(nn.Module):
             if not bool(unfinished):
                 break
             tok = run_seq[:, :, cur - 1].reshape(B * nb)
+            if stepper is not None:
+                logits = stepper.step(tok, beam_src.view(-1), cur - 1)
+                continue
             attn = torch.cat([attn, torch.ones(B * nb, 1, dtype=attn.dtype, device=dev)], dim=1)
             emb = self.model.embed_tokens(tok)[:, None, :]
             logits = self.forward(emb.to(inputs_embeds.dtype), attention_mask=attn, past_key_values=cache)[:, -1]
