@@ -1,23 +1,33 @@
 #!/bin/bash
 # Dev helper run ON the GPU box via gpurun: tests, bench lines, rocprofv3 kernel stats + PMC passes.
-# Everything lands in gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
+# Only text summaries land in gpurun_out/ (it is size-capped); raw rocprof databases stay in /tmp on the box.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
 TAG=${1:-r01}
-(timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -15) > $O/pytest_gpu.log
+(timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6) > $O/pytest_gpu.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > $O/smoke.log
-for w in scan_fwd_target scan_fwd_cfg2 scan_fwd_target_bf16; do
+(timeout 900 python bench.py 2>&1 | tail -1) > $O/bench_default.json
+for w in scan_fwd_target scan_fwd_cfg2 scan_fwd_target_bf16 arm_pretrain_base_192 decode_llama7b_128; do
   (timeout 600 python bench.py --workload $w 2>&1 | tail -1) > $O/bench_$w.json
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_stats_$TAG -o scan -- python $R/bench.py --workload scan_fwd_target --steps 50 --warmup 5 --no-cpu-baseline > $O/prof_stats_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_fetch_$TAG -o scan -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_fetch_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_write_$TAG -o scan -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_write_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $O/prof_sq_$TAG -o scan -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_sq_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/prof_sq2_$TAG -o scan -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_sq2_$TAG.log 2>&1
+P=/tmp/prof_$TAG; mkdir -p $P
+prof() { # name, rocprof args..., -- cmd
+  local name=$1; shift
+  timeout 900 rocprofv3 "$@" > $P/$name.log 2>&1
+}
+prof scan_stats --kernel-trace --stats -d $P/scan_stats -o r -- python $R/bench.py --workload scan_fwd_target --steps 100 --warmup 10 --no-cpu-baseline
+prof scan_fetch --kernel-trace --pmc FETCH_SIZE -d $P/scan_fetch -o r -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline
+prof scan_write --kernel-trace --pmc WRITE_SIZE -d $P/scan_write -o r -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline
+prof scan_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $P/scan_sq -o r -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline
+prof scan_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $P/scan_sq2 -o r -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline
+prof pretrain_stats --kernel-trace --stats -d $P/pretrain_stats -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 3 --warmup 1 --no-cpu-baseline
+prof decode_stats --kernel-trace --stats -d $P/decode_stats -o r -- python $R/bench.py --workload decode_llama7b_128 --steps 1 --warmup 1
 cd $R
-find $O -name "*.csv" | head -50 > $O/csv_list.txt
-cat $O/pytest_gpu.log $O/smoke.log $O/bench_*.json
+for n in scan_stats scan_fetch scan_write scan_sq scan_sq2 pretrain_stats decode_stats; do
+  python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -45 | cut -c1-170 > $O/prof_${TAG}_$n.txt
+done
+cat $O/pytest_gpu.log $O/smoke.log; for f in $O/bench_*.json; do echo "== $f"; cut -c1-260 $f; done
