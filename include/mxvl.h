@@ -135,6 +135,48 @@ typedef struct mxvl_conv1d_bwd_desc {
   void *dbias;   /* (dim) fp32, accumulated into, optional */
 } mxvl_conv1d_bwd_desc;
 
+/*
+ * Single-token decoder step of the report generator (bf16 weights and activations, fp32 accumulation), rows =
+ * batch * beams <= 8.  Replaces per-token HF `LlamaForCausalLM.forward` + cuBLAS GEMVs
+ * (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301; layer arithmetic as restated in
+ * EMRRG/models/hybrid_decoder_layer.py:185-199, 266-337, 392-457).
+ *
+ * mxvl_decode_gemv:  y[m][n] = epi( sum_k W[n][k] * xhat[m][k] ),  xhat = x, or RMSNorm(x; norm_weight, eps) when
+ * norm_weight != NULL.  epi: + bias[n]; + residual[m][n]; swiglu = 1: y = silu(W xhat) * (W2 xhat); out_f32: fp32 y.
+ * W, W2: (N, K) row-major bf16 (nn.Linear layout).  rows * K * 2 bytes must fit in LDS (<= 150 KiB).
+ */
+typedef struct mxvl_gemv_desc {
+  int32_t rows, K, N;
+  int32_t swiglu, out_f32;
+  float eps;
+  const void *x;            /* (rows, K) bf16 */
+  const void *norm_weight;  /* (K) bf16, optional */
+  const void *W, *W2;       /* (N, K) bf16; W2 only with swiglu */
+  const void *bias;         /* (N) bf16, optional */
+  const void *residual;     /* (rows, N) bf16, optional */
+  void *y;                  /* (rows, N) bf16, or fp32 when out_f32 */
+} mxvl_gemv_desc;
+
+/*
+ * mxvl_decode_attn: RoPE on the new q/k, append k/v at *pos to the cache, one-query attention per (row, head).
+ * The cache is (rows, n_kv_heads, max_len, head_dim) bf16 indexed by PHYSICAL slot; slot_table[row][t] names the slot
+ * holding position t of the hypothesis that `row` continues, so beam re-ordering never moves cache lines.
+ */
+typedef struct mxvl_decode_attn_desc {
+  int32_t rows, n_heads, n_kv_heads, head_dim, max_len;
+  float scale;
+  const void *qkv;          /* (rows, (n_heads + 2*n_kv_heads) * head_dim) bf16: fused q|k|v projection */
+  const void *cos, *sin;    /* (rows, head_dim) fp32 at the current position */
+  void *k_cache, *v_cache;
+  const void *slot_table;   /* (rows, max_len) int32 */
+  const void *pos;          /* device int64 scalar: position being written */
+  const void *mask;         /* (rows, max_len) int64, nonzero = may attend */
+  void *out;                /* (rows, n_heads * head_dim) bf16 */
+} mxvl_decode_attn_desc;
+
+int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);
+int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
+
 int mxvl_abi_version(void);
 /* time steps covered by one checkpoint chunk for a sequence of `seqlen` steps and `dstate` states */
 int mxvl_scan_chunk_len(int seqlen, int dstate);

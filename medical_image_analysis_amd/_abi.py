@@ -29,7 +29,7 @@ STATUS = {
 SYMBOLS = [
     "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fwd", "mxvl_scan_bwd",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
-    "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel",
+    "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
 ]
 
 
@@ -77,6 +77,24 @@ class Conv1dBwdDesc(ctypes.Structure):
     ]
 
 
+class GemvDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("K", c_int32), ("N", c_int32), ("swiglu", c_int32), ("out_f32", c_int32),
+        ("eps", ctypes.c_float),
+        ("x", c_void_p), ("norm_weight", c_void_p), ("W", c_void_p), ("W2", c_void_p), ("bias", c_void_p),
+        ("residual", c_void_p), ("y", c_void_p),
+    ]
+
+
+class DecodeAttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32), ("max_len", c_int32),
+        ("scale", ctypes.c_float),
+        ("qkv", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p),
+        ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p), ("out", c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -94,7 +112,7 @@ def load() -> ctypes.CDLL:
     if lib.mxvl_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libmxvl.so ABI {lib.mxvl_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
-    for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd"):
+    for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_conv1d_update.restype = c_int

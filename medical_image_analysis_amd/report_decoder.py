@@ -151,6 +151,123 @@ class _GraphStepper:
         return self.logits
 
 
+class _KernelStepper:
+    """One decode step on the hand-written HIP kernels (csrc/decode.hip): per layer a fused RMSNorm+QKV GEMV, the
+    RoPE/cache-append/attention kernel, o_proj GEMV (+residual), fused RMSNorm + gate/up GEMV + SwiGLU, down GEMV
+    (+residual); then RMSNorm + lm_head.  161 launches per token for 32 layers, captured once in a hipGraph.
+    Beam re-ordering permutes a (rows, max_len) int32 slot table; cache lines never move."""
+
+    @staticmethod
+    def supported(model, rows, dtype, device):
+        cfg = model.config
+        D = cfg.hidden_size // cfg.num_attention_heads
+        conditioned = any(model.model.layers[i].vis_x is not None for i in model.hybrid_layers)
+        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and 256 % D == 0
+                and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and not conditioned
+                and rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024)
+
+    def __init__(self, model, rows, prompt_mask, dyn_cache, max_new, dtype):
+        import ctypes
+        from . import _abi
+        self._abi, self._ct = _abi, ctypes
+        self.lib = _abi.load()
+        dev = prompt_mask.device
+        cfg = model.config
+        self.model, self.rows = model, rows
+        self.H, self.Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.D = cfg.hidden_size // self.H
+        self.hidden, self.inter, self.V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+        self.P = prompt_mask.shape[1]
+        self.max_len = self.P + max_new
+        model.fuse_qkv_()
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        L = cfg.num_hidden_layers
+        self.kc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
+        self.vc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
+        self.x = torch.zeros(rows, self.hidden, **bf)
+        self.x2 = torch.zeros(rows, self.hidden, **bf)
+        self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
+        self.att = torch.zeros(rows, self.H * self.D, **bf)
+        self.act = torch.zeros(rows, self.inter, **bf)
+        self.logits = torch.zeros(rows, self.V, dtype=torch.float32, device=dev)
+        self.cos = torch.zeros(rows, self.D, dtype=torch.float32, device=dev)
+        self.sin = torch.zeros(rows, self.D, dtype=torch.float32, device=dev)
+        self.slot = torch.zeros(rows, self.max_len, dtype=torch.int32, device=dev)
+        self.own = torch.arange(rows, dtype=torch.int32, device=dev)[:, None]
+        self.mask = torch.zeros(rows, self.max_len, dtype=torch.long, device=dev)
+        self.n_real = torch.zeros(rows, 1, dtype=torch.long, device=dev)
+        self.tok = torch.zeros(rows, dtype=torch.long, device=dev)
+        self.beam = torch.arange(rows, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.step_no = torch.zeros(1, dtype=torch.long, device=dev)
+        self.graph = None
+        self.reset(prompt_mask, dyn_cache)
+
+    def reset(self, prompt_mask, dyn_cache):
+        rep = self.rows // prompt_mask.shape[0]
+        for i in range(len(self.kc)):
+            n = dyn_cache.k[i].shape[-2]
+            self.kc[i][:, :, :n] = dyn_cache.k[i].repeat_interleave(rep, dim=0)
+            self.vc[i][:, :, :n] = dyn_cache.v[i].repeat_interleave(rep, dim=0)
+        self.mask.zero_()
+        self.mask[:, :self.P] = prompt_mask.repeat_interleave(rep, dim=0)
+        self.n_real.copy_(self.mask[:, :self.P].sum(-1, keepdim=True))
+        self.slot.copy_(self.own.expand(-1, self.max_len))
+
+    def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False):
+        d = self._abi.GemvDesc()
+        d.rows, d.K, d.N = self.rows, K, N
+        d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), eps
+        d.x, d.norm_weight, d.W = x.data_ptr(), self._abi.ptr(norm), W.data_ptr()
+        d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), y.data_ptr()
+        self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
+
+    def _body(self):
+        m = self.model
+        self.slot.copy_(self.slot.index_select(0, self.beam))
+        self.slot.index_copy_(1, self.pos, self.own)
+        self.mask.index_fill_(1, self.pos, 1)
+        self.x.copy_(m.model.embed_tokens(self.tok))
+        cos, sin = m.model.rotary_emb(self.cos, self.n_real + self.step_no)   # fp32 (rows, 1, D)
+        self.cos.copy_(cos[:, 0])
+        self.sin.copy_(sin[:, 0])
+        a = self._abi.DecodeAttnDesc()
+        a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
+        a.scale = self.D ** -0.5
+        a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
+        a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
+        sp = self._abi.stream_ptr(self.x.device)
+        for i, layer in enumerate(m.model.layers):
+            at = layer.self_attn
+            self._gemv(self.x, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], norm=layer.input_layernorm.weight,
+                       eps=layer.input_layernorm.variance_epsilon, bias=at.qkv_bias)
+            a.k_cache, a.v_cache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
+            self._abi.check(self.lib.mxvl_decode_attn(self._ct.byref(a), sp), "mxvl_decode_attn")
+            self._gemv(self.att, at.o_proj.weight, self.x2, self.H * self.D, self.hidden, res=self.x)
+            self._gemv(self.x2, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter,
+                       norm=layer.post_attention_layernorm.weight, eps=layer.post_attention_layernorm.variance_epsilon,
+                       W2=layer.mlp.up_proj.weight)
+            self._gemv(self.act, layer.mlp.down_proj.weight, self.x, self.inter, self.hidden, res=self.x2)
+        self._gemv(self.x, m.lm_head.weight, self.logits, self.hidden, self.V, norm=m.model.norm.weight,
+                   eps=m.model.norm.variance_epsilon, out_f32=True)
+        return self.logits
+
+    def step(self, tok, beam_idx, k):
+        self.tok.copy_(tok)
+        self.beam.copy_(beam_idx)
+        self.pos.fill_(self.P + k)
+        self.step_no.fill_(k)
+        if self.graph is None:
+            out = self._body().clone()      # eager first token = the warm-up hipGraph capture needs
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+            return out
+        self.graph.replay()
+        return self.logits
+
+
 class _Stack(nn.Module):
     def __init__(self, cfg, hybrid_layers, impl, gating):
         super().__init__()
@@ -189,6 +306,21 @@ class ReportDecoder(nn.Module):
         bad = [m for m in missing if not (m.endswith("_proj.bias") or "cross_attn" in m)]
         if bad or unexpected:
             raise RuntimeError(f"state_dict mismatch: missing {bad}, unexpected {list(unexpected)}")
+
+    def fuse_qkv_(self):
+        """Re-home q/k/v weights (and biases) of every layer in ONE (H+2Hkv)*D x hidden buffer; the nn.Linear
+        parameters become views of it, so state_dict keys and the torch path are unchanged and no memory is added."""
+        for layer in self.model.layers:
+            at = layer.self_attn
+            if getattr(at, "qkv_weight", None) is not None:
+                continue
+            with torch.no_grad():
+                W = torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], dim=0).contiguous()
+                b = torch.cat([at.q_proj.bias, at.k_proj.bias, at.v_proj.bias], dim=0).contiguous()
+                nq, nk = at.q_proj.weight.shape[0], at.k_proj.weight.shape[0]
+                at.q_proj.weight.data, at.k_proj.weight.data, at.v_proj.weight.data = W[:nq], W[nq:nq + nk], W[nq + nk:]
+                at.q_proj.bias.data, at.k_proj.bias.data, at.v_proj.bias.data = b[:nq], b[nq:nq + nk], b[nq + nk:]
+            at.qkv_weight, at.qkv_bias = W, b
 
     def get_input_embeddings(self):
         return self.model.embed_tokens
@@ -276,10 +408,12 @@ class ReportDecoder(nn.Module):
         stepper = None
         if use_graph:
             # the captured graph is reused by later calls with the same shapes (capture costs ~a hundred ms for 32 layers)
-            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev))
+            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph))
             stepper = getattr(self, "_steppers", {}).get(key)
             if stepper is None:
-                stepper = _GraphStepper(self, B * nb, attention_mask, cache, max_new_tokens, inputs_embeds.dtype)
+                cls = _KernelStepper if (use_graph != "torch" and _KernelStepper.supported(
+                    self, B * nb, inputs_embeds.dtype, dev)) else _GraphStepper
+                stepper = cls(self, B * nb, attention_mask, cache, max_new_tokens, inputs_embeds.dtype)
                 self.__dict__.setdefault("_steppers", {})[key] = stepper
             else:
                 stepper.reset(attention_mask, cache)
