@@ -49,19 +49,48 @@ __device__ inline float wave_sum(float v) {
   return v;
 }
 
+__device__ inline uint4 ldw(const uint16_t* row, int kk, int K) {
+  return kk < K ? *(const uint4*)(row + kk) : make_uint4(0, 0, 0, 0);
+}
+
+// Work unit = one output column n: weight row n of W (with SwiGLU: gate row n of W, then up row n of W2).  Units are
+// dealt round-robin to the 16 x gridDim.x waves of the launch, a whole weight row per wave at a time, so every wave
+// streams 2*K contiguous bytes with PF 16-byte loads in flight per lane.  The next row's first PF loads are issued
+// before the current row's cross-lane reduction, and the very first row's before the RMSNorm prologue, so the HBM
+// stream never waits for the prologue or an epilogue.
 template <int M>
 __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   constexpr int NW = 16;  // waves per workgroup (one workgroup per CU)
+  constexpr int PF = 8;   // 16-byte loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) uint16_t sx[];  // [M][K] (normalised) activations, bf16
   __shared__ float s_rstd[kMaxRows];
   __shared__ float s_part[kMaxRows][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = p.K, N = p.N;
+  const int S = p.swiglu ? 2 : 1;
+  const int TW = gridDim.x * NW;                      // waves in the launch
+  const int n_first = blockIdx.x * NW + wave;
+  const int n_items = n_first < N ? ((N - 1 - n_first) / TW + 1) * S : 0;   // weight rows this wave streams
+  auto row_ptr = [&](int item) -> const uint16_t* {
+    const int n = n_first + (p.swiglu ? item >> 1 : item) * TW;
+    return ((p.swiglu && (item & 1)) ? p.W2 : p.W) + (size_t)n * K;
+  };
+  uint4 pre[PF];
+  if (n_items > 0) {
+    const uint16_t* w = row_ptr(0);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) pre[j] = ldw(w, lane * 8 + j * 512, K);
+  }
 
   if (p.g) {  // RMSNorm statistics in fp32, as Qwen2RMSNorm (hybrid_decoder_layer.py:193-198)
+#pragma unroll
     for (int m = 0; m < M; ++m) {
       float s = 0.0f;
-      for (int k = tid; k < K; k += 1024) { const float v = bf2f(p.x[(size_t)m * K + k]); s = fmaf(v, v, s); }
+      for (int k = tid * 2; k < K; k += 2048) {
+        const uint32_t raw = *(const uint32_t*)(p.x + (size_t)m * K + k);
+        const float a = bf2f((uint16_t)raw), b = bf2f((uint16_t)(raw >> 16));
+        s = fmaf(a, a, fmaf(b, b, s));
+      }
       s = wave_sum(s);
       if (lane == 0) s_part[m][wave] = s;
     }
@@ -87,54 +116,54 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   }
   __syncthreads();
 
-  const int per_wg = (N + gridDim.x - 1) / gridDim.x;
-  const int n_lo = blockIdx.x * per_wg, n_hi = min(N, n_lo + per_wg);
-  for (int n0 = n_lo + wave * 2; n0 < n_hi; n0 += NW * 2) {   // two weight rows in flight per wave
-    float acc[2][M], acc2[2][M];
+  float gate[M];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+  for (int m = 0; m < M; ++m) gate[m] = 0.0f;
+  for (int item = 0; item < n_items; ++item) {
+    float acc[M];
 #pragma unroll
-      for (int m = 0; m < M; ++m) { acc[r][m] = 0.0f; acc2[r][m] = 0.0f; }
-    const int n1 = (n0 + 1 < n_hi) ? n0 + 1 : n0;
-    const uint16_t* w0 = p.W + (size_t)n0 * K;
-    const uint16_t* w1 = p.W + (size_t)n1 * K;
-    const uint16_t* v0 = p.swiglu ? p.W2 + (size_t)n0 * K : nullptr;
-    const uint16_t* v1 = p.swiglu ? p.W2 + (size_t)n1 * K : nullptr;
-#pragma unroll 4
-    for (int kk = lane * 8; kk < K; kk += 512) {
-      const uint4 a0 = *(const uint4*)(w0 + kk);
-      const uint4 a1 = *(const uint4*)(w1 + kk);
-      uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0;
-      if (p.swiglu) { b0 = *(const uint4*)(v0 + kk); b1 = *(const uint4*)(v1 + kk); }
+    for (int m = 0; m < M; ++m) acc[m] = 0.0f;
+    const uint16_t* w = row_ptr(item);
 #pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
-        acc[0][m] = dot2(a0.x, xv.x, dot2(a0.y, xv.y, dot2(a0.z, xv.z, dot2(a0.w, xv.w, acc[0][m]))));
-        acc[1][m] = dot2(a1.x, xv.x, dot2(a1.y, xv.y, dot2(a1.z, xv.z, dot2(a1.w, xv.w, acc[1][m]))));
-        if (p.swiglu) {
-          acc2[0][m] = dot2(b0.x, xv.x, dot2(b0.y, xv.y, dot2(b0.z, xv.z, dot2(b0.w, xv.w, acc2[0][m]))));
-          acc2[1][m] = dot2(b1.x, xv.x, dot2(b1.y, xv.y, dot2(b1.z, xv.z, dot2(b1.w, xv.w, acc2[1][m]))));
+    for (int j = 0; j < PF; ++j) {
+      const int kk = lane * 8 + j * 512;
+      if (kk < K) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
+          acc[m] = dot2(pre[j].x, xv.x, dot2(pre[j].y, xv.y, dot2(pre[j].z, xv.z, dot2(pre[j].w, xv.w, acc[m]))));
         }
       }
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int n = n0 + r;
+#pragma unroll 4
+    for (int kk = lane * 8 + PF * 512; kk < K; kk += 512) {
+      const uint4 a0 = *(const uint4*)(w + kk);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
-        float v = wave_sum(acc[r][m]);
-        const float v2 = p.swiglu ? wave_sum(acc2[r][m]) : 0.0f;
-        if (lane == 0 && n < n_hi) {
-          const size_t o = (size_t)m * N + n;
-          if (p.swiglu) {  // bf16(bf16(silu(gate)) * up), gate/up rounded to bf16 first (what the torch modules do)
-            const float gte = bf2f(f2bf(v)), up = bf2f(f2bf(v2));
-            ((uint16_t*)p.y)[o] = f2bf(bf2f(f2bf(gte * sigmoid(gte))) * up);
-          } else {
-            if (p.bias) v += bf2f(p.bias[n]);
-            if (p.res) v = bf2f(f2bf(v)) + bf2f(p.res[o]);  // the linear output rounds to bf16 before the residual add
-            if (p.out_f32) ((float*)p.y)[o] = v; else ((uint16_t*)p.y)[o] = f2bf(v);
-          }
+        const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
+        acc[m] = dot2(a0.x, xv.x, dot2(a0.y, xv.y, dot2(a0.z, xv.z, dot2(a0.w, xv.w, acc[m]))));
+      }
+    }
+    if (item + 1 < n_items) {  // next row's head goes in flight before this row's reduction
+      const uint16_t* wn = row_ptr(item + 1);
+#pragma unroll
+      for (int j = 0; j < PF; ++j) pre[j] = ldw(wn, lane * 8 + j * 512, K);
+    }
+    const int n = n_first + (p.swiglu ? item >> 1 : item) * TW;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float v = wave_sum(acc[m]);
+      const size_t o = (size_t)m * N + n;
+      if (p.swiglu) {
+        if (!(item & 1)) gate[m] = v;
+        else if (lane == 0) {  // bf16(bf16(silu(gate)) * up), gate/up rounded to bf16 first (what the torch modules do)
+          const float gte = bf2f(f2bf(gate[m])), up = bf2f(f2bf(v));
+          ((uint16_t*)p.y)[o] = f2bf(bf2f(f2bf(gte * sigmoid(gte))) * up);
         }
+      } else if (lane == 0) {
+        if (p.bias) v += bf2f(p.bias[n]);
+        if (p.res) v = bf2f(f2bf(v)) + bf2f(p.res[o]);  // the linear output rounds to bf16 before the residual add
+        if (p.out_f32) ((float*)p.y)[o] = v; else ((uint16_t*)p.y)[o] = f2bf(v);
       }
     }
   }
@@ -153,15 +182,23 @@ struct AttnArgs {
   uint16_t* out;             // (rows, H * D)
 };
 
-__global__ __launch_bounds__(256) void decode_attn_kernel(const AttnArgs p) {
+constexpr int kAttnWaves = 8;
+
+// One workgroup per (head, row).  A cached K or V line of D bf16 is read by LPR = D/8 lanes with one 16-byte load
+// each, so a wave covers 64/LPR positions per load and the workgroup 8 x 64/LPR; K and V of a position are loaded
+// together and folded into a running (max, sum, out[8]) per lane group (one-pass softmax), merged once at the end.
+template <int D>
+__global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const AttnArgs p) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = kAttnWaves * RPW;
   extern __shared__ float sm[];
-  const int D = p.D, T = p.max_len;
-  float* sq = sm;            // [D] rotated query
-  float* sk = sq + D;        // [D] rotated new key
-  float* sv = sk + D;        // [D] new value
-  float* sc = sv + D;        // [T] scores / probabilities
-  float* red = sc + T;       // [8] reductions + [2][D] partial outputs
-  float* so = red + 8;
+  const int T = p.max_len;
+  float* sq = sm;                 // [D] rotated query
+  float* sk = sq + D;             // [D] rotated new key
+  float* sv = sk + D;             // [D] new value
+  float* gm = sv + D;             // [NG] group maxima
+  float* gl = gm + NG;            // [NG] group sums
+  float* go = gl + NG;            // [NG][D] group outputs
+  int* ssl = (int*)(go + NG * D); // [T] slot of each position, -1 = masked
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, m = blockIdx.y;
   const int group = p.H / p.Hkv, hk = h / group;
@@ -170,6 +207,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const AttnArgs p) {
   const uint16_t* q = p.qkv + row + (size_t)h * D;
   const uint16_t* kn = p.qkv + row + (size_t)(p.H + hk) * D;
   const uint16_t* vn = p.qkv + row + (size_t)(p.H + p.Hkv + hk) * D;
+  for (int t = tid; t <= pos; t += kAttnWaves * 64)
+    ssl[t] = p.mask[(size_t)m * T + t] != 0 ? p.slot[(size_t)m * T + t] : -1;
   // RoPE (hybrid_decoder_layer.py:284-322): x*cos + rotate_half(x)*sin, computed in the activation dtype (bf16)
   if (tid < D) {
     const int d = tid, half = D / 2;
@@ -178,7 +217,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const AttnArgs p) {
     const float kd = bf2f(kn[d]), ko = d < half ? -bf2f(kn[d + half]) : bf2f(kn[d - half]);
     const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * s))));
     const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * s))));
-    sq[d] = qr;
+    sq[d] = qr * p.scale;
     sk[d] = kr;
     sv[d] = bf2f(vn[d]);
     if (h % group == 0) {  // one head of the group appends to the cache (slot m owns position pos of beam m)
@@ -188,71 +227,79 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const AttnArgs p) {
     }
   }
   __syncthreads();
-  // scores over the allowed cached positions (t <= pos); position pos uses the fresh key
-  float lmax = -INFINITY;
-  for (int t = tid; t <= pos; t += 256) {
-    float s = -INFINITY;
-    if (p.mask[(size_t)m * T + t] != 0) {
-      float acc = 0.0f;
-      if (t == pos) {
-        for (int d = 0; d < D; ++d) acc = fmaf(sq[d], sk[d], acc);
-      } else {
-        const int sl = p.slot[(size_t)m * T + t];
-        const uint4* kr = (const uint4*)(p.kc + (((size_t)sl * p.Hkv + hk) * T + t) * D);
-        for (int d8 = 0; d8 < D / 8; ++d8) {
-          const uint4 kv = kr[d8];
-          const uint32_t w[4] = {kv.x, kv.y, kv.z, kv.w};
+  const int sub = lane % LPR, g = wave * RPW + lane / LPR;
+  float qv[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc = fmaf(sq[d8 * 8 + 2 * j], __builtin_bit_cast(float, w[j] << 16), acc);
-            acc = fmaf(sq[d8 * 8 + 2 * j + 1], __builtin_bit_cast(float, w[j] & 0xffff0000u), acc);
-          }
-        }
-      }
-      s = acc * p.scale;
+  for (int j = 0; j < 8; ++j) qv[j] = sq[sub * 8 + j];
+  float mx = -1e30f, l = 0.0f, o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+  auto fold = [&](bool live, const float* kf, const float* vf) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(qv[j], kf[j], s);
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    const float mn = live ? fmaxf(mx, s) : mx;
+    const float corr = fast_exp(mx - mn), pr = live ? fast_exp(s - mn) : 0.0f;
+    mx = mn;
+    l = fmaf(l, corr, pr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fmaf(o[j], corr, pr * vf[j]);
+  };
+  auto unpack = [](const uint4 v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = __builtin_bit_cast(float, w[j] << 16);
+      f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
     }
-    sc[t] = s;
-    lmax = fmaxf(lmax, s);
-  }
+  };
+  constexpr int U = 4;
+  for (int t0 = g; t0 < pos; t0 += NG * U) {   // cached positions 0 .. pos-1
+    uint4 kq[U], vq[U];
+    bool live[U];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off, 64));
-  if (lane == 0) red[wave] = lmax;
-  __syncthreads();
-  const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float lsum = 0.0f;
-  for (int t = tid; t <= pos; t += 256) {
-    const float e = (sc[t] == -INFINITY) ? 0.0f : fast_exp(sc[t] - gmax);
-    sc[t] = e;
-    lsum += e;
-  }
-  lsum = wave_sum(lsum);
-  __syncthreads();
-  if (lane == 0) red[4 + wave] = lsum;
-  __syncthreads();
-  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  // out[d] = sum_t p_t V[t][d]: thread = (d, half of the positions)
-  const int d = tid % D, part = tid / D, parts = 256 / D;
-  float o = 0.0f;
-  if (part < parts) {
-    for (int t = part; t <= pos; t += parts) {
-      const float pt = sc[t];
-      if (pt != 0.0f) {
-        float v;
-        if (t == pos) v = sv[d];
-        else {
-          const int sl = p.slot[(size_t)m * T + t];
-          v = bf2f(p.vc[(((size_t)sl * p.Hkv + hk) * T + t) * D + d]);
-        }
-        o = fmaf(pt, v, o);
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      const int sl = t < pos ? ssl[t] : -1;
+      live[u] = sl >= 0;
+      kq[u] = make_uint4(0, 0, 0, 0);
+      vq[u] = kq[u];
+      if (live[u]) {
+        const size_t a = (((size_t)sl * p.Hkv + hk) * T + t) * D + sub * 8;
+        kq[u] = *(const uint4*)(p.kc + a);
+        vq[u] = *(const uint4*)(p.vc + a);
       }
     }
-    so[part * D + d] = o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kf[8], vf[8];
+      unpack(kq[u], kf);
+      unpack(vq[u], vf);
+      fold(live[u], kf, vf);
+    }
   }
+  if (g == 0) {  // the fresh position (always attended: its mask bit was just set)
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kf[j] = sk[sub * 8 + j]; vf[j] = sv[sub * 8 + j]; }
+    fold(ssl[pos] >= 0, kf, vf);
+  }
+  if (sub == 0) { gm[g] = mx; gl[g] = l; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) go[g * D + sub * 8 + j] = o[j];
   __syncthreads();
   if (tid < D) {
-    float tot = 0.0f;
-    for (int q2 = 0; q2 < parts; ++q2) tot += so[q2 * D + tid];
-    p.out[(size_t)m * p.H * D + (size_t)h * D + tid] = f2bf(tot * inv);
+    float gmax = -1e30f;
+    for (int i = 0; i < NG; ++i) gmax = fmaxf(gmax, gm[i]);
+    float num = 0.0f, den = 0.0f;
+    for (int i = 0; i < NG; ++i) {
+      const float w = fast_exp(gm[i] - gmax);
+      num = fmaf(w, go[i * D + tid], num);
+      den = fmaf(w, gl[i], den);
+    }
+    p.out[(size_t)m * p.H * D + (size_t)h * D + tid] = f2bf(num / den);
   }
 }
 
@@ -263,7 +310,7 @@ static int dec_check() {
 
 template <int M>
 static int launch_gemv(const GemvArgs& a, hipStream_t s) {
-  const int grid = std::max(1, std::min(256, (a.N + 31) / 32));
+  const int grid = std::max(1, std::min(256, (a.N + 15) / 16));
   const size_t lds = (size_t)M * a.K * sizeof(uint16_t);
   if (lds > 150 * 1024) return MXVL_ERR_UNSUPPORTED;  // rows * K bf16 must fit one CU's LDS
   if (lds > 64 * 1024) {
@@ -312,15 +359,23 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   if (!d || !d->qkv || !d->cos || !d->sin || !d->k_cache || !d->v_cache || !d->slot_table || !d->pos || !d->mask || !d->out)
     return MXVL_ERR_NULL;
   if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0) return MXVL_ERR_SHAPE;
-  if (d->head_dim % 8 != 0 || d->head_dim > 256 || 256 % d->head_dim != 0) return MXVL_ERR_UNSUPPORTED;
+  if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;
   AttnArgs a;
   a.rows = d->rows; a.H = d->n_heads; a.Hkv = d->n_kv_heads; a.D = d->head_dim; a.max_len = d->max_len;
   a.scale = d->scale; a.qkv = (const uint16_t*)d->qkv; a.cosv = (const float*)d->cos; a.sinv = (const float*)d->sin;
   a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
   a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
-  const size_t lds = sizeof(float) * ((size_t)3 * a.D + a.max_len + 8 + (256 / a.D) * a.D);
+  const int NG = kAttnWaves * 64 / (a.D / 8);
+  const size_t lds = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
   if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.rows), dim3(256), lds, (hipStream_t)hip_stream, a);
+  const dim3 grid(a.H, a.rows), block(kAttnWaves * 64);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (a.D) {
+    case 64: hipLaunchKernelGGL(decode_attn_kernel<64>, grid, block, lds, s, a); break;
+    case 128: hipLaunchKernelGGL(decode_attn_kernel<128>, grid, block, lds, s, a); break;
+    case 256: hipLaunchKernelGGL(decode_attn_kernel<256>, grid, block, lds, s, a); break;
+    default: return MXVL_ERR_UNSUPPORTED;
+  }
   return dec_check();
 }
 

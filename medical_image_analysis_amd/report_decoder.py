@@ -88,7 +88,31 @@ class StaticKVCache:
             self.v[i].copy_(self.v[i].index_select(0, beam_idx))
 
 
-class _GraphStepper:
+class _SearchFusion:
+    """step_search(): decoder step + beam-search update (`_BeamState.advance`) as ONE captured hipGraph per token; the
+    host only reads the 1-byte `unfinished` flag between replays."""
+    sgraph = None
+    sstate = None
+
+    def _search_body(self, state):
+        self.tok.copy_(state.tok)
+        self.beam.copy_(state.beam_src)
+        self.step_no.copy_((state.cur - 1).view(1))
+        self.pos.copy_((state.cur + (self.P - 1)).view(1))
+        state.advance(self._body())
+
+    def step_search(self, state):
+        if self.sgraph is None or self.sstate is not state:
+            self._search_body(state)            # eager once: the warm-up capture needs; advances exactly one token
+            torch.cuda.synchronize()
+            self.sgraph, self.sstate = torch.cuda.CUDAGraph(), state
+            with torch.cuda.graph(self.sgraph):
+                self._search_body(state)
+            return
+        self.sgraph.replay()
+
+
+class _GraphStepper(_SearchFusion):
     """One decode step (beam re-order of the cache + one-token forward) captured ONCE in a hipGraph and replayed per
     token: a 32-layer decoder is ~1400 kernel launches per token in eager mode -- launch-bound at batch 1-3."""
 
@@ -151,7 +175,112 @@ class _GraphStepper:
         return self.logits
 
 
-class _KernelStepper:
+class _BeamState:
+    """HF beam search (transformers generation/utils.py `_beam_search`, the vectorised form) as ONE static-shape
+    update per generated token: every tensor has a fixed shape and the step index `cur` is a device scalar, so the
+    same code runs eagerly (CPU tests, torch fallback) and inside the captured hipGraph of the decode step.
+    Processors: RepetitionPenalty + MinNewTokensLength on the log-probabilities; criteria: MaxLength + EosToken."""
+
+    def __init__(self, B, nb, vocab, max_new, fill, eos, min_new, rep_pen, len_pen, early_stopping, dev):
+        self.B, self.nb, self.V, self.max_new = B, nb, vocab, max_new
+        self.fill, self.min_new, self.rep_pen, self.early = fill, min_new, rep_pen, early_stopping
+        self.eos_t = torch.tensor(eos, device=dev, dtype=torch.long)
+        self.keep = max(2, 1 + len(eos)) * nb
+        self.top_mask = torch.zeros(self.keep, dtype=torch.bool, device=dev)
+        self.top_mask[:nb] = True
+        self.ar = torch.arange(max_new, device=dev)
+        self.row0 = torch.arange(B, device=dev)[:, None] * nb
+        # (cur+1)**length_penalty and the early-stop heuristic's hypothesis length, as fp32 tables indexed by cur
+        steps = torch.arange(1, max_new + 1, dtype=torch.float64)
+        self.len_tab = steps.pow(len_pen).to(torch.float32).to(dev)
+        hyp = torch.full_like(steps, float(max_new)) if (early_stopping == "never" and len_pen > 0.0) else steps
+        self.hyp_tab = hyp.pow(len_pen).to(torch.float32).to(dev)
+        self.run_seq = torch.empty(B, nb, max_new, dtype=torch.long, device=dev)
+        self.fin_seq = torch.empty_like(self.run_seq)
+        self.run_score = torch.empty(B, nb, device=dev)
+        self.fin_score = torch.empty(B, nb, device=dev)
+        self.fin_done = torch.empty(B, nb, dtype=torch.bool, device=dev)
+        self.heur_open = torch.empty(B, 1, dtype=torch.bool, device=dev)
+        self.cur = torch.zeros((), dtype=torch.long, device=dev)
+        self.tok = torch.zeros(B * nb, dtype=torch.long, device=dev)
+        self.beam_src = torch.zeros(B * nb, dtype=torch.long, device=dev)
+        self.unfinished = torch.ones((), dtype=torch.bool, device=dev)
+        self.reset()
+
+    def reset(self):
+        self.run_seq.fill_(self.fill)
+        self.fin_seq.fill_(self.fill)
+        self.run_score.fill_(-1e9)
+        self.run_score[:, 0] = 0.0
+        self.fin_score.fill_(-1e9)
+        self.fin_done.fill_(False)
+        self.heur_open.fill_(True)
+        self.cur.zero_()
+        self.unfinished.fill_(True)
+
+    def advance(self, logits):
+        """Consume the (B*nb, V) logits of step `cur`; leaves the next tokens in .tok, the parent beam of every live
+        beam (flat row index) in .beam_src, and whether decoding goes on in .unfinished."""
+        B, nb, V, keep, cur = self.B, self.nb, self.V, self.keep, self.cur
+        has_eos = self.eos_t.numel() > 0
+        logp = torch.log_softmax(logits.float(), dim=-1)
+        if self.rep_pen != 1.0:                                                 # RepetitionPenaltyLogitsProcessor
+            flat = self.run_seq.view(B * nb, -1)
+            idx = torch.where(self.ar[None, :] < cur, flat, flat[:, :1])        # unwritten slots alias token 0 of the row
+            sc = torch.gather(logp, 1, idx)
+            pen = torch.where(sc < 0, sc * self.rep_pen, sc / self.rep_pen)
+            logp = logp.scatter(1, idx, torch.where(cur > 0, pen, sc))
+        if has_eos and self.min_new > 0:                                        # MinNewTokensLengthLogitsProcessor
+            col = logp.index_select(1, self.eos_t)
+            logp.index_copy_(1, self.eos_t, torch.where(cur < self.min_new, torch.full_like(col, -float("inf")), col))
+        acc = (logp.view(B, nb, V) + self.run_score[:, :, None]).view(B, nb * V)
+        top_lp, top_ix = torch.topk(acc, k=keep)
+        src_beam = top_ix // V
+        new_tok = top_ix % V
+        top_seq = torch.take_along_dim(self.run_seq, src_beam[:, :, None], dim=1)
+        top_seq.scatter_(2, cur.view(1, 1, 1).expand(B, keep, 1), new_tok[:, :, None])
+        hits = (cur + 1 >= self.max_new).expand(B, keep)                         # MaxLengthCriteria
+        if has_eos:
+            hits = hits | (new_tok[:, :, None] == self.eos_t).any(-1)            # EosTokenCriteria
+        # live beams for the next step: best nb candidates that did not stop
+        live_lp = top_lp + hits.float() * -1e9
+        nxt = torch.topk(live_lp, k=nb)[1]
+        run_seq = torch.take_along_dim(top_seq, nxt[:, :, None], dim=1)
+        run_score = torch.take_along_dim(live_lp, nxt, dim=1)
+        beam_src = torch.take_along_dim(src_beam, nxt, dim=1) + self.row0
+        # finished pool: candidates among the top nb that just stopped, scored with the length penalty
+        just = hits & self.top_mask[None, :]
+        cand = top_lp / self.len_tab.index_select(0, cur.view(1))
+        if self.early is True:
+            cand = cand + self.fin_done.all(-1, keepdim=True).float() * -1e9
+        cand = cand + (~self.heur_open).float() * -1e9 + (~just).float() * -1e9
+        m_seq = torch.cat([self.fin_seq, top_seq], dim=1)
+        m_score = torch.cat([self.fin_score, cand], dim=1)
+        m_done = torch.cat([self.fin_done, just], dim=1)
+        best = torch.topk(m_score, k=nb)[1]
+        fin_seq = torch.take_along_dim(m_seq, best[:, :, None], dim=1)
+        fin_score = torch.take_along_dim(m_score, best, dim=1)
+        fin_done = torch.take_along_dim(m_done, best, dim=1)
+        # early-stop heuristic of early_stopping=False: best live score at the CURRENT length vs worst finished
+        best_live = run_score[:, :1] / self.hyp_tab.index_select(0, cur.view(1))
+        worst_fin = torch.where(fin_done, fin_score.min(dim=1, keepdim=True)[0], torch.full_like(fin_score, -1e9))
+        heur_open = self.heur_open & (best_live > worst_fin).any(dim=-1, keepdim=True)
+        unfinished = heur_open.any() & ~hits.all()
+        if self.early is True:
+            unfinished = unfinished & ~fin_done.all()
+        self.tok.copy_(torch.take_along_dim(new_tok, nxt, dim=1).reshape(-1))
+        self.beam_src.copy_(beam_src.reshape(-1))
+        self.run_seq.copy_(run_seq)
+        self.run_score.copy_(run_score)
+        self.fin_seq.copy_(fin_seq)
+        self.fin_score.copy_(fin_score)
+        self.fin_done.copy_(fin_done)
+        self.heur_open.copy_(heur_open)
+        self.unfinished.copy_(unfinished)
+        self.cur.add_(1)
+
+
+class _KernelStepper(_SearchFusion):
     """One decode step on the hand-written HIP kernels (csrc/decode.hip): per layer a fused RMSNorm+QKV GEMV, the
     RoPE/cache-append/attention kernel, o_proj GEMV (+residual), fused RMSNorm + gate/up GEMV + SwiGLU, down GEMV
     (+residual); then RMSNorm + lm_head.  161 launches per token for 32 layers, captured once in a hipGraph.
@@ -162,7 +291,7 @@ class _KernelStepper:
         cfg = model.config
         D = cfg.hidden_size // cfg.num_attention_heads
         conditioned = any(model.model.layers[i].vis_x is not None for i in model.hybrid_layers)
-        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and 256 % D == 0
+        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and D in (64, 128, 256)
                 and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and not conditioned
                 and rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024)
 
@@ -395,9 +524,6 @@ class ReportDecoder(nn.Module):
         eos_t = torch.tensor(eos, device=dev, dtype=torch.long)
         # beam search pads with `pad_token_id or eos[0]` in HF (a falsy pad id 0 falls through to EOS); greedy pads with pad
         fill = (pad_token_id or (eos[0] if eos else -1)) if nb > 1 else (pad_token_id if pad_token_id is not None else (eos[0] if eos else -1))
-        keep = max(2, 1 + len(eos)) * nb
-        top_mask = torch.zeros(keep, dtype=torch.bool, device=dev)
-        top_mask[:nb] = True
         if attention_mask is None:
             attention_mask = torch.ones(inputs_embeds.shape[:2], dtype=torch.long, device=dev)
 
@@ -420,74 +546,32 @@ class ReportDecoder(nn.Module):
         if nb == 1:
             return self._greedy(logits, cache, attention_mask, inputs_embeds.dtype, eos_t, fill, min_new_tokens,
                                 max_new_tokens, repetition_penalty, stepper)
-        if stepper is None:
-            cache.expand(nb)
-        attn = attention_mask.repeat_interleave(nb, dim=0)
         vocab = logits.shape[-1]
         logits = logits.repeat_interleave(nb, dim=0)
-
-        run_seq = torch.full((B, nb, max_new_tokens), fill, dtype=torch.long, device=dev)
-        fin_seq = run_seq.clone()
-        run_score = torch.zeros(B, nb, device=dev)
-        run_score[:, 1:] = -1e9
-        fin_score = torch.full((B, nb), -1e9, device=dev)
-        fin_done = torch.zeros(B, nb, dtype=torch.bool, device=dev)
-        heur_open = torch.ones(B, 1, dtype=torch.bool, device=dev)
-        cur = 0
-        while True:
-            logp = torch.log_softmax(logits.float(), dim=-1)                       # (B*nb, V)
-            flat_seq = run_seq.view(B * nb, -1)[:, :cur]
-            if repetition_penalty != 1.0 and cur > 0:                              # RepetitionPenaltyLogitsProcessor
-                sc = torch.gather(logp, 1, flat_seq)
-                sc = torch.where(sc < 0, sc * repetition_penalty, sc / repetition_penalty)
-                logp = logp.scatter(1, flat_seq, sc)
-            if eos and cur < min_new_tokens:                                       # MinNewTokensLengthLogitsProcessor
-                logp[:, eos_t] = -float("inf")
-            acc = (logp.view(B, nb, vocab) + run_score[:, :, None]).view(B, nb * vocab)
-            top_lp, top_ix = torch.topk(acc, k=keep)
-            src_beam = top_ix // vocab
-            top_seq = torch.take_along_dim(run_seq, src_beam[:, :, None], dim=1)
-            top_seq[:, :, cur] = top_ix % vocab
-            hits = torch.full((B, keep), cur + 1 >= max_new_tokens, dtype=torch.bool, device=dev)   # MaxLengthCriteria
-            if eos:
-                hits |= torch.isin(top_seq[:, :, cur], eos_t)                       # EosTokenCriteria
-            # live beams for the next step: best nb candidates that did not stop
-            live_lp = top_lp + hits.float() * -1e9
-            nxt = torch.topk(live_lp, k=nb)[1]
-            run_seq = torch.take_along_dim(top_seq, nxt[:, :, None], dim=1)
-            run_score = torch.take_along_dim(live_lp, nxt, dim=1)
-            beam_src = torch.take_along_dim(src_beam, nxt, dim=1) + torch.arange(B, device=dev)[:, None] * nb
-            # finished pool: candidates among the top nb that just stopped, scored with the length penalty
-            just = hits & top_mask[None, :]
-            cand = top_lp / ((cur + 1) ** length_penalty)
-            cand = cand + (fin_done.all(-1, keepdim=True) & (early_stopping is True)).float() * -1e9
-            cand = cand + (~heur_open).float() * -1e9 + (~just).float() * -1e9
-            m_seq = torch.cat([fin_seq, top_seq], dim=1)
-            m_score = torch.cat([fin_score, cand], dim=1)
-            m_done = torch.cat([fin_done, just], dim=1)
-            best = torch.topk(m_score, k=nb)[1]
-            fin_seq = torch.take_along_dim(m_seq, best[:, :, None], dim=1)
-            fin_score = torch.take_along_dim(m_score, best, dim=1)
-            fin_done = torch.take_along_dim(m_done, best, dim=1)
-            if stepper is None:
-                cache.reorder(beam_src.view(-1))
-            cur += 1
-            # early-stop heuristic of early_stopping=False: best live score at the CURRENT length vs worst finished
-            hyp_len = (max_new_tokens if (early_stopping == "never" and length_penalty > 0.0) else cur)
-            best_live = run_score[:, :1] / (hyp_len ** length_penalty)
-            worst_fin = torch.where(fin_done, fin_score.min(dim=1, keepdim=True)[0], torch.full_like(fin_score, -1e9))
-            heur_open = heur_open & (best_live > worst_fin).any(dim=-1, keepdim=True)
-            unfinished = heur_open.any() & ~(fin_done.all() & (early_stopping is True)) & ~hits.all()
-            if not bool(unfinished):
-                break
-            tok = run_seq[:, :, cur - 1].reshape(B * nb)
+        skey = (B, nb, vocab, max_new_tokens, fill, tuple(eos), min_new_tokens, repetition_penalty, length_penalty,
+                early_stopping, str(dev))
+        state = self.__dict__.setdefault("_beam_states", {}).get(skey)
+        if state is None:
+            state = _BeamState(B, nb, vocab, max_new_tokens, fill, eos, min_new_tokens, repetition_penalty, length_penalty,
+                               early_stopping, dev)
+            self._beam_states[skey] = state
+        else:
+            state.reset()
+        state.advance(logits)                                    # step 0: the prefill logits
+        if stepper is None:
+            cache.expand(nb)
+            attn = attention_mask.repeat_interleave(nb, dim=0)
+        while bool(state.unfinished):
             if stepper is not None:
-                logits = stepper.step(tok, beam_src.view(-1), cur - 1)
+                stepper.step_search(state)                       # decoder step + search update, one hipGraph replay
                 continue
+            cache.reorder(state.beam_src)
             attn = torch.cat([attn, torch.ones(B * nb, 1, dtype=attn.dtype, device=dev)], dim=1)
-            emb = self.model.embed_tokens(tok)[:, None, :]
+            emb = self.model.embed_tokens(state.tok)[:, None, :]
             logits = self.forward(emb.to(inputs_embeds.dtype), attention_mask=attn, past_key_values=cache)[:, -1]
-        out = fin_seq[:, 0]
+            state.advance(logits)
+        fin_seq = state.fin_seq
+        out = fin_seq[:, 0].clone()
         # trim to the longest returned hypothesis (HF trims by the recorded beam indices)
         lens = []
         for b in range(B):
