@@ -165,7 +165,7 @@ def run_decode(args, rank, world, dev, dist):
         "config": {"workload": f"{args.workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
                    "new_tokens": int(out.shape[1]), "parallelism": f"replicas x{world} (no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step (weight streaming; library GEMV + SDPA)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step = 161 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)",
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}))
 
 

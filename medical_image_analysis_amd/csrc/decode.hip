@@ -14,6 +14,7 @@
 //   decode_attn_kernel   RoPE on q/k, append k/v to the cache, one-query attention over the cached positions with a
 //                        per-beam slot table (beam re-ordering moves 4-byte slot ids, never the cache itself).
 #include <algorithm>
+#include <cstdlib>
 
 #include "mxvl_common.h"
 
@@ -22,7 +23,7 @@ namespace mxvl {
 constexpr int kMaxRows = 8;
 
 struct GemvArgs {
-  int rows, K, N, swiglu, out_f32;
+  int rows, K, N, swiglu, out_f32, ablate;
   float eps;
   const uint16_t *x, *g, *W, *W2, *bias, *res;
   void* y;
@@ -49,8 +50,14 @@ __device__ inline float wave_sum(float v) {
   return v;
 }
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// weights are read exactly once per token: non-temporal loads keep them from displacing the activations in L2
+__device__ inline uint4 ldnt(const uint16_t* p) {
+  const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ inline uint4 ldw(const uint16_t* row, int kk, int K) {
-  return kk < K ? *(const uint4*)(row + kk) : make_uint4(0, 0, 0, 0);
+  return kk < K ? ldnt(row + kk) : make_uint4(0, 0, 0, 0);
 }
 
 // Work unit = one output column n: weight row n of W (with SwiGLU: gate row n of W, then up row n of W2).  Units are
@@ -63,10 +70,10 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   constexpr int NW = 16;  // waves per workgroup (one workgroup per CU)
   constexpr int PF = 8;   // 16-byte loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) uint16_t sx[];  // [M][K] (normalised) activations, bf16
-  __shared__ float s_rstd[kMaxRows];
   __shared__ float s_part[kMaxRows][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = p.K, N = p.N;
+  if (p.ablate == 1) return;
   const int S = p.swiglu ? 2 : 1;
   const int TW = gridDim.x * NW;                      // waves in the launch
   const int n_first = blockIdx.x * NW + wave;
@@ -82,40 +89,60 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     for (int j = 0; j < PF; ++j) pre[j] = ldw(w, lane * 8 + j * 512, K);
   }
 
-  if (p.g) {  // RMSNorm statistics in fp32, as Qwen2RMSNorm (hybrid_decoder_layer.py:193-198)
+  // Stage x (or RMSNorm(x)*g, Qwen2RMSNorm hybrid_decoder_layer.py:193-198: bf16(bf16(x*rstd) * g)) in LDS.  One
+  // 16-byte global load per thread per (row, 8192-column block), ALL issued before the first use: the prologue costs
+  // one L2 round trip, not one per element.
+  if (p.ablate == 2) return;
+  if (p.ablate != 3)
+  for (int c0 = 0; c0 < K; c0 += 8192) {
+    const int kk = c0 + tid * 8;
+    const bool on = kk < K;
+    uint4 xr[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      float s = 0.0f;
-      for (int k = tid * 2; k < K; k += 2048) {
-        const uint32_t raw = *(const uint32_t*)(p.x + (size_t)m * K + k);
-        const float a = bf2f((uint16_t)raw), b = bf2f((uint16_t)(raw >> 16));
-        s = fmaf(a, a, fmaf(b, b, s));
+    for (int m = 0; m < M; ++m) xr[m] = on ? *(const uint4*)(p.x + (size_t)m * K + kk) : make_uint4(0, 0, 0, 0);
+    if (!p.g) {
+      if (on) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) *(uint4*)(sx + (size_t)m * K + kk) = xr[m];
       }
-      s = wave_sum(s);
-      if (lane == 0) s_part[m][wave] = s;
+    } else {
+      // K <= 8192 on this path (checked by the launcher): the whole row is in the workgroup's registers
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const uint32_t w[4] = {xr[m].x, xr[m].y, xr[m].z, xr[m].w};
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf2f((uint16_t)w[j]), b = bf2f((uint16_t)(w[j] >> 16));
+          s = fmaf(a, a, fmaf(b, b, s));
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_part[m][wave] = s;
+      }
+      __syncthreads();
+      const uint4 gv = on ? *(const uint4*)(p.g + kk) : make_uint4(0, 0, 0, 0);
+      const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) tot += s_part[m][w2];
+        const float rstd = rsqrtf(tot / (float)K + p.eps);
+        const uint32_t w[4] = {xr[m].x, xr[m].y, xr[m].z, xr[m].w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf2f(f2bf(bf2f((uint16_t)w[j]) * rstd)) * bf2f((uint16_t)gw[j]);
+          const float b = bf2f(f2bf(bf2f((uint16_t)(w[j] >> 16)) * rstd)) * bf2f((uint16_t)(gw[j] >> 16));
+          o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+        }
+        if (on) *(uint4*)(sx + (size_t)m * K + kk) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
     }
-    __syncthreads();
-    if (tid < M) {
-      float s = 0.0f;
-      for (int w = 0; w < NW; ++w) s += s_part[tid][w];
-      s_rstd[tid] = rsqrtf(s / (float)K + p.eps);
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < M * (K / 2); i += 1024) {  // stage x (or bf16(bf16(x*rstd) * g)) once per workgroup
-    const int m = i / (K / 2), kk = (i - m * (K / 2)) * 2;
-    const uint32_t raw = *(const uint32_t*)(p.x + (size_t)m * K + kk);
-    uint32_t packed = raw;
-    if (p.g) {
-      const uint32_t gg = *(const uint32_t*)(p.g + kk);
-      const float a = bf2f(f2bf(bf2f((uint16_t)raw) * s_rstd[m])) * bf2f((uint16_t)gg);
-      const float b = bf2f(f2bf(bf2f((uint16_t)(raw >> 16)) * s_rstd[m])) * bf2f((uint16_t)(gg >> 16));
-      packed = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-    }
-    *(uint32_t*)(sx + (size_t)m * K + kk) = packed;
   }
   __syncthreads();
 
+  if (p.ablate == 4) return;
   float gate[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) gate[m] = 0.0f;
@@ -137,7 +164,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     }
 #pragma unroll 4
     for (int kk = lane * 8 + PF * 512; kk < K; kk += 512) {
-      const uint4 a0 = *(const uint4*)(w + kk);
+      const uint4 a0 = ldnt(w + kk);
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
@@ -335,8 +362,11 @@ int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (!d || !d->x || !d->W || !d->y) return MXVL_ERR_NULL;
   if (d->rows <= 0 || d->rows > kMaxRows || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
+  if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
   GemvArgs a;
+  static const int ablate = getenv("MXVL_GEMV_ABLATE") ? atoi(getenv("MXVL_GEMV_ABLATE")) : 0;
+  a.ablate = ablate;
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32; a.eps = d->eps;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->norm_weight; a.W = (const uint16_t*)d->W;
   a.W2 = (const uint16_t*)d->W2; a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;

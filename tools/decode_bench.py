@@ -15,19 +15,27 @@ def gemv(x, W, y, norm=None, W2=None, res=None, out_f32=False):
     _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "gemv")
 
 
-def timeit(fn, n=50):
-    for _ in range(5): fn()
+def timeit(fn, n=48):
+    """n calls captured in one hipGraph (what the decode step does), replayed 5x: per-call time without host launch cost"""
+    for _ in range(8): fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (5 * n) * 1e3
 
 
 bf = dict(dtype=torch.bfloat16, device=dev)
-shapes = [("qkv+norm", 4096, 12288, True, False), ("o+res", 4096, 4096, False, False), ("gate/up swiglu+norm", 4096, 11008, True, True),
+shapes = [("tiny+norm", 4096, 256, True, False), ("tiny", 4096, 256, False, False), ("tinyK11008", 11008, 256, False, False),
+          ("qkv+norm", 4096, 12288, True, False), ("o+res", 4096, 4096, False, False), ("gate/up swiglu+norm", 4096, 11008, True, True),
           ("down+res", 11008, 4096, False, False), ("lm_head+norm", 4096, 32000, True, False)]
+import os
+if os.environ.get('ONLY_TINY'): shapes = shapes[:3]
 NL = 8   # rotate over NL weight copies so the 256 MB L2/MALL does not serve re-reads
 for name, K, N, norm, swi in shapes:
     Ws = [torch.randn(N, K, **bf) * 0.02 for _ in range(NL)]
@@ -50,6 +58,7 @@ for name, K, N, norm, swi in shapes:
         us = timeit(fl, 48)
         print(f"{'  (torch linear)':24s} {'':30s} {us:8.1f} us  {byt / us / 1e3:8.1f} GB/s")
     del Ws, W2s
+if os.environ.get('ONLY_TINY'): sys.exit(0)
 # attention kernel at position 300
 H, D, T = 32, 128, 358
 qkv = torch.randn(rows, 3 * H * D, **bf)
