@@ -175,6 +175,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   };
 
   const int nchunks = (L + CH - 1) / CH;
+  const long long clk0 = clock64(), wall0 = wall_clock64();   // (ablate & 16) measurement: shader clock vs 100 MHz wall
   float un[T], dn[T];
   bc_fetch(0);
   row_fetch(pu, 0, un);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       float x = dn[i] + bias;
-      if (p.softplus) x = softplus(x);
+      if (p.softplus && !(p.ablate & 4)) x = softplus(x);
       if (!full) x = (t0 + j * T + i < L) ? x : 0.0f;  // padding steps are the identity map
       dl[i] = x;
       du[i] = x * un[i];
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     const float* cC = cB + N * CH;
 
 #pragma unroll 4
-    for (int n = 0; n < ((p.ablate & 1) ? 0 : N); ++n) {
+    for (int n = 0; n < ((p.ablate & 1) ? 0 : (p.ablate & 2) ? N / 2 : N); ++n) {
       const float A2 = ac[n].x;
       const float car = ac_in[n].y;                           // state entering the chunk (lane 0), 0 elsewhere
       float a[T], bb[T], cv[T];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     if (more) bc_commit((c + 1) & 1);
     if (has_z) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) y[i] *= silu(zz[i]);
+      for (int i = 0; i < T; ++i) y[i] *= (p.ablate & 4) ? zz[i] : silu(zz[i]);
     }
     if (p.ablate & 8) continue;
     if (VEC && full) {
@@ -294,6 +295,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
   }
 
+  if ((p.ablate & 16) && tid == 0) {   // per-workgroup start / end wall ticks (use with ablate & 8: no out stores)
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    ((float*)p.out)[4 * wg] = (float)(wall0 & 0xffffff);
+    ((float*)p.out)[4 * wg + 1] = (float)(wall_clock64() & 0xffffff);
+    ((float*)p.out)[4 * wg + 2] = (float)(clock64() - clk0);
+    ((float*)p.out)[4 * wg + 3] = (float)((__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffff) | ((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf) << 16));
+  }
   if (p.last_state) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
