@@ -195,6 +195,14 @@ int mxvl_state_update(void *state, const void *x, const void *dt, const void *A,
                       const void *C, const void *D, const void *z, const void *dt_bias, void *out,
                       int batch, int dim, int dstate, int io_dtype, int dt_softplus, void *hip_stream);
 
+/* VMamba SS2D 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67, CrossScan / CrossMerge).
+ * mxvl_cross_scan : x (batch,channels,height,width) -> xs (batch,4,channels,height*width): row-major, column-major
+ *                   and their reversals.   mxvl_cross_merge: ys (batch,4,channels,L) -> y (batch,channels,L) =
+ *                   (ys0 + flip(ys2)) + transpose(ys1 + flip(ys3)), each add rounded to the io dtype (bit-exact with
+ *                   the reference's tensor adds).  Each is the other's backward.  Contiguous tensors, one io dtype. */
+int mxvl_cross_scan(const void *x, void *xs, int batch, int channels, int height, int width, int io_dtype, void *hip_stream);
+int mxvl_cross_merge(const void *ys, void *y, int batch, int channels, int height, int width, int io_dtype, void *hip_stream);
+
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
 /* kernel-variant override for A/B measurements (bench.py only); 0 = automatic */

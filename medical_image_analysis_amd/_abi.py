@@ -30,6 +30,7 @@ SYMBOLS = [
     "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fwd", "mxvl_scan_bwd",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
+    "mxvl_cross_scan", "mxvl_cross_merge",
 ]
 
 
@@ -119,6 +120,9 @@ def load() -> ctypes.CDLL:
     lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
     lib.mxvl_state_update.restype = c_int
     lib.mxvl_state_update.argtypes = [c_void_p] * 10 + [c_int] * 5 + [c_void_p]
+    for name in ("mxvl_cross_scan", "mxvl_cross_merge"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int
     lib.mxvl_scan_n_chunks.restype = c_int
     lib.mxvl_set_scan_variant.argtypes = [c_int]

@@ -93,3 +93,68 @@ def visionmamba_forward_ref(sd, imgs, patch=16, depth=None, dec_heads=None):
     t = _cluster_order(t, hw)[:, 1:].reshape(B, -1, p * p * 3)
     loss = ((pred - t) ** 2).mean(-1).mean(0)
     return loss, latent, pred
+
+
+# ---- VMamba (R2GenCSR/VMamba/classification/models/vmamba.py) ---------------------------------------------------------
+def ss2d_forward_ref(sd, pre, x, forward_type="v3noz", channel_first=False):
+    """SS2D v2-family forward (vmamba.py:1110-1129 -> cross_selective_scan :318-427), forward only, fp32 host math on
+    the C scan / cross-scan oracles.  x: (B,H,W,C) channel-last or (B,C,H,W) channel_first."""
+    noz = forward_type.endswith("noz")
+    g = lambda n: sd[pre + n].float()
+    lin = (lambda t, w: F.conv2d(t, w[:, :, None, None])) if channel_first else (lambda t, w: F.linear(t, w))
+    x = lin(x.float(), g("in_proj.weight").reshape(g("in_proj.weight").shape[0], -1))
+    z = None
+    if not noz:
+        x, z = x.chunk(2, dim=1 if channel_first else -1)
+        z = F.silu(z)
+    if not channel_first:
+        x = x.permute(0, 3, 1, 2).contiguous()
+    if pre + "conv2d.weight" in sd:
+        w = g("conv2d.weight")
+        x = F.conv2d(x, w, sd.get(pre + "conv2d.bias"), padding=(w.shape[-1] - 1) // 2, groups=w.shape[0])
+    x = F.silu(x)
+    B, D, H, W = x.shape
+    xw, dtw, dtb = g("x_proj_weight"), g("dt_projs_weight"), g("dt_projs_bias")
+    K, _, R = dtw.shape
+    N = g("A_logs").shape[1]
+    L = H * W
+    xs = orc.cross_scan_ref(x.contiguous())                                  # (B, 4, D, L)
+    x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, xw)
+    dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+    dts = torch.einsum("bkrl,kdr->bkdl", dts, dtw)
+    ys = orc.selective_scan_ref(xs.reshape(B, K * D, L), dts.reshape(B, K * D, L), -torch.exp(g("A_logs")), Bs.contiguous(),
+                                Cs.contiguous(), g("Ds"), None, dtb.reshape(-1), True)
+    y = orc.cross_merge_ref(ys.reshape(B, K, D, L), H, W)                     # (B, D, L)
+    if channel_first:
+        y = y.view(B, D, H, W)
+        y = F.layer_norm(y.permute(0, 2, 3, 1), (D,), g("out_norm.weight"), g("out_norm.bias")).permute(0, 3, 1, 2)
+    else:
+        y = y.to(torch.bfloat16)                                              # vmamba.py:420 (hard-coded cast)
+        y = F.layer_norm(y.transpose(1, 2).float(), (D,), g("out_norm.weight"), g("out_norm.bias")).view(B, H, W, D)
+    if z is not None:
+        y = y * z
+    return lin(y, g("out_proj.weight").reshape(g("out_proj.weight").shape[0], -1))
+
+
+def vssm_forward_ref(sd, img, depths, forward_type="v3noz", global_features=False):
+    """VSSM forward (vmamba.py:1538-1604) for the channel-last LN configuration with patch-embed v2 and v3
+    down-sampling (the R2GenCSR recipe, configs/vssm1/vssm_base_224.yaml)."""
+    g = lambda n: sd[n].float()
+    ln = lambda t, n: F.layer_norm(t, (t.shape[-1],), g(n + ".weight"), g(n + ".bias"))
+    x = F.conv2d(img.float(), g("patch_embed.0.weight"), g("patch_embed.0.bias"), stride=2, padding=1)
+    x = ln(x.permute(0, 2, 3, 1), "patch_embed.2").permute(0, 3, 1, 2)
+    x = F.conv2d(F.gelu(x), g("patch_embed.5.weight"), g("patch_embed.5.bias"), stride=2, padding=1)
+    x = ln(x.permute(0, 2, 3, 1), "patch_embed.7")
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            pre = f"layers.{i}.blocks.{j}."
+            x = x + ss2d_forward_ref(sd, pre + "op.", ln(x, pre + "norm"), forward_type)
+            h = F.gelu(F.linear(ln(x, pre + "norm2"), g(pre + "mlp.fc1.weight"), g(pre + "mlp.fc1.bias")))
+            x = x + F.linear(h, g(pre + "mlp.fc2.weight"), g(pre + "mlp.fc2.bias"))
+        if i < len(depths) - 1:
+            pre = f"layers.{i}.downsample."
+            x = F.conv2d(x.permute(0, 3, 1, 2), g(pre + "1.weight"), g(pre + "1.bias"), stride=2, padding=1)
+            x = ln(x.permute(0, 2, 3, 1), pre + "3")
+    if global_features:
+        return ln(x, "classifier.norm").mean(dim=(1, 2))
+    return x

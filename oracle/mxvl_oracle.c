@@ -310,3 +310,42 @@ void orc_state_update(float *state, const float *x, const float *dt, const float
       out[(size_t)b * dim + d] = y;
     }
 }
+
+/* ---- VMamba 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67) --------------------------
+ * cross_scan : x (B,C,H,W) -> xs (B,4,C,L): xs0 row-major, xs1 column-major, xs2 / xs3 their reversals (:27-35).
+ * cross_merge: ys (B,4,C,L) -> y (B,C,L) = (ys0 + flip ys2) + transpose(ys1 + flip ys3) (:48-55), fp32 adds in that
+ * association. */
+void orc_cross_scan(const float *x, float *xs, int B, int C, int H, int W) {
+  const long L = (long)H * W;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      const float *src = x + ((long)b * C + c) * L;
+      float *o0 = xs + (((long)b * 4 + 0) * C + c) * L, *o1 = xs + (((long)b * 4 + 1) * C + c) * L;
+      float *o2 = xs + (((long)b * 4 + 2) * C + c) * L, *o3 = xs + (((long)b * 4 + 3) * C + c) * L;
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+          const float v = src[(long)h * W + w];
+          const long lr = (long)h * W + w, lc = (long)w * H + h;
+          o0[lr] = v; o2[L - 1 - lr] = v; o1[lc] = v; o3[L - 1 - lc] = v;
+        }
+    }
+}
+
+void orc_cross_merge(const float *ys, float *y, int B, int C, int H, int W) {
+  const long L = (long)H * W;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c) {
+      const float *i0 = ys + (((long)b * 4 + 0) * C + c) * L, *i1 = ys + (((long)b * 4 + 1) * C + c) * L;
+      const float *i2 = ys + (((long)b * 4 + 2) * C + c) * L, *i3 = ys + (((long)b * 4 + 3) * C + c) * L;
+      float *dst = y + ((long)b * C + c) * L;
+      for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+          const long lr = (long)h * W + w, lc = (long)w * H + h;
+          const float a = i0[lr] + i2[L - 1 - lr];
+          const float t = i1[lc] + i3[L - 1 - lc];
+          dst[lr] = a + t;
+        }
+    }
+}

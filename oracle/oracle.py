@@ -35,8 +35,7 @@ def build(force: bool = False) -> str:
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()     # no-op when libmxvl_oracle.so is newer than its source
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.orc_max_threads.restype = ctypes.c_int
     return _lib
@@ -200,3 +199,27 @@ def mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
                                     A, B, C, D, delta_bias, delta_softplus)
     return F.linear(y.permute(0, 2, 1), out_proj_weight.float(),
                     None if out_proj_bias is None else out_proj_bias.float())
+
+
+def cross_scan_ref(x):
+    """vmamba.py:25-35 CrossScan.forward: (B,C,H,W) -> (B,4,C,H*W).  fp32 through the C loops; other dtypes are pure
+    data movement, so they round-trip through fp32 exactly."""
+    B, C, H, W = x.shape
+    xf = _f32(x)
+    out = torch.empty(B, 4, C, H * W, dtype=torch.float32)
+    lib().orc_cross_scan(_p(xf), _p(out), B, C, H, W)
+    return out.to(x.dtype)
+
+
+def cross_merge_ref(ys, H, W):
+    """vmamba.py:46-55 CrossMerge.forward: (B,4,C,L) -> (B,C,L).  The reference adds TENSORS, i.e. every add rounds to
+    the tensor dtype; for bf16/fp16 that is restated here with torch CPU ops in the same association."""
+    B, K, C, L = ys.shape
+    if ys.dtype == torch.float32:
+        yf = _f32(ys)
+        out = torch.empty(B, C, L, dtype=torch.float32)
+        lib().orc_cross_merge(_p(yf), _p(out), B, C, H, W)
+        return out
+    a = ys[:, 0] + ys[:, 2].flip(-1)
+    t = ys[:, 1] + ys[:, 3].flip(-1)
+    return a + t.reshape(B, C, W, H).transpose(2, 3).reshape(B, C, L)

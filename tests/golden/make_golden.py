@@ -479,6 +479,73 @@ def gen_decode():
     save("decode_tiny_llama", inputs_embeds=np_(emb), attention_mask=att.numpy().copy(), **out)
 
 
+def gen_vmamba(scan_ref):
+    """VMamba / SS2D (R2GenCSR/VMamba/classification/models/vmamba.py) on CPU.  The vendored CUDA extension
+    `selective_scan_cuda_oflex` is replaced by a stub that evaluates the reference's own selective_scan_ref (forward)
+    and differentiates it with autograd (backward); fvcore / csm_triton (Triton) are import-only stubs."""
+    fv = types.ModuleType("fvcore"); fvn = types.ModuleType("fvcore.nn")
+    fvn.FlopCountAnalysis = fvn.flop_count_str = fvn.flop_count = fvn.parameter_count = None
+    sys.modules["fvcore"], sys.modules["fvcore.nn"] = fv, fvn
+    csm = types.ModuleType("csm_triton")
+    csm.CrossScanTriton = csm.CrossMergeTriton = csm.CrossScanTriton1b1 = None
+    sys.modules["csm_triton"] = csm
+
+    def fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows, oflex=True):
+        out = scan_ref(u, delta, A, B, C, D, None, delta_bias, delta_softplus)
+        return [out.float() if oflex else out.to(u.dtype), torch.empty(0)]
+
+    def bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (u, delta, A, B, C, D, delta_bias)]
+        with torch.enable_grad():
+            out = scan_ref(*leaves[:6], None, leaves[6], delta_softplus)
+            return list(torch.autograd.grad(out, leaves, dout.to(out.dtype)))
+
+    for name in ("selective_scan_cuda_oflex", "selective_scan_cuda_core", "selective_scan_cuda"):
+        m = types.ModuleType(name)
+        m.fwd, m.bwd = fwd, bwd
+        sys.modules[name] = m
+    vm = _load(os.path.join(REF, "R2GenCSR/VMamba/classification/models/vmamba.py"), "vmamba_ref")
+
+    g = torch.Generator().manual_seed(7)
+    # (1) the orderings: bit-exact data movement + three adds
+    x = torch.randn(2, 3, 5, 7, generator=g)
+    ys = torch.randn(2, 4, 3, 5, 7, generator=g)
+    xb, ysb = x.to(torch.bfloat16), ys.to(torch.bfloat16)
+    save("vmamba_cross", x=np_(x), xs=np_(vm.CrossScan.apply(x)), ys=np_(ys), y=np_(vm.CrossMerge.apply(ys)),
+         xs_bf16=np_(vm.CrossScan.apply(xb)), y_bf16=np_(vm.CrossMerge.apply(ysb)))
+
+    # (2) SS2D blocks, forward + backward
+    for tag, kw, hw in (("v3noz_n1", dict(d_model=16, d_state=1, forward_type="v3noz", conv_bias=False), (6, 5)),
+                        ("v2_n4", dict(d_model=16, d_state=4, forward_type="v2", conv_bias=True), (4, 7)),
+                        ("v3_ln2d", dict(d_model=8, d_state=2, forward_type="v3", channel_first=True), (5, 5))):
+        torch.manual_seed(11)
+        m = vm.SS2D(ssm_ratio=2.0, **kw)
+        _randomize(m)
+        with torch.no_grad():
+            m.A_logs.add_(0.2 * torch.randn(m.A_logs.shape, generator=g))
+        cf = kw.get("channel_first", False)
+        shape = (2, kw["d_model"], *hw) if cf else (2, *hw, kw["d_model"])
+        xin = torch.randn(*shape, generator=g).requires_grad_(True)
+        out = m(xin)
+        cot = torch.randn(out.shape, generator=g)
+        (out * cot).sum().backward()
+        arrs = {"sd." + k: np_(v) for k, v in m.state_dict().items()}
+        arrs.update({"grad." + k: np_(p.grad) for k, p in m.named_parameters()})
+        save("vmamba_ss2d_" + tag, x=np_(xin), out=np_(out), cot=np_(cot), dx=np_(xin.grad), **arrs)
+
+    # (3) a tiny VSSM with the R2GenCSR recipe (d_state 1, v3noz, patch-embed v2, down-sampling v3)
+    torch.manual_seed(12)
+    net = vm.VSSM(depths=[1, 1, 2, 1], dims=8, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
+                  mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0).eval()
+    _randomize(net)
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        feat = net(img)
+        pooled = net(img, global_features=True)
+    arrs = {"sd." + k: np_(v) for k, v in net.state_dict().items()}
+    save("vmamba_vssm_tiny", img=np_(img), feat=np_(feat), pooled=np_(pooled), **arrs)
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -510,6 +577,7 @@ def main():
     models_pretrain = _load(os.path.join(pt_dir, "models_pretrain.py"), "models_pretrain_ref")
     gen_pretrain(models_pretrain)
     sys.path.remove(pt_dir)
+    gen_vmamba(scan_ref)
     gen_vit_mae()
     gen_hybrid_decoder()
     gen_decode()
