@@ -441,8 +441,9 @@ class ReportDecoder(nn.Module):
         parameters become views of it, so state_dict keys and the torch path are unchanged and no memory is added."""
         for layer in self.model.layers:
             at = layer.self_attn
-            if getattr(at, "qkv_weight", None) is not None:
-                continue
+            W = getattr(at, "qkv_weight", None)
+            if W is not None and W.data_ptr() == at.q_proj.weight.data_ptr() and W.dtype == at.q_proj.weight.dtype:
+                continue        # still fused (a later .to(device/dtype) re-creates the parameters and un-fuses them)
             with torch.no_grad():
                 W = torch.cat([at.q_proj.weight, at.k_proj.weight, at.v_proj.weight], dim=0).contiguous()
                 b = torch.cat([at.q_proj.bias, at.k_proj.bias, at.v_proj.bias], dim=0).contiguous()

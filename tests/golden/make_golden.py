@@ -546,6 +546,22 @@ def gen_vmamba(scan_ref):
     save("vmamba_vssm_tiny", img=np_(img), feat=np_(feat), pooled=np_(pooled), **arrs)
 
 
+def gen_handoff():
+    """Stage hand-off host logic: the reference's interpolate_pos_embed (arm/Finetuning/util/pos_embed.py:75-101) and the
+    stage-1 -> stage-2 key rewriting (models/MambaXrayVL_CLIP.py:38-62, restated below on a synthetic key list because the
+    module itself imports lightning / peft)."""
+    pe_mod = _load(os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/arm/Finetuning/util/pos_embed.py"), "pos_embed_ref")
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for tag, old, new in (("up", 4, 6), ("same", 3, 3), ("down", 8, 5)):
+        model = types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=new * new),
+                                      pos_embed=torch.zeros(1, new * new + 1, 8))
+        pe = torch.randn(1, old * old, 8, generator=g)
+        res = pe_mod.interpolate_pos_embed(model, {"pos_embed": pe.clone()})
+        out[f"{tag}_in"], out[f"{tag}_out"], out[f"{tag}_grid"] = np_(pe), np_(res["pos_embed"]), np.array([old, new])
+    save("handoff_pos_embed", **out)
+
+
 def main():
     torch.set_num_threads(8)
     scan_ref = load_scan_ref()
@@ -578,6 +594,7 @@ def main():
     gen_pretrain(models_pretrain)
     sys.path.remove(pt_dir)
     gen_vmamba(scan_ref)
+    gen_handoff()
     gen_vit_mae()
     gen_hybrid_decoder()
     gen_decode()
