@@ -195,6 +195,32 @@ int mxvl_state_update(void *state, const void *x, const void *dt, const void *A,
                       const void *C, const void *D, const void *z, const void *dt_bias, void *out,
                       int batch, int dim, int dstate, int io_dtype, int dt_softplus, void *hip_stream);
 
+/* Residual add + LayerNorm of an ARM / VisionMamba block (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:
+ * 110-116 `x + mixer(norm1(x))`, `x + mlp(norm2(x))`; the reference's fused_add_norm path pairs them the same way):
+ *   h = x + branch (branch may be NULL: h is x and is not written);  n = (h - mean) * rstd * gamma + beta.
+ * res_dtype is the dtype of x, h, dx, dh; branch_dtype of branch / dbranch; out_dtype of n / dn (MXVL_F32 | MXVL_BF16,
+ * combinations f32/f32/f32, f32/bf16/bf16, f32/f32/bf16, bf16/bf16/bf16); cols % 256 == 0, cols <= 2048.
+ * Backward: dx = dh + LN'(dn) (dh may be NULL), optionally also written in the branch dtype to dbranch; dgamma/dbeta
+ * leave as n_partials = mxvl_add_layernorm_partials(rows) partial rows the caller sums. */
+typedef struct mxvl_add_ln_desc {
+  int32_t rows, cols, res_dtype, branch_dtype, out_dtype;
+  float eps;
+  const void *x, *branch, *gamma, *beta; /* gamma, beta: (cols) fp32; beta optional */
+  void *h, *n, *mean, *rstd;             /* mean, rstd: (rows) fp32 */
+} mxvl_add_ln_desc;
+typedef struct mxvl_add_ln_bwd_desc {
+  int32_t rows, cols, res_dtype, branch_dtype, out_dtype, n_partials;
+  const void *dn, *dh, *h, *gamma, *mean, *rstd;
+  void *dx, *dbranch, *partial_dgamma, *partial_dbeta; /* partials: (n_partials, cols) fp32 */
+} mxvl_add_ln_bwd_desc;
+int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc *desc, void *hip_stream);
+int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc *desc, void *hip_stream);
+int mxvl_add_layernorm_partials(int rows);
+/* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
+ * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */
+int mxvl_swiglu_fwd(const void *ab, void *y, int rows, int hidden, int io_dtype, void *hip_stream);
+int mxvl_swiglu_bwd(const void *ab, const void *dy, void *dab, int rows, int hidden, int io_dtype, void *hip_stream);
+
 /* VMamba SS2D 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67, CrossScan / CrossMerge).
  * mxvl_cross_scan : x (batch,channels,height,width) -> xs (batch,4,channels,height*width): row-major, column-major
  *                   and their reversals.   mxvl_cross_merge: ys (batch,4,channels,L) -> y (batch,channels,L) =

@@ -31,6 +31,7 @@ SYMBOLS = [
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
+    "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
 ]
 
 
@@ -96,6 +97,24 @@ class DecodeAttnDesc(ctypes.Structure):
     ]
 
 
+class AddLnDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
+        ("eps", ctypes.c_float),
+        ("x", c_void_p), ("branch", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("h", c_void_p), ("n", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+    ]
+
+
+class AddLnBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
+        ("n_partials", c_int32),
+        ("dn", c_void_p), ("dh", c_void_p), ("h", c_void_p), ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+        ("dx", c_void_p), ("dbranch", c_void_p), ("partial_dgamma", c_void_p), ("partial_dbeta", c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -120,6 +139,15 @@ def load() -> ctypes.CDLL:
     lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
     lib.mxvl_state_update.restype = c_int
     lib.mxvl_state_update.argtypes = [c_void_p] * 10 + [c_int] * 5 + [c_void_p]
+    for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    lib.mxvl_add_layernorm_partials.restype = c_int
+    lib.mxvl_add_layernorm_partials.argtypes = [c_int]
+    lib.mxvl_swiglu_fwd.restype = c_int
+    lib.mxvl_swiglu_fwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.mxvl_swiglu_bwd.restype = c_int
+    lib.mxvl_swiglu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     for name in ("mxvl_cross_scan", "mxvl_cross_merge"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]

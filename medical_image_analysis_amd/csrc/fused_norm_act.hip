@@ -1,0 +1,289 @@
+// fused_norm_act.hip -- the HBM-bound glue between the GEMMs of an ARM / VisionMamba block, for gfx950.
+//
+//   add + LayerNorm   h = x + branch;  n = LN(h)            (models_mamba.py:110-116: x + mixer(norm1(x)), x + mlp(norm2(x));
+//                                                            the reference's fused_add_norm Triton path does the same pairing)
+//   SwiGLU gate       y = silu(a) * b,  [a | b] = one GEMM   (models_mamba.py:59-83: act(w1 x) * w2 x)
+//
+// In eager PyTorch under bf16 autocast each residual+norm is 3 kernels and 5 tensor passes (fp32 add, fp32 LayerNorm,
+// bf16 cast for the next GEMM) and its backward 4 more; here it is one kernel forward (read x, branch; write h, n) and
+// one backward (read dn, dh, h; write dx, dbranch; per-workgroup partial dgamma/dbeta).  A row is owned by one wave:
+// 16-byte loads, values stay in registers, statistics in fp32 (two-pass variance), one DPP/shuffle reduction each.
+#include <algorithm>
+
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+struct NormArgs {
+  int rows, C;
+  float eps;
+  const void *x, *br;          // residual stream in, branch output (may be null)
+  const float *gamma, *beta;   // (C) fp32; beta may be null
+  void *h, *n;                 // x + br (written only when br != null), LN(h)
+  float *mean, *rstd;          // (rows)
+};
+struct NormBwdArgs {
+  int rows, C;
+  const void *dn, *dh, *h;     // grad of n, grad of h (may be null), saved h
+  const float *gamma, *mean, *rstd;
+  void *dx, *dbr;              // grad wrt x (res dtype), optional copy in the branch dtype
+  float *pgamma, *pbeta;       // (gridDim.x, C) partial sums
+};
+
+__device__ inline float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T> __device__ inline void ld4v(const T* p, float (&v)[4]) {
+  const float4 a = ld4<T>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <typename T> __device__ inline void st4v(T* p, const float (&v)[4]) { st4<T>(p, make_float4(v[0], v[1], v[2], v[3])); }
+
+// K = C / 256: every lane owns K groups of 4 consecutive columns: column (k*64 + lane)*4
+template <typename res_t, typename br_t, typename out_t, int K>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const NormArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C;
+  float g[K][4], bta[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    ld4v<float>(p.gamma + c, g[k]);
+    if (p.beta) ld4v<float>(p.beta + c, bta[k]);
+    else { bta[k][0] = bta[k][1] = bta[k][2] = bta[k][3] = 0.0f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+    float v[K][4];
+    const res_t* xr = (const res_t*)p.x + (size_t)row * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k) ld4v<res_t>(xr + (k * 64 + lane) * 4, v[k]);
+    if (p.br) {
+      const br_t* br = (const br_t*)p.br + (size_t)row * C;
+      res_t* hr = (res_t*)p.h + (size_t)row * C;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float b[4];
+        ld4v<br_t>(br + (k * 64 + lane) * 4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[k][j] += b[j];
+          if constexpr (sizeof(res_t) == 2) {  // the stream itself is half precision: normalise what is stored
+            res_t t; Io<res_t>::st(&t, v[k][j]); v[k][j] = Io<res_t>::ld(&t);
+          }
+        }
+        st4v<res_t>(hr + (k * 64 + lane) * 4, v[k]);
+      }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    const float mean = wsum(s) / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(wsum(q) / (float)C + p.eps);
+    out_t* nr = (out_t*)p.n + (size_t)row * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaf((v[k][j] - mean) * rstd, g[k][j], bta[k][j]);
+      st4v<out_t>(nr + (k * 64 + lane) * 4, o);
+    }
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  }
+}
+
+template <typename res_t, typename br_t, typename out_t, int K>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
+  __shared__ float sred[2][4][K * 256];   // [gamma|beta][wave][column]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C;
+  float g[K][4], ag[K][4], ab[K][4];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    ld4v<float>(p.gamma + (k * 64 + lane) * 4, g[k]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ag[k][j] = 0.0f; ab[k][j] = 0.0f; }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float xh[K][4], dy[K][4];
+    const res_t* hr = (const res_t*)p.h + (size_t)row * C;
+    const out_t* dr = (const out_t*)p.dn + (size_t)row * C;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      ld4v<res_t>(hr + (k * 64 + lane) * 4, xh[k]);
+      ld4v<out_t>(dr + (k * 64 + lane) * 4, dy[k]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[k][j] = (xh[k][j] - mean) * rstd;
+        ag[k][j] = fmaf(dy[k][j], xh[k][j], ag[k][j]);
+        ab[k][j] += dy[k][j];
+        dy[k][j] *= g[k][j];
+        s1 += dy[k][j];
+        s2 = fmaf(dy[k][j], xh[k][j], s2);
+      }
+    }
+    const float m1 = wsum(s1) / (float)C, m2 = wsum(s2) / (float)C;
+    res_t* dxr = (res_t*)p.dx + (size_t)row * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rstd * (dy[k][j] - m1 - xh[k][j] * m2);
+      if (p.dh) {
+        float r[4];
+        ld4v<res_t>((const res_t*)p.dh + (size_t)row * C + (k * 64 + lane) * 4, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += r[j];
+      }
+      st4v<res_t>(dxr + (k * 64 + lane) * 4, o);
+      if (p.dbr) st4v<br_t>((br_t*)p.dbr + (size_t)row * C + (k * 64 + lane) * 4, o);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    *(float4*)&sred[0][wave][(k * 64 + lane) * 4] = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
+    *(float4*)&sred[1][wave][(k * 64 + lane) * 4] = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    p.pgamma[(size_t)blockIdx.x * C + c] = (sred[0][0][c] + sred[0][1][c]) + (sred[0][2][c] + sred[0][3][c]);
+    p.pbeta[(size_t)blockIdx.x * C + c] = (sred[1][0][c] + sred[1][1][c]) + (sred[1][2][c] + sred[1][3][c]);
+  }
+}
+
+// ---- SwiGLU gate: ab (rows, 2H) -> y (rows, H) = silu(ab[:, :H]) * ab[:, H:] ------------------------------------------
+// H need not be a multiple of 8 (2730 for ARM-large), so rows are only 4-byte aligned in bf16: 2 elements per thread.
+template <typename io_t>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const io_t* __restrict__ ab, io_t* __restrict__ y, int rows, int H) {
+  using io = Io<io_t>;
+  const int half = (H + 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * half; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / half), c = (int)(i - (size_t)r * half) * 2;
+    const io_t* a = ab + (size_t)r * 2 * H + c;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (c + j < H) {
+        const float av = io::ld(a + j), bv = io::ld(a + H + j);
+        io_t t; io::st(&t, silu(av));                      // torch rounds act(w1 x) to the io dtype before the product
+        io::st(y + (size_t)r * H + c + j, io::ld(&t) * bv);
+      }
+  }
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy,
+                                                          io_t* __restrict__ dab, int rows, int H) {
+  using io = Io<io_t>;
+  const int half = (H + 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * half; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / half), c = (int)(i - (size_t)r * half) * 2;
+    const io_t* a = ab + (size_t)r * 2 * H + c;
+    io_t* d = dab + (size_t)r * 2 * H + c;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (c + j < H) {
+        const float av = io::ld(a + j), bv = io::ld(a + H + j), g = io::ld(dy + (size_t)r * H + c + j);
+        const float sg = sigmoid(av), sl = av * sg;
+        io::st(d + j, g * bv * (sg * (1.0f + av * (1.0f - sg))));   // d silu(a) = s (1 + a (1 - s))
+        io::st(d + H + j, g * sl);
+      }
+  }
+}
+
+template <typename R, typename B, typename O, int K>
+static void launch_ln(bool bwd, const void* args, int rows, hipStream_t s) {
+  const int wgs = std::min((rows + 3) / 4, 2048);
+  if (bwd) hipLaunchKernelGGL((add_ln_bwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormBwdArgs*)args);
+  else hipLaunchKernelGGL((add_ln_fwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormArgs*)args);
+}
+template <typename R, typename B, typename O>
+static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s) {
+  switch (C / 256) {
+    case 1: launch_ln<R, B, O, 1>(bwd, args, rows, s); break;
+    case 2: launch_ln<R, B, O, 2>(bwd, args, rows, s); break;
+    case 3: launch_ln<R, B, O, 3>(bwd, args, rows, s); break;
+    case 4: launch_ln<R, B, O, 4>(bwd, args, rows, s); break;
+    case 6: launch_ln<R, B, O, 6>(bwd, args, rows, s); break;
+    case 8: launch_ln<R, B, O, 8>(bwd, args, rows, s); break;
+    default: return MXVL_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+static int dispatch_ln(bool bwd, const void* args, int rows, int C, int res_dt, int br_dt, int out_dt, hipStream_t s) {
+  if (C % 256 != 0) return MXVL_ERR_UNSUPPORTED;
+  if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_F32) return dispatch_k<float, float, float>(bwd, args, rows, C, s);
+  if (res_dt == MXVL_F32 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<float, bf16_t, bf16_t>(bwd, args, rows, C, s);
+  if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_BF16) return dispatch_k<float, float, bf16_t>(bwd, args, rows, C, s);
+  if (res_dt == MXVL_BF16 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<bf16_t, bf16_t, bf16_t>(bwd, args, rows, C, s);
+  return MXVL_ERR_DTYPE;
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" {
+
+int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc* d, void* hip_stream) {
+  if (!d || !d->x || !d->gamma || !d->n || !d->mean || !d->rstd) return MXVL_ERR_NULL;
+  if (d->branch && !d->h) return MXVL_ERR_NULL;
+  if (d->rows <= 0 || d->cols <= 0) return MXVL_ERR_SHAPE;
+  NormArgs a;
+  a.rows = d->rows; a.C = d->cols; a.eps = d->eps; a.x = d->x; a.br = d->branch; a.gamma = (const float*)d->gamma;
+  a.beta = (const float*)d->beta; a.h = d->h; a.n = d->n; a.mean = (float*)d->mean; a.rstd = (float*)d->rstd;
+  return dispatch_ln(false, &a, d->rows, d->cols, d->res_dtype, d->branch_dtype, d->out_dtype, (hipStream_t)hip_stream);
+}
+
+int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc* d, void* hip_stream) {
+  if (!d || !d->dn || !d->h || !d->gamma || !d->mean || !d->rstd || !d->dx || !d->partial_dgamma || !d->partial_dbeta) return MXVL_ERR_NULL;
+  if (d->rows <= 0 || d->cols <= 0) return MXVL_ERR_SHAPE;
+  if (d->n_partials != std::min((d->rows + 3) / 4, 2048)) return MXVL_ERR_SHAPE;
+  NormBwdArgs a;
+  a.rows = d->rows; a.C = d->cols; a.dn = d->dn; a.dh = d->dh; a.h = d->h; a.gamma = (const float*)d->gamma;
+  a.mean = (const float*)d->mean; a.rstd = (const float*)d->rstd; a.dx = d->dx; a.dbr = d->dbranch;
+  a.pgamma = (float*)d->partial_dgamma; a.pbeta = (float*)d->partial_dbeta;
+  return dispatch_ln(true, &a, d->rows, d->cols, d->res_dtype, d->branch_dtype, d->out_dtype, (hipStream_t)hip_stream);
+}
+
+int mxvl_add_layernorm_partials(int rows) { return std::min((rows + 3) / 4, 2048); }
+
+int mxvl_swiglu_fwd(const void* ab, void* y, int rows, int hidden, int io_dtype, void* hip_stream) {
+  if (!ab || !y) return MXVL_ERR_NULL;
+  if (rows <= 0 || hidden <= 0) return MXVL_ERR_SHAPE;
+  const size_t work = (size_t)rows * ((hidden + 1) / 2);
+  const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 64);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32: hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ab, (float*)y, rows, hidden); break;
+    case MXVL_BF16: hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (bf16_t*)y, rows, hidden); break;
+    case MXVL_F16: hipLaunchKernelGGL(swiglu_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)ab, (f16_t*)y, rows, hidden); break;
+    default: return MXVL_ERR_DTYPE;
+  }
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+int mxvl_swiglu_bwd(const void* ab, const void* dy, void* dab, int rows, int hidden, int io_dtype, void* hip_stream) {
+  if (!ab || !dy || !dab) return MXVL_ERR_NULL;
+  if (rows <= 0 || hidden <= 0) return MXVL_ERR_SHAPE;
+  const size_t work = (size_t)rows * ((hidden + 1) / 2);
+  const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 64);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32: hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ab, (const float*)dy, (float*)dab, rows, hidden); break;
+    case MXVL_BF16: hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (const bf16_t*)dy, (bf16_t*)dab, rows, hidden); break;
+    case MXVL_F16: hipLaunchKernelGGL(swiglu_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)ab, (const f16_t*)dy, (f16_t*)dab, rows, hidden); break;
+    default: return MXVL_ERR_DTYPE;
+  }
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+}  // extern "C"

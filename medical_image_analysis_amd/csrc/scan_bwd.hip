@@ -37,28 +37,6 @@ struct ScanBwdArgs {
   float *dA, *dB, *dC, *dD, *dbias;
 };
 
-template <typename io_t> __device__ inline float4 ld4b(const io_t* p);
-template <> __device__ inline float4 ld4b<float>(const float* p) { return *(const float4*)p; }
-template <> __device__ inline float4 ld4b<bf16_t>(const bf16_t* p) {
-  const uint2 r = *(const uint2*)p;
-  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
-                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
-}
-template <> __device__ inline float4 ld4b<f16_t>(const f16_t* p) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  const h4 r = *(const h4*)p;
-  return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
-}
-template <typename io_t> __device__ inline void st4b(io_t* p, float4 v);
-template <> __device__ inline void st4b<float>(float* p, float4 v) { *(float4*)p = v; }
-template <> __device__ inline void st4b<bf16_t>(bf16_t* p, float4 v) {
-  *(uint2*)p = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
-}
-template <> __device__ inline void st4b<f16_t>(f16_t* p, float4 v) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  *(h4*)p = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-}
-
 // forward inclusive scan + exclusive shift over a 16-lane DPP row (see scan_fwd.hip)
 __device__ inline void scan16_fwd(float& h0, float& P0, float& x0) {
   asm volatile(
@@ -163,7 +141,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
     if (t0 + CH <= L) {
       if constexpr (VEC) {
-        const float4 a0 = ld4b<io_t>(q + t0), a1 = ld4b<io_t>(q + t0 + 4);
+        const float4 a0 = ld4<io_t>(q + t0), a1 = ld4<io_t>(q + t0 + 4);
         v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
       } else {
 #pragma unroll
@@ -177,8 +155,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   auto row_store = [&](io_t* q, const void* base, int64_t bs, int64_t ds, int t0, const float (&v)[T]) {
     if (VEC && t0 + CH <= L) {
       if (row_ok) {
-        st4b<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
-        st4b<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
+        st4<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
+        st4<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
       }
     } else {
       float4* so4 = (float4*)(sO + row * CH + j * T);

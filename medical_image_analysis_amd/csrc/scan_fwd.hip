@@ -40,28 +40,6 @@ struct ScanArgs {
 };
 
 // ---- 4-wide global access (row starts 16-byte aligned for fp32, 8-byte for 16-bit types) --------
-template <typename io_t> __device__ inline float4 ld4(const io_t* p);
-template <> __device__ inline float4 ld4<float>(const float* p) { return *(const float4*)p; }
-template <> __device__ inline float4 ld4<bf16_t>(const bf16_t* p) {
-  const uint2 r = *(const uint2*)p;
-  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
-                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
-}
-template <> __device__ inline float4 ld4<f16_t>(const f16_t* p) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  const h4 r = *(const h4*)p;
-  return make_float4((float)r.x, (float)r.y, (float)r.z, (float)r.w);
-}
-template <typename io_t> __device__ inline void st4(io_t* p, float4 v);
-template <> __device__ inline void st4<float>(float* p, float4 v) { *(float4*)p = v; }
-template <> __device__ inline void st4<bf16_t>(bf16_t* p, float4 v) {
-  *(uint2*)p = make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
-}
-template <> __device__ inline void st4<f16_t>(f16_t* p, float4 v) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  *(h4*)p = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-}
-
 // ---- inclusive scan of the affine maps (P,h) over the 16 lanes of a DPP row, then the exclusive
 // shift.  x enters holding the state that precedes lane 0 (the carry) and leaves holding the
 // state that precedes each lane.  Lanes without a source lane are disabled by DPP bound_ctrl=0,

@@ -1,0 +1,143 @@
+"""HBM-bound glue of an ARM / VisionMamba block as single HIP kernels (csrc/fused_norm_act.hip).
+
+  add_layer_norm(x, branch, weight, bias, eps)  ->  (h, n) = (x + branch, LayerNorm(h))
+      the residual add + pre-norm pairing of CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:110-116
+      (`hidden + mixer(norm1(hidden))`, `hidden + mlp(norm2(hidden))`); under bf16 autocast the residual stream stays
+      fp32 and n leaves in bf16, which is what `autocast(LayerNorm) -> fp32 -> Linear's bf16 cast` produces.
+  swiglu(ab)  ->  silu(ab[..., :H]) * ab[..., H:]     (models_mamba.py:82 `act(w1 x) * w2 x`, [w1 x | w2 x] from one GEMM)
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _abi
+
+_LN_DTYPES = {(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
+              (torch.float32, torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16, torch.bfloat16)}
+
+
+def add_layer_norm_supported(x, cols):
+    return x.is_cuda and cols % 256 == 0 and cols // 256 in (1, 2, 3, 4, 6, 8)
+
+
+def _autocast_dtype(x):
+    if torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return x.dtype
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, branch, weight, bias, eps, out_dtype):
+        lib = _abi.load()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        b2 = None
+        if branch is not None:
+            b2 = branch.reshape(-1, C)
+            if not b2.is_contiguous():
+                b2 = b2.contiguous()
+        br_dtype = b2.dtype if b2 is not None else (torch.float32 if out_dtype == torch.float32 else out_dtype)
+        if (x2.dtype, br_dtype, out_dtype) not in _LN_DTYPES:      # bring rare combinations to a built one
+            if b2 is not None and b2.dtype != out_dtype:
+                b2 = b2.to(torch.float32 if x2.dtype == torch.float32 else out_dtype)
+                br_dtype = b2.dtype
+            if (x2.dtype, br_dtype, out_dtype) not in _LN_DTYPES:
+                raise RuntimeError(f"mxvl add_layer_norm: unsupported dtypes {x2.dtype}/{br_dtype}/{out_dtype}")
+        w = weight.float().contiguous()
+        bta = bias.float().contiguous() if bias is not None else None
+        h = torch.empty_like(x2) if b2 is not None else x2
+        n = torch.empty(x2.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        d = _abi.AddLnDesc()
+        d.rows, d.cols, d.eps = rows, C, eps
+        d.res_dtype, d.branch_dtype, d.out_dtype = _abi.dtype_code(x2.dtype), _abi.dtype_code(br_dtype), _abi.dtype_code(out_dtype)
+        d.x, d.branch, d.gamma, d.beta = x2.data_ptr(), _abi.ptr(b2), w.data_ptr(), _abi.ptr(bta)
+        d.h, d.n, d.mean, d.rstd = h.data_ptr(), n.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        with torch.cuda.device(x.device):
+            _abi.check(lib.mxvl_add_layernorm_fwd(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_add_layernorm_fwd")
+        ctx.save_for_backward(h, w, mean, rstd)
+        ctx.meta = (x.shape, branch is not None, br_dtype, branch.dtype if branch is not None else None, out_dtype,
+                    weight.dtype, bias is not None, bias.dtype if bias is not None else None)
+        return h.view(x.shape), n.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh, dn):
+        h, w, mean, rstd = ctx.saved_tensors
+        shape, has_br, br_dtype, br_orig, out_dtype, w_dtype, has_bias, b_dtype = ctx.meta
+        lib = _abi.load()
+        rows, C = h.shape
+        dn2 = dn.reshape(rows, C).to(out_dtype).contiguous()
+        dh2 = dh.reshape(rows, C).to(h.dtype).contiguous() if dh is not None else None
+        dx = torch.empty_like(h)
+        dbr = torch.empty((rows, C), dtype=br_dtype, device=h.device) if has_br and br_dtype != h.dtype else None
+        n_part = lib.mxvl_add_layernorm_partials(rows)
+        pg = torch.empty((n_part, C), dtype=torch.float32, device=h.device)
+        pb = torch.empty_like(pg)
+        d = _abi.AddLnBwdDesc()
+        d.rows, d.cols, d.n_partials = rows, C, n_part
+        d.res_dtype, d.branch_dtype, d.out_dtype = _abi.dtype_code(h.dtype), _abi.dtype_code(br_dtype), _abi.dtype_code(out_dtype)
+        d.dn, d.dh, d.h, d.gamma, d.mean, d.rstd = dn2.data_ptr(), _abi.ptr(dh2), h.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        d.dx, d.dbranch, d.partial_dgamma, d.partial_dbeta = dx.data_ptr(), _abi.ptr(dbr), pg.data_ptr(), pb.data_ptr()
+        with torch.cuda.device(h.device):
+            _abi.check(lib.mxvl_add_layernorm_bwd(ctypes.byref(d), _abi.stream_ptr(h.device)), "mxvl_add_layernorm_bwd")
+        dgamma = pg.sum(0).to(w_dtype)
+        dbeta = pb.sum(0).to(b_dtype) if has_bias else None
+        dx_v = dx.view(shape)
+        dbranch = None
+        if has_br:
+            dbranch = (dbr if dbr is not None else dx).view(shape)
+            if dbranch.dtype != br_orig:
+                dbranch = dbranch.to(br_orig)
+        return dx_v, dbranch, dgamma, dbeta, None, None
+
+
+def add_layer_norm(x, branch, weight, bias, eps=1e-5, out_dtype=None):
+    """(h, n) = (x + branch, LayerNorm(h) * weight + bias); branch=None -> h is x.  out_dtype: dtype of n (default: the
+    autocast dtype when autocast is on, else x.dtype)."""
+    _abi.require_gpu(x, branch)
+    out_dtype = out_dtype or _autocast_dtype(x)
+    if x.dtype == torch.bfloat16:
+        out_dtype = torch.bfloat16
+    return _AddLayerNorm.apply(x, branch, weight, bias, eps, out_dtype)
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ab):
+        lib = _abi.load()
+        H = ab.shape[-1] // 2
+        ab2 = ab.reshape(-1, 2 * H)
+        if not ab2.is_contiguous():
+            ab2 = ab2.contiguous()
+        y = torch.empty((ab2.shape[0], H), dtype=ab.dtype, device=ab.device)
+        with torch.cuda.device(ab.device):
+            _abi.check(lib.mxvl_swiglu_fwd(ab2.data_ptr(), y.data_ptr(), ab2.shape[0], H, _abi.dtype_code(ab.dtype),
+                                           _abi.stream_ptr(ab.device)), "mxvl_swiglu_fwd")
+        ctx.save_for_backward(ab2)
+        ctx.shape = ab.shape
+        return y.view(*ab.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ab2,) = ctx.saved_tensors
+        lib = _abi.load()
+        H = ab2.shape[1] // 2
+        dy2 = dy.reshape(-1, H).to(ab2.dtype).contiguous()
+        dab = torch.empty_like(ab2)
+        with torch.cuda.device(ab2.device):
+            _abi.check(lib.mxvl_swiglu_bwd(ab2.data_ptr(), dy2.data_ptr(), dab.data_ptr(), ab2.shape[0], H,
+                                           _abi.dtype_code(ab2.dtype), _abi.stream_ptr(ab2.device)), "mxvl_swiglu_bwd")
+        return dab.view(ctx.shape)
+
+
+def swiglu(ab):
+    """ab (..., 2H) = [a | b] -> silu(a) * b (..., H)."""
+    _abi.require_gpu(ab)
+    return _SwiGLU.apply(ab)

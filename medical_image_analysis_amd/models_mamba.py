@@ -19,6 +19,8 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+from . import fused_ops
+
 from .mamba_simple import Mamba
 
 
@@ -96,6 +98,11 @@ class SwiGLU(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if x.is_cuda and isinstance(self.act, nn.SiLU) and isinstance(self.ffn_ln, nn.Identity):
+            # [w1 x | w2 x] from ONE GEMM, then the gate as one HIP kernel (csrc/fused_norm_act.hip)
+            w = torch.cat([self.w1.weight, self.w2.weight], dim=0)
+            b = torch.cat([self.w1.bias, self.w2.bias], dim=0)
+            return self.drop(self.w3(fused_ops.swiglu(torch.nn.functional.linear(x, w, b))))
         return self.drop(self.w3(self.ffn_ln(self.act(self.w1(x)) * self.w2(x))))
 
 
@@ -125,8 +132,41 @@ class Block(nn.Module):
         segmentation = segmentation + self.drop_path(self.mlp(self.norm2(segmentation)))
         return hidden_states, segmentation
 
+    def fusable(self, hidden_states):
+        """add + LayerNorm as one HIP kernel: plain LayerNorms, width a multiple of 256, fp32 or bf16 stream."""
+        return (type(self.norm1) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm and self.norm1.elementwise_affine
+                and fused_ops.add_layer_norm_supported(hidden_states, hidden_states.shape[-1])
+                and hidden_states.dtype in (torch.float32, torch.bfloat16))
+
+    def forward_fused(self, h, pending, inference_params=None):
+        """The same block on a (stream, pending-branch) pair: the true hidden state is h + pending.  Each residual add
+        rides in the LayerNorm kernel that follows it (the pairing of the reference's fused_add_norm path)."""
+        h, n = fused_ops.add_layer_norm(h, pending, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        m = self.drop_path(self.mixer(n, inference_params=inference_params))
+        h, n = fused_ops.add_layer_norm(h, m, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return h, self.drop_path(self.mlp(n))
+
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
+
+
+def run_blocks(layers, hidden_states, inference_params=None, taps=None):
+    """Run a stack of Blocks; `taps` (1-based layer counts) -> list of the hidden states after those layers."""
+    feats = []
+    if len(layers) and hidden_states.is_contiguous() and all(hasattr(l, "fusable") and l.fusable(hidden_states) for l in layers):
+        h, pending = hidden_states, None
+        for count, layer in enumerate(layers, start=1):
+            h, pending = layer.forward_fused(h, pending, inference_params)
+            if taps and count in taps:
+                h, pending = h + pending, None
+                feats.append(h)
+        hidden_states = h if pending is None else h + pending
+    else:
+        for count, layer in enumerate(layers, start=1):
+            hidden_states = layer(hidden_states, inference_params=inference_params)
+            if taps and count in taps:
+                feats.append(hidden_states)
+    return (hidden_states, feats) if taps else hidden_states
 
 
 def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, drop_path=0.0, rms_norm=False, residual_in_fp32=False,
@@ -258,8 +298,7 @@ class ARM(nn.Module):
         x = torch.cat((x[:, :tp], cls_token, x[:, tp:]), dim=1)
         hidden_states = self.pos_drop(x + self.pos_embed)
         if segmentation is None:
-            for layer in self.layers:
-                hidden_states = layer(hidden_states, inference_params=inference_params)
+            hidden_states = run_blocks(self.layers, hidden_states, inference_params)
         else:
             for layer in self.layers:
                 hidden_states, segmentation = layer(hidden_states, segmentation=segmentation,

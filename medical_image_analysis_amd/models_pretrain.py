@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .models_mamba import Block as _FtBlock  # noqa: F401  (same Block arithmetic; kept for isinstance checks)
-from .models_mamba import DropPath, PatchEmbed, SwiGLU, _init_weights, segm_init_weights, trunc_normal_
+from .models_mamba import DropPath, PatchEmbed, SwiGLU, _init_weights, run_blocks, segm_init_weights, trunc_normal_
 from .mamba_simple import Mamba
 
 
@@ -127,6 +127,9 @@ class Block(nn.Module):
     def forward(self, hidden_states, residual=None, inference_params=None):
         hidden_states = hidden_states + self.drop_path(self.mixer(self.norm1(hidden_states), inference_params=inference_params))
         return hidden_states + self.drop_path(self.mlp(self.norm2(hidden_states)))
+
+    fusable = _FtBlock.fusable                # residual add + LayerNorm as one HIP kernel (models_mamba.run_blocks)
+    forward_fused = _FtBlock.forward_fused
 
     def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
@@ -233,11 +236,7 @@ class VisionMamba(nn.Module):
         hw = int(math.isqrt(N))
         x = cluster_order(x, hw)
         hidden_states = x[:, :-1].reshape(B, -1, C)  # the last cluster is only ever a target
-        feats = []
-        for count, layer in enumerate(self.layers, start=1):
-            hidden_states = layer(hidden_states, inference_params=inference_params)
-            if count in self.skip:
-                feats.append(hidden_states)
+        hidden_states, feats = run_blocks(self.layers, hidden_states.contiguous(), inference_params, taps=self.skip)
         feats = torch.cat([self.norm_1(feats[0]), self.norm_2(feats[1]), self.norm_3(feats[2]), self.norm_4(feats[3])], dim=-1)
         feats = self.enc2dec(feats)
         B, N, C = feats.shape

@@ -46,8 +46,9 @@ def _worker(rank, world, port, out):
     for _ in range(3):
         x = torch.randn(4, 7, 12, generator=g)
         losses.append(eng.reduced_loss(eng.step(x)))
-    sd = {k: v.clone() for k, v in eng.raw_model.state_dict().items()}
-    out.put((rank, losses, sd))
+    # plain numpy through the queue: tensors travel as file descriptors that die with the worker process
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in eng.raw_model.state_dict().items()}
+    out.put((rank, [float(l) for l in losses], sd))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,7 +67,7 @@ def test_ddp_step_matches_single_process_on_the_concatenated_batch():
     (_, l0, sd0), (_, l1, sd1) = results
     assert l0 == l1, "all_reduce_mean(loss) must agree on every rank"
     for k in sd0:
-        assert torch.equal(sd0[k], sd1[k]), f"replicas diverged at {k}"
+        assert (sd0[k] == sd1[k]).all(), f"replicas diverged at {k}"
     # single process, global batch = concat of the two shards: mean loss over 8 samples == mean of rank means
     from medical_image_analysis_amd.pretrain_engine import PretrainEngine
     eng = PretrainEngine(TinyLossModel(), lr=1e-2, amp_dtype=None, device=None)
@@ -76,7 +77,7 @@ def test_ddp_step_matches_single_process_on_the_concatenated_batch():
         loss = float(eng.step(x))
         assert abs(loss - l0[step]) < 1e-5
     for k, v in eng.raw_model.state_dict().items():
-        assert torch.allclose(v, sd0[k], atol=1e-5, rtol=1e-4), k
+        assert torch.allclose(v, torch.from_numpy(sd0[k]), atol=1e-5, rtol=1e-4), k
 
 
 def test_weight_decay_groups_follow_timm_rule():
