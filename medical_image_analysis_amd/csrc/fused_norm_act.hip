@@ -161,41 +161,117 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
 }
 
 // ---- SwiGLU gate: ab (rows, 2H) -> y (rows, H) = silu(ab[:, :H]) * ab[:, H:] ------------------------------------------
-// H need not be a multiple of 8 (2730 for ARM-large), so rows are only 4-byte aligned in bf16: 2 elements per thread.
+// H need not be a multiple of 8 (2730 for ARM-large): rows are only 4-byte aligned in bf16.  A wave walks a row in
+// 512-column tiles; a lane owns the column PAIRS lane*2 + k*128 (k = 0..3), so every load instruction of the wave is
+// one contiguous 256-byte (bf16) / 512-byte (fp32) segment and four of them are in flight per operand.
+template <typename io_t> struct Pair;
+template <> struct Pair<float> {
+  __device__ static inline void ld(const float* p, float& a, float& b) { const float2 v = *(const float2*)p; a = v.x; b = v.y; }
+  __device__ static inline void st(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+};
+template <> struct Pair<bf16_t> {
+  __device__ static inline void ld(const bf16_t* p, float& a, float& b) {
+    const uint32_t v = *(const uint32_t*)p;
+    a = __builtin_bit_cast(float, v << 16); b = __builtin_bit_cast(float, v & 0xffff0000u);
+  }
+  __device__ static inline void st(bf16_t* p, float a, float b) { *(uint32_t*)p = cvt_pk_bf16(a, b); }
+};
+template <> struct Pair<f16_t> {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  __device__ static inline void ld(const f16_t* p, float& a, float& b) { const h2 v = *(const h2*)p; a = (float)v.x; b = (float)v.y; }
+  __device__ static inline void st(f16_t* p, float a, float b) { *(h2*)p = h2{(_Float16)a, (_Float16)b}; }
+};
+
 template <typename io_t>
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const io_t* __restrict__ ab, io_t* __restrict__ y, int rows, int H) {
-  using io = Io<io_t>;
-  const int half = (H + 1) / 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * half; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i / half), c = (int)(i - (size_t)r * half) * 2;
-    const io_t* a = ab + (size_t)r * 2 * H + c;
+__device__ inline float rnd_io(float v) {  // value after a round trip through the io dtype
+  if constexpr (sizeof(io_t) == 4) return v;
+  io_t t;
+  Io<io_t>::st(&t, v);
+  return Io<io_t>::ld(&t);
+}
+
+// H must be even (pairs); odd H goes through the scalar tail kernel below
+template <typename io_t, bool BWD>
+__global__ __launch_bounds__(256) void swiglu_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy, io_t* __restrict__ out,
+                                                      int rows, int H) {
+  using P = Pair<io_t>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles = (H + 511) / 512;
+  const long total = (long)rows * tiles;
+  for (long t = (long)blockIdx.x * 4 + wave; t < total; t += (long)gridDim.x * 4) {
+    const int r = (int)(t / tiles), c0 = (int)(t - (long)r * tiles) * 512 + lane * 2;
+    const io_t* a = ab + (size_t)r * 2 * H;
+    float av[4][2], bv[4][2], gv[4][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (c + j < H) {
-        const float av = io::ld(a + j), bv = io::ld(a + H + j);
-        io_t t; io::st(&t, silu(av));                      // torch rounds act(w1 x) to the io dtype before the product
-        io::st(y + (size_t)r * H + c + j, io::ld(&t) * bv);
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * 128;
+      av[k][0] = av[k][1] = bv[k][0] = bv[k][1] = gv[k][0] = gv[k][1] = 0.0f;
+      if (c < H) {
+        P::ld(a + c, av[k][0], av[k][1]);
+        P::ld(a + H + c, bv[k][0], bv[k][1]);
+        if constexpr (BWD) P::ld(dy + (size_t)r * H + c, gv[k][0], gv[k][1]);
       }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * 128;
+      if (c >= H) continue;
+      if constexpr (!BWD) {
+        // torch rounds act(w1 x) to the io dtype before the product
+        P::st(out + (size_t)r * H + c, rnd_io<io_t>(silu(av[k][0])) * bv[k][0], rnd_io<io_t>(silu(av[k][1])) * bv[k][1]);
+      } else {
+        float da[2], db[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float sg = sigmoid(av[k][j]);
+          da[j] = gv[k][j] * bv[k][j] * (sg * (1.0f + av[k][j] * (1.0f - sg)));   // d silu(a) = s (1 + a (1 - s))
+          db[j] = gv[k][j] * (av[k][j] * sg);
+        }
+        io_t* d = out + (size_t)r * 2 * H;
+        P::st(d + c, da[0], da[1]);
+        P::st(d + H + c, db[0], db[1]);
+      }
+    }
   }
 }
 
-template <typename io_t>
-__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy,
-                                                          io_t* __restrict__ dab, int rows, int H) {
+template <typename io_t, bool BWD>
+__global__ __launch_bounds__(256) void swiglu_scalar_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy,
+                                                             io_t* __restrict__ out, int rows, int H) {
   using io = Io<io_t>;
-  const int half = (H + 1) / 2;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * half; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i / half), c = (int)(i - (size_t)r * half) * 2;
-    const io_t* a = ab + (size_t)r * 2 * H + c;
-    io_t* d = dab + (size_t)r * 2 * H + c;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (c + j < H) {
-        const float av = io::ld(a + j), bv = io::ld(a + H + j), g = io::ld(dy + (size_t)r * H + c + j);
-        const float sg = sigmoid(av), sl = av * sg;
-        io::st(d + j, g * bv * (sg * (1.0f + av * (1.0f - sg))));   // d silu(a) = s (1 + a (1 - s))
-        io::st(d + H + j, g * sl);
-      }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * H; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / H), c = (int)(i - (size_t)r * H);
+    const float av = io::ld(ab + (size_t)r * 2 * H + c), bv = io::ld(ab + (size_t)r * 2 * H + H + c);
+    if constexpr (!BWD) {
+      io::st(out + i, rnd_io<io_t>(silu(av)) * bv);
+    } else {
+      const float g = io::ld(dy + i), sg = sigmoid(av);
+      io::st(out + (size_t)r * 2 * H + c, g * bv * (sg * (1.0f + av * (1.0f - sg))));
+      io::st(out + (size_t)r * 2 * H + H + c, g * (av * sg));
+    }
+  }
+}
+
+template <typename io_t, bool BWD>
+static int launch_swiglu(const void* ab, const void* dy, void* out, int rows, int H, hipStream_t s) {
+  if (H % 2 == 0) {
+    const long work = (long)rows * ((H + 511) / 512);
+    const int grid = (int)std::min<long>((work + 3) / 4, 256L * 32);
+    hipLaunchKernelGGL((swiglu_kernel<io_t, BWD>), dim3(grid), dim3(256), 0, s, (const io_t*)ab, (const io_t*)dy, (io_t*)out, rows, H);
+  } else {
+    const size_t work = (size_t)rows * H;
+    const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL((swiglu_scalar_kernel<io_t, BWD>), dim3(grid), dim3(256), 0, s, (const io_t*)ab, (const io_t*)dy, (io_t*)out, rows, H);
+  }
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+template <bool BWD>
+static int dispatch_swiglu(const void* ab, const void* dy, void* out, int rows, int H, int dt, hipStream_t s) {
+  switch (dt) {
+    case MXVL_F32: return launch_swiglu<float, BWD>(ab, dy, out, rows, H, s);
+    case MXVL_BF16: return launch_swiglu<bf16_t, BWD>(ab, dy, out, rows, H, s);
+    case MXVL_F16: return launch_swiglu<f16_t, BWD>(ab, dy, out, rows, H, s);
+    default: return MXVL_ERR_DTYPE;
   }
 }
 
@@ -259,31 +335,13 @@ int mxvl_add_layernorm_partials(int rows) { return std::min((rows + 3) / 4, 2048
 int mxvl_swiglu_fwd(const void* ab, void* y, int rows, int hidden, int io_dtype, void* hip_stream) {
   if (!ab || !y) return MXVL_ERR_NULL;
   if (rows <= 0 || hidden <= 0) return MXVL_ERR_SHAPE;
-  const size_t work = (size_t)rows * ((hidden + 1) / 2);
-  const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 64);
-  hipStream_t s = (hipStream_t)hip_stream;
-  switch (io_dtype) {
-    case MXVL_F32: hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ab, (float*)y, rows, hidden); break;
-    case MXVL_BF16: hipLaunchKernelGGL(swiglu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (bf16_t*)y, rows, hidden); break;
-    case MXVL_F16: hipLaunchKernelGGL(swiglu_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)ab, (f16_t*)y, rows, hidden); break;
-    default: return MXVL_ERR_DTYPE;
-  }
-  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+  return dispatch_swiglu<false>(ab, nullptr, y, rows, hidden, io_dtype, (hipStream_t)hip_stream);
 }
 
 int mxvl_swiglu_bwd(const void* ab, const void* dy, void* dab, int rows, int hidden, int io_dtype, void* hip_stream) {
   if (!ab || !dy || !dab) return MXVL_ERR_NULL;
   if (rows <= 0 || hidden <= 0) return MXVL_ERR_SHAPE;
-  const size_t work = (size_t)rows * ((hidden + 1) / 2);
-  const int grid = (int)std::min<size_t>((work + 255) / 256, 256 * 64);
-  hipStream_t s = (hipStream_t)hip_stream;
-  switch (io_dtype) {
-    case MXVL_F32: hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ab, (const float*)dy, (float*)dab, rows, hidden); break;
-    case MXVL_BF16: hipLaunchKernelGGL(swiglu_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (const bf16_t*)dy, (bf16_t*)dab, rows, hidden); break;
-    case MXVL_F16: hipLaunchKernelGGL(swiglu_bwd_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)ab, (const f16_t*)dy, (f16_t*)dab, rows, hidden); break;
-    default: return MXVL_ERR_DTYPE;
-  }
-  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+  return dispatch_swiglu<true>(ab, dy, dab, rows, hidden, io_dtype, (hipStream_t)hip_stream);
 }
 
 }  // extern "C"

@@ -21,6 +21,25 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+
+
+def enable_tuned_gemms(path: str | None = None) -> bool:
+    """Library GEMMs (in/out/x/dt projections, SwiGLU, decoder) keep going to hipBLASLt / rocBLAS, but with the
+    per-shape solution picked offline on an MI355X by PyTorch TunableOp (tools/tune_gemms.py; e.g. the merged
+    SwiGLU w1|w2 GEMM 32640x5460x1024: 0.55 ms default -> 0.27 ms tuned).  Read-only at run time: no tuning, no file
+    writes; shapes that are not in the file use the library default.  MXVL_TUNED_GEMMS=0 disables it."""
+    path = path or TUNED_GEMMS
+    if os.environ.get("MXVL_TUNED_GEMMS", "1") == "0" or not torch.cuda.is_available() or not os.path.exists(path):
+        return False
+    if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1":      # an explicit tuning session (tools/tune_gemms.py) owns the settings
+        return False
+    tun = torch.cuda.tunable
+    tun.enable(True)
+    tun.tuning_enable(False)
+    return bool(tun.read_file(path))
+
+
 def init_distributed(backend: str | None = None):
     """env:// rendezvous (RANK / WORLD_SIZE / LOCAL_RANK from torchrun), as misc.init_distributed_mode."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -55,6 +74,7 @@ class PretrainEngine:
     def __init__(self, model: nn.Module, lr: float = 1.5e-4, weight_decay: float = 0.05, clip_grad: float | None = 3.0,
                  amp_dtype: torch.dtype | None = torch.bfloat16, bucket_cap_mb: int = 256, device=None):
         self.device = device
+        self.tuned_gemms = enable_tuned_gemms() if (device is not None and torch.device(device).type == "cuda") else False
         self.amp_dtype = amp_dtype
         self.clip_grad = clip_grad
         self.world = dist.get_world_size() if dist.is_initialized() else 1

@@ -1,0 +1,33 @@
+"""Re-tune the library GEMM solutions (hipBLASLt / rocBLAS) the pre-training step uses, via PyTorch TunableOp.
+Run ON an MI355X:  python tools/tune_gemms.py [workload ...]   -> medical_image_analysis_amd/tuned/tunableop_gfx950.csv
+The product only READS that file (pretrain_engine.enable_tuned_gemms); shapes that are not in it use the library default."""
+import os, subprocess, sys, glob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "medical_image_analysis_amd", "tuned", "tunableop_gfx950.csv")
+workloads = sys.argv[1:] or ["arm_pretrain_large_1024", "arm_pretrain_base_192"]
+tmp = "/tmp/mxvl_tune"
+os.makedirs(tmp, exist_ok=True)
+lines, header = {}, []
+if os.path.exists(OUT):
+    for ln in open(OUT):
+        (header if ln.startswith("Validator") else lines.setdefault(",".join(ln.split(",")[:2]), ln) and [])
+for w in workloads:
+    base = os.path.join(tmp, f"tune_{w}.csv")
+    for f in glob.glob(base.replace(".csv", "*.csv")):
+        os.remove(f)
+    env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=base,
+               PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS="15", PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS="10", MXVL_TUNED_GEMMS="0")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
+                           "--no-cpu-baseline"], env=env, cwd=ROOT)
+    for f in glob.glob(base.replace(".csv", "*.csv")):
+        for ln in open(f):
+            if ln.startswith("Validator"):
+                if ln not in header:
+                    header.append(ln)
+            else:
+                lines[",".join(ln.split(",")[:2])] = ln
+with open(OUT, "w") as f:
+    f.writelines(header)
+    f.writelines(lines[k] for k in sorted(lines))
+print(f"wrote {OUT}: {len(lines)} tuned GEMM shapes")
