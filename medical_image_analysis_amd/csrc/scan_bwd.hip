@@ -184,18 +184,35 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     const int t0 = c * CH;
     const bool full = t0 + CH <= L;
     __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible)
-    // ---- B/C tile of this chunk + zero the dB/dC accumulators + state entering the chunk ----------
-    for (int i = tid; i < N * CH; i += NT) {
-      const int n = i / CH, e = i - n * CH;
-      const int t = t0 + e;
-      float bv = 0.0f, cv = 0.0f;
-      if (t < L) {
-        bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
-        cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
+    // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
+    float uu[T], dl[T], zz[T], go[T];
+    row_fetch(pu, t0, uu);
+    row_fetch(pd, t0, dl);
+    row_fetch(pg, t0, go);
+    if (has_z) row_fetch(pz, t0, zz);
+    // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
+    if (VEC && full) {
+      for (int i = tid; i < N * (CH / 4); i += NT) {   // 16-byte loads, 4 consecutive steps per thread
+        const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
+        const float4 bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e);
+        const float4 cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e);
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4;
+        *(float4*)(sB + pos) = bv;
+        *(float4*)(sC + pos) = cv;
       }
-      const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
-      sB[pos] = bv;
-      sC[pos] = cv;
+    } else {
+      for (int i = tid; i < N * CH; i += NT) {
+        const int n = i / CH, e = i - n * CH;
+        const int t = t0 + e;
+        float bv = 0.0f, cv = 0.0f;
+        if (t < L) {
+          bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
+          cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
+        }
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
+        sB[pos] = bv;
+        sC[pos] = cv;
+      }
     }
     for (int i = lane; i < RPW * N; i += 64) {
       const int rr = i / N, n = i - rr * N;
@@ -204,11 +221,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       if (c > 0 && dd < d_end) h0 = p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n];
       sAC[(wave * RPW + rr) * N + n].y = h0;
     }
-    float uu[T], dl[T], zz[T], go[T];
-    row_fetch(pu, t0, uu);
-    row_fetch(pd, t0, dl);
-    row_fetch(pg, t0, go);
-    if (has_z) row_fetch(pz, t0, zz);
     __syncthreads();
 
     float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
@@ -389,6 +401,13 @@ static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
 
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it goes out as global
+  // atomics (the atomics are ~1/3 of the kernel at 16 rows) at the same 8 waves per CU.  Used when 32-row tiles still
+  // give every CU a workgroup.
+  static const int forced = getenv("MXVL_BWD_WAVES") ? atoi(getenv("MXVL_BWD_WAVES")) : 0;
+  const long tiles32 = (long)a.batch * a.G * ((a.dim / a.G + 31) / 32);
+  const bool wide = forced ? forced == 8 : ((a.dim / a.G) % 32 == 0 && tiles32 >= 256);
+  if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
   return a.vec_ok ? launch_bwd<io_t, 4, true>(a, stream) : launch_bwd<io_t, 4, false>(a, stream);
 }
 
@@ -428,10 +447,11 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
     const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
     const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,
                                d->dout_bs, d->dout_ds, d->du_bs, d->du_ds, d->ddelta_bs, d->ddelta_ds,
-                               f->z ? d->dz_bs : 0, f->z ? d->dz_ds : 0};
+                               f->z ? d->dz_bs : 0, f->z ? d->dz_ds : 0,
+                               f->B_bs, f->B_gs, f->B_ns, f->C_bs, f->C_gs, f->C_ns};
     bool ok = true;
     for (int64_t s : strides) ok = ok && (s % 4 == 0);
-    const void* ptrs[] = {f->u, f->delta, f->z, d->dout, d->du, d->ddelta, d->dz};
+    const void* ptrs[] = {f->u, f->delta, f->z, d->dout, d->du, d->ddelta, d->dz, f->B, f->C};
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
     a.vec_ok = ok ? 1 : 0;
   }

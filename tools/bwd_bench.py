@@ -26,5 +26,8 @@ def run(B, D, L, N, dtype, iters=10):
     print(f"bwd B={B} D={D} L={L} N={N} {str(dtype)[6:]} ablate={os.environ.get('MXVL_BWD_ABLATE','0')}: {us:9.1f} us  {nb/us*1e-6:6.3f} TB/s (incl. torch.zeros of the accumulators)")
 
 if __name__ == "__main__":
+    if len(sys.argv) > 4:
+        run(*map(int, sys.argv[1:5]), getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32)
+        sys.exit(0)
     run(8, 1024, 4080, 16, torch.bfloat16)
     run(8, 1536, 4096, 16, torch.float32)
