@@ -288,6 +288,9 @@ class _KernelStepper(_SearchFusion):
 
     @staticmethod
     def supported(model, rows, dtype, device):
+        if torch.device(device).type == "cuda":
+            from . import _abi
+            _abi.load()          # a missing libmxvl.so is an error on a GPU box, never a silent torch path
         cfg = model.config
         D = cfg.hidden_size // cfg.num_attention_heads
         conditioned = any(model.model.layers[i].vis_x is not None for i in model.hybrid_layers)

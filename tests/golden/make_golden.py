@@ -267,6 +267,23 @@ def gen_mamba_v3(mamba_mod):
         save(name, hidden=np_(hidden), out=np_(out), dout=np_(g), dhidden=np_(hidden.grad), **sd, **grads)
 
 
+def gen_mamba_v4(mamba_mod):
+    """Reference 6-direction "bone" mixer (mamba_simple.py:533-646): v3's four scans on hidden_states plus two on the
+    segmentation stream; returns (out, out_d)."""
+    torch.manual_seed(0)
+    m = mamba_mod.Mamba(d_model=32, expand=1, bimamba_type="v4", if_devide_out=True)
+    _randomize(m)
+    hidden = torch.randn(2, 10, 32, requires_grad=True)
+    seg = torch.randn(2, 10, 32, requires_grad=True)
+    out, out_d = m(hidden, segmenttation_features=seg)
+    g, gd = torch.randn_like(out), torch.randn_like(out_d)
+    ((out * g).sum() + (out_d * gd).sum()).backward()
+    sd = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+    grads = {("g_" + k): np_(p.grad) for k, p in m.named_parameters() if p.grad is not None}
+    save("mamba_v4_L10", hidden=np_(hidden), seg=np_(seg), out=np_(out), out_d=np_(out_d), dout=np_(g), dout_d=np_(gd),
+         dhidden=np_(hidden.grad), dseg=np_(seg.grad), **sd, **grads)
+
+
 def gen_arm(models_mamba):
     """Reference ARM encoder (models_mamba.py:215-394), depth 2, 48x48 / patch 16 -> 3x3 patches + middle cls."""
     torch.manual_seed(0)
@@ -578,6 +595,7 @@ def main():
     mamba_mod.mamba_inner_fn_no_out_proj = no_out
     mamba_mod.mamba_inner_fn = with_out
     gen_mamba_v3(mamba_mod)
+    gen_mamba_v4(mamba_mod)
     install_timm_stubs()
     models_mamba = _load(os.path.join(ft_dir, "models_mamba.py"), "models_mamba_ref")
     gen_arm(models_mamba)
