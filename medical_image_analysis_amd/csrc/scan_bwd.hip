@@ -179,6 +179,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     }
   };
 
+  // Half-precision io: the NEXT chunk's rows (u, delta, dout, z: 8 elements = one 16-byte load each) are requested before the
+  // state loop of the current chunk and sit packed in 16 VGPRs while it runs, so their HBM latency is hidden behind it
+  // (at 2 waves/SIMD there is little else to hide it).  fp32 rows would need 32 VGPRs: they take the direct path.
+  constexpr bool PF = VEC && sizeof(io_t) == 2;
+  uint4 ru = make_uint4(0, 0, 0, 0), rd = ru, rg = ru, rz = ru;
+  bool have_pf = false;
+  auto unpack = [&](const uint4& r, float (&v)[T]) {
+    io_t tmp[T];
+    *(uint4*)tmp = r;
+#pragma unroll
+    for (int i = 0; i < T; ++i) v[i] = io::ld(tmp + i);
+  };
+
   const int nchunks = (L + CH - 1) / CH;
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * CH;
@@ -186,10 +199,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible)
     // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
     float uu[T], dl[T], zz[T], go[T];
-    row_fetch(pu, t0, uu);
-    row_fetch(pd, t0, dl);
-    row_fetch(pg, t0, go);
-    if (has_z) row_fetch(pz, t0, zz);
+    if (PF && have_pf) {
+      unpack(ru, uu);
+      unpack(rd, dl);
+      unpack(rg, go);
+      if (has_z) unpack(rz, zz);
+    } else {
+      row_fetch(pu, t0, uu);
+      row_fetch(pd, t0, dl);
+      row_fetch(pg, t0, go);
+      if (has_z) row_fetch(pz, t0, zz);
+    }
     // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
     if (VEC && full) {
       for (int i = tid; i < N * (CH / 4); i += NT) {   // 16-byte loads, 4 consecutive steps per thread
@@ -222,6 +242,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       sAC[(wave * RPW + rr) * N + n].y = h0;
     }
     __syncthreads();
+    if constexpr (PF) {
+      have_pf = c > 0;          // chunk c-1 is always a full chunk
+      if (have_pf) {
+        const int tn = t0 - CH;
+        ru = *(const uint4*)(pu + tn);
+        rd = *(const uint4*)(pd + tn);
+        rg = *(const uint4*)(pg + tn);
+        if (has_z) rz = *(const uint4*)(pz + tn);
+      }
+    }
 
     float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
 #pragma unroll
