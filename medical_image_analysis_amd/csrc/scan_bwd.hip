@@ -254,21 +254,35 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     }
 
     float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
+    // uniform flag tests outside the per-step loops (a branch per step serialises the transcendental chains)
+#pragma unroll
+    for (int i = 0; i < T; ++i) { dl[i] += bias; dsp[i] = 1.0f; }
+    if (p.softplus) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        dsp[i] = (dl[i] > 20.0f) ? 1.0f : sigmoid(dl[i]);  // d softplus / dx
+        dl[i] = softplus(dl[i]);
+      }
+    }
+    if (!full) {
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        if (!(t0 + j * T + i < L)) { dl[i] = 0.0f; dsp[i] = 0.0f; }
+    }
+    if (!row_ok) {  // clamped duplicate rows must not add into the shared dB/dC tile
+#pragma unroll
+      for (int i = 0; i < T; ++i) go[i] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i) dy[i] = go[i];
+    if (has_z) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) dy[i] = go[i] * silu(zz[i]);
+    }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      float x = dl[i] + bias;
-      float ds = 1.0f;
-      if (p.softplus) {
-        ds = (x > 20.0f) ? 1.0f : sigmoid(x);  // d softplus / dx
-        x = softplus(x);
-      }
-      if (!full && !(t0 + j * T + i < L)) { x = 0.0f; ds = 0.0f; }
-      dl[i] = x;
-      dsp[i] = ds;
-      du[i] = x * uu[i];
+      du[i] = dl[i] * uu[i];
       y[i] = Dv * uu[i];
-      if (!row_ok) go[i] = 0.0f;  // clamped duplicate rows must not add into the shared dB/dC tile
-      dy[i] = has_z ? go[i] * silu(zz[i]) : go[i];
       sgB[i] = 0.0f;
       sAh[i] = 0.0f;
     }
@@ -380,7 +394,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       o_dd[i] = dd;
       dD_acc = fmaf(dy[i], uu[i], dD_acc);
       dbias_acc += dd;
-      if (has_z) {
+    }
+    if (has_z) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
         const float s = sigmoid(zz[i]);
         o_dz[i] = go[i] * y[i] * s * fmaf(zz[i], 1.0f - s, 1.0f);
       }

@@ -189,13 +189,20 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     __syncthreads();  // B/C tile c is complete in buffer c&1; nobody still reads buffer (c+1)&1
 
     float dl[T], du[T], y[T], zz[T];
+    // flag tests stay OUTSIDE the per-step loops: a uniform branch per step serialises the 8 exp -> log -> rcp chains
+#pragma unroll
+    for (int i = 0; i < T; ++i) dl[i] = dn[i] + bias;
+    if (p.softplus) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) dl[i] = softplus(dl[i]);
+    }
+    if (!full) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) dl[i] = (t0 + j * T + i < L) ? dl[i] : 0.0f;  // padding steps are the identity map
+    }
 #pragma unroll
     for (int i = 0; i < T; ++i) {
-      float x = dn[i] + bias;
-      if (p.softplus && !(p.ablate & 4)) x = softplus(x);
-      if (!full) x = (t0 + j * T + i < L) ? x : 0.0f;  // padding steps are the identity map
-      dl[i] = x;
-      du[i] = x * un[i];
+      du[i] = dl[i] * un[i];
       y[i] = Dv * un[i];
     }
     // requests for the next chunk (and this chunk's z) go out before the long state loop
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     if (more) bc_commit((c + 1) & 1);
     if (has_z) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) y[i] *= (p.ablate & 4) ? zz[i] : silu(zz[i]);
+      for (int i = 0; i < T; ++i) y[i] *= silu(zz[i]);
     }
     if (p.ablate & 8) continue;
     if (VEC && full) {
