@@ -16,6 +16,7 @@ csrc/selective_scan/cus/selective_scan.cpp:165-215 raised as RuntimeError.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -268,7 +269,7 @@ def _bmm_f32(a, b):
 
 def wgrad_splits(K, M, N):
     """Number of token slices: enough (slices x 256^2 output tiles) to give every CU work, a power of two dividing K."""
-    if K < 4096:
+    if K < 4096 or os.environ.get("MXVL_WGRAD_SPLITS") == "0":
         return 1
     tiles = -(-M // 256) * -(-N // 256)
     S = 1
