@@ -229,6 +229,16 @@ int mxvl_swiglu_bwd(const void *ab, const void *dy, void *dab, int rows, int hid
 int mxvl_cross_scan(const void *x, void *xs, int batch, int channels, int height, int width, int io_dtype, void *hip_stream);
 int mxvl_cross_merge(const void *ys, void *y, int batch, int channels, int height, int width, int io_dtype, void *hip_stream);
 
+/* Depthwise 3x3 convolution (padding 1) + optional SiLU of VMamba's SS2D block: `self.act(self.conv2d(x))`,
+ * nn.Conv2d(d_inner, d_inner, 3, padding=1, groups=d_inner) (R2GenCSR/VMamba/classification/models/vmamba.py:746-755, 1121-1123).
+ * x, y, dy, dx: (batch, channels, height, width) contiguous in the io dtype; weight (channels, 9) fp32, bias (channels) fp32 or
+ * NULL; dweight / dbias fp32, ACCUMULATED into (caller zero-fills).  ksize must be 3, height*width <= 4096. */
+int mxvl_dwconv2d_fwd(const void *x, const void *weight, const void *bias, void *y, int batch, int channels, int height,
+                      int width, int ksize, int io_dtype, int silu, void *hip_stream);
+int mxvl_dwconv2d_bwd(const void *x, const void *weight, const void *bias, const void *dy, void *dx, void *dweight,
+                      void *dbias, int batch, int channels, int height, int width, int ksize, int io_dtype, int silu,
+                      void *hip_stream);
+
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
 /* kernel-variant override for A/B measurements (bench.py only); 0 = automatic */

@@ -71,6 +71,57 @@ class CrossMerge(torch.autograd.Function):
         return _cross(g, B, C, H, W, merge=False).view(B, 4, C, H, W)
 
 
+# ---- depthwise 3x3 conv + SiLU of SS2D ----------------------------------------------------------------------------------
+class _DwConv2dAct(torch.autograd.Function):
+    """act(conv2d(x)) for nn.Conv2d(C, C, 3, padding=1, groups=C) as one HIP kernel each way (csrc/dwconv2d.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, silu):
+        lib = _abi.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        w = weight.reshape(C, 9).float().contiguous()
+        b = bias.float().contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _abi.check(lib.mxvl_dwconv2d_fwd(x.data_ptr(), w.data_ptr(), _abi.ptr(b), y.data_ptr(), B, C, H, W, 3,
+                                             _abi.dtype_code(x.dtype), int(silu), _abi.stream_ptr(x.device)), "mxvl_dwconv2d_fwd")
+        ctx.save_for_backward(x, w, b)
+        ctx.meta = (silu, weight.shape, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b = ctx.saved_tensors
+        silu, wshape, wdt, bdt = ctx.meta
+        lib = _abi.load()
+        B, C, H, W = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device) if b is not None else None
+        with torch.cuda.device(x.device):
+            _abi.check(lib.mxvl_dwconv2d_bwd(x.data_ptr(), w.data_ptr(), _abi.ptr(b), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                             _abi.ptr(db), B, C, H, W, 3, _abi.dtype_code(x.dtype), int(silu),
+                                             _abi.stream_ptr(x.device)), "mxvl_dwconv2d_bwd")
+        return dx, dw.view(wshape).to(wdt), (db.to(bdt) if db is not None else None), None
+
+
+def dwconv3x3_act(x, conv: nn.Conv2d, act: nn.Module):
+    """act(conv(x)); the HIP kernel when conv is the SS2D depthwise 3x3 / padding 1 and the plane fits its LDS tile."""
+    C = x.shape[1]
+    fits = (x.is_cuda and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == C and conv.in_channels == C and conv.out_channels == C and x.shape[2] * x.shape[3] <= 4096
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
+    if not fits:
+        return act(conv(x))
+    if torch.is_autocast_enabled("cuda"):
+        x = x.to(torch.get_autocast_dtype("cuda"))       # what autocast would feed the convolution
+    if isinstance(act, nn.SiLU):
+        return _DwConv2dAct.apply(x, conv.weight, conv.bias, True)
+    return act(_DwConv2dAct.apply(x, conv.weight, conv.bias, False))
+
+
 # ---- selective scan with the vendored extension's calling convention -------------------------------------------------
 class SelectiveScanOflex(torch.autograd.Function):
     """forward(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows, backnrows, oflex) (vmamba.py:294-312).
@@ -384,9 +435,8 @@ class SS2D(nn.Module):
                 z = self.act(z)
         if not self.channel_first:
             x = x.permute(0, 3, 1, 2).contiguous()
-        if self.d_conv > 1:
-            x = self.conv2d(x)
-        y = self.forward_core(self.act(x))
+        x = dwconv3x3_act(x, self.conv2d, self.act) if self.d_conv > 1 else self.act(x)
+        y = self.forward_core(x)
         if z is not None:
             y = y * z
         return self.dropout(self.out_proj(y))

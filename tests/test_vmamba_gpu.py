@@ -108,3 +108,43 @@ def test_r2gencsr_encoder_runs_bf16():
     pooled.float().square().mean().backward()
     grads = [p.grad for p in net.parameters() if p.grad is not None]
     assert len(grads) > 100 and all(torch.isfinite(g_).all() for g_ in grads)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 56, 56), (3, 16, 28, 28), (2, 40, 14, 14), (5, 33, 7, 7), (1, 3, 9, 13), (2, 4, 64, 64)])
+@pytest.mark.parametrize("dtype,bias,silu", [(torch.float32, True, True), (torch.float32, False, False), (torch.bfloat16, False, True)])
+def test_dwconv3x3_act_forward_backward_vs_torch(shape, dtype, bias, silu):
+    """csrc/dwconv2d.hip against torch's fp32 conv2d (+SiLU) on the CPU: forward, dx, dweight, dbias."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    vm = _vm()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + C)
+    conv = nn.Conv2d(C, C, 3, padding=1, groups=C, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(C, 1, 3, 3, generator=g) * 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    x = torch.randn(B, C, H, W, generator=g).to(dtype)
+    dy = torch.randn(B, C, H, W, generator=g).to(dtype)
+    xr = x.detach().float().clone().requires_grad_(True)
+    act = nn.SiLU() if silu else nn.Identity()
+    yr = act(conv(xr))
+    yr.backward(dy.float())
+    ref_dw, ref_db = conv.weight.grad.clone(), (conv.bias.grad.clone() if bias else None)
+    conv.zero_grad()
+    convd = nn.Conv2d(C, C, 3, padding=1, groups=C, bias=bias).to(DEV)
+    convd.load_state_dict(conv.state_dict())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = vm.dwconv3x3_act(xd, convd, act)
+    y.backward(dy.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+
+    def close(a, b, what, scale_tol=tol):
+        err = float((a.detach().float().cpu() - b).abs().max())
+        assert err <= scale_tol * max(1.0, float(b.abs().max())), f"{what}: {err}"
+
+    close(y, yr.detach(), "y")
+    close(xd.grad, xr.grad, "dx")
+    close(convd.weight.grad, ref_dw, "dweight", tol * 4)
+    if bias:
+        close(convd.bias.grad, ref_db, "dbias", tol * 4)
