@@ -59,6 +59,12 @@ MAE_WORKLOADS = {
     "mae_vit_large_1280": (32, "HD_Xray_Pretrain_MAE: mae_vit_large_patch16 (1280x1280 1-channel X-rays, 64x64 patches -> 400 tokens, "
                                "encoder 1024x24x16h, decoder 512x8x16h), chest-region masking (mask_type 1, ratios 0.85 / 0.95), bf16 autocast"),
 }
+VMAMBA_WORKLOADS = {
+    # name: (per-GPU batch, description)
+    "vmamba_base_224": (32, "configs[4]: R2GenCSR visual encoder VMamba-base (vssm1_base_0229: dims 128..1024, depths [2,2,15,2], d_state 1, "
+                            "SS2D v3noz) at 224x224, encoder training step (forward + backward + AdamW on a synthetic pooled-feature loss), "
+                            "bf16 autocast"),
+}
 DECODE_WORKLOADS = {
     # name: (vocab, hidden, inter, layers, heads, kv_heads, prompt_len, new_tokens, beams, batch, description)
     "decode_llama7b_128": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 1,
@@ -344,13 +350,80 @@ def run_mae(args, rank, world, dev, dist):
                      "kernel": "whole step (library GEMM + SDPA; analytic flops of the visible tokens)"}}))
 
 
+def run_vmamba(args, rank, world, dev, dist):
+    """R2GenCSR's VMamba encoder (R2GenCSR/models/R2GenCSR.py:75-100 builds it; :233 calls it with global_features)."""
+    import torch.nn as nn
+    import medical_image_analysis_amd.selective_scan_interface as ssi
+    from medical_image_analysis_amd.vmamba import vssm1_base_0229
+    from medical_image_analysis_amd.pretrain_engine import PretrainEngine
+    B, desc = VMAMBA_WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+
+    class PooledLoss(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, imgs):
+            return self.net(imgs, global_features=True).float().square().mean(-1)
+
+    torch.manual_seed(0)
+    model = PooledLoss(vssm1_base_0229(drop_path_rate=0.0)).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    eng = PretrainEngine(model, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    batches = [torch.randn(B, 3, 224, 224, generator=g).to(dev) for _ in range(2)]
+    steps, warmup = args.steps, args.warmup
+    for i in range(warmup):
+        eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ssi.KERNEL_TIMERS = timers = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ssi.KERNEL_TIMERS = None
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    if rank != 0:
+        return
+    stats = {}
+    for kind, e0, e1, nbytes in timers:
+        d = stats.setdefault(kind, [0.0, 0, 0])
+        d[0] += e0.elapsed_time(e1); d[1] += 1; d[2] += nbytes
+    kind = max(stats, key=lambda k: stats[k][0])
+    tot_ms, calls, tot_bytes = stats[kind]
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "encoder training images/sec (forward + backward + grad-clip + AdamW)", "value": B * world * steps / wall,
+        "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
+        "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world, "params": n_params,
+                   "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)", "final_loss": float(loss.mean())},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": kind + " (all SS2D stages: L = 3136 / 784 / 196 / 49, 4 direction groups, d_state 1)",
+                     "kernel_ms": tot_ms / calls, "launches_timed": calls, "algorithmic_bytes_per_launch": tot_bytes // calls,
+                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="0 = workload default (20 training steps / 200 kernel launches)")
     ap.add_argument("--warmup", type=int, default=-1, help="-1 = workload default (3 / 20)")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD,
-                    choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS) + sorted(MAE_WORKLOADS))
+                    choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS) + sorted(MAE_WORKLOADS) + sorted(VMAMBA_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -385,13 +458,14 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    pre = args.workload in PRETRAIN_WORKLOADS or args.workload in MAE_WORKLOADS
+    pre = args.workload in PRETRAIN_WORKLOADS or args.workload in MAE_WORKLOADS or args.workload in VMAMBA_WORKLOADS
     if args.steps <= 0:
         args.steps = 20 if pre else 200
     if args.warmup < 0:
         args.warmup = 3 if pre else 20
     if pre:
-        (run_mae if args.workload in MAE_WORKLOADS else run_pretrain)(args, rank, world, dev, dist)
+        runner = run_mae if args.workload in MAE_WORKLOADS else run_vmamba if args.workload in VMAMBA_WORKLOADS else run_pretrain
+        runner(args, rank, world, dev, dist)
         if dist is not None:
             dist.destroy_process_group()
         return
