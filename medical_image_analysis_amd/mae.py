@@ -23,7 +23,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .models_mamba import DropPath, to_2tuple, trunc_normal_
+from . import fused_ops
+from .models_mamba import DropPath, run_blocks, to_2tuple, trunc_normal_
 from .models_pretrain import get_2d_sincos_pos_embed as _sincos_no_cls
 import numpy as np
 
@@ -97,6 +98,17 @@ class Block(nn.Module):
     def forward(self, x):
         x = x + self.drop_path(self.attn(self.norm1(x)))
         return x + self.drop_path(self.mlp(self.norm2(x)))
+
+    def fusable(self, x):
+        return (type(self.norm1) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm and x.dtype in (torch.float32, torch.bfloat16)
+                and fused_ops.add_layer_norm_supported(x, x.shape[-1]))
+
+    def forward_fused(self, h, pending, inference_params=None):
+        """(stream, pending branch) form for models_mamba.run_blocks: each residual add rides in the next LayerNorm kernel."""
+        h, n = fused_ops.add_layer_norm(h, pending, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        a = self.drop_path(self.attn(n))
+        h, n = fused_ops.add_layer_norm(h, a, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return h, self.drop_path(self.mlp(n))
 
 
 class SmallPatchEmbed(nn.Module):
@@ -234,8 +246,7 @@ class MaskedAutoencoderViT(nn.Module):
             x, mask, ids_restore = self.random_masking(x, mask_ratio_outer, noise)
         cls = (self.cls_token + self.pos_embed[:, :1, :]).expand(x.shape[0], -1, -1)
         x = torch.cat((cls, x), dim=1)
-        for blk in self.blocks:
-            x = blk(x)
+        x = run_blocks(self.blocks, x.contiguous())
         return self.norm(x), mask, ids_restore
 
     def forward_decoder(self, x, ids_restore):
@@ -244,8 +255,7 @@ class MaskedAutoencoderViT(nn.Module):
         x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
         x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).expand(-1, -1, x.shape[2]))
         x = torch.cat([x[:, :1, :], x_], dim=1) + self.decoder_pos_embed
-        for blk in self.decoder_blocks:
-            x = blk(x)
+        x = run_blocks(self.decoder_blocks, x.contiguous())
         x = self.decoder_norm(x)
         tezheng = x
         return self.decoder_pred(x)[:, 1:, :], tezheng
@@ -350,9 +360,7 @@ class ViT(nn.Module):
         x = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1) + self.pos_embed
         x = self.pos_drop(x)
-        for blk in self.blocks[:-1]:  # the reference skips the last block and the final norm (vit.py:280)
-            x = blk(x)
-        return x
+        return run_blocks(self.blocks[:-1], x.contiguous())  # the reference skips the last block and the final norm (vit.py:280)
 
 
 def vit_base(img_size=(224, 224), stride_size=16, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, **kwargs):

@@ -165,7 +165,7 @@ def run_blocks(layers, hidden_states, inference_params=None, taps=None):
         hidden_states = h if pending is None else h + pending
     else:
         for count, layer in enumerate(layers, start=1):
-            hidden_states = layer(hidden_states, inference_params=inference_params)
+            hidden_states = layer(hidden_states) if inference_params is None else layer(hidden_states, inference_params=inference_params)
             if taps and count in taps:
                 feats.append(hidden_states)
     return (hidden_states, feats) if taps else hidden_states

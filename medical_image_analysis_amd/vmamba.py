@@ -24,7 +24,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _abi
+from . import fused_ops
 from . import selective_scan_interface as ssi
+from .models_mamba import run_blocks
 
 
 # ---- the 4-direction orderings ------------------------------------------------------------------------------------
@@ -477,6 +479,18 @@ class VSSBlock(nn.Module):
             return torch.utils.checkpoint.checkpoint(self._forward, x)
         return self._forward(x)
 
+    def fusable(self, x):
+        """Pre-norm, channel-last LayerNorms of a width the add+LayerNorm kernel takes (256 / 512 / 1024 of VSSM-base)."""
+        return (self.ssm_branch and self.mlp_branch and not self.post_norm and not self.use_checkpoint
+                and type(self.norm) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm
+                and x.dtype in (torch.float32, torch.bfloat16) and fused_ops.add_layer_norm_supported(x, x.shape[-1]))
+
+    def forward_fused(self, h, pending, inference_params=None):
+        h, n = fused_ops.add_layer_norm(h, pending, self.norm.weight, self.norm.bias, self.norm.eps)
+        m = self.drop_path(self.op(n))
+        h, n = fused_ops.add_layer_norm(h, m, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return h, self.drop_path(self.mlp(n))
+
 
 _NORMS = dict(ln=nn.LayerNorm, ln2d=LayerNorm2d, bn=nn.BatchNorm2d)
 _ACTS = dict(silu=nn.SiLU, gelu=nn.GELU, relu=nn.ReLU, sigmoid=nn.Sigmoid)
@@ -565,7 +579,7 @@ class VSSM(nn.Module):
             raise NotImplementedError("feature-map PNG dumps (matplotlib) are a debugging aid of the reference, not built")
         x = self.patch_embed(x)
         for layer in self.layers:
-            x = layer(x)
+            x = layer.downsample(run_blocks(list(layer.blocks), x.contiguous()))
         return self.classifier(x) if global_features else x
 
 
@@ -587,7 +601,7 @@ class Backbone_VSSM(VSSM):
         x = self.patch_embed(x)
         outs = []
         for i, layer in enumerate(self.layers):
-            o = layer.blocks(x)
+            o = run_blocks(list(layer.blocks), x.contiguous())
             x = layer.downsample(o)
             if i in self.out_indices:
                 o = getattr(self, f"outnorm{i}")(o)
