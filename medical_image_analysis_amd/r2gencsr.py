@@ -1,0 +1,144 @@
+"""R2GenCSR report generator on the MI355X-native VMamba encoder and report decoder.
+
+Host-side mirror of R2GenCSR/models/R2GenCSR.py (`R2GenCSR`, :56-700) for its default configuration (`--chosen vmamba`,
+`--proj linear`): VMamba-base encoder (`vmamba.vssm1_base_0229`), `llama_proj`, `layer_norm`, the prompt wrapping, and the
+**context-sample residuals** (:437-474): a few fixed "negative" (normal) and "positive" (abnormal) training images are encoded
+with the same encoder under no_grad, their pooled features are subtracted from the study's pooled feature, wrapped in their
+text prompts and prepended to the LLM input.  Same `args` fields, sub-module names and delta-checkpoint keys.
+
+Outside the path and not built: the pandas / FieldParser code that PICKS the context images from the annotation file
+(:309-374; pass the picked image tensors to `set_context_samples`), the Swin / Vim encoder choices, the Q-Former projector
+(HF Blip2QFormerModel), PEFT-LoRA, evalcap scoring.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import checkpoint_compat as compat
+from .mambaxray_vl import MambaXrayVLDownStream, _get, _load_tokenizer, _reject_unbuilt, build_report_decoder
+from .vmamba import vssm1_base_0229
+
+
+class R2GenCSR(MambaXrayVLDownStream):
+    def __init__(self, args, tokenizer=None, llm=None, encoder=None):
+        nn.Module.__init__(self)
+        _reject_unbuilt(args)
+        if _get(args, "chosen", "vmamba") != "vmamba":
+            raise NotImplementedError("only --chosen vmamba (the default) is built; Swin / Vim encoders are third-party models")
+        if _get(args, "proj", "linear") == "qformer":
+            raise NotImplementedError("--proj qformer wraps HF Blip2QFormerModel (third-party); the default linear projector is built")
+        self.args = self.hparams = args
+        self.proj, self.chosen, self.llm = "linear", "vmamba", _get(args, "llm", "llama2")
+        self.visual_encoder = encoder if encoder is not None else vssm1_base_0229()
+        vision_model = str(_get(args, "vision_model", "None"))
+        if vision_model != "None":
+            ck = torch.load(vision_model, map_location="cpu")
+            self.visual_encoder.load_state_dict(ck["model"] if "model" in ck else ck, strict=False)   # :101-105
+        if _get(args, "freeze_vm", False):
+            for p in self.visual_encoder.parameters():
+                p.requires_grad = False
+        self.llama_model = llm if llm is not None else build_report_decoder(_get(args, "llama_model", None) or "llama2-7b")
+        self.llama_tokenizer = tokenizer if tokenizer is not None else _load_tokenizer(_get(args, "llama_model"))
+        self.llama_tokenizer.pad_token_id = 0
+        if self.llm != "llama2":
+            self.llama_tokenizer.bos_token_id = 0
+        self.embed_tokens = self.llama_model.get_input_embeddings()
+        if _get(args, "llm_freeze", True):
+            for p in self.llama_model.parameters():
+                p.requires_grad = False
+        hidden = self.llama_model.config.hidden_size
+        self.llama_proj = nn.Linear(self.visual_encoder.num_features, hidden)
+        self.layer_norm = nn.LayerNorm(hidden)
+        self.end_sym = _get(args, "end_sym", "</s>")
+        self.prompt = _get(args, "instruction", "Generate a comprehensive and detailed diagnosis report for this chest xray image.")
+        self.val_step_outputs, self.test_step_outputs = [], []
+        self.val_score = 0.0
+        self.negative_samples = self.positive_samples = None
+        if _get(args, "delta_file") is not None:
+            compat.load_delta(self, _get(args, "delta_file"))
+
+    def set_context_samples(self, negative_images, positive_images):
+        """The `context_pair` normal / abnormal reference studies, (n, 3, H, W) each (what context_sample() :309-374 loads)."""
+        self.negative_samples = {"image": negative_images}
+        self.positive_samples = {"image": positive_images}
+
+    # ---- :228-264 ---------------------------------------------------------------------------------------------------------
+    def encode_img(self, images, global_only=False, global_only_return=False, use_feature_mean=True, featuremap_folder=None):
+        embeds = []
+        for image in images:
+            e = self.visual_encoder(image, global_only)
+            embeds.append(e if global_only else e.flatten(1, 2))               # 'b h w e -> b (h w) e'
+        if _get(self.args, "use_feature_mean", True) or global_only:
+            image_embeds = torch.stack(embeds).mean(0)
+            if global_only_return:
+                return image_embeds, None
+        else:
+            if len(embeds) == 1:
+                embeds = embeds + embeds                                        # same token count as two-view training
+            image_embeds = torch.cat(embeds, dim=1)
+        inputs_llama = self.llama_proj(image_embeds)
+        return inputs_llama, torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=inputs_llama.device)
+
+    def image_prompt_wrap(self, img_embeds, atts_img, prompt):
+        before, after = prompt.split("<ImageHere>")
+        B = img_embeds.shape[0]
+        pb = self._embed_text(before, img_embeds.device).expand(B, -1, -1).to(img_embeds.dtype)
+        pa = self._embed_text(after, img_embeds.device).expand(B, -1, -1).to(img_embeds.dtype)
+        wrapped = torch.cat([pb, img_embeds, pa], dim=1)
+        return wrapped, atts_img[:, :1].expand(-1, wrapped.shape[1])
+
+    # ---- :376-474 ---------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def context_encode_with_wrap(self, image, img_embeds, global_contex=True):
+        if self.negative_samples is None or self.positive_samples is None:
+            raise RuntimeError("context_pair > 0 needs set_context_samples(negative_images, positive_images)")
+        a = self.args
+        dev = img_embeds.device
+        before = bool(_get(a, "before_proj_res", False))
+        g_emb, _ = self.encode_img(image, global_only=True, global_only_return=before)
+        p_emb, p_att = self.encode_img([self.positive_samples["image"].to(dev)], global_only=global_contex, global_only_return=before)
+        n_emb, n_att = self.encode_img([self.negative_samples["image"].to(dev)], global_only=global_contex, global_only_return=before)
+        pos_prompt, neg_prompt = _get(a, "positive"), _get(a, "negative")
+        ones = lambda t: torch.ones(t.shape[:-1], dtype=torch.long, device=dev)
+
+        if before:                                           # residual in encoder space, then project (:391-419)
+            g = g_emb[:, None, :].expand(-1, p_emb.shape[0], -1)
+            p_emb, n_emb = self.llama_proj(g - p_emb), self.llama_proj(g - n_emb)
+            pw, pa = self.image_prompt_wrap(p_emb, ones(p_emb), pos_prompt)
+            nw, na = self.image_prompt_wrap(n_emb, ones(n_emb), neg_prompt)
+            return torch.cat((nw, pw), dim=1), torch.cat((na, pa), dim=1)
+        if _get(a, "after_proj_res_visual_only", False):     # (:421-439)
+            g = g_emb[:, None, :].expand(-1, p_emb.shape[0], -1)
+            p_emb, n_emb = g - p_emb, g - n_emb
+            pw, pa = self.image_prompt_wrap(p_emb, p_att[:, None], pos_prompt)
+            nw, na = self.image_prompt_wrap(n_emb, n_att[:, None], neg_prompt)
+            atts = torch.cat((na, pa), dim=1)
+            return torch.cat((nw, pw), dim=1), atts[:1].expand(p_emb.shape[0], -1)
+        if global_contex:                                    # pooled context features: one token per reference study
+            p_emb, n_emb, p_att, n_att = p_emb[:, None, :], n_emb[:, None, :], p_att[:, None], n_att[:, None]
+        else:
+            p_emb, n_emb = self.layer_norm(p_emb), self.layer_norm(n_emb)
+        pw, pa = self.image_prompt_wrap(p_emb, p_att, pos_prompt)
+        nw, na = self.image_prompt_wrap(n_emb, n_att, neg_prompt)
+        ctx = torch.cat((nw, pw), dim=1)                     # [negative, positive]
+        att = torch.cat((na, pa), dim=1)
+        B = img_embeds.shape[0]
+        ctx = ctx.reshape(1, -1, ctx.shape[-1]).expand(B, -1, -1)
+        att = att.reshape(1, -1).expand(B, -1)
+        return g_emb[:, None, :].expand(-1, ctx.shape[1], -1) - ctx, att       # global feature minus every context token
+
+    def _prefix(self, samples):
+        image = samples["image"]
+        img_embeds, atts_img = self.encode_img(image)
+        img_embeds = self.layer_norm(img_embeds)
+        if _get(self.args, "context_pair", 0) > 0:
+            ctx, ctx_att = self.context_encode_with_wrap(image, img_embeds, global_contex=True)
+            img_embeds, atts_img = self.prompt_wrap(img_embeds, atts_img)
+            img_embeds = torch.cat((ctx.to(img_embeds.dtype), img_embeds), dim=1)
+            atts_img = torch.cat((ctx_att, atts_img), dim=1)
+        else:
+            img_embeds, atts_img = self.prompt_wrap(img_embeds, atts_img)
+        bos = torch.full((img_embeds.shape[0], 1), self.llama_tokenizer.bos_token_id, dtype=torch.long, device=img_embeds.device)
+        embeds = torch.cat([self.embed_tokens(bos).to(img_embeds.dtype), img_embeds], dim=1)
+        return embeds, torch.cat([atts_img[:, :1], atts_img], dim=1)

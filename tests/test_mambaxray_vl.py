@@ -164,3 +164,48 @@ def test_clip_step_and_stage1_handoff(tmp_path):
     assert torch.isfinite(loss)
     loss.backward()
     assert m.logit_scale.grad is not None and m.visual_encoder.layers[0].mixer.A_log.grad is not None
+
+
+@pytest.mark.gpu
+def test_r2gencsr_context_residuals_loss_and_generate():
+    """R2GenCSR mirror: VMamba encoder + linear projector + context-sample residual prefix (R2GenCSR.py:376-474, 480-495)."""
+    from medical_image_analysis_amd import mambaxray_vl as mx
+    from medical_image_analysis_amd.r2gencsr import R2GenCSR
+    from medical_image_analysis_amd.vmamba import VSSM
+    torch.manual_seed(0)
+    enc = VSSM(depths=[1, 1, 2, 1], dims=32, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
+               mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0)
+    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=4, max_position_embeddings=1024), dtype=torch.bfloat16)
+    args = mx.default_args(max_length=16, min_new_tokens=4, max_new_tokens=8, context_pair=3, freeze_vm=False, llm_freeze=True,
+                           positive="Note: <Img><ImageHere></Img> with disease .", negative="Note: <Img><ImageHere></Img> is healthy .",
+                           use_feature_mean=True, instruction="Generate a report .")
+    m = R2GenCSR(args, tokenizer=WordTokenizer(), llm=llm, encoder=enc).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    m.set_context_samples(torch.randn(3, 3, 224, 224, generator=g).to(DEV), torch.randn(3, 3, 224, 224, generator=g).to(DEV))
+    batch = _samples(2)
+    tok = WordTokenizer()
+    n_neg = len(tok._ids("Note: <Img>")) + 1 + len(tok._ids("</Img> is healthy ."))
+    n_pos = len(tok._ids("Note: <Img>")) + 1 + len(tok._ids("</Img> with disease ."))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        img, att = m.encode_img(batch["image"])
+        assert img.shape == (2, 49, 128)                                  # 7x7 feature map -> 49 image tokens
+        ctx, catt = m.context_encode_with_wrap(batch["image"], img)
+        assert ctx.shape == (2, 3 * (n_neg + n_pos), 128) and catt.shape == ctx.shape[:2]
+        pooled, _ = m.encode_img(batch["image"], global_only=True)
+        # the residual of a context IMAGE token is (projected pooled study feature) - (projected pooled context feature)
+        neg_pooled, _ = m.encode_img([m.negative_samples["image"]], global_only=True)
+        k = len(tok._ids("Note: <Img>"))
+        want = pooled[:, None, :] - neg_pooled[None, :, :]
+        got = torch.stack([ctx[:, i * (n_neg + n_pos) + k] for i in range(3)], dim=1)   # [neg_i tokens | pos_i tokens] per study
+        assert torch.allclose(got.float(), want.float(), atol=2e-2, rtol=2e-2)
+        loss = m(batch)["loss"]
+        assert torch.isfinite(loss)
+        loss.backward()
+        hypo, ref = m.validation_step(batch)
+    assert m.llama_proj.weight.grad is not None and m.visual_encoder.layers[0].blocks[0].op.A_logs.grad is not None
+    assert len(hypo) == 2 and all(4 <= len(h.split()) <= 8 for h in hypo)
+    m.args.before_proj_res = True
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ctx2, att2 = m.context_encode_with_wrap(batch["image"], img)
+    assert ctx2.shape == (2, n_neg + n_pos + 4, 128)                      # residuals of the 3 studies as 3-token image spans
