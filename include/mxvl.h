@@ -195,6 +195,27 @@ int mxvl_state_update(void *state, const void *x, const void *dt, const void *A,
                       const void *C, const void *D, const void *z, const void *dt_bias, void *out,
                       int batch, int dim, int dstate, int io_dtype, int dt_softplus, void *hip_stream);
 
+/* One beam-search update of report generation (what HF `generate(num_beams>1)` does between two decoder steps; call site
+ * CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301): log-softmax, repetition penalty, min-new-tokens,
+ * top-`keep` over beams*vocab, live-beam / finished-pool bookkeeping, early-stop heuristic.  All state tensors are updated
+ * in place; *cur is incremented; *unfinished = decoding continues.  beams <= 4, keep <= 8.  Dtypes: logits, scores, tables
+ * fp32; sequences, cur, eos, tok, beam_src int64; fin_done, heur_open, unfinished 1-byte booleans. */
+typedef struct mxvl_beam_desc {
+  int32_t batch, beams, vocab, max_new, min_new, n_eos, early_stopping, keep; /* early_stopping: 1 = True, 0 = False/"never" */
+  float repetition_penalty;
+  int32_t reserved0;
+  const void *logits;              /* (batch*beams, vocab) */
+  void *run_seq, *fin_seq;         /* (batch, beams, max_new) */
+  void *run_score, *fin_score;     /* (batch, beams) */
+  void *fin_done, *heur_open;      /* (batch, beams), (batch) */
+  void *cur;                       /* scalar */
+  const void *eos;                 /* (n_eos) */
+  const void *len_tab, *hyp_tab;   /* (max_new): (t+1)^length_penalty, hypothesis-length^length_penalty */
+  void *tok, *beam_src;            /* (batch*beams): next token, parent row of every live beam */
+  void *unfinished;                /* scalar */
+} mxvl_beam_desc;
+int mxvl_beam_step(const mxvl_beam_desc *desc, void *hip_stream);
+
 /* Residual add + LayerNorm of an ARM / VisionMamba block (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:
  * 110-116 `x + mixer(norm1(x))`, `x + mlp(norm2(x))`; the reference's fused_add_norm path pairs them the same way):
  *   h = x + branch (branch may be NULL: h is x and is not written);  n = (h - mean) * rstd * gamma + beta.

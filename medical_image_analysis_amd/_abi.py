@@ -32,7 +32,7 @@ SYMBOLS = [
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd",
+    "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step",
 ]
 
 
@@ -116,6 +116,17 @@ class AddLnBwdDesc(ctypes.Structure):
     ]
 
 
+class BeamDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("beams", c_int32), ("vocab", c_int32), ("max_new", c_int32), ("min_new", c_int32), ("n_eos", c_int32),
+        ("early_stopping", c_int32), ("keep", c_int32),
+        ("repetition_penalty", ctypes.c_float), ("reserved0", c_int32),
+        ("logits", c_void_p), ("run_seq", c_void_p), ("fin_seq", c_void_p), ("run_score", c_void_p), ("fin_score", c_void_p),
+        ("fin_done", c_void_p), ("heur_open", c_void_p), ("cur", c_void_p), ("eos", c_void_p), ("len_tab", c_void_p),
+        ("hyp_tab", c_void_p), ("tok", c_void_p), ("beam_src", c_void_p), ("unfinished", c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -140,6 +151,8 @@ def load() -> ctypes.CDLL:
     lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
     lib.mxvl_state_update.restype = c_int
     lib.mxvl_state_update.argtypes = [c_void_p] * 10 + [c_int] * 5 + [c_void_p]
+    lib.mxvl_beam_step.restype = c_int
+    lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

@@ -1,0 +1,381 @@
+// beam_step.hip -- one beam-search update of the report decoder as ONE kernel, for gfx950.
+//
+// Replaces the ~100 tiny kernels HF `generate` (transformers generation/utils.py `_beam_search`, vectorised form; called from
+// CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301 with num_beams=3, repetition_penalty=2.0,
+// length_penalty=2.0, min_new_tokens) spends per generated token on log-softmax, RepetitionPenalty / MinNewTokensLength
+// processors, a sort-based top-k over beams*vocab candidates and the beam bookkeeping: ~0.5 ms of a 3.9 ms token.
+// Same arithmetic, same order of the fp32 operations as report_decoder._BeamState.advance (the torch restatement that is
+// checked token-exact against HF): this kernel is tested against that function.
+//
+// One workgroup (512 threads) walks the batch elements.  Per element: (1) online max / sum-exp of every beam row (32
+// independent loads in flight per thread: a single workgroup is latency-, not bandwidth-limited on 384 KB of logits), (2) every
+// thread keeps the `keep` best penalised candidates of its strided share, history membership through an LDS bitmap,
+// (3) `keep` rounds of a block arg-max merge them, (4) a few lanes do the bookkeeping on the `keep` survivors.
+#include <math.h>
+#include <stdlib.h>
+
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+constexpr int kBeamThreads = 512, kBeamWaves = kBeamThreads / 64, kMaxKeep = 8, kMaxBeams = 4, kMaxEos = 4, kMaxSurv = 256;   // 8 waves: 256 VGPRs each
+
+struct BeamArgs {
+  int batch, nb, V, max_new, min_new, n_eos, early, keep, ablate;   // early: 1 = early_stopping True
+  float rep_pen;
+  const float* logits;                 // (batch*nb, V)
+  long long *run_seq, *fin_seq;        // (batch, nb, max_new)
+  float *run_score, *fin_score;        // (batch, nb)
+  unsigned char *fin_done, *heur_open; // (batch, nb), (batch)
+  long long* cur;                      // scalar, incremented at the end
+  const long long* eos;                // (n_eos)
+  const float *len_tab, *hyp_tab;      // (max_new)
+  long long *tok, *beam_src;           // (batch*nb)
+  unsigned char* unfinished;           // scalar
+};
+
+__device__ inline bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
+  __shared__ float s_red[16];
+  __shared__ int s_redi[16];
+  __shared__ float s_rowmax[kMaxBeams], s_logz[kMaxBeams];
+  __shared__ float s_top_lp[kMaxKeep];
+  __shared__ int s_top_ix[kMaxKeep];
+  __shared__ int s_sel_src[kMaxBeams], s_sel_tok[kMaxBeams];      // per new live beam: parent beam, new token
+  __shared__ int s_fin_from[kMaxBeams];                            // per new finished slot: < nb old slot, else nb + candidate
+  __shared__ int s_any_open, s_all_hits, s_all_done, s_nsurv;
+  __shared__ float s_surv_v[kMaxSurv];
+  __shared__ int s_surv_i[kMaxSurv];
+  __shared__ float s_bk_f[4 * kMaxKeep + 3 * kMaxBeams];
+  __shared__ int s_bk_i[6 * kMaxKeep + 3 * kMaxBeams];
+  __shared__ float s_in_fscore[kMaxBeams], s_in_rscore[kMaxBeams], s_tabs[2];
+  __shared__ int s_in_fdone[kMaxBeams], s_in_open;
+  __shared__ float s_out_rscore[kMaxBeams], s_out_fscore[kMaxBeams];
+  __shared__ int s_out_fdone[kMaxBeams], s_out_open;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = p.nb, V = p.V, keep = p.keep, max_new = p.max_new;
+  const int words = (V + 31) / 32;
+  unsigned int* bitmap = smem_u;                                   // [nb][words] history membership
+  long long* old_run = (long long*)(smem_u + ((nb * words + 1) & ~1));   // [nb][max_new]
+  long long* old_fin = old_run + nb * max_new;                     // [nb][max_new]
+  const int cur = (int)*p.cur;
+  if (tid == 0) { s_any_open = 0; s_all_hits = 1; s_all_done = 1; }
+  int eos32[kMaxEos];                  // the EOS ids live in registers: they are tested against every candidate
+#pragma unroll
+  for (int e = 0; e < kMaxEos; ++e) eos32[e] = e < p.n_eos ? (int)p.eos[e] : -1;
+
+  for (int b = 0; b < p.batch; ++b) {
+    __syncthreads();
+    const float* lg = p.logits + (size_t)b * nb * V;
+    long long* rs = p.run_seq + (size_t)b * nb * max_new;
+    long long* fs = p.fin_seq + (size_t)b * nb * max_new;
+    // the few scalars the bookkeeping lane needs: one parallel round trip now instead of ~25 serial ones later
+    if (tid < nb) {
+      s_in_fscore[tid] = p.fin_score[b * nb + tid];
+      s_in_rscore[tid] = p.run_score[b * nb + tid];
+      s_in_fdone[tid] = p.fin_done[b * nb + tid];
+    } else if (tid == 64) {
+      s_in_open = p.heur_open[b];
+    } else if (tid == 65) {
+      s_tabs[0] = p.len_tab[cur];
+    } else if (tid == 66) {
+      s_tabs[1] = p.hyp_tab[cur];
+    }
+    for (int i = tid; i < nb * words; i += kBeamThreads) bitmap[i] = 0u;
+    for (int i = tid; i < nb * max_new; i += kBeamThreads) { old_run[i] = rs[i]; old_fin[i] = fs[i]; }
+    __syncthreads();
+    if (p.rep_pen != 1.0f && cur > 0)
+      for (int i = tid; i < nb * cur; i += kBeamThreads) {
+        const int r = i / cur, t = i - r * cur;
+        const int v = (int)old_run[r * max_new + t];
+        if (v >= 0 && v < V) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
+      }
+    // ---- (1) log-softmax statistics per beam row: one sweep, U independent loads in flight per thread --------------
+    constexpr int U = 16;
+    for (int r = 0; r < nb; ++r) {
+      const float* row = lg + (size_t)r * V;
+      float m = -INFINITY, s = 0.0f;
+      for (int base = 0; base < V; base += kBeamThreads * U) {
+        float x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = base + u * kBeamThreads + tid;
+          x[u] = v < V ? row[v] : -INFINITY;
+        }
+        float cm = x[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) cm = fmaxf(cm, x[u]);
+        const float mn = fmaxf(m, cm);
+        if (mn > -INFINITY) {
+          float cs = 0.0f;
+#pragma unroll
+          for (int u = 0; u < U; ++u) cs += fast_exp(x[u] - mn);
+          s = s * fast_exp(m - mn) + cs;
+          m = mn;
+        }
+      }
+      float wm = m;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+      if (lane == 0) s_red[wave] = wm;
+      __syncthreads();
+      float mx = s_red[0];
+#pragma unroll
+      for (int w = 1; w < kBeamWaves; ++w) mx = fmaxf(mx, s_red[w]);
+      __syncthreads();
+      float ws = (m > -INFINITY) ? s * fast_exp(m - mx) : 0.0f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ws += __shfl_xor(ws, off, 64);
+      if (lane == 0) s_red[wave] = ws;
+      __syncthreads();
+      if (tid == 0) {
+        float ss = 0.0f;
+        for (int w = 0; w < kBeamWaves; ++w) ss += s_red[w];
+        s_rowmax[r] = mx;
+        s_logz[r] = logf(ss);
+      }
+      __syncthreads();
+    }
+    if (p.ablate == 1) continue;
+    // ---- (2) every thread keeps its TWO best penalised, score-shifted candidates (branch-free insertion) ---------------
+    // A sorted `keep`-deep list per thread costs a wave-wide insertion for almost every element (some lane always
+    // inserts): 100 us.  Two entries per thread are exact unless one thread owns three of the final `keep` -- detected
+    // below and repaired by a rescan of that thread's share (practically never taken).
+    auto cand_value = [&](int r, int v, float raw, float mx, float lz, float sc, bool mask_eos) -> float {
+      float x = (raw - mx) - lz;                                              // log_softmax
+      if ((bitmap[r * words + (v >> 5)] >> (v & 31)) & 1u) x = x < 0.0f ? x * p.rep_pen : x / p.rep_pen;
+      if (mask_eos) {
+#pragma unroll
+        for (int e = 0; e < kMaxEos; ++e)
+          if (eos32[e] == v) x = -INFINITY;
+      }
+      return x + sc;
+    };
+    float v1 = -INFINITY, v2 = -INFINITY;
+    int i1 = 0x7fffffff, i2 = 0x7fffffff;
+    for (int r = 0; r < nb; ++r) {
+      const float* row = lg + (size_t)r * V;
+      const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
+      const bool mask_eos = cur < p.min_new;
+      for (int base = 0; base < V; base += kBeamThreads * U) {
+        float xs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = base + u * kBeamThreads + tid;
+          xs[u] = v < V ? row[v] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = base + u * kBeamThreads + tid;
+          if (v < V) {
+            const float x = cand_value(r, v, xs[u], mx, lz, sc, mask_eos);
+            const int idx = r * V + v;
+            const bool b1 = better(x, idx, v1, i1), b2 = better(x, idx, v2, i2);
+            v2 = b1 ? v1 : (b2 ? x : v2);
+            i2 = b1 ? i1 : (b2 ? idx : i2);
+            v1 = b1 ? x : v1;
+            i1 = b1 ? idx : i1;
+          }
+        }
+      }
+    }
+    if (p.ablate == 2) continue;
+    // ---- (3) `keep` rounds of block arg-max over the thread-local heads --------------------------------------------------
+    int head = 0;
+    for (int round = 0; round < keep; ++round) {
+      float v = head == 0 ? v1 : head == 1 ? v2 : -INFINITY;
+      int ix = head == 0 ? i1 : head == 1 ? i2 : 0x7fffffff;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(ix, off, 64);
+        if (better(ov, oi, v, ix)) { v = ov; ix = oi; }
+      }
+      if (lane == 0) { s_red[wave] = v; s_redi[wave] = ix; }
+      __syncthreads();
+      if (tid == 0) {
+        float bv = s_red[0];
+        int bi = s_redi[0];
+        for (int w = 1; w < kBeamWaves; ++w)
+          if (better(s_red[w], s_redi[w], bv, bi)) { bv = s_red[w]; bi = s_redi[w]; }
+        s_top_lp[round] = bv;
+        s_top_ix[round] = bi;
+      }
+      __syncthreads();
+      const int win = s_top_ix[round];
+      if ((head == 0 && i1 == win) || (head == 1 && i2 == win)) ++head;
+    }
+    // exactness: a thread with both entries among the winners may hold more candidates above the keep-th value
+    if (tid == 0) s_nsurv = 0;
+    __syncthreads();
+    const bool suspect = head == 2 && keep > 2;
+    if (__syncthreads_or(suspect ? 1 : 0)) {
+      const float tau = s_top_lp[keep - 1];
+      const int tau_ix = s_top_ix[keep - 1];
+      if (suspect) {
+        for (int r = 0; r < nb; ++r) {
+          const float* row = lg + (size_t)r * V;
+          const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
+          for (int v = tid; v < V; v += kBeamThreads) {
+            const int idx = r * V + v;
+            if (idx == i1 || idx == i2) continue;
+            const float x = cand_value(r, v, row[v], mx, lz, sc, cur < p.min_new);
+            if (better(x, idx, tau, tau_ix)) {
+              const int slot = atomicAdd(&s_nsurv, 1);
+              if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {     // insertion of the (few) survivors into the sorted winners
+        const int ns = s_nsurv < kMaxSurv ? s_nsurv : kMaxSurv;
+        for (int q = 0; q < ns; ++q) {
+          float x = s_surv_v[q];
+          int ix = s_surv_i[q];
+          for (int k = 0; k < keep; ++k)
+            if (better(x, ix, s_top_lp[k], s_top_ix[k])) {
+              const float tv = s_top_lp[k]; s_top_lp[k] = x; x = tv;
+              const int ti = s_top_ix[k]; s_top_ix[k] = ix; ix = ti;
+            }
+        }
+      }
+      __syncthreads();
+    }
+    if (p.ablate == 3) continue;
+    // ---- (4) bookkeeping on the survivors (one lane; everything here is `keep` <= 8 wide) -----------------------------
+    if (tid == 0) {
+      float* top_lp = s_bk_f;                      // dynamically indexed: LDS, not private (scratch) arrays
+      float* live_lp = s_bk_f + kMaxKeep;
+      float* cand = s_bk_f + 2 * kMaxKeep;
+      float* ms = s_bk_f + 3 * kMaxKeep;           // [kMaxBeams + kMaxKeep]
+      float* new_score = ms + kMaxBeams + kMaxKeep;
+      float* fscore = new_score + kMaxBeams;
+      int* src = s_bk_i;
+      int* ntok = s_bk_i + kMaxKeep;
+      int* hits = s_bk_i + 2 * kMaxKeep;
+      int* used = s_bk_i + 3 * kMaxKeep;
+      int* md = s_bk_i + 4 * kMaxKeep;             // [kMaxBeams + kMaxKeep]
+      int* mu = md + kMaxBeams + kMaxKeep;
+      int* fdone = mu + kMaxBeams + kMaxKeep;
+      bool all_done_b = true;
+      for (int i = 0; i < nb; ++i) all_done_b = all_done_b && s_in_fdone[i];
+      const bool open_b = s_in_open != 0;
+      for (int k = 0; k < keep; ++k) {
+        top_lp[k] = s_top_lp[k];
+        src[k] = s_top_ix[k] / V;
+        ntok[k] = s_top_ix[k] - src[k] * V;
+        bool h = cur + 1 >= max_new;
+#pragma unroll
+        for (int e = 0; e < kMaxEos; ++e) h = h || (eos32[e] == ntok[k]);
+        hits[k] = h ? 1 : 0;
+        if (!h) s_all_hits = 0;
+        live_lp[k] = top_lp[k] + (h ? 1.0f : 0.0f) * -1e9f;
+        const bool just = h && k < nb;
+        float c = top_lp[k] / s_tabs[0];
+        if (p.early == 1) c = c + (all_done_b ? 1.0f : 0.0f) * -1e9f;
+        c = (c + (open_b ? 0.0f : 1.0f) * -1e9f) + (just ? 0.0f : 1.0f) * -1e9f;
+        cand[k] = c;
+        used[k] = 0;
+      }
+      // live beams: the nb best of live_lp (descending, first index wins ties)
+      for (int i = 0; i < nb; ++i) {
+        int best = -1;
+        for (int k = 0; k < keep; ++k)
+          if (!used[k] && (best < 0 || live_lp[k] > live_lp[best])) best = k;
+        used[best] = 1;
+        new_score[i] = live_lp[best];
+        s_sel_src[i] = src[best];
+        s_sel_tok[i] = ntok[best];
+      }
+      // finished pool: the nb best of [old finished scores | candidate scores]
+      for (int i = 0; i < nb; ++i) { ms[i] = s_in_fscore[i]; md[i] = s_in_fdone[i] != 0; mu[i] = 0; }
+      for (int k = 0; k < keep; ++k) { ms[nb + k] = cand[k]; md[nb + k] = hits[k] && k < nb; mu[nb + k] = 0; }
+      for (int i = 0; i < nb; ++i) {
+        int best = -1;
+        for (int k = 0; k < nb + keep; ++k)
+          if (!mu[k] && (best < 0 || ms[k] > ms[best])) best = k;
+        mu[best] = 1;
+        fscore[i] = ms[best];
+        fdone[i] = md[best];
+        s_fin_from[i] = best;
+      }
+      float fmin = fscore[0];
+      bool fall = true;
+      for (int i = 0; i < nb; ++i) { fmin = fminf(fmin, fscore[i]); fall = fall && fdone[i]; }
+      const float best_live = new_score[0] / s_tabs[1];
+      bool any = false;
+      for (int i = 0; i < nb; ++i) any = any || (best_live > (fdone[i] ? fmin : -1e9f));
+      const bool open_new = open_b && any;
+      s_out_open = open_new ? 1 : 0;
+      if (open_new) s_any_open = 1;
+      if (!fall) s_all_done = 0;
+      for (int i = 0; i < nb; ++i) {
+        s_out_rscore[i] = new_score[i];
+        s_out_fscore[i] = fscore[i];
+        s_out_fdone[i] = fdone[i] ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (tid < nb) {
+      p.run_score[b * nb + tid] = s_out_rscore[tid];
+      p.fin_score[b * nb + tid] = s_out_fscore[tid];
+      p.fin_done[b * nb + tid] = (unsigned char)s_out_fdone[tid];
+      p.tok[b * nb + tid] = s_sel_tok[tid];
+      p.beam_src[b * nb + tid] = (long long)s_sel_src[tid] + (long long)b * nb;
+    } else if (tid == 64) {
+      p.heur_open[b] = (unsigned char)s_out_open;
+    }
+    // sequences: new live rows = parent row + new token at `cur`; finished rows from the old pool or from a candidate
+    for (int i = tid; i < nb * max_new; i += kBeamThreads) {
+      const int r = i / max_new, t = i - r * max_new;
+      rs[i] = (t == cur) ? (long long)s_sel_tok[r] : old_run[s_sel_src[r] * max_new + t];
+      const int from = s_fin_from[r];
+      long long fv;
+      if (from < nb) fv = old_fin[from * max_new + t];
+      else {
+        const int k = from - nb;
+        const int sb = s_top_ix[k] / V;
+        fv = (t == cur) ? (long long)(s_top_ix[k] - sb * V) : old_run[sb * max_new + t];
+      }
+      fs[i] = fv;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool unf = s_any_open && !s_all_hits;
+    if (p.early == 1) unf = unf && !s_all_done;
+    *p.unfinished = unf ? 1 : 0;
+    *p.cur = cur + 1;
+  }
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
+  if (!d || !d->logits || !d->run_seq || !d->fin_seq || !d->run_score || !d->fin_score || !d->fin_done || !d->heur_open ||
+      !d->cur || !d->len_tab || !d->hyp_tab || !d->tok || !d->beam_src || !d->unfinished)
+    return MXVL_ERR_NULL;
+  if (d->n_eos > 0 && !d->eos) return MXVL_ERR_NULL;
+  if (d->batch <= 0 || d->beams <= 0 || d->vocab <= 0 || d->max_new <= 0) return MXVL_ERR_SHAPE;
+  if (d->n_eos > kMaxEos || d->beams > kMaxBeams || d->keep > kMaxKeep || d->keep < d->beams || (long long)d->beams * d->vocab > 0x7fffffffLL)
+    return MXVL_ERR_UNSUPPORTED;
+  BeamArgs a;
+  a.batch = d->batch; a.nb = d->beams; a.V = d->vocab; a.max_new = d->max_new; a.min_new = d->min_new; a.n_eos = d->n_eos;
+  a.early = d->early_stopping; a.keep = d->keep; a.rep_pen = d->repetition_penalty;
+  { const char* e = getenv("MXVL_BEAM_ABLATE"); a.ablate = e ? atoi(e) : 0; }   // measurement only
+  a.logits = (const float*)d->logits; a.run_seq = (long long*)d->run_seq; a.fin_seq = (long long*)d->fin_seq;
+  a.run_score = (float*)d->run_score; a.fin_score = (float*)d->fin_score; a.fin_done = (unsigned char*)d->fin_done;
+  a.heur_open = (unsigned char*)d->heur_open; a.cur = (long long*)d->cur; a.eos = (const long long*)d->eos;
+  a.len_tab = (const float*)d->len_tab; a.hyp_tab = (const float*)d->hyp_tab; a.tok = (long long*)d->tok;
+  a.beam_src = (long long*)d->beam_src; a.unfinished = (unsigned char*)d->unfinished;
+  const size_t words = (size_t)(a.V + 31) / 32;
+  const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
+  if (lds > 60 * 1024) return MXVL_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(kBeamThreads), lds, (hipStream_t)hip_stream, a);
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}

@@ -183,6 +183,7 @@ class _BeamState:
 
     def __init__(self, B, nb, vocab, max_new, fill, eos, min_new, rep_pen, len_pen, early_stopping, dev):
         self.B, self.nb, self.V, self.max_new = B, nb, vocab, max_new
+        self.use_hip = True      # tests flip this to compare the HIP kernel with the torch restatement
         self.fill, self.min_new, self.rep_pen, self.early = fill, min_new, rep_pen, early_stopping
         self.eos_t = torch.tensor(eos, device=dev, dtype=torch.long)
         self.keep = max(2, 1 + len(eos)) * nb
@@ -218,9 +219,38 @@ class _BeamState:
         self.cur.zero_()
         self.unfinished.fill_(True)
 
+    def _hip_supported(self, logits):
+        words = (self.V + 31) // 32
+        lds = 4 * ((self.nb * words + 1) & ~1) + 16 * self.nb * self.max_new
+        return (logits.is_cuda and self.nb <= 4 and self.keep <= 8 and self.eos_t.numel() <= 4 and lds <= 60 * 1024 and logits.dtype == torch.float32
+                and logits.is_contiguous())
+
+    def _advance_hip(self, logits):
+        """csrc/beam_step.hip: the whole update below as one kernel (capturable in the decode step's hipGraph)."""
+        import ctypes
+        from . import _abi
+        lib = _abi.load()
+        d = _abi.BeamDesc()
+        d.batch, d.beams, d.vocab, d.max_new, d.min_new = self.B, self.nb, self.V, self.max_new, self.min_new
+        d.n_eos, d.early_stopping, d.keep, d.repetition_penalty = self.eos_t.numel(), int(self.early is True), self.keep, self.rep_pen
+        d.logits, d.run_seq, d.fin_seq = logits.data_ptr(), self.run_seq.data_ptr(), self.fin_seq.data_ptr()
+        d.run_score, d.fin_score, d.fin_done = self.run_score.data_ptr(), self.fin_score.data_ptr(), self.fin_done.data_ptr()
+        d.heur_open, d.cur, d.eos = self.heur_open.data_ptr(), self.cur.data_ptr(), _abi.ptr(self.eos_t if self.eos_t.numel() else None)
+        d.len_tab, d.hyp_tab = self.len_tab.data_ptr(), self.hyp_tab.data_ptr()
+        d.tok, d.beam_src, d.unfinished = self.tok.data_ptr(), self.beam_src.data_ptr(), self.unfinished.data_ptr()
+        with torch.cuda.device(logits.device):
+            _abi.check(lib.mxvl_beam_step(ctypes.byref(d), _abi.stream_ptr(logits.device)), "mxvl_beam_step")
+
     def advance(self, logits):
         """Consume the (B*nb, V) logits of step `cur`; leaves the next tokens in .tok, the parent beam of every live
         beam (flat row index) in .beam_src, and whether decoding goes on in .unfinished."""
+        if self.use_hip and logits.is_cuda:
+            lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+            if self._hip_supported(lg):
+                return self._advance_hip(lg)
+        return self.advance_torch(logits)
+
+    def advance_torch(self, logits):
         B, nb, V, keep, cur = self.B, self.nb, self.V, self.keep, self.cur
         has_eos = self.eos_t.numel() > 0
         logp = torch.log_softmax(logits.float(), dim=-1)

@@ -109,3 +109,41 @@ def test_hip_decode_step_matches_torch_step_bf16():
         assert a.shape == b.shape
         agree = (a == b).float().mean().item()
         assert agree >= 0.75, f"beams={beams}: only {agree:.2f} of the tokens agree between the HIP and torch decode paths"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(B=1, nb=3, V=32000, max_new=24, min_new=6, rep=2.0, lp=2.0, early=False),
+                                 dict(B=2, nb=2, V=997, max_new=12, min_new=0, rep=1.0, lp=1.0, early=True),
+                                 dict(B=3, nb=4, V=5000, max_new=16, min_new=3, rep=1.3, lp=0.5, early="never")])
+def test_beam_step_kernel_equals_torch_restatement(cfg):
+    """csrc/beam_step.hip against _BeamState.advance_torch (itself token-exact with HF on the goldens): identical live
+    beams, scores, parents, stop flag and finished hypotheses along a whole decode with EOS hits and random logits."""
+    from medical_image_analysis_amd.report_decoder import _BeamState
+    dev = "cuda:0"
+    B, nb, V = cfg["B"], cfg["nb"], cfg["V"]
+    mk = lambda: _BeamState(B, nb, V, cfg["max_new"], 0, [2], cfg["min_new"], cfg["rep"], cfg["lp"], cfg["early"], dev)
+    hip, ref = mk(), mk()
+    ref.use_hip = False
+    g = torch.Generator().manual_seed(V)
+    steps = 0
+    while bool(ref.unfinished):
+        logits = 3.0 * torch.randn(B * nb, V, generator=g)
+        if steps >= cfg["min_new"]:
+            logits[:, 2] += 6.0 * (torch.rand(B * nb, generator=g) < 0.4).float()     # some beams end with EOS
+        if steps % 3 == 1 and V > 2100:   # three+ winners owned by ONE kernel thread (tokens equal mod 512): the repair path
+            logits[0, [5, 517, 1029, 1541]] += torch.tensor([30.0, 29.0, 28.5, 28.0])
+        logits = logits.to(dev)
+        hip.advance(logits.clone())
+        ref.advance(logits.clone())
+        steps += 1
+        c = int(ref.cur)
+        assert int(hip.cur) == c and bool(hip.unfinished) == bool(ref.unfinished), f"step {steps}"
+        if bool(ref.unfinished):   # once every candidate has stopped the "live" beams are exact -1e9 ties: their order is arbitrary
+            assert torch.equal(hip.tok, ref.tok) and torch.equal(hip.beam_src, ref.beam_src), f"step {steps}: next tokens / parents"
+            assert torch.equal(hip.run_seq[:, :, :c], ref.run_seq[:, :, :c]), f"step {steps}: live sequences"
+            assert torch.allclose(hip.run_score, ref.run_score, rtol=2e-6, atol=2e-5), f"step {steps}: live scores"
+        assert torch.equal(hip.fin_done, ref.fin_done) and torch.equal(hip.heur_open, ref.heur_open), f"step {steps}"
+        done = ref.fin_done
+        assert torch.allclose(hip.fin_score[done], ref.fin_score[done], rtol=2e-6, atol=2e-5)
+        assert torch.equal(hip.fin_seq[done], ref.fin_seq[done]), f"step {steps}: finished hypotheses"
+    assert steps >= 2
