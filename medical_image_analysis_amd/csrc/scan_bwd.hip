@@ -147,6 +147,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 #pragma unroll
         for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
       }
+    } else if (VEC && t0 + j * T + T <= L) {   // ragged last chunk, aligned rows: this lane's 8 steps are all valid
+      const float4 a0 = ld4<io_t>(q + t0), a1 = ld4<io_t>(q + t0 + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
     } else {
 #pragma unroll
       for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
@@ -157,6 +160,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       if (row_ok) {
         st4<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
         st4<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
+      }
+    } else if (VEC) {   // ragged last chunk of aligned rows
+      if (row_ok) {
+        if (t0 + j * T + T <= L) {
+          st4<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
+          st4<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
+        } else {
+#pragma unroll
+          for (int i = 0; i < T; ++i)
+            if (t0 + j * T + i < L) io::st(q + t0 + i, v[i]);
+        }
       }
     } else {
       float4* so4 = (float4*)(sO + row * CH + j * T);

@@ -168,6 +168,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
         for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
       }
+    } else if (VEC && t0 + j * T + T <= L) {   // ragged last chunk, aligned rows: this lane's 8 steps are all valid
+#pragma unroll
+      for (int k = 0; k < TQ; ++k) {
+        const float4 a = ld4<io_t>(q + t0 + 4 * k);
+        v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
@@ -280,6 +286,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
         for (int k = 0; k < TQ; ++k)
           st4<io_t>(po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]));
+      }
+    } else if (VEC) {   // ragged last chunk of aligned rows: whole lane groups as vectors, the boundary lane element-wise
+      if (row_ok) {
+        if (t0 + j * T + T <= L) {
+#pragma unroll
+          for (int k = 0; k < TQ; ++k)
+            st4<io_t>(po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]));
+        } else {
+#pragma unroll
+          for (int i = 0; i < T; ++i)
+            if (t0 + j * T + i < L) io::st(po + t0 + i, y[i]);
+        }
       }
     } else {
       float4* so4 = (float4*)(sO + row * CH + j * T);

@@ -164,7 +164,18 @@ class Mamba(nn.Module):
             x_d = xd[:, :D]
             parts += [x_d, self._permute(x_d, fwd[1], inv[1])]
         K = len(sfxs)
-        X = torch.stack(parts, dim=1)                                        # (B, K, D, L)
+        # Sequences whose length is not a multiple of 8 (197 = 14*14 + cls) are run zero-padded at the END: conv and scan are
+        # causal, so the first L outputs (and every gradient: the padded outputs get no gradient) are unchanged, while every
+        # row starts 16-byte aligned and the kernels take their vector paths (scalar-path scan at L = 197: 1.9x slower).
+        Lp = (L + 7) // 8 * 8
+        if Lp != L and x.is_cuda:
+            X = x.new_zeros(Bz, K, D, Lp)
+            for k, part in enumerate(parts):
+                X[:, k, :, :L] = part
+        else:
+            Lp = L
+            X = torch.stack(parts, dim=1)                                    # (B, K, D, L)
+        L_true, L = L, Lp
         mods = [self._dir(s) for s in sfxs]
         conv_w = torch.cat([m[0].weight for m in mods], dim=0)               # (K*D, 1, W)
         conv_b = torch.cat([m[0].bias for m in mods], dim=0) if mods[0][0].bias is not None else None
@@ -180,6 +191,8 @@ class Mamba(nn.Module):
         y = selective_scan_fn(Xc.view(Bz, K * D, L), dt.to(io).view(Bz, K * D, L), A,
                               x_dbl[:, :, R:R + N].to(io), x_dbl[:, :, R + N:R + 2 * N].to(io), Dv, z=None,
                               delta_bias=dbias, delta_softplus=True).view(Bz, K, D, L)
+        if L != L_true:
+            y, L = y[..., :L_true], L_true
         # merge: direction k's output at step l belongs to token perm_k[l]  (:522-529)
         main = (y[:, 0] + self._permute(y[:, 1], inv[1], fwd[1]) + self._permute(y[:, 2], inv[2], fwd[2])
                 + self._permute(y[:, 3], inv[3], fwd[3]))
