@@ -10,7 +10,7 @@ TAG=${1:-r01}
 (timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6) > $O/pytest_gpu.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3) > $O/smoke.log
 (timeout 900 python bench.py 2>&1 | tail -1) > $O/bench_default.json
-for w in scan_fwd_target scan_fwd_cfg2 scan_fwd_target_bf16 arm_pretrain_base_192 decode_llama7b_128; do
+for w in scan_fwd_target scan_fwd_cfg2 scan_fwd_target_bf16 arm_pretrain_base_192 decode_llama7b_128 mae_vit_large_1280 vmamba_base_224 arm_encoder_large_224; do
   (timeout 600 python bench.py --workload $w 2>&1 | tail -1) > $O/bench_$w.json
 done
 cd /tmp && export TMPDIR=/tmp
