@@ -195,6 +195,21 @@ int mxvl_state_update(void *state, const void *x, const void *dt, const void *A,
                       const void *C, const void *D, const void *z, const void *dt_bias, void *out,
                       int batch, int dim, int dstate, int io_dtype, int dt_softplus, void *hip_stream);
 
+/* Scan-order re-orderings of the 4- / 6-direction Mamba mixer (bimamba v3 / v4; CXPMRG_Bench_MambaXray_VL/arm/Finetuning/
+ * mamba_simple.py:447-532: flips, the middle-cls transpose :476-482, its inverse and the direction sum :522-527).
+ *   mxvl_dir_gather: rows (batch,dim,seqlen) -> stacked (batch,n_dirs,dim,padded_len): stacked[b,k,d,l] = rows[b,d,index[k][l]], 0 for
+ *                    l >= seqlen;      mxvl_dir_merge: stacked -> rows: rows[b,d,t] = sum_k stacked[b,k,d,index[k][t]] (fp32 sum).
+ * index: (n_dirs, seqlen) int32 permutations; gather with the permutations and merge with their inverses are each other's adjoint.
+ * Strides in elements, innermost stride 1; seqlen <= 5120. */
+typedef struct mxvl_dir_perm_desc {
+  int32_t batch, dim, seqlen, padded_len, n_dirs, io_dtype;
+  int64_t rows_bs, rows_ds, stacked_bs, stacked_ks, stacked_ds;
+  const void *index;
+  void *rows, *stacked;      /* gather reads rows and writes stacked; merge reads stacked and writes rows */
+} mxvl_dir_perm_desc;
+int mxvl_dir_gather(const mxvl_dir_perm_desc *desc, void *hip_stream);
+int mxvl_dir_merge(const mxvl_dir_perm_desc *desc, void *hip_stream);
+
 /* One beam-search update of report generation (what HF `generate(num_beams>1)` does between two decoder steps; call site
  * CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301): log-softmax, repetition penalty, min-new-tokens,
  * top-`keep` over beams*vocab, live-beam / finished-pool bookkeeping, early-stop heuristic.  All state tensors are updated

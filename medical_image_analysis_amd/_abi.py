@@ -32,7 +32,7 @@ SYMBOLS = [
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step",
+    "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
 ]
 
 
@@ -116,6 +116,14 @@ class AddLnBwdDesc(ctypes.Structure):
     ]
 
 
+class DirPermDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("padded_len", c_int32), ("n_dirs", c_int32), ("io_dtype", c_int32),
+        ("rows_bs", c_int64), ("rows_ds", c_int64), ("stacked_bs", c_int64), ("stacked_ks", c_int64), ("stacked_ds", c_int64),
+        ("index", c_void_p), ("rows", c_void_p), ("stacked", c_void_p),
+    ]
+
+
 class BeamDesc(ctypes.Structure):
     _fields_ = [
         ("batch", c_int32), ("beams", c_int32), ("vocab", c_int32), ("max_new", c_int32), ("min_new", c_int32), ("n_eos", c_int32),
@@ -151,6 +159,9 @@ def load() -> ctypes.CDLL:
     lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
     lib.mxvl_state_update.restype = c_int
     lib.mxvl_state_update.argtypes = [c_void_p] * 10 + [c_int] * 5 + [c_void_p]
+    for name in ("mxvl_dir_gather", "mxvl_dir_merge"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_beam_step.restype = c_int
     lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):

@@ -45,6 +45,82 @@ def _middle_cls_transpose_index(L: int, device) -> torch.Tensor:
     return torch.where(l == tp, torch.full_like(l, tp), src)
 
 
+def _dir_perm(merge, rows, stacked, index, L, Lp):
+    """One mxvl_dir_gather / mxvl_dir_merge launch.  rows: (B, D, L) view (L stride 1); stacked: (B, K, D, Lp) view."""
+    import ctypes
+    from . import _abi
+    lib = _abi.load()
+    d = _abi.DirPermDesc()
+    B, K, D, _ = stacked.shape
+    d.batch, d.dim, d.seqlen, d.padded_len, d.n_dirs, d.io_dtype = B, D, L, Lp, K, _abi.dtype_code(rows.dtype)
+    d.rows_bs, d.rows_ds = rows.stride(0), rows.stride(1)
+    d.stacked_bs, d.stacked_ks, d.stacked_ds = stacked.stride(0), stacked.stride(1), stacked.stride(2)
+    d.index, d.rows, d.stacked = index.data_ptr(), rows.data_ptr(), stacked.data_ptr()
+    fn = lib.mxvl_dir_merge if merge else lib.mxvl_dir_gather
+    with torch.cuda.device(rows.device):
+        _abi.check(fn(ctypes.byref(d), _abi.stream_ptr(rows.device)), "mxvl_dir_merge" if merge else "mxvl_dir_gather")
+
+
+def _rows_view(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class _DirGather(torch.autograd.Function):
+    """x (B, D, L) [and the v4 segmentation stream xd] -> X (B, K, D, Lp): every scan direction's ordering of the tokens, rows
+    zero-padded to Lp (csrc/dir_perm.hip).  Backward = the merge with the inverse permutations."""
+
+    @staticmethod
+    def forward(ctx, x, xd, perm, inv, perm_d, inv_d, Lp):
+        B, D, L = x.shape
+        K = perm.shape[0] + (perm_d.shape[0] if xd is not None else 0)
+        X = torch.empty((B, K, D, Lp), dtype=x.dtype, device=x.device)
+        _dir_perm(False, _rows_view(x), X[:, :perm.shape[0]], perm, L, Lp)
+        if xd is not None:
+            _dir_perm(False, _rows_view(xd.to(x.dtype)), X[:, perm.shape[0]:], perm_d, L, Lp)
+        ctx.save_for_backward(inv, inv_d)
+        ctx.meta = (L, Lp, perm.shape[0], xd is not None, None if xd is None else xd.dtype)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        inv, inv_d = ctx.saved_tensors
+        L, Lp, K0, has_d, d_dtype = ctx.meta
+        dX = dX.contiguous()
+        B, K, D, _ = dX.shape
+        dx = torch.empty((B, D, L), dtype=dX.dtype, device=dX.device)
+        _dir_perm(True, dx, dX[:, :K0], inv, L, Lp)
+        dxd = None
+        if has_d:
+            dxd = torch.empty((B, D, L), dtype=dX.dtype, device=dX.device)
+            _dir_perm(True, dxd, dX[:, K0:], inv_d, L, Lp)
+            dxd = dxd.to(d_dtype)
+        return dx, dxd, None, None, None, None, None
+
+
+class _DirMerge(torch.autograd.Function):
+    """y (B, K, D, Lp) -> (B, D, L): sum over the directions of each one's output brought back to token order."""
+
+    @staticmethod
+    def forward(ctx, y, inv, perm, L):
+        B, K, D, Lp = y.shape
+        if y.stride(-1) != 1:
+            y = y.contiguous()
+        out = torch.empty((B, D, L), dtype=y.dtype, device=y.device)
+        _dir_perm(True, out, y, inv, L, Lp)
+        ctx.save_for_backward(perm)
+        ctx.meta = (K, Lp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (perm,) = ctx.saved_tensors
+        K, Lp = ctx.meta
+        B, D, L = dout.shape
+        dy = torch.empty((B, K, D, Lp), dtype=dout.dtype, device=dout.device)
+        _dir_perm(False, _rows_view(dout), dy, perm, L, Lp)
+        return dy, None, None, None
+
+
 class _PermuteLast(torch.autograd.Function):
     """y[..., l] = x[..., perm[l]] for a PERMUTATION perm of the last axis (the scan orders of the v3 / v4 mixer).  The gradient
     of a gather by a permutation is the gather by its inverse: autograd's generic advanced-indexing backward (index_put with
@@ -143,7 +219,7 @@ class Mamba(nn.Module):
             ar = torch.arange(L, device=device)
             for k in range(4):
                 inv[k, fwd[k]] = ar
-            self._perm_cache[key] = (fwd, inv)
+            self._perm_cache[key] = (fwd, inv, fwd.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous())
         return self._perm_cache[key]
 
     # ---------------------------------------------------------------------------------------------------
@@ -155,24 +231,25 @@ class Mamba(nn.Module):
         """v3 (4 directions) / v4 (+2 'bone' directions on xd): one conv launch, one GEMM pair, one scan launch."""
         Bz, _, L = xz.shape
         D, N, R = self.d_inner, self.d_state, self.dt_rank
-        fwd, inv = self._perms(L, xz.device)
+        fwd, inv, fwd32, inv32 = self._perms(L, xz.device)
         x, z = xz[:, :D], xz[:, D:]
         sfxs = ["", "_b", "_c", "_c_b"]
-        parts = [self._permute(x, fwd[k], inv[k]) if k else x for k in range(4)]
+        x_d = None
         if xd is not None:  # v4: the masked ('segmentation') stream, forward and reversed (:598-629)
             sfxs += ["_d", "_d_b"]
             x_d = xd[:, :D]
-            parts += [x_d, self._permute(x_d, fwd[1], inv[1])]
         K = len(sfxs)
         # Sequences whose length is not a multiple of 8 (197 = 14*14 + cls) are run zero-padded at the END: conv and scan are
         # causal, so the first L outputs (and every gradient: the padded outputs get no gradient) are unchanged, while every
         # row starts 16-byte aligned and the kernels take their vector paths (scalar-path scan at L = 197: 1.9x slower).
         Lp = (L + 7) // 8 * 8
-        if Lp != L and x.is_cuda:
-            X = x.new_zeros(Bz, K, D, Lp)
-            for k, part in enumerate(parts):
-                X[:, k, :, :L] = part
+        hip_perm = x.is_cuda and L <= 5120 and Bz <= 65535
+        if hip_perm:     # all orderings in one kernel (csrc/dir_perm.hip); its backward is the matching merge
+            X = _DirGather.apply(x, x_d, fwd32, inv32, fwd32[:2], inv32[:2], Lp)
         else:
+            parts = [self._permute(x, fwd[k], inv[k]) if k else x for k in range(4)]
+            if x_d is not None:
+                parts += [x_d, self._permute(x_d, fwd[1], inv[1])]
             Lp = L
             X = torch.stack(parts, dim=1)                                    # (B, K, D, L)
         L_true, L = L, Lp
@@ -191,16 +268,19 @@ class Mamba(nn.Module):
         y = selective_scan_fn(Xc.view(Bz, K * D, L), dt.to(io).view(Bz, K * D, L), A,
                               x_dbl[:, :, R:R + N].to(io), x_dbl[:, :, R + N:R + 2 * N].to(io), Dv, z=None,
                               delta_bias=dbias, delta_softplus=True).view(Bz, K, D, L)
-        if L != L_true:
-            y, L = y[..., :L_true], L_true
         # merge: direction k's output at step l belongs to token perm_k[l]  (:522-529)
-        main = (y[:, 0] + self._permute(y[:, 1], inv[1], fwd[1]) + self._permute(y[:, 2], inv[2], fwd[2])
-                + self._permute(y[:, 3], inv[3], fwd[3]))
+        if hip_perm:
+            main = _DirMerge.apply(y[:, :4], inv32, fwd32, L_true)
+            bone = _DirMerge.apply(y[:, 4:6], inv32[:2], fwd32[:2], L_true) if xd is not None else None
+            L = L_true
+        else:
+            main = (y[:, 0] + self._permute(y[:, 1], inv[1], fwd[1]) + self._permute(y[:, 2], inv[2], fwd[2])
+                    + self._permute(y[:, 3], inv[3], fwd[3]))
+            bone = (y[:, 4] + self._permute(y[:, 5], inv[1], fwd[1])) if xd is not None else None
         if xd is None:
             gated = main * (F.silu(z.float()).to(io) / 4.0)
             return F.linear(gated.transpose(1, 2), self.out_proj.weight.to(io),
                             None if self.out_proj.bias is None else self.out_proj.bias.to(io))
-        bone = y[:, 4] + self._permute(y[:, 5], inv[1], fwd[1])
         zd = xd[:, D:]
         bone = bone * F.silu(zd.float()).to(io)        # the bone stream is gated by ITS OWN z half (xd's)
         gated = (main * F.silu(z.float()).to(io) + bone) / 6.0

@@ -99,3 +99,41 @@ def test_decode_step_kernels_golden():
         assert_close(out, g["outs"][:, t], 2e-5, 1e-4, f"out[{t}]")
         assert_close(conv_state, g["conv_states"][t], 1e-6, 1e-6, f"conv_state[{t}]")
         assert_close(ssm_state, g["ssm_states"][t], 1e-5, 1e-4, f"ssm_state[{t}]")
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 197, 200), (1, 7, 10, 16), (3, 5, 4097, 4104), (2, 8, 64, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dir_gather_merge_equal_torch_indexing(shape, dtype):
+    """csrc/dir_perm.hip: the gather is pure data movement (bit-exact, zero padding); the merge sums the K directions in
+    fp32 in ascending order and rounds once; each is the other's adjoint (the autograd pair the v3 / v4 mixer uses)."""
+    from medical_image_analysis_amd.mamba_simple import _DirGather, _DirMerge
+    B, D, L, Lp = shape
+    g = torch.Generator().manual_seed(L)
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(4)])
+    inv = torch.empty_like(perm)
+    for k in range(4):
+        inv[k, perm[k]] = torch.arange(L)
+    x = torch.randn(B, 2 * D, L, generator=g).to(dtype)[:, :D]            # a strided half, as xz's x part
+    p32, i32 = perm.to(DEV, torch.int32), inv.to(DEV, torch.int32)
+    xd = x.to(DEV).requires_grad_(True)
+    X = _DirGather.apply(xd, None, p32, i32, p32[:2], i32[:2], Lp)
+    ref = torch.zeros(B, 4, D, Lp, dtype=dtype)
+    for k in range(4):
+        ref[:, k, :, :L] = x[:, :, perm[k]]
+    assert torch.equal(X.cpu(), ref)
+    y = torch.randn(B, 4, D, Lp, generator=g).to(dtype)
+    yd = y.to(DEV).requires_grad_(True)
+    out = _DirMerge.apply(yd, i32, p32, L)
+    want = sum(y[:, k, :, :L].float()[:, :, inv[k]] for k in range(4))
+    tol = 0 if dtype == torch.float32 else 2e-2
+    assert float((out.float().cpu() - want).abs().max()) <= tol * float(want.abs().max()) + (0 if dtype == torch.float32 else 0)
+    # adjoint pair: <gather(x), y> == <x, merge(y)> on the valid steps
+    gy = torch.randn(B, D, L, generator=g).to(dtype).to(DEV)
+    out.backward(gy)
+    dy_ref = torch.zeros(B, 4, D, Lp, dtype=dtype)
+    for k in range(4):
+        dy_ref[:, k, :, :L] = gy.cpu()[:, :, perm[k]]
+    assert torch.equal(yd.grad.cpu(), dy_ref)
+    X.backward(y.to(DEV))
+    dx_ref = sum(y[:, k, :, :L].float()[:, :, inv[k]] for k in range(4))
+    assert float((xd.grad.float().cpu() - dx_ref).abs().max()) <= tol * float(dx_ref.abs().max())
