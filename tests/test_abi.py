@@ -26,7 +26,9 @@ def test_library_exports_every_declared_symbol():
 
 @pytest.mark.parametrize("cstruct,pystruct", [("mxvl_scan_desc", _abi.ScanDesc), ("mxvl_scan_bwd_desc", _abi.ScanBwdDesc),
                                               ("mxvl_conv1d_desc", _abi.Conv1dDesc), ("mxvl_conv1d_bwd_desc", _abi.Conv1dBwdDesc),
-                                              ("mxvl_gemv_desc", _abi.GemvDesc), ("mxvl_decode_attn_desc", _abi.DecodeAttnDesc)])
+                                              ("mxvl_gemv_desc", _abi.GemvDesc), ("mxvl_decode_attn_desc", _abi.DecodeAttnDesc),
+                                              ("mxvl_dir_perm_desc", _abi.DirPermDesc), ("mxvl_beam_desc", _abi.BeamDesc),
+                                              ("mxvl_add_ln_desc", _abi.AddLnDesc), ("mxvl_add_ln_bwd_desc", _abi.AddLnBwdDesc)])
 def test_ctypes_struct_mirrors_header(cstruct, pystruct):
     m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
@@ -35,7 +37,7 @@ def test_ctypes_struct_mirrors_header(cstruct, pystruct):
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|mxvl_scan_desc|mxvl_conv1d_desc)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|int8_t|uint8_t|int16_t|uint64_t|mxvl_scan_desc|mxvl_conv1d_desc|mxvl_add_ln_desc)\s*", "", decl)
         names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
     assert names == [f[0] for f in pystruct._fields_]
 
