@@ -37,6 +37,22 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    written by tools/gpu_round.sh: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command, KB units,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  None when no pass was recorded for the workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(workload)
+        except (OSError, ValueError):
+            continue
+        if rec:
+            return {"bytes": rec["bytes"], "source": os.path.basename(path), "fetch_kb": rec["fetch_kb"], "write_kb": rec["write_kb"]}
+    return None
+
 WORKLOADS = {
     # name: (B, D, L, N, torch dtype name, description)
     "scan_fwd_cfg2": (32, 768, 196, 16, "float32",
@@ -533,6 +549,11 @@ def main():
                          "kernel": "scan_fwd_stream_kernel", "algorithmic_bytes_per_launch": nbytes,
                          "kernel_ms": kern_ms},
         }
+        pmc = pmc_traffic(args.workload)
+        if pmc is not None:
+            out["roofline"]["traffic"] = pmc["bytes"]
+            out["roofline"]["traffic_source"] = (f"profiles/{pmc['source']}: FETCH_SIZE {pmc['fetch_kb']} KB x2 + WRITE_SIZE "
+                                                 f"{pmc['write_kb']} KB per launch (separate rocprofv3 --pmc passes of this command)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_scan(B, D, L, N)
         print(json.dumps(out))

@@ -30,4 +30,5 @@ cd $R
 for n in scan_stats scan_fetch scan_write scan_sq scan_sq2 pretrain_stats decode_stats; do
   python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -45 | cut -c1-170 > $O/prof_${TAG}_$n.txt
 done
+python tools/pmc_traffic.py scan_fwd_target scan_fwd_stream_kernel $O/prof_${TAG}_scan_fetch.txt $O/prof_${TAG}_scan_write.txt $O/${TAG}_pmc_traffic.json > /dev/null 2>&1
 cat $O/pytest_gpu.log $O/smoke.log; for f in $O/bench_*.json; do echo "== $f"; cut -c1-260 $f; done
