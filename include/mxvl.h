@@ -74,7 +74,12 @@ typedef struct mxvl_scan_desc {
   int32_t batch, dim, seqlen, dstate, n_groups;
   int32_t io_dtype; /* mxvl_dtype */
   uint32_t flags;
-  int32_t reserved0;
+  /* 0 or 1: delta is (batch, dim, seqlen) and delta_bias (dim).  k > 1 (k divides dim): delta is (batch, dim/k, seqlen) and
+   * delta_bias (dim/k); channel d reads row d / k -- the vendored oflex kernels' dim_deltagroups_ratio
+   * (cusoflex/selective_scan_oflex.cpp:59, selective_scan_fwd_kernel_oflex.cuh:91-107).  mxvl_scan_bwd still produces
+   * ddelta (batch, dim, seqlen) and ddelta_bias (dim) PER CHANNEL; the caller sums each group of k (the reference reduces
+   * them with atomics into the small tensors, selective_scan_bwd_kernel_oflex.cuh:104-121). */
+  int32_t delta_group_ratio;
   /* element strides; the seqlen stride of every io tensor is 1 */
   int64_t u_bs, u_ds;
   int64_t delta_bs, delta_ds;
@@ -274,6 +279,33 @@ int mxvl_dwconv2d_fwd(const void *x, const void *weight, const void *bias, void 
 int mxvl_dwconv2d_bwd(const void *x, const void *weight, const void *bias, const void *dy, void *dx, void *dweight,
                       void *dbias, int batch, int channels, int height, int width, int ksize, int io_dtype, int silu,
                       void *hip_stream);
+
+/* Image pre-processing of the report-generation data pipeline: `AutoImageProcessor(...)(img, return_tensors="pt",
+ * size=input_size).pixel_values[0]` (CXPMRG_Bench_MambaXray_VL/dataset/data_helper.py:17-26, :70-76) = Pillow `Image.resize`
+ * (libImaging/Resample.c, 8-bit two-pass fixed-point convolution) + transformers rescale/normalize.  Bit-exact integer resize;
+ * the float value of each byte comes from the caller's table, so the output equals the CPU pipeline bit for bit.
+ *   mxvl_resample_ksize / mxvl_resample_coeffs: HOST-ONLY (no GPU): Resample.c precompute_coeffs + normalize_coeffs_8bpc for the
+ *     whole-image box.  bounds: (out_size, 2) int32 {first source index, tap count}; kk: (ksize, out_size) int32, tap-major,
+ *     22-bit fixed point, zero past the tap count.  in_size == out_size gives the identity (ksize 1), i.e. a skipped pass.
+ *   mxvl_image_preprocess: src (in_h, in_w, 3) uint8 -> out (3, out_h, out_w) in out_dtype; tmp is a caller-provided
+ *     (in_h, out_w, 3) uint8 workspace (Pillow's intermediate image); lut (3, 256) fp32 = value of byte v in channel c after
+ *     rescale + normalise.  All pointers are device pointers; in_w <= 20000. */
+typedef enum mxvl_resample { MXVL_RESAMPLE_BILINEAR = 2, MXVL_RESAMPLE_BICUBIC = 3 } mxvl_resample; /* PIL.Image.Resampling values */
+typedef struct mxvl_image_desc {
+  int32_t in_h, in_w, out_h, out_w;
+  int32_t ksize_h, ksize_v;
+  int32_t out_dtype; /* mxvl_dtype */
+  int32_t reserved0;
+  const void *src;
+  const void *bounds_h, *kk_h; /* horizontal pass: in_w -> out_w */
+  const void *bounds_v, *kk_v; /* vertical pass:   in_h -> out_h */
+  const void *lut;
+  void *tmp;
+  void *out;
+} mxvl_image_desc;
+int mxvl_resample_ksize(int in_size, int out_size, int filter);
+int mxvl_resample_coeffs(int in_size, int out_size, int filter, int32_t *bounds, int32_t *kk);
+int mxvl_image_preprocess(const mxvl_image_desc *desc, void *hip_stream);
 
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);

@@ -33,13 +33,14 @@ SYMBOLS = [
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
+    "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess",
 ]
 
 
 class ScanDesc(ctypes.Structure):
     _fields_ = [
         ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("dstate", c_int32), ("n_groups", c_int32),
-        ("io_dtype", c_int32), ("flags", c_uint32), ("reserved0", c_int32),
+        ("io_dtype", c_int32), ("flags", c_uint32), ("delta_group_ratio", c_int32),
         ("u_bs", c_int64), ("u_ds", c_int64), ("delta_bs", c_int64), ("delta_ds", c_int64),
         ("z_bs", c_int64), ("z_ds", c_int64), ("out_bs", c_int64), ("out_ds", c_int64),
         ("B_bs", c_int64), ("B_gs", c_int64), ("B_ns", c_int64),
@@ -135,6 +136,15 @@ class BeamDesc(ctypes.Structure):
     ]
 
 
+class ImageDesc(ctypes.Structure):
+    _fields_ = [
+        ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
+        ("ksize_h", c_int32), ("ksize_v", c_int32), ("out_dtype", c_int32), ("reserved0", c_int32),
+        ("src", c_void_p), ("bounds_h", c_void_p), ("kk_h", c_void_p), ("bounds_v", c_void_p), ("kk_v", c_void_p),
+        ("lut", c_void_p), ("tmp", c_void_p), ("out", c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -180,6 +190,12 @@ def load() -> ctypes.CDLL:
     for name in ("mxvl_cross_scan", "mxvl_cross_merge"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]
+    lib.mxvl_resample_ksize.restype = c_int
+    lib.mxvl_resample_ksize.argtypes = [c_int, c_int, c_int]
+    lib.mxvl_resample_coeffs.restype = c_int
+    lib.mxvl_resample_coeffs.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.mxvl_image_preprocess.restype = c_int
+    lib.mxvl_image_preprocess.argtypes = [c_void_p, c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int
     lib.mxvl_scan_n_chunks.restype = c_int
     lib.mxvl_set_scan_variant.argtypes = [c_int]

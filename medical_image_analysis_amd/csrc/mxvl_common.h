@@ -106,4 +106,11 @@ __device__ inline float dpp(float old, float src) {
                                          ROW_MASK, 0xf, false));
 }
 
+// Row of `delta` / entry of `delta_bias` that channel d reads when delta carries dim / ratio channels (the vendored oflex
+// kernels' dim_deltagroups_ratio, cusoflex/selective_scan_fwd_kernel_oflex.cuh:91-107).  ratio is a kernel argument: the
+// select is on a scalar condition and the division is one v_mul_hi by the host-computed reciprocal (delta_magic).
+__device__ inline int delta_row(int d, int ratio, uint32_t magic) { return ratio <= 1 ? d : (int)__umulhi((uint32_t)d, magic); }
+// magic = floor(2^32 / ratio) + 1: umulhi(d, magic) == d / ratio for every d with d * ratio < 2^32 (checked by the callers: d < dim)
+inline uint32_t delta_magic(int ratio) { return ratio <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)ratio + 1ull); }
+
 }  // namespace mxvl

@@ -26,7 +26,8 @@ constexpr int kCkptLenB = 128;
 
 struct ScanBwdArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok, ablate;
+  int softplus, vec_ok, ablate, dl_ratio;
+  uint32_t dl_magic;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, do_bs, do_ds;
   int64_t du_bs, du_ds, dd_bs, dd_ds, dz_bs, dz_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   const bool row_ok = d < d_end;
   const int dc = row_ok ? d : d_end - 1;
 
+  const int dr = delta_row(dc, p.dl_ratio, p.dl_magic);   // delta / delta_bias row read by this channel (gradients stay per channel)
   const io_t* __restrict__ pu = (const io_t*)p.u + (int64_t)b * p.u_bs + (int64_t)dc * p.u_ds + j * T;
-  const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dc * p.dl_ds + j * T;
+  const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dr * p.dl_ds + j * T;
   const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
   const io_t* __restrict__ pg = (const io_t*)p.dout + (int64_t)b * p.do_bs + (int64_t)dc * p.do_ds + j * T;
   io_t* __restrict__ qdu = (io_t*)p.du + (int64_t)b * p.du_bs + (int64_t)dc * p.du_ds + j * T;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     sG[i] = 0.0f;
     if (rr < DT) sdA[i] = 0.0f;
   }
-  const float bias = p.bias ? p.bias[dc] : 0.0f;
+  const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
   float dD_acc = 0.0f, dbias_acc = 0.0f;
 
@@ -502,6 +504,8 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.A = (const float*)f->A; a.D = (const float*)f->D; a.bias = (const float*)f->delta_bias; a.ckpt = (const float*)f->ckpt;
   a.du = d->du; a.ddelta = d->ddelta; a.dz = d->dz;
   a.dA = (float*)d->dA; a.dB = (float*)d->dB; a.dC = (float*)d->dC; a.dD = (float*)d->dD; a.dbias = (float*)d->ddelta_bias;
+  a.dl_ratio = f->delta_group_ratio > 1 ? f->delta_group_ratio : 1;
+  a.dl_magic = delta_magic(a.dl_ratio);
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
   { const char* e = getenv("MXVL_BWD_ABLATE"); a.ablate = e ? atoi(e) : 0; }  // measurement only
   {

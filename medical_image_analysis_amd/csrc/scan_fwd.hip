@@ -30,7 +30,8 @@ constexpr int kCkptLen = 128;  // checkpoint spacing in time steps (mxvl_scan_ch
 
 struct ScanArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok, ablate;
+  int softplus, vec_ok, ablate, dl_ratio;
+  uint32_t dl_magic;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, o_bs, o_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
   const void *u, *delta, *B, *C, *z;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     const int dd = d0 + rr;
     sAC[i] = make_float2(dd < d_end ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
   }
-  const float bias = (p.bias && row_ok) ? p.bias[d] : 0.0f;
+  const float bias = (p.bias && row_ok) ? p.bias[delta_row(d, p.dl_ratio, p.dl_magic)] : 0.0f;
   const float Dv = (p.D && row_ok) ? p.D[d] : 0.0f;
 
   const int nchunks = (L + CH - 1) / CH;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
         const int dd = d0 + wrow;
         if (dd < d_end) {
           *(float4*)(sU + wrow * CH + e4) = ld4<io_t>(up + (int64_t)dd * p.u_ds + t0 + e4);
-          *(float4*)(sD + wrow * CH + e4) = ld4<io_t>(dp + (int64_t)dd * p.dl_ds + t0 + e4);
+          *(float4*)(sD + wrow * CH + e4) = ld4<io_t>(dp + (int64_t)delta_row(dd, p.dl_ratio, p.dl_magic) * p.dl_ds + t0 + e4);
           if (has_z) *(float4*)(sZ + wrow * CH + e4) = ld4<io_t>(zp + (int64_t)dd * p.z_ds + t0 + e4);
         }
       }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
         const int wrow = wave * RPW + rr;
         const int dd = d0 + wrow;
         const io_t* pu = up + (int64_t)dd * p.u_ds + t0;
-        const io_t* pd = dp + (int64_t)dd * p.dl_ds + t0;
+        const io_t* pd = dp + (int64_t)delta_row(dd, p.dl_ratio, p.dl_magic) * p.dl_ds + t0;
         const io_t* pz = has_z ? zp + (int64_t)dd * p.z_ds + t0 : nullptr;
 #pragma unroll
         for (int e = lane; e < CH; e += 64) {
@@ -465,6 +466,8 @@ int mxvl_scan_check(const mxvl_scan_desc* d) {
   if (d->io_dtype != MXVL_F32 && d->io_dtype != MXVL_BF16 && d->io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
   if (d->batch <= 0 || d->dim <= 0 || d->seqlen <= 0 || d->dstate <= 0 || d->n_groups <= 0) return MXVL_ERR_SHAPE;
   if (d->dim % d->n_groups != 0) return MXVL_ERR_SHAPE;
+  if (d->delta_group_ratio < 0 || (d->delta_group_ratio > 1 && d->dim % d->delta_group_ratio != 0)) return MXVL_ERR_SHAPE;
+  if (d->delta_group_ratio > 1 && (uint64_t)d->dim * (uint64_t)d->delta_group_ratio >= (1ull << 32)) return MXVL_ERR_UNSUPPORTED;
   if (d->dstate > MXVL_MAX_DSTATE) return MXVL_ERR_DSTATE;
   const int64_t s[] = {d->u_bs, d->u_ds, d->delta_bs, d->delta_ds, d->B_bs, d->B_gs, d->B_ns,
                        d->C_bs, d->C_gs, d->C_ns, d->A_ds, d->A_ns};
@@ -489,6 +492,8 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.u = d->u; a.delta = d->delta; a.B = d->B; a.C = d->C; a.z = d->z;
   a.A = (const float*)d->A; a.D = (const float*)d->D; a.bias = (const float*)d->delta_bias;
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
+  a.dl_ratio = d->delta_group_ratio > 1 ? d->delta_group_ratio : 1;
+  a.dl_magic = delta_magic(a.dl_ratio);
   a.ablate = (g_variant >> 8) & 0xff;  // measurement-only knobs (tools/scan_bench.py); 0 in production
   // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
   {

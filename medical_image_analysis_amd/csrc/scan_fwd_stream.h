@@ -63,8 +63,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const bool row_ok = d < d_end;
   const int dc = row_ok ? d : d_end - 1;  // clamped row: loads stay in bounds, stores are masked
 
+  const int dr = delta_row(dc, p.dl_ratio, p.dl_magic);   // delta / delta_bias row of this channel
   const io_t* __restrict__ pu = (const io_t*)p.u + (int64_t)b * p.u_bs + (int64_t)dc * p.u_ds + j * T;
-  const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dc * p.dl_ds + j * T;
+  const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dr * p.dl_ds + j * T;
   const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
   io_t* __restrict__ po = (io_t*)p.out + (int64_t)b * p.o_bs + (int64_t)dc * p.o_ds + j * T;
   const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     const int dd = d0 + rr;
     sAC[i] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
   }
-  const float bias = p.bias ? p.bias[dc] : 0.0f;
+  const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
 
   // element e = jj*T + i of a tile row lives at quarter-major position (i/4)*(LPR*4) + jj*4 + i%4

@@ -63,8 +63,11 @@ def _prep(u, delta, A, B, C, D, z, delta_bias):
     batch, dim, L = u.shape
     N = A.shape[1]
     G = B.shape[1]
-    if tuple(delta.shape) != (batch, dim, L):
-        raise RuntimeError("selective_scan: delta must have the shape of u")
+    # delta may carry fewer channels than u: (batch, dim1, L) with dim % dim1 == 0, channel d reading row d // (dim // dim1)
+    # (the vendored oflex extension's dim_deltagroups_ratio, cusoflex/selective_scan_oflex.cpp:59,183-186)
+    dim1 = delta.shape[1] if delta.dim() == 3 else -1
+    if delta.dim() != 3 or delta.shape[0] != batch or delta.shape[2] != L or dim1 <= 0 or dim % dim1 != 0:
+        raise RuntimeError("selective_scan: delta must be (batch, dim, seqlen) or (batch, dim1, seqlen) with dim % dim1 == 0")
     if tuple(A.shape) != (dim, N):
         raise RuntimeError("selective_scan: A must be (dim, dstate)")
     if dim % G != 0:
@@ -81,8 +84,8 @@ def _prep(u, delta, A, B, C, D, z, delta_bias):
             raise RuntimeError("selective_scan: D must be (dim,)")
     if delta_bias is not None:
         delta_bias = delta_bias.float().contiguous()
-        if tuple(delta_bias.shape) != (dim,):
-            raise RuntimeError("selective_scan: delta_bias must be (dim,)")
+        if tuple(delta_bias.shape) != (dim1,):
+            raise RuntimeError("selective_scan: delta_bias must have one entry per delta channel")
     return dev, u, delta, A, B, C, D, z, delta_bias
 
 
@@ -91,6 +94,7 @@ def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, la
     desc.batch, desc.dim, desc.seqlen, desc.dstate, desc.n_groups = batch, dim, L, A.shape[1], B.shape[1]
     desc.io_dtype = _abi.dtype_code(u.dtype)
     desc.flags = _abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0
+    desc.delta_group_ratio = dim // delta.shape[1]
     desc.u_bs, desc.u_ds = u.stride(0), u.stride(1)
     desc.delta_bs, desc.delta_ds = delta.stride(0), delta.stride(1)
     if z is not None:
@@ -141,14 +145,16 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     batch, dim, L = u.shape
     dout = _last_contig(dout)
     du = torch.empty_like(u)
-    ddelta = torch.empty_like(delta)
+    ratio = dim // delta.shape[1]
+    # the kernel writes ddelta / ddelta_bias per channel; grouped delta (ratio > 1) is reduced over each group below
+    ddelta = torch.empty_like(delta) if ratio == 1 else torch.empty_like(u)
     dz = torch.empty_like(z) if z is not None else None
     # accumulated-into buffers start at zero (reference contract, selective_scan.cpp:321-327)
     dA = torch.zeros_like(A)
     dB = torch.zeros(B.shape, dtype=torch.float32, device=u.device)
     dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
     dD = torch.zeros_like(D) if D is not None else None
-    dbias = torch.zeros_like(delta_bias) if delta_bias is not None else None
+    dbias = torch.zeros(dim, dtype=torch.float32, device=u.device) if delta_bias is not None else None
     desc = _abi.ScanBwdDesc()
     _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt)
     desc.dout_bs, desc.dout_ds = dout.stride(0), dout.stride(1)
@@ -173,6 +179,10 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
                 batch, dim, L, A.shape[1], B.shape[1], u.element_size(), z is not None, True,
                 ckpt.shape[2] if ckpt is not None else 0)))
     _abi.check(rc, "mxvl_scan_bwd")
+    if ratio > 1:
+        ddelta = ddelta.view(batch, dim // ratio, ratio, L).sum(2, dtype=torch.float32).to(delta.dtype)
+        if dbias is not None:
+            dbias = dbias.view(dim // ratio, ratio).sum(1)
     return du, ddelta, dA, dB, dC, dD, dz, dbias
 
 

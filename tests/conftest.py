@@ -53,3 +53,19 @@ def assert_close(got, ref, atol, rtol, what=""):
     assert not bool(bad.any()), (f"{what}: {int(bad.sum())} / {bad.numel()} elements out of tolerance; "
                                  f"max err {err.max().item():.3e} (atol {atol}, rtol {rtol}), "
                                  f"max |ref| {ref.abs().max().item():.3e}")
+
+
+def synthetic_xray(h, w, seed):
+    """Deterministic (H, W, 3) uint8 test image: smooth anatomy-like gradients and edges plus sensor noise, grey replicated
+    to RGB with small per-channel offsets (the reference converts every radiograph to RGB first, data_helper.py:71-74).
+    Shared by tests/golden/make_golden.py (which stores only the expected outputs) and the tests (which rebuild the input)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    base = 120 + 90 * np.sin(x / (0.11 * w + 3)) * np.cos(y / (0.07 * h + 5)) + 40 * ((x / w - 0.5) ** 2 + (y / h - 0.5) ** 2 < 0.09)
+    base += 60 * (np.abs(x - 0.3 * w) < 2) - 50 * (np.abs(y - 0.6 * h) < 1)           # sharp edges: bicubic undershoot / clipping
+    noise = rs.randint(-25, 26, size=(h, w, 3))
+    img = base[:, :, None] + np.array([0, 3, -4])[None, None, :] + noise
+    img[: max(1, h // 16), : max(1, w // 16)] = 255                                   # saturated corner markers
+    img[-max(1, h // 16):, -max(1, w // 16):] = 0
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -616,7 +616,56 @@ def main():
     gen_vit_mae()
     gen_hybrid_decoder()
     gen_decode()
+    gen_image_preprocess()
+
+
+# cases of tests/golden/image_preprocess.npz: (name, in_h, in_w, out_h, out_w, PIL resample, seed)
+IMAGE_CASES = [
+    ("down_bicubic", 301, 257, 32, 32, 3, 1),        # both passes, wide support (ksize 39 / 35)
+    ("up_bicubic", 23, 31, 64, 48, 3, 2),            # upscaling: support stays 2, clipped windows at the borders
+    ("down_bilinear", 200, 150, 56, 40, 2, 3),
+    ("h_only", 48, 300, 48, 96, 3, 4),               # height unchanged: Pillow skips the vertical pass
+    ("v_only", 300, 64, 80, 64, 3, 5),               # width unchanged: Pillow skips the horizontal pass
+    ("same", 40, 40, 40, 40, 3, 6),                  # Image.resize returns a copy
+    ("xray_224", 1160, 953, 224, 224, 3, 7),         # the reference configuration: large radiograph -> 224 x 224
+    ("tiny", 2, 5, 5, 4, 3, 8),
+]
+
+
+def gen_image_preprocess():
+    """The image leg of the data pipeline (CXPMRG_Bench_MambaXray_VL/dataset/data_helper.py:17-26): real Pillow
+    `Image.resize` bytes and real transformers ViTImageProcessor pixel_values (swin_base_patch4_window7_224's
+    preprocessor_config: size 224, resample 3, rescale 1/255, ImageNet mean/std), inputs rebuilt by conftest.synthetic_xray."""
+    import PIL
+    from PIL import Image
+    import transformers
+    from transformers import ViTImageProcessor
+    sys.path.insert(0, os.path.dirname(HERE))
+    from conftest import synthetic_xray
+    out = {"pillow_version": np.array(PIL.__version__), "transformers_version": np.array(transformers.__version__),
+           "cases": np.array([c[0] for c in IMAGE_CASES]), "shapes": np.array([c[1:] for c in IMAGE_CASES], dtype=np.int64)}
+    for name, h, w, oh, ow, kind, seed in IMAGE_CASES:
+        img = synthetic_xray(h, w, seed)
+        out[name + "_resized"] = np.array(Image.fromarray(img).resize((ow, oh), resample=kind))
+        proc = ViTImageProcessor(do_resize=True, size={"height": oh, "width": ow}, resample=kind, do_rescale=True,
+                                 rescale_factor=1 / 255, do_normalize=True, image_mean=[0.485, 0.456, 0.406],
+                                 image_std=[0.229, 0.224, 0.225])
+        pv = proc(img, return_tensors="pt", size={"height": oh, "width": ow}).pixel_values[0].numpy()
+        assert pv.dtype == np.float32 and pv.shape == (3, oh, ow)
+        if oh * ow <= 64 * 64:
+            out[name + "_pixel_values"] = pv
+        else:   # large outputs: the bytes above pin the resize; the float map is pinned by its 3 x 256 table
+            out[name + "_pixel_values_sum"] = pv.astype(np.float64).sum(axis=(1, 2))
+    # transformers' byte -> float map, read off the processor itself (a 256-wide image that is not resized)
+    ramp = np.ascontiguousarray(np.broadcast_to(np.arange(256, dtype=np.uint8)[None, :, None], (8, 256, 3)))
+    proc = ViTImageProcessor(do_resize=False, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+                             image_mean=[0.485, 0.456, 0.406], image_std=[0.229, 0.224, 0.225])
+    out["byte_table"] = proc(ramp, return_tensors="pt").pixel_values[0].numpy()[:, 0, :]
+    save("image_preprocess", **out)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "image":
+        gen_image_preprocess()
+    else:
+        main()

@@ -217,3 +217,71 @@ def test_scan_bwd_linearity_full_size():
         ref = a[k].float() + 2.0 * b[k].float()
         scale = max(1.0, float(ref.abs().max()))
         assert_close(c[k], ref, 5e-5 * scale, 1e-4, k)
+
+
+# ---------------------------------------------------------------------------------------------------
+# delta with fewer channels than u (the oflex extension's dim_deltagroups_ratio; reference test:
+# test_selective_scan.py:365-371 DIM=768, DIM1=24, DSTATE=1, and :453-457 / :510-517 for how it is checked)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,D,D1,L,N,G,dtype", [
+    (2, 768, 24, 64, 1, 1, torch.float32),      # the reference test's shape (ratio 32, dstate 1)
+    (2, 768, 24, 256, 1, 2, torch.bfloat16),
+    (2, 96, 32, 197, 16, 1, torch.float32),     # ratio 3 (not a power of two), ragged chunk
+    (8, 256, 64, 512, 16, 1, torch.float32),    # enough rows for the streaming kernel, ratio 4
+    (1, 48, 48, 130, 8, 1, torch.float32),      # ratio 1 through the same code path
+])
+def test_scan_delta_channel_groups(B, D, D1, L, N, G, dtype):
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    ratio = D // D1
+    cpu = scan_inputs(B, D, L, N, G, False, True, True, seed=21, dtype=dtype)
+    g = torch.Generator().manual_seed(22)
+    delta1 = (0.5 * torch.rand(B, D1, L, generator=g)).to(dtype)
+    bias1 = 0.5 * torch.rand(D1, generator=g)
+    dout = torch.randn(B, D, L, generator=g).to(dtype)
+    # the reference's expansion: every delta channel repeated ratio times in place
+    delta_full = delta1.unsqueeze(2).repeat(1, 1, ratio, 1).flatten(1, 2).contiguous()
+    bias_full = bias1.unsqueeze(1).repeat(1, ratio).view(-1)
+    for sp in (False, True):
+        x = _to(dict(cpu, delta=delta1, delta_bias=bias1), dev)
+        leaves = {k: (v.clone().requires_grad_(True) if v is not None else None) for k, v in x.items()}
+        out, last = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                                      delta_bias=leaves["delta_bias"], delta_softplus=sp, return_last_state=True)
+        out.backward(dout.to(dev))
+        # (1) same kernels on the expanded delta: forward bit-identical, gradients = per-group sums
+        xf = _to(dict(cpu, delta=delta_full, delta_bias=bias_full), dev)
+        lf = {k: (v.clone().requires_grad_(True) if v is not None else None) for k, v in xf.items()}
+        out_f, last_f = selective_scan_fn(lf["u"], lf["delta"], lf["A"], lf["B"], lf["C"], lf["D"],
+                                          delta_bias=lf["delta_bias"], delta_softplus=sp, return_last_state=True)
+        out_f.backward(dout.to(dev))
+        assert torch.equal(out, out_f) and torch.equal(last, last_f)
+        assert torch.equal(leaves["u"].grad, lf["u"].grad)
+        for k in ("A", "B", "C", "D"):   # accumulated with fp32 atomics: equal up to summation order
+            r = lf[k].grad.float()
+            t = 1e-5 if dtype == torch.float32 else 2e-2
+            assert_close(leaves[k].grad.float(), r, t * max(1.0, float(r.abs().max())), t, "d" + k)
+        dd = lf["delta"].grad.float().view(B, D1, ratio, L).sum(2)
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert_close(leaves["delta"].grad.float(), dd, tol * max(1.0, float(dd.abs().max())), tol, "ddelta")
+        db = lf["delta_bias"].grad.view(D1, ratio).sum(1)
+        assert_close(leaves["delta_bias"].grad, db, 1e-5 * max(1.0, float(db.abs().max())), 1e-5, "ddelta_bias")
+        assert leaves["delta"].grad.shape == delta1.shape and leaves["delta_bias"].grad.shape == bias1.shape
+        # (2) against the CPU oracle on the expanded tensors
+        ref, ref_last = orc.selective_scan_ref(cpu["u"], delta_full, cpu["A"], cpu["B"], cpu["C"], cpu["D"], None,
+                                               bias_full, sp, return_last_state=True)
+        if dtype == torch.float32:
+            assert_close(out, ref, _atol(ref), 1e-5, "out")
+            assert_close(last, ref_last, _atol(ref_last), 1e-5, "last_state")
+        else:
+            assert_close(out.float(), ref.float(), 5e-2, 3e-2, "out")
+
+
+def test_scan_delta_channel_groups_rejects_bad_shapes():
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    x = _to(scan_inputs(1, 48, 32, 4), dev)
+    with pytest.raises(RuntimeError):   # 48 % 5 != 0
+        selective_scan_fn(x["u"], x["delta"][:, :5].contiguous(), x["A"], x["B"], x["C"])
+    with pytest.raises(RuntimeError):   # delta_bias follows delta's channel count
+        selective_scan_fn(x["u"], x["delta"][:, :12].contiguous(), x["A"], x["B"], x["C"], delta_bias=torch.zeros(48, device=dev))
