@@ -26,6 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import checkpoint_compat as compat
+from . import report_metrics
 from .models_mamba import arm_base_pz16, arm_large_pz16
 from .report_decoder import ReportDecoder
 
@@ -203,6 +204,27 @@ class MambaXrayVLDownStream(nn.Module):
 
     def test_step(self, samples, batch_idx=0):
         return self._eval_step(samples, self.test_step_outputs)
+
+    def score(self, ref, hypo):
+        """{id: [report]} x {id: [generated report]} -> {"Bleu_1".."Bleu_4", "ROUGE_L", "CIDEr"} (:134-157; METEOR needs the
+        meteor-1.5.jar the reference does not ship)."""
+        return report_metrics.score(ref, hypo, dataset=_get(self.args, "dataset", None))
+
+    def epoch_scores(self, outputs=None, clear=True):
+        """What on_validation_epoch_end / on_test_epoch_end compute from the collected step outputs (:329-341, :406-418):
+        (scores, ref, hypo) with the reference's {id: [text]} dictionaries."""
+        outputs = self.val_step_outputs if outputs is None else outputs
+        ref, hypo, ids = [], [], []
+        for o in outputs:
+            ref.extend(o["ref"])
+            hypo.extend(o["hypo"])
+            ids.extend(o["id"])
+        ref = {k: [v] for k, v in zip(ids, ref)}
+        hypo = {k: [v] for k, v in zip(ids, hypo)}
+        scores = self.score(ref=ref, hypo=hypo)
+        if clear:
+            outputs.clear()
+        return scores, ref, hypo
 
     def decode(self, output_token):
         if len(output_token) and output_token[0] == 0:   # a leading <unk>

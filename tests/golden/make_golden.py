@@ -617,6 +617,8 @@ def main():
     gen_hybrid_decoder()
     gen_decode()
     gen_image_preprocess()
+    gen_report_metrics()
+    gen_clean_report()
 
 
 # cases of tests/golden/image_preprocess.npz: (name, in_h, in_w, out_h, out_w, PIL resample, seed)
@@ -664,8 +666,90 @@ def gen_image_preprocess():
     save("image_preprocess", **out)
 
 
+# corpora of tests/golden/report_metrics.npz: {name: [(hypothesis, [references...]), ...]} -- sentences written for this fixture
+METRIC_CORPORA = {
+    "single_ref": [
+        ("the lungs are clear . no pleural effusion or pneumothorax . heart size is normal .",
+         ["the lungs are clear . there is no pleural effusion or pneumothorax . the heart size is normal ."]),
+        ("there is a small left pleural effusion with adjacent atelectasis .",
+         ["small left pleural effusion with associated left basilar atelectasis . no pneumothorax ."]),
+        ("no acute cardiopulmonary process .", ["no acute cardiopulmonary abnormality ."]),
+        ("heart size is mildly enlarged . the mediastinal contours are stable . no focal consolidation .",
+         ["the heart is mildly enlarged . mediastinal and hilar contours are unchanged . there is no focal consolidation ."]),
+        ("the the the lungs lungs are are clear clear .", ["the lungs are clear ."]),
+        ("right lower lobe opacity may represent pneumonia in the appropriate clinical setting .",
+         ["right lower lobe opacity may represent pneumonia in the appropriate clinical setting ."]),
+    ],
+    "multi_ref": [
+        ("lungs are clear .", ["the lungs are clear .", "clear lungs bilaterally .", "lungs are clear without focal consolidation ."]),
+        ("", ["no acute findings .", "no acute cardiopulmonary process ."]),
+        ("normal", ["normal chest radiograph .", "normal"]),
+        ("endotracheal tube tip terminates approximately 4 cm above the carina . enteric tube courses below the diaphragm .",
+         ["the endotracheal tube terminates 4 cm above the carina . an enteric tube courses below the diaphragm and out of view .",
+          "endotracheal tube in standard position . enteric tube tip is not seen ."]),
+        ("moderate cardiomegaly with  pulmonary vascular congestion .",
+         ["moderate cardiomegaly and pulmonary vascular congestion suggest mild pulmonary edema .",
+          "there is moderate cardiomegaly . pulmonary vascular congestion is present ."]),
+    ],
+    "one_id": [
+        ("low lung volumes . bibasilar atelectasis .", ["lung volumes are low with bibasilar atelectasis .", "low lung volumes ."]),
+    ],
+}
+
+
+def gen_report_metrics():
+    """The reference's own scorers (CXPMRG_Bench_MambaXray_VL/evalcap/{bleu,rouge,cider}, pure Python) on the corpora above:
+    the numbers `MambaXrayVLDownStream.score` (models/MambaXrayVL_DownStream.py:134-157) reports, METEOR excluded (needs
+    meteor-1.5.jar, which the reference does not ship)."""
+    ev = os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/evalcap")
+    bleu = _load(os.path.join(ev, "bleu/bleu.py"), "ref_evalcap_bleu")
+    rouge = _load(os.path.join(ev, "rouge/rouge.py"), "ref_evalcap_rouge")
+    sys.path.insert(0, os.path.join(ev, "cider"))
+    cider = _load(os.path.join(ev, "cider/cider.py"), "ref_evalcap_cider")
+    out = {"corpora": np.array(sorted(METRIC_CORPORA))}
+    for name, rows in METRIC_CORPORA.items():
+        gts = {f"id{i}": list(refs) for i, (_, refs) in enumerate(rows)}
+        res = {f"id{i}": [hyp] for i, (hyp, _) in enumerate(rows)}
+        out[name + "_hyp"] = np.array([h for h, _ in rows])
+        out[name + "_refs"] = np.array(["\t".join(r) for _, r in rows])          # references of one id, tab-separated
+        b, b_each = bleu.Bleu(4).compute_score(gts, res)
+        out[name + "_bleu"] = np.array(b, dtype=np.float64)
+        out[name + "_bleu_each"] = np.array(b_each, dtype=np.float64)
+        r, r_each = rouge.Rouge().compute_score(gts, res)
+        out[name + "_rouge"] = np.float64(r)
+        out[name + "_rouge_each"] = np.asarray(r_each, dtype=np.float64)
+        c, c_each = cider.Cider().compute_score(gts, res)
+        out[name + "_cider"] = np.float64(c)
+        out[name + "_cider_each"] = np.asarray(c_each, dtype=np.float64)
+    save("report_metrics", **out)
+
+
+REPORT_TEXTS = [   # written for this fixture: numbered findings, doubled dots, anonymisation underscores, quotes, brackets
+    "1. The heart is normal in size.. 2. Lungs are clear. 3. No \"acute\" findings/abnormality: see prior (2019) [AP].",
+    "FINDINGS:  The lungs are clear.\n No pleural effusion___ or pneumothorax...  Heart size: normal; 4. ET tube 'ok' {stable}.",
+    "", "No change", "A. B. C.  D", "x..y...z. 5. done 2. twice",
+    "IMPRESSION: 1. Low lung volumes.  2. Mild cardiomegaly, unchanged.   3. No effusion!  Compare w/ ___ study; follow-up?",
+]
+
+
+def gen_clean_report():
+    """`FieldParser.clean_report` of the reference (CXPMRG_Bench_MambaXray_VL/dataset/data_helper.py:28-61), called on an
+    instance made without __init__ (which needs a local HF processor directory)."""
+    mod = _load(os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/dataset/data_helper.py"), "ref_data_helper")
+    out = {"texts": np.array(REPORT_TEXTS)}
+    for ds in ("iu_xray", "mimic_cxr", "chinese"):
+        p = mod.FieldParser.__new__(mod.FieldParser)
+        p.dataset = ds
+        out[ds] = np.array([p.clean_report(t) for t in REPORT_TEXTS])
+    save("clean_report", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "image":
+    if len(sys.argv) > 1 and sys.argv[1] == "text":
+        gen_clean_report()
+    elif len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        gen_report_metrics()
+    elif len(sys.argv) > 1 and sys.argv[1] == "image":
         gen_image_preprocess()
     else:
         main()

@@ -1,0 +1,66 @@
+"""Input pipeline mirror (data_pipeline.py) of CXPMRG_Bench_MambaXray_VL/dataset/data_helper.py: report cleaning against the
+reference's own outputs (tests/golden/clean_report.npz), study parsing, raw collation; on the GPU the device-side batcher
+against the CPU oracle of the reference's image processor."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, synthetic_xray
+from medical_image_analysis_amd import data_pipeline as dp
+
+G = np.load(os.path.join(GOLDEN, "clean_report.npz"))
+
+
+@pytest.mark.parametrize("dataset", ["iu_xray", "mimic_cxr", "chinese"])
+def test_clean_report_equals_reference(dataset):
+    for text, want in zip(G["texts"], G[dataset]):
+        assert dp.clean_report(str(text), dataset) == str(want)
+    # every dataset name other than iu_xray / chinese takes the MIMIC-CXR rules (the reference's `else` branch)
+    assert dp.clean_report(str(G["texts"][1]), "chexpert_plus") == str(G["mimic_cxr"][1])
+
+
+def _write_study(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rgb = synthetic_xray(90, 70, 3)
+    grey = synthetic_xray(64, 80, 4)[:, :, 0]
+    os.makedirs(tmp_path / "s1")
+    Image.fromarray(rgb).save(tmp_path / "s1" / "a.png")
+    Image.fromarray(grey).save(tmp_path / "s1" / "b.png")           # single-channel file: converted to RGB on load
+    meta = {k: [{"id": "s1", "report": "1. Heart size normal.. Lungs clear.", "image_path": ["s1/a.png", "s1/b.png"]}]
+            for k in ("train", "val", "test")}
+    (tmp_path / "ann.json").write_text(json.dumps(meta))
+    args = SimpleNamespace(dataset="mimic_cxr", annotation=str(tmp_path / "ann.json"), base_dir=str(tmp_path), input_size=32)
+    return args, rgb, grey
+
+
+def test_parse_dataset_returns_raw_images_and_clean_text(tmp_path):
+    args, rgb, grey = _write_study(tmp_path)
+    train, val, test = dp.create_datasets(args)
+    assert len(train) == len(val) == len(test) == 1
+    s = train[0]
+    assert s["id"] == "s1" and s["input_text"] == "heart size normal . lungs clear ."
+    assert [tuple(i.shape) for i in s["image"]] == [(90, 70, 3), (64, 80, 3)] and s["image"][0].dtype == torch.uint8
+    assert np.array_equal(s["image"][0].numpy(), rgb)
+    assert np.array_equal(s["image"][1].numpy(), np.repeat(grey[:, :, None], 3, 2))
+    batch = dp.collate_raw([s, s])
+    assert batch["id"] == ["s1", "s1"] and len(batch["image"]) == 2 and len(batch["image"][0]) == 2
+
+
+@pytest.mark.gpu
+def test_device_batcher_equals_reference_pipeline(tmp_path):
+    from oracle import image_ref as ir
+    args, rgb, grey = _write_study(tmp_path)
+    ds = dp.ParseDataset(args, "train")
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, collate_fn=dp.collate_raw)
+    batch = dp.DeviceBatcher(args)(next(iter(loader)))
+    assert [tuple(v.shape) for v in batch["image"]] == [(1, 3, 32, 32)] * 2 and batch["image"][0].is_cuda
+    assert np.array_equal(batch["image"][0][0].cpu().numpy(), ir.preprocess_ref(rgb, 32, 3))
+    assert np.array_equal(batch["image"][1][0].cpu().numpy(), ir.preprocess_ref(np.repeat(grey[:, :, None], 3, 2), 32, 3))
+    # the reference's in-parser placement (FieldParser._parse_image) gives the same tensors
+    from medical_image_analysis_amd.image_processing import XrayImageProcessor
+    s = dp.ParseDataset(args, "train", processor=XrayImageProcessor())[0]
+    assert torch.equal(s["image"][0], batch["image"][0][0])

@@ -122,6 +122,10 @@ def test_downstream_loss_generate_and_delta(tmp_path):
         hypo, ref = m.validation_step(batch)
     assert len(hypo) == 2 and all(isinstance(h, str) and 4 <= len(h.split()) <= 8 for h in hypo)
     assert ref[0].startswith("w") and "<unk>" not in ref[0]
+    scores, ref_d, hyp_d = m.epoch_scores()                            # on_validation_epoch_end's scoring (:329-341)
+    assert sorted(ref_d) == sorted(batch["id"]) and all(len(v) == 1 for v in hyp_d.values())
+    assert list(scores) == ["Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4", "ROUGE_L", "CIDEr"] and m.val_step_outputs == []
+    assert all(0.0 <= float(v) <= 10.0 for v in scores.values())
     path = os.path.join(tmp_path, "checkpoints", "delta.pth")
     m.save_checkpoint(path, epoch=1, step=7)
     saved = torch.load(path)["model"]
