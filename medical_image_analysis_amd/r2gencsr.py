@@ -6,9 +6,13 @@ Host-side mirror of R2GenCSR/models/R2GenCSR.py (`R2GenCSR`, :56-700) for its de
 with the same encoder under no_grad, their pooled features are subtracted from the study's pooled feature, wrapped in their
 text prompts and prepended to the LLM input.  Same `args` fields, sub-module names and delta-checkpoint keys.
 
+`--proj qformer` builds `qformer.EncoderProjectorQFormer` (HF Blip2 Q-Former restated under HF's key names) for the study's own
+image tokens (:258-262).  The reference also routes the POOLED (B, E) context features through it (:394-402 and the global
+branch of encode_img), which Blip2QFormerModel rejects (it needs (B, L, E)), so context_pair > 0 with the Q-Former raises here
+too -- with a message instead of an unpacking error.
+
 Outside the path and not built: the pandas / FieldParser code that PICKS the context images from the annotation file
-(:309-374; pass the picked image tensors to `set_context_samples`), the Swin / Vim encoder choices, the Q-Former projector
-(HF Blip2QFormerModel), PEFT-LoRA, evalcap scoring.
+(:309-374; pass the picked image tensors to `set_context_samples`), the Swin / Vim encoder choices, PEFT-LoRA.
 """
 from __future__ import annotations
 
@@ -17,6 +21,7 @@ import torch.nn as nn
 
 from . import checkpoint_compat as compat
 from .mambaxray_vl import MambaXrayVLDownStream, _get, _load_tokenizer, _reject_unbuilt, build_report_decoder
+from .qformer import EncoderProjectorQFormer
 from .vmamba import vssm1_base_0229
 
 
@@ -26,10 +31,8 @@ class R2GenCSR(MambaXrayVLDownStream):
         _reject_unbuilt(args)
         if _get(args, "chosen", "vmamba") != "vmamba":
             raise NotImplementedError("only --chosen vmamba (the default) is built; Swin / Vim encoders are third-party models")
-        if _get(args, "proj", "linear") == "qformer":
-            raise NotImplementedError("--proj qformer wraps HF Blip2QFormerModel (third-party); the default linear projector is built")
         self.args = self.hparams = args
-        self.proj, self.chosen, self.llm = "linear", "vmamba", _get(args, "llm", "llama2")
+        self.proj, self.chosen, self.llm = _get(args, "proj", "linear"), "vmamba", _get(args, "llm", "llama2")
         self.visual_encoder = encoder if encoder is not None else vssm1_base_0229()
         vision_model = str(_get(args, "vision_model", "None"))
         if vision_model != "None":
@@ -48,7 +51,10 @@ class R2GenCSR(MambaXrayVLDownStream):
             for p in self.llama_model.parameters():
                 p.requires_grad = False
         hidden = self.llama_model.config.hidden_size
-        self.llama_proj = nn.Linear(self.visual_encoder.num_features, hidden)
+        if self.proj != "qformer":                                                        # :176-179
+            self.llama_proj = nn.Linear(self.visual_encoder.num_features, hidden)
+        else:
+            self.llama_proj = EncoderProjectorQFormer(0, encoder_dim=self.visual_encoder.num_features, llm_dim=hidden)
         self.layer_norm = nn.LayerNorm(hidden)
         self.end_sym = _get(args, "end_sym", "</s>")
         self.prompt = _get(args, "instruction", "Generate a comprehensive and detailed diagnosis report for this chest xray image.")
@@ -77,8 +83,17 @@ class R2GenCSR(MambaXrayVLDownStream):
             if len(embeds) == 1:
                 embeds = embeds + embeds                                        # same token count as two-view training
             image_embeds = torch.cat(embeds, dim=1)
-        inputs_llama = self.llama_proj(image_embeds)
+        inputs_llama = self._project(image_embeds)
         return inputs_llama, torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=inputs_llama.device)
+
+    def _project(self, embeds):
+        if self.proj != "qformer":
+            return self.llama_proj(embeds)
+        if embeds.dim() != 3:
+            raise RuntimeError("--proj qformer needs (B, L, E) encoder tokens; the reference feeds pooled (B, E) context features "
+                               "to Blip2QFormerModel here (R2GenCSR.py:258-262 with global_only, :394-402), which it rejects")
+        mask = torch.ones(embeds.shape[:-1], dtype=torch.long, device=embeds.device)
+        return self.llama_proj(embeds, mask)
 
     def image_prompt_wrap(self, img_embeds, atts_img, prompt):
         before, after = prompt.split("<ImageHere>")
@@ -104,7 +119,7 @@ class R2GenCSR(MambaXrayVLDownStream):
 
         if before:                                           # residual in encoder space, then project (:391-419)
             g = g_emb[:, None, :].expand(-1, p_emb.shape[0], -1)
-            p_emb, n_emb = self.llama_proj(g - p_emb), self.llama_proj(g - n_emb)
+            p_emb, n_emb = self._project(g - p_emb), self._project(g - n_emb)
             pw, pa = self.image_prompt_wrap(p_emb, ones(p_emb), pos_prompt)
             nw, na = self.image_prompt_wrap(n_emb, ones(n_emb), neg_prompt)
             return torch.cat((nw, pw), dim=1), torch.cat((na, pa), dim=1)

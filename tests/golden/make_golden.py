@@ -619,6 +619,7 @@ def main():
     gen_image_preprocess()
     gen_report_metrics()
     gen_clean_report()
+    gen_qformer()
 
 
 # cases of tests/golden/image_preprocess.npz: (name, in_h, in_w, out_h, out_w, PIL resample, seed)
@@ -744,8 +745,30 @@ def gen_clean_report():
     save("clean_report", **out)
 
 
+def gen_qformer():
+    """HF `Blip2QFormerModel` (the module R2GenCSR's EncoderProjectorQFormer wraps, R2GenCSR/models/R2GenCSR.py:24-54) at a
+    small width: weights, inputs (with a padded encoder row) and last_hidden_state; 2 layers, cross-attention in layer 0."""
+    from transformers import Blip2QFormerConfig, Blip2QFormerModel
+    torch.manual_seed(0)
+    cfg = Blip2QFormerConfig(hidden_size=64, num_attention_heads=4, intermediate_size=128, encoder_hidden_size=32, num_hidden_layers=2)
+    assert cfg.cross_attention_frequency == 2 and cfg.layer_norm_eps == 1e-12 and cfg.hidden_act == "gelu"
+    m = Blip2QFormerModel(cfg).eval()
+    _randomize(m)
+    q = torch.randn(2, 8, 64)
+    enc = torch.randn(2, 49, 32)
+    atts = torch.ones(2, 49, dtype=torch.long)
+    atts[1, 40:] = 0
+    with torch.no_grad():
+        out = m(query_embeds=q, encoder_hidden_states=enc, encoder_attention_mask=atts, return_dict=True).last_hidden_state
+        out_nomask = m(query_embeds=q, encoder_hidden_states=enc, return_dict=True).last_hidden_state
+    arrs = {"sd." + k: np_(v) for k, v in m.state_dict().items()}
+    save("qformer", query=np_(q), enc=np_(enc), atts=atts.numpy(), out=np_(out), out_nomask=np_(out_nomask), **arrs)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "text":
+    if len(sys.argv) > 1 and sys.argv[1] == "qformer":
+        gen_qformer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "text":
         gen_clean_report()
     elif len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_report_metrics()
