@@ -64,7 +64,7 @@ WORKLOADS = {
 }
 PRETRAIN_WORKLOADS = {
     # name: (img, patch, embed_dim, depth, dec_dim, per-GPU batch, description)
-    "arm_pretrain_large_1024": (1024, 16, 1024, 24, 512, 8,
+    "arm_pretrain_large_1024": (1024, 16, 1024, 24, 512, 16,
                                 "configs[2]: MambaXray-VL-Large (VisionMamba 1024x24, dec 512x4) stage-1 ARM pre-training "
                                 "step, 1024x1024 synthetic X-rays (4096 patches, 4080-token scan), bf16 autocast"),
     "arm_pretrain_base_192": (192, 16, 768, 12, 512, 64,

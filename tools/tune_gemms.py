@@ -5,7 +5,13 @@ import os, subprocess, sys, glob
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "medical_image_analysis_amd", "tuned", "tunableop_gfx950.csv")
-workloads = sys.argv[1:] or ["arm_pretrain_large_1024", "arm_pretrain_base_192"]
+argv = sys.argv[1:]
+batch = []
+if "--batch" in argv:                      # per-GPU batch override (GEMM shapes follow the token count)
+    i = argv.index("--batch")
+    batch = ["--batch", argv[i + 1]]
+    del argv[i:i + 2]
+workloads = argv or ["arm_pretrain_large_1024", "arm_pretrain_base_192"]
 tmp = "/tmp/mxvl_tune"
 os.makedirs(tmp, exist_ok=True)
 lines, header = {}, []
@@ -19,7 +25,7 @@ for w in workloads:
     env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=base,
                PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS="15", PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS="10", MXVL_TUNED_GEMMS="0")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
-                           "--no-cpu-baseline"], env=env, cwd=ROOT)
+                           "--no-cpu-baseline"] + batch, env=env, cwd=ROOT)
     for f in glob.glob(base.replace(".csv", "*.csv")):
         for ln in open(f):
             if ln.startswith("Validator"):
