@@ -198,13 +198,30 @@ def run_decode(args, rank, world, dev, dist):
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}))
 
 
+def host_physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo; falls back to half the hardware threads."""
+    pairs, phys = set(), None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    pairs.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return len(pairs) or max(1, (os.cpu_count() or 2) // 2)
+
+
 def cpu_baseline_pretrain(model, img, patch, depth, budget_s=25.0):
     """FORWARD pass of the same model on the host: oracle/models_ref.py (functional restatement of the reference's
     VisionMamba.forward over the C scan/conv oracles), fp32, all cores.  The reference's own training step cannot
     run without its CUDA wheels; forward-only is what the CPU oracle offers, and the sample says so."""
     from oracle import models_ref
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    # one socket's worth of physical cores: with every hardware thread of a 2-socket host (256 on the pool's EPYC 9575F
+    # boxes) torch's intra-op pools oversubscribe and this forward ran 5x slower than on 8 cores
+    cores = min(host_physical_cores(), 64)
     orc.set_threads(cores)
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
