@@ -205,12 +205,21 @@ int mxvl_state_update(void *state, const void *x, const void *dt, const void *A,
  *   mxvl_dir_gather: rows (batch,dim,seqlen) -> stacked (batch,n_dirs,dim,padded_len): stacked[b,k,d,l] = rows[b,d,index[k][l]], 0 for
  *                    l >= seqlen;      mxvl_dir_merge: stacked -> rows: rows[b,d,t] = sum_k stacked[b,k,d,index[k][t]] (fp32 sum).
  * index: (n_dirs, seqlen) int32 permutations; gather with the permutations and merge with their inverses are each other's adjoint.
- * Strides in elements, innermost stride 1; seqlen <= 5120. */
+ * Strides in elements, innermost stride 1; seqlen <= 5120.
+ * Output gate (gate != NULL; the reference's `y * silu(z)` of every direction and the `/ 4`, :522-529, which commute with the
+ * re-ordering): merge writes rows = (sum_k ...) * silu(gate) * gate_scale and, when pre != NULL, the ungated sum to pre;
+ * gather then is that merge's backward: rows holds d(out), stacked receives gather(rows * silu(gate) * gate_scale) and
+ * dgate = rows * pre * gate_scale * silu'(gate) (pre and dgate required).  gate / pre / dgate are (batch, dim, seqlen). */
 typedef struct mxvl_dir_perm_desc {
   int32_t batch, dim, seqlen, padded_len, n_dirs, io_dtype;
   int64_t rows_bs, rows_ds, stacked_bs, stacked_ks, stacked_ds;
   const void *index;
   void *rows, *stacked;      /* gather reads rows and writes stacked; merge reads stacked and writes rows */
+  const void *gate;          /* optional */
+  void *pre, *dgate;
+  int64_t gate_bs, gate_ds, pre_bs, pre_ds, dgate_bs, dgate_ds;
+  float gate_scale;
+  int32_t reserved0;
 } mxvl_dir_perm_desc;
 int mxvl_dir_gather(const mxvl_dir_perm_desc *desc, void *hip_stream);
 int mxvl_dir_merge(const mxvl_dir_perm_desc *desc, void *hip_stream);

@@ -122,6 +122,9 @@ class DirPermDesc(ctypes.Structure):
         ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("padded_len", c_int32), ("n_dirs", c_int32), ("io_dtype", c_int32),
         ("rows_bs", c_int64), ("rows_ds", c_int64), ("stacked_bs", c_int64), ("stacked_ks", c_int64), ("stacked_ds", c_int64),
         ("index", c_void_p), ("rows", c_void_p), ("stacked", c_void_p),
+        ("gate", c_void_p), ("pre", c_void_p), ("dgate", c_void_p),
+        ("gate_bs", c_int64), ("gate_ds", c_int64), ("pre_bs", c_int64), ("pre_ds", c_int64), ("dgate_bs", c_int64), ("dgate_ds", c_int64),
+        ("gate_scale", ctypes.c_float), ("reserved0", c_int32),
     ]
 
 

@@ -8,6 +8,12 @@
 //   dir_merge  : y (B,K,D,Lp)     -> out (B,D,L)    out[b,d,t] = sum_k y[b,k,d,inv[k][t]]           (fp32 sum, k ascending)
 // perm / inv are (K, L) int32 permutations of [0, L).  One workgroup per (b, d) row: the row goes through LDS once, global
 // reads and writes are coalesced, the permutation is applied on the LDS side.
+//
+// Output gate.  Every direction's scan output is gated by silu(z) of ITS ordering of z; the gate commutes with the
+// re-ordering -- sum_k P_k^-1 (y_k * silu(P_k z)) = silu(z) * sum_k P_k^-1 y_k -- so the scans run ungated and the merge
+// applies silu(z) * scale once, in registers (`gate`): the reference's `* silu(z)` per direction and `/ 4` (:522-529) cost
+// no tensor pass of their own.  The ungated sum goes to `pre` for the backward, which is the gather with the same gate:
+// d(stacked) = gather(d(out) * silu(z) * scale) and d(z) = d(out) * pre * scale * silu'(z), all from the row in LDS.
 #include "mxvl_common.h"
 
 namespace mxvl {
@@ -19,6 +25,12 @@ struct PermArgs {
   const int* idx;                // (K, L)
   const void* src;
   void* dst;
+  // optional output gate (see the header comment); all (B,D,L)-shaped with their own batch / row strides
+  const void* gate;
+  void* pre;                     // merge: written (may be NULL);  gather: read
+  void* dgate;                   // gather only
+  long long g_bs, g_ds, p_bs, p_ds, dg_bs, dg_ds;
+  float scale;
 };
 
 template <typename io_t>
@@ -27,7 +39,19 @@ __global__ __launch_bounds__(256) void dir_gather_kernel(const PermArgs p) {
   using io = Io<io_t>;
   const int d = blockIdx.x, b = blockIdx.y;
   const io_t* x = (const io_t*)p.src + (long long)b * p.x_bs + (long long)d * p.x_ds;
-  for (int t = threadIdx.x; t < p.L; t += 256) srow[t] = io::ld(x + t);
+  if (p.gate) {   // backward of the gated merge: x is d(out)
+    const io_t* z = (const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds;
+    const io_t* pre = (const io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds;
+    io_t* dz = (io_t*)p.dgate + (long long)b * p.dg_bs + (long long)d * p.dg_ds;
+    for (int t = threadIdx.x; t < p.L; t += 256) {
+      const float g = io::ld(x + t) * p.scale, zv = io::ld(z + t);
+      const float sg = sigmoid(zv);
+      srow[t] = g * (zv * sg);
+      io::st(dz + t, g * io::ld(pre + t) * (sg * fmaf(zv, 1.0f - sg, 1.0f)));
+    }
+  } else {
+    for (int t = threadIdx.x; t < p.L; t += 256) srow[t] = io::ld(x + t);
+  }
   __syncthreads();
   for (int k = 0; k < p.K; ++k) {
     io_t* X = (io_t*)p.dst + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)d * p.X_ds;
@@ -58,6 +82,19 @@ __global__ __launch_bounds__(256) void dir_merge_kernel(const PermArgs p) {
     }
   }
   io_t* out = (io_t*)p.dst + (long long)b * p.x_bs + (long long)d * p.x_ds;
+  if (p.gate) {
+    const io_t* z = (const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds;
+    io_t* pre = p.pre ? (io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = threadIdx.x + i * 256;
+      if (t < p.L) {
+        if (pre) io::st(pre + t, acc[i]);
+        io::st(out + t, acc[i] * silu(io::ld(z + t)) * p.scale);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = threadIdx.x + i * 256;
@@ -75,6 +112,9 @@ static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   a.idx = (const int*)d->index;
   a.src = merge ? d->stacked : d->rows;
   a.dst = merge ? (void*)d->rows : (void*)d->stacked;
+  a.gate = d->gate; a.pre = d->pre; a.dgate = d->dgate; a.scale = d->gate_scale;
+  a.g_bs = d->gate_bs; a.g_ds = d->gate_ds; a.p_bs = d->pre_bs; a.p_ds = d->pre_ds; a.dg_bs = d->dgate_bs; a.dg_ds = d->dgate_ds;
+  if (d->gate && !merge && (!d->pre || !d->dgate)) return MXVL_ERR_NULL;   // the gated gather is a backward: it needs pre and dgate
   const dim3 grid(a.D, a.B);
   const size_t lds = sizeof(float) * (size_t)a.L;
   hipStream_t s = (hipStream_t)stream;

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from .selective_scan_interface import mamba_inner_fn, proj_in, selective_scan_fn
+from .selective_scan_interface import _SplitHalves, mamba_inner_fn, proj_in, selective_scan_fn
 from .selective_state_update import selective_state_update
 
 _SUFFIXES = {"v2": ["_b"], "v3": ["_b", "_c", "_c_b"], "v4": ["_b", "_c", "_c_b", "_d", "_d_b"]}
@@ -45,8 +45,9 @@ def _middle_cls_transpose_index(L: int, device) -> torch.Tensor:
     return torch.where(l == tp, torch.full_like(l, tp), src)
 
 
-def _dir_perm(merge, rows, stacked, index, L, Lp):
-    """One mxvl_dir_gather / mxvl_dir_merge launch.  rows: (B, D, L) view (L stride 1); stacked: (B, K, D, Lp) view."""
+def _dir_perm(merge, rows, stacked, index, L, Lp, gate=None, pre=None, dgate=None, scale=1.0):
+    """One mxvl_dir_gather / mxvl_dir_merge launch.  rows: (B, D, L) view (L stride 1); stacked: (B, K, D, Lp) view.
+    gate / pre / dgate: the optional silu output gate of the merge and of its backward (csrc/dir_perm.hip)."""
     import ctypes
     from . import _abi
     lib = _abi.load()
@@ -56,6 +57,12 @@ def _dir_perm(merge, rows, stacked, index, L, Lp):
     d.rows_bs, d.rows_ds = rows.stride(0), rows.stride(1)
     d.stacked_bs, d.stacked_ks, d.stacked_ds = stacked.stride(0), stacked.stride(1), stacked.stride(2)
     d.index, d.rows, d.stacked = index.data_ptr(), rows.data_ptr(), stacked.data_ptr()
+    if gate is not None:
+        d.gate, d.gate_bs, d.gate_ds, d.gate_scale = gate.data_ptr(), gate.stride(0), gate.stride(1), scale
+        if pre is not None:
+            d.pre, d.pre_bs, d.pre_ds = pre.data_ptr(), pre.stride(0), pre.stride(1)
+        if dgate is not None:
+            d.dgate, d.dgate_bs, d.dgate_ds = dgate.data_ptr(), dgate.stride(0), dgate.stride(1)
     fn = lib.mxvl_dir_merge if merge else lib.mxvl_dir_gather
     with torch.cuda.device(rows.device):
         _abi.check(fn(ctypes.byref(d), _abi.stream_ptr(rows.device)), "mxvl_dir_merge" if merge else "mxvl_dir_gather")
@@ -119,6 +126,35 @@ class _DirMerge(torch.autograd.Function):
         dy = torch.empty((B, K, D, Lp), dtype=dout.dtype, device=dout.device)
         _dir_perm(False, _rows_view(dout), dy, perm, L, Lp)
         return dy, None, None, None
+
+
+class _DirMergeGate(torch.autograd.Function):
+    """(sum over the directions of y (B, K, D, Lp), each brought back to token order) * silu(z) * scale -> (B, D, L): the
+    merge, the per-direction output gate and the reference's division as ONE kernel; backward = the gather with the same gate,
+    which also produces dz (csrc/dir_perm.hip)."""
+
+    @staticmethod
+    def forward(ctx, y, z, inv, perm, L, scale):
+        B, K, D, Lp = y.shape
+        if y.stride(-1) != 1:
+            y = y.contiguous()
+        z = _rows_view(z)
+        out = torch.empty((B, D, L), dtype=y.dtype, device=y.device)
+        pre = torch.empty((B, D, L), dtype=y.dtype, device=y.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        _dir_perm(True, out, y, inv, L, Lp, gate=z, pre=pre, scale=scale)
+        ctx.save_for_backward(perm, z, pre)
+        ctx.meta = (K, Lp, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        perm, z, pre = ctx.saved_tensors
+        K, Lp, scale = ctx.meta
+        B, D, L = dout.shape
+        dy = torch.empty((B, K, D, Lp), dtype=dout.dtype, device=dout.device)
+        dz = torch.empty((B, D, L), dtype=z.dtype, device=dout.device)
+        _dir_perm(False, _rows_view(dout.to(z.dtype)), dy, perm, L, Lp, gate=z, pre=pre, dgate=dz, scale=scale)
+        return dy, dz, None, None, None, None
 
 
 class _PermuteLast(torch.autograd.Function):
@@ -232,7 +268,7 @@ class Mamba(nn.Module):
         Bz, _, L = xz.shape
         D, N, R = self.d_inner, self.d_state, self.dt_rank
         fwd, inv, fwd32, inv32 = self._perms(L, xz.device)
-        x, z = xz[:, :D], xz[:, D:]
+        x, z = _SplitHalves.apply(xz)       # the gradient of xz is written once, channel-major (proj_in's layout)
         sfxs = ["", "_b", "_c", "_c_b"]
         x_d = None
         if xd is not None:  # v4: the masked ('segmentation') stream, forward and reversed (:598-629)
@@ -269,9 +305,13 @@ class Mamba(nn.Module):
                               x_dbl[:, :, R:R + N].to(io), x_dbl[:, :, R + N:R + 2 * N].to(io), Dv, z=None,
                               delta_bias=dbias, delta_softplus=True).view(Bz, K, D, L)
         # merge: direction k's output at step l belongs to token perm_k[l]  (:522-529)
+        if hip_perm and xd is None:   # v3: merge + silu(z) gate + /4 in one kernel
+            gated = _DirMergeGate.apply(y, z, inv32, fwd32, L_true, 0.25)
+            return F.linear(gated.transpose(1, 2), self.out_proj.weight.to(io),
+                            None if self.out_proj.bias is None else self.out_proj.bias.to(io))
         if hip_perm:
             main = _DirMerge.apply(y[:, :4], inv32, fwd32, L_true)
-            bone = _DirMerge.apply(y[:, 4:6], inv32[:2], fwd32[:2], L_true) if xd is not None else None
+            bone = _DirMerge.apply(y[:, 4:6], inv32[:2], fwd32[:2], L_true)
             L = L_true
         else:
             main = (y[:, 0] + self._permute(y[:, 1], inv[1], fwd[1]) + self._permute(y[:, 2], inv[2], fwd[2])
