@@ -270,6 +270,12 @@ int mxvl_add_layernorm_partials(int rows);
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */
 int mxvl_swiglu_fwd(const void *ab, void *y, int rows, int hidden, int io_dtype, void *hip_stream);
 int mxvl_swiglu_bwd(const void *ab, const void *dy, void *dab, int rows, int hidden, int io_dtype, void *hip_stream);
+/* same backward, also leaving the column sums of dab -- the bias gradient of the w1|w2 GEMM -- as n_partials =
+ * mxvl_swiglu_partials(rows, hidden) fp32 rows of `partial` (n_partials, 2*hidden) that the caller adds up; hidden must be even
+ * (mxvl_swiglu_partials returns 0 otherwise). */
+int mxvl_swiglu_partials(int rows, int hidden);
+int mxvl_swiglu_bwd_colsum(const void *ab, const void *dy, void *dab, void *partial, int n_partials, int rows, int hidden,
+                           int io_dtype, void *hip_stream);
 
 /* VMamba SS2D 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67, CrossScan / CrossMerge).
  * mxvl_cross_scan : x (batch,channels,height,width) -> xs (batch,4,channels,height*width): row-major, column-major

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess",
 ]
@@ -186,6 +187,10 @@ def load() -> ctypes.CDLL:
     lib.mxvl_swiglu_fwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.mxvl_swiglu_bwd.restype = c_int
     lib.mxvl_swiglu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.mxvl_swiglu_partials.restype = c_int
+    lib.mxvl_swiglu_partials.argtypes = [c_int, c_int]
+    lib.mxvl_swiglu_bwd_colsum.restype = c_int
+    lib.mxvl_swiglu_bwd_colsum.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.mxvl_dwconv2d_fwd.restype = c_int
     lib.mxvl_dwconv2d_fwd.argtypes = [c_void_p] * 4 + [c_int] * 7 + [c_void_p]
     lib.mxvl_dwconv2d_bwd.restype = c_int

@@ -137,6 +137,62 @@ class _SwiGLU(torch.autograd.Function):
         return dab.view(ctx.shape)
 
 
+class _LinearSwiGLU(torch.autograd.Function):
+    """silu(w1 x) * (w2 x) with [w1; w2] as ONE GEMM (models_mamba.py:59-83) as a single autograd node, so the backward can
+    hand the GEMM its bias gradient for free: `mxvl_swiglu_bwd_colsum` leaves the column sums of d[a|b] while it writes them
+    (a separate `dab.sum(0)` re-reads the whole tensor: 713 MB per ARM-large layer at 16 x 4080 tokens).  The weight gradient
+    is the split-K batched GEMM of selective_scan_interface.splitk_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .selective_scan_interface import _compute_dtype
+        lib = _abi.load()
+        cd = _compute_dtype(x)
+        x2 = x.reshape(-1, x.shape[-1]).to(cd)
+        w = weight.to(cd)
+        ab = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
+        H = ab.shape[1] // 2
+        y = torch.empty((ab.shape[0], H), dtype=ab.dtype, device=ab.device)
+        with torch.cuda.device(ab.device):
+            _abi.check(lib.mxvl_swiglu_fwd(ab.data_ptr(), y.data_ptr(), ab.shape[0], H, _abi.dtype_code(ab.dtype),
+                                           _abi.stream_ptr(ab.device)), "mxvl_swiglu_fwd")
+        ctx.save_for_backward(x2, w, ab)
+        ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y.view(*x.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .selective_scan_interface import splitk_wgrad
+        x2, w, ab = ctx.saved_tensors
+        shape, xdt, wdt, bdt = ctx.meta
+        lib = _abi.load()
+        rows, H = ab.shape[0], ab.shape[1] // 2
+        dy2 = dy.reshape(-1, H).to(ab.dtype).contiguous()
+        dab = torch.empty_like(ab)
+        n_part = lib.mxvl_swiglu_partials(rows, H) if bdt is not None else 0
+        db = None
+        with torch.cuda.device(ab.device):
+            if n_part > 0:
+                partial = torch.empty((n_part, 2 * H), dtype=torch.float32, device=ab.device)
+                _abi.check(lib.mxvl_swiglu_bwd_colsum(ab.data_ptr(), dy2.data_ptr(), dab.data_ptr(), partial.data_ptr(), n_part, rows, H,
+                                                      _abi.dtype_code(ab.dtype), _abi.stream_ptr(ab.device)), "mxvl_swiglu_bwd_colsum")
+                db = partial.sum(0).to(bdt)
+            else:
+                _abi.check(lib.mxvl_swiglu_bwd(ab.data_ptr(), dy2.data_ptr(), dab.data_ptr(), rows, H, _abi.dtype_code(ab.dtype),
+                                               _abi.stream_ptr(ab.device)), "mxvl_swiglu_bwd")
+                if bdt is not None:
+                    db = dab.sum(0, dtype=torch.float32).to(bdt)
+        dx = torch.matmul(dab, w).view(shape).to(xdt)
+        dw = splitk_wgrad(dab, x2, wdt)
+        return dx, dw, db
+
+
+def linear_swiglu(x, weight, bias=None):
+    """silu(x w1^T + b1) * (x w2^T + b2) for weight = [w1; w2] (2H, K), bias = [b1 | b2]."""
+    _abi.require_gpu(x, weight, bias)
+    return _LinearSwiGLU.apply(x, weight, bias)
+
+
 def swiglu(ab):
     """ab (..., 2H) = [a | b] -> silu(a) * b (..., H)."""
     _abi.require_gpu(ab)

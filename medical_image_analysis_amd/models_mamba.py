@@ -103,7 +103,7 @@ class SwiGLU(nn.Module):
             # [w1 x | w2 x] from ONE GEMM, then the gate as one HIP kernel (csrc/fused_norm_act.hip)
             w = torch.cat([self.w1.weight, self.w2.weight], dim=0)
             b = torch.cat([self.w1.bias, self.w2.bias], dim=0)
-            h = fused_ops.swiglu(linear_splitk(x, w, b))
+            h = fused_ops.linear_swiglu(x, w, b)
             return self.drop(linear_splitk(h, self.w3.weight, self.w3.bias))
         return self.drop(self.w3(self.ffn_ln(self.act(self.w1(x)) * self.w2(x))))
 

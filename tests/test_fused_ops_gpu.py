@@ -87,3 +87,30 @@ def test_swiglu_forward_backward(H, dtype):
         yt = (F.silu(ab.detach()[..., :H]) * ab.detach()[..., H:]).float()
         d = (y.float() - yt).abs()
         assert float((d > 0).float().mean()) < 2e-2 and float((d / yt.abs().clamp_min(1e-6)).max()) <= 2.0 ** -6
+
+
+@pytest.mark.parametrize("rows,K,H", [(2 * 197, 64, 170), (9000, 96, 2730), (33, 32, 7)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_swiglu_equals_unfused_pipeline(rows, K, H, dtype):
+    """One autograd node for `silu(w1 x) * w2 x` (models_mamba.py:59-83) whose backward takes the GEMM's bias gradient from the
+    gate kernel's column sums: outputs and all three gradients against plain torch in fp32 (H = 7: the odd-width path that
+    still reduces dab separately; rows > the partial-row count: several rows per wave)."""
+    from medical_image_analysis_amd.fused_ops import linear_swiglu
+    g = torch.Generator().manual_seed(rows + H)
+    x = torch.randn(rows, K, generator=g).to(DEV, dtype).requires_grad_(True)
+    w = (torch.randn(2 * H, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)      # fp32 master weights
+    b = (0.1 * torch.randn(2 * H, generator=g)).to(DEV).requires_grad_(True)
+    gy = torch.randn(rows, H, generator=g).to(DEV, dtype)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        y = linear_swiglu(x, w, b)
+    assert y.dtype == dtype
+    y.backward(gy)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ab = xr @ wr.t() + br
+    yr = F.silu(ab[:, :H]) * ab[:, H:]
+    yr.backward(gy.double())
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-5
+    for name, got, want in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad)):
+        err = float((got.double() - want.detach()).abs().max())
+        assert err <= tol * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
+    assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32
