@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const io_t* __restrict__ ab
 }
 
 // Backward that also leaves the column sums of d[a|b] (the bias gradient of the w1|w2 GEMM that produced ab): a wave keeps
-// ONE 512-column tile and walks the rows rg, rg + R, ...; the sums of what it stored (rounded to the io dtype, like a
+// ONE column tile (<= 512 wide) and walks the rows rg, rg + R, ...; the sums of what it stored (rounded to the io dtype, like a
 // separate reduction over dab would see them) stay in 16 registers per lane and leave as row rg of `partial` (R, 2H) fp32.
 // Saves the second full read of dab (713 MB per ARM-large layer at 16 x 4080 tokens) that `dab.sum(0)` costs.
 template <typename io_t>
@@ -249,7 +249,11 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const io_t* __re
   const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= (long)tiles * R) return;
   const int tile = (int)(w % tiles), rg = (int)(w / tiles);
-  const int c0 = tile * 512 + lane * 2;
+  // equal-width column tiles (even, <= 512): with fixed 512-wide tiles the last tile of H = 2730 holds 170 columns and the
+  // waves that own it would idle two thirds of the time
+  const int tw = ((H + tiles - 1) / tiles + 1) & ~1;
+  const int c0 = tile * tw + lane * 2;
+  const int cend = min(H, (tile + 1) * tw);
   float sa[4][2], sb[4][2];
 #pragma unroll
   for (int k = 0; k < 4; ++k) sa[k][0] = sa[k][1] = sb[k][0] = sb[k][1] = 0.0f;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const io_t* __re
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k * 128;
       av[k][0] = av[k][1] = bv[k][0] = bv[k][1] = gv[k][0] = gv[k][1] = 0.0f;
-      if (c < H) {
+      if (c < cend) {
         P::ld(a + c, av[k][0], av[k][1]);
         P::ld(a + H + c, bv[k][0], bv[k][1]);
         P::ld(dy + (size_t)r * H + c, gv[k][0], gv[k][1]);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const io_t* __re
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c0 + k * 128;
-      if (c >= H) continue;
+      if (c >= cend) continue;
       float da[2], db[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const io_t* __re
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + k * 128;
-    if (c < H) {
+    if (c < cend) {
       pr[c] = sa[k][0]; pr[c + 1] = sa[k][1];
       pr[H + c] = sb[k][0]; pr[H + c + 1] = sb[k][1];
     }

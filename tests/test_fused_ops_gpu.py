@@ -40,8 +40,8 @@ def test_add_layer_norm_forward_backward(C, dtypes):
     lo = res_dt == torch.bfloat16
     tol_h = 2e-2 if lo else 1e-6
     tol_n = 2e-2 if out_dt == torch.bfloat16 else 2e-5
-    assert float((h.float() - hr).abs().max()) <= tol_h * float(hr.abs().max())
-    assert float((n.float() - nr).abs().max()) <= tol_n * float(nr.abs().max())
+    assert float((h.detach().float() - hr.detach()).abs().max()) <= tol_h * float(hr.detach().abs().max())
+    assert float((n.detach().float() - nr.detach()).abs().max()) <= tol_n * float(nr.detach().abs().max())
     tol_g = 2e-2 if lo else 1e-4
     assert float((x.grad.float() - xr.grad).abs().max()) <= tol_g * float(xr.grad.abs().max())
     if br is not None:

@@ -126,7 +126,7 @@ def test_dir_gather_merge_equal_torch_indexing(shape, dtype):
     out = _DirMerge.apply(yd, i32, p32, L)
     want = sum(y[:, k, :, :L].float()[:, :, inv[k]] for k in range(4))
     tol = 0 if dtype == torch.float32 else 2e-2
-    assert float((out.float().cpu() - want).abs().max()) <= tol * float(want.abs().max()) + (0 if dtype == torch.float32 else 0)
+    assert float((out.detach().float().cpu() - want).abs().max()) <= tol * float(want.abs().max())
     # adjoint pair: <gather(x), y> == <x, merge(y)> on the valid steps
     gy = torch.randn(B, D, L, generator=g).to(dtype).to(DEV)
     out.backward(gy)
