@@ -22,7 +22,6 @@ UnboundLocalError / AttributeError).
 """
 from __future__ import annotations
 
-import math
 from typing import Optional, Tuple
 
 import torch

@@ -1,5 +1,5 @@
 """Dev tool: which aten ops launch the generic strided elementwise / reduce kernels in one pre-training step."""
-import sys, os, collections
+import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 from torch.profiler import profile, ProfilerActivity

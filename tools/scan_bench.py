@@ -1,6 +1,6 @@
 """Quick A/B of the scan kernel variants on the GPU (dev tool; bench.py is the contract).
 usage: python tools/scan_bench.py [B D L N dtype]"""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from medical_image_analysis_amd import _abi
