@@ -171,7 +171,8 @@ class XrayImageProcessor:
                 if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
                     raise ValueError(f"expected an (H, W, 3) uint8 image (data_helper.py:71-74 converts to RGB first), got "
                                      f"{a.shape} {a.dtype}")
-                im = torch.from_numpy(np.ascontiguousarray(a))
+                a = np.ascontiguousarray(a)
+                im = torch.from_numpy(a if a.flags.writeable else a.copy())     # PIL hands out read-only buffers
             im = im.to(dev, non_blocking=True)
             h, w = (oh, ow) if self.do_resize else (im.shape[0], im.shape[1])
             if (h, w) != (oh, ow):
