@@ -102,6 +102,81 @@ __global__ __launch_bounds__(256) void dir_merge_kernel(const PermArgs p) {
   }
 }
 
+// ---- short rows (padded_len <= 256: the 197-token encoders) -----------------------------------------------------------
+// One element per thread.  The generic kernels above walk a dependent chain per direction (row load -> barrier -> index load
+// -> LDS -> store) with 2 bytes per lane in flight: at 200-element rows they are latency-bound (measured 0.74 TB/s merge,
+// 1.26 TB/s gather on the ARM-large 224 step).  Here every global load a thread needs -- its element of all K direction rows
+// and its K indices -- is issued before the first use, so one round trip covers them all.
+constexpr int kMaxDirs = 6;
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void dir_gather_short_kernel(const PermArgs p) {
+  __shared__ float srow[256];
+  using io = Io<io_t>;
+  const int d = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const bool live = t < p.L;
+  const io_t* x = (const io_t*)p.src + (long long)b * p.x_bs + (long long)d * p.x_ds;
+  // unconditional loads from clamped (always valid) addresses: no control flow between them, so all are in flight together
+  const int tc = live ? t : 0;
+  int ixv[kMaxDirs];
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) ixv[k] = p.idx[(k < p.K ? k : 0) * p.L + tc];
+  float v = io::ld(x + tc);
+  if (p.gate) {   // backward of the gated merge: x is d(out)
+    const float zv = io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc);
+    const float pre = io::ld((const io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds + tc);
+    const float g = v * p.scale, sg = sigmoid(zv);
+    v = g * (zv * sg);
+    if (live) io::st((io_t*)p.dgate + (long long)b * p.dg_bs + (long long)d * p.dg_ds + t, g * pre * (sg * fmaf(zv, 1.0f - sg, 1.0f)));
+  }
+  srow[t] = v;
+  __syncthreads();
+  if (t >= p.Lp) return;
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) {
+    if (k < p.K) {
+      io_t* X = (io_t*)p.dst + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)d * p.X_ds;
+      io::st(X + t, live ? srow[ixv[k]] : 0.0f);
+    }
+  }
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void dir_merge_short_kernel(const PermArgs p) {
+  __shared__ float srow[kMaxDirs * 256];
+  using io = Io<io_t>;
+  const int d = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const bool live = t < p.L;
+  // unconditional loads from clamped (always valid) addresses: no control flow between them, so all are in flight together
+  const int tc = live ? t : 0;
+  float yv[kMaxDirs];
+  int ixv[kMaxDirs];
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) {
+    const int kc = k < p.K ? k : 0;
+    const io_t* y = (const io_t*)p.src + (long long)b * p.X_bs + (long long)kc * p.X_ks + (long long)d * p.X_ds;
+    yv[k] = io::ld(y + tc);
+    ixv[k] = p.idx[kc * p.L + tc];
+  }
+  float zv = 0.0f;
+  if (p.gate) zv = io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc);
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) srow[k * 256 + t] = yv[k];
+  __syncthreads();
+  if (!live) return;
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k)
+    if (k < p.K) acc += srow[k * 256 + ixv[k]];          // k ascending, like the generic kernel
+  io_t* out = (io_t*)p.dst + (long long)b * p.x_bs + (long long)d * p.x_ds;
+  if (p.gate) {
+    if (p.pre) io::st((io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds + t, acc);
+    io::st(out + t, acc * silu(zv) * p.scale);
+  } else {
+    io::st(out + t, acc);
+  }
+}
+
 static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   if (!d || !d->rows || !d->stacked || !d->index) return MXVL_ERR_NULL;
   if (d->batch <= 0 || d->dim <= 0 || d->seqlen <= 0 || d->n_dirs <= 0 || d->padded_len < d->seqlen) return MXVL_ERR_SHAPE;
@@ -118,9 +193,12 @@ static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   const dim3 grid(a.D, a.B);
   const size_t lds = sizeof(float) * (size_t)a.L;
   hipStream_t s = (hipStream_t)stream;
+  const bool short_rows = a.Lp <= 256 && a.K <= kMaxDirs;
 #define MXVL_PERM(T)                                                                                   \
   do {                                                                                                  \
-    if (merge) hipLaunchKernelGGL(dir_merge_kernel<T>, grid, dim3(256), lds, s, a);                     \
+    if (short_rows && merge) hipLaunchKernelGGL(dir_merge_short_kernel<T>, grid, dim3(256), 0, s, a);   \
+    else if (short_rows) hipLaunchKernelGGL(dir_gather_short_kernel<T>, grid, dim3(256), 0, s, a);      \
+    else if (merge) hipLaunchKernelGGL(dir_merge_kernel<T>, grid, dim3(256), lds, s, a);                \
     else hipLaunchKernelGGL(dir_gather_kernel<T>, grid, dim3(256), lds, s, a);                          \
   } while (0)
   switch (d->io_dtype) {
