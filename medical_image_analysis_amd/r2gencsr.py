@@ -11,8 +11,10 @@ image tokens (:258-262).  The reference also routes the POOLED (B, E) context fe
 branch of encode_img), which Blip2QFormerModel rejects (it needs (B, L, E)), so context_pair > 0 with the Q-Former raises here
 too -- with a message instead of an unpacking error.
 
-Outside the path and not built: the pandas / FieldParser code that PICKS the context images from the annotation file
-(:309-374; pass the picked image tensors to `set_context_samples`), the Swin / Vim encoder choices, PEFT-LoRA.
+`context_sample` keeps the reference's pandas selection of the context studies (:308-374) and pre-processes their images on the
+device; `set_context_samples` injects already-prepared image batches instead.
+
+Outside the path and not built: the Swin / Vim encoder choices, PEFT-LoRA.
 """
 from __future__ import annotations
 
@@ -68,6 +70,56 @@ class R2GenCSR(MambaXrayVLDownStream):
         """The `context_pair` normal / abnormal reference studies, (n, 3, H, W) each (what context_sample() :309-374 loads)."""
         self.negative_samples = {"image": negative_images}
         self.positive_samples = {"image": positive_images}
+
+    def pick_context_studies(self, num=3, chexbert_csv=None):
+        """Which training studies serve as the normal ("negative") / abnormal ("positive") context (:308-360): the reference's
+        pandas selection, same calls and seeds -- `chexbert`: rows of an annotation csv split on `no_finding`; `random`: 60
+        random training rows for both; otherwise a substring split of the report text ('未见' on impressions for the
+        chinese set, 'note' for mimic_cxr / iu_xray); then `.sample(30, random_state=context_pair_seed)[:num]` of each."""
+        import json
+        import pandas as pd
+        a = self.args
+        with open(a.annotation, "r", encoding="utf-8") as f:
+            df = pd.DataFrame(json.loads(f.read())["train"])
+        seed = _get(a, "context_pair_seed", 0)
+        mode = _get(a, "context_retrieval_mode", None)
+        if a.dataset == "chinese":
+            hit = df["impressions"].str.contains("未见")
+            negative, positive = df[hit], df[~hit]
+        elif a.dataset in ("mimic_cxr", "iu_xray"):
+            if mode == "chexbert":
+                if chexbert_csv is None:
+                    raise ValueError("context_retrieval_mode='chexbert' needs the ann_chexbert.csv path (the reference hard-codes "
+                                     "'../_dataset/<dataset>/ann_chexbert.csv')")
+                import ast
+                ann = pd.read_csv(chexbert_csv)
+                ann["image_path"] = ann["image_path"].apply(ast.literal_eval)
+                negative, positive = ann[ann["no_finding"] == 1], ann[ann["no_finding"] != 1]
+            elif mode == "random":
+                negative = df.sample(60, random_state=seed)
+                positive = df.sample(60, random_state=seed)
+            else:
+                hit = df["report"].str.contains("note")
+                negative, positive = df[~hit], df[hit]
+        else:
+            raise ValueError(f"dataset {a.dataset!r}: the reference picks context studies for chinese / mimic_cxr / iu_xray only")
+        negative = negative.sample(30, random_state=seed).to_dict("records")[:num]
+        positive = positive.sample(30, random_state=seed).to_dict("records")[:num]
+        return negative, positive
+
+    def context_sample(self, num=3, chexbert_csv=None, processor=None):
+        """`context_sample` (:308-374): pick the studies, parse them (first view of each) and keep them as the context batches.
+        Images are pre-processed on the device by data_pipeline.DeviceBatcher, in bf16 like the reference's `.to(bfloat16)`."""
+        from .data_pipeline import DeviceBatcher, FieldParser, collate_raw
+        negative, positive = self.pick_context_studies(num, chexbert_csv)
+        parser = FieldParser(self.args)
+        batcher = DeviceBatcher(self.args, processor=processor, dtype=torch.bfloat16)
+        out = []
+        for studies in (negative, positive):
+            batch = batcher(collate_raw([parser.transform_with_parse(s) for s in studies]))
+            out.append({"id": batch["id"], "input_text": batch["input_text"], "image": batch["image"][0]})
+        self.negative_samples, self.positive_samples = out
+        return self.negative_samples, self.positive_samples
 
     # ---- :228-264 ---------------------------------------------------------------------------------------------------------
     def encode_img(self, images, global_only=False, global_only_return=False, use_feature_mean=True, featuremap_folder=None):
