@@ -105,13 +105,34 @@ class MambaXrayVLDownStream(nn.Module):
         if vision_model != "None" and os.path.exists(vision_model):
             ckpt = torch.load(vision_model, map_location="cpu")
             compat.load_visual_encoder(self.visual_encoder, ckpt, strict=True)
+        # EMRRG (EMRRG/models/MambaXrayVL_DownStream.py:59-89): lora_X adapters go on every mixer BEFORE the freeze, so
+        # `freeze_vm` freezes them too, exactly as the reference's loop over named_parameters() does
+        self.use_lora_X = bool(_get(args, "lora_X", False))
+        if self.use_lora_X:
+            from .lora_x import apply_lora_X
+            apply_lora_X(self.visual_encoder, dim_X=_get(args, "dim_X", 64), s_X=_get(args, "s_X", 1.0),
+                         reference_late_binding=bool(_get(args, "lora_X_reference_late_binding", False)))
         if _get(args, "freeze_vm", False):
             for p in self.visual_encoder.parameters():
                 p.requires_grad = False
 
         iu = "iu" in str(_get(args, "dataset", ""))
         source = _get(args, "llama_model", None) or ("qwen1.5-1.8b" if iu else "llama2-7b")
-        self.llama_model = llm if llm is not None else build_report_decoder(source)
+        # EMRRG hybrid decoder (:60-64, :159-208): every `cross_attn_every_n_layers`-th layer is a Qwen2HybridDecoderLayer
+        # (q/k/v biases + gated image cross-attention, identity until condition_vis_x is called -- the reference never calls it)
+        self.use_hybrid_decoder = bool(_get(args, "use_hybrid_decoder", False))
+        hybrid = {}
+        if self.use_hybrid_decoder and llm is None:
+            n_layers = (dict(QWEN15_1P8B) if source == "qwen1.5-1.8b" else dict(LLAMA2_7B))["num_hidden_layers"]
+            if isinstance(source, dict):
+                n_layers = source.get("num_hidden_layers", n_layers)
+            elif os.path.isdir(str(source)):
+                with open(os.path.join(source, "config.json")) as f:
+                    n_layers = json.load(f)["num_hidden_layers"]
+            hybrid = dict(hybrid_layers=tuple(range(0, n_layers, _get(args, "cross_attn_every_n_layers", 4))),
+                          cross_attn_implementation=_get(args, "cross_attn_implementation", "text-only-vanilla"),
+                          cross_attn_gating_type=_get(args, "cross_attn_gating_type", "channel-wise-dynamic-sigmoid"))
+        self.llama_model = llm if llm is not None else build_report_decoder(source, **hybrid)
         self.llama_tokenizer = tokenizer if tokenizer is not None else _load_tokenizer(_get(args, "llama_model"))
         self.llama_tokenizer.pad_token_id = 0
         if iu:
@@ -205,9 +226,17 @@ class MambaXrayVLDownStream(nn.Module):
     def test_step(self, samples, batch_idx=0):
         return self._eval_step(samples, self.test_step_outputs)
 
+    def clear_hybrid_layers(self):
+        """EMRRG :232-246: drop the image conditioning of every hybrid layer."""
+        if not self.use_hybrid_decoder:
+            return
+        for layer in self.llama_model.model.layers:
+            if hasattr(layer, "clear_vis_x"):
+                layer.clear_vis_x()
+
     def score(self, ref, hypo):
         """{id: [report]} x {id: [generated report]} -> {"Bleu_1".."Bleu_4", "ROUGE_L", "CIDEr"} (:134-157; METEOR needs the
-        meteor-1.5.jar the reference does not ship)."""
+        meteor-1.5.jar the reference does not ship -- EMRRG's copy of this method has it commented out, :255)."""
         return report_metrics.score(ref, hypo, dataset=_get(self.args, "dataset", None))
 
     def epoch_scores(self, outputs=None, clear=True):

@@ -248,3 +248,32 @@ def test_r2gencsr_qformer_projector():
     with pytest.raises(RuntimeError):      # pooled context features cannot go through a Q-Former (they cannot in the reference either)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             m(batch)
+
+
+def test_emrrg_options_wire_lora_x_and_hybrid_decoder():
+    """EMRRG's MambaXrayVLDownStream(args) (EMRRG/models/MambaXrayVL_DownStream.py:59-89, 159-208): `lora_X` adapters on every
+    mixer (frozen with the encoder when freeze_vm is set, like the reference's loop), every n-th LLM layer a hybrid layer with
+    q/k/v biases and image cross-attention, `clear_hybrid_layers`.  Construction only: runs on the CPU."""
+    from medical_image_analysis_amd import mambaxray_vl as mx
+    from medical_image_analysis_amd.hybrid_decoder_layer import Qwen2HybridDecoderLayer
+    tiny = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=6, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=128)
+    args = mx.default_args(vision_model="Base-None", llama_model=tiny, freeze_vm=True, lora_X=True, dim_X=8, s_X=0.5,
+                           use_hybrid_decoder=True, cross_attn_every_n_layers=4, cross_attn_gating_type="whole-dynamic-tanh-warmup",
+                           cross_attn_implementation="vanilla")
+    m = mx.MambaXrayVLDownStream(args, tokenizer=WordTokenizer())
+    mixers = [mod for mod in m.visual_encoder.modules() if hasattr(mod, "in_proj") and hasattr(mod, "out_proj")]
+    assert len(mixers) == 12 and all(mod.lora_X.adapter_down.weight.shape == (8, 768) for mod in mixers)
+    assert all(mod.lora_X.adapter_up.weight.shape == (384, 8) and mod.s_X == 0.5 for mod in mixers)      # out = d_inner // 2
+    assert not any(p.requires_grad for p in m.visual_encoder.parameters())                                  # adapters frozen too
+    layers = m.llama_model.model.layers
+    assert all(isinstance(l, Qwen2HybridDecoderLayer) for l in layers)
+    assert [i for i, l in enumerate(layers) if l.is_hyper_enabled] == [0, 4]
+    assert any("cross_attn" in n for n, _ in layers[0].named_parameters()) and not any("cross_attn" in n for n, _ in layers[1].named_parameters())
+    layers[0].condition_vis_x(torch.zeros(1, 3, 32))
+    m.clear_hybrid_layers()
+    assert layers[0].vis_x is None
+    # defaults: no adapters, plain decoder
+    m2 = mx.MambaXrayVLDownStream(mx.default_args(vision_model="Base-None", llama_model=tiny), tokenizer=WordTokenizer())
+    assert not any(hasattr(mod, "lora_X") for mod in m2.visual_encoder.modules())
+    assert not any(l.is_hyper_enabled for l in m2.llama_model.model.layers)
