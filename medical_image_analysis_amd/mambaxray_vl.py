@@ -228,7 +228,7 @@ class MambaXrayVLDownStream(nn.Module):
 
     def clear_hybrid_layers(self):
         """EMRRG :232-246: drop the image conditioning of every hybrid layer."""
-        if not self.use_hybrid_decoder:
+        if not getattr(self, "use_hybrid_decoder", False):
             return
         for layer in self.llama_model.model.layers:
             if hasattr(layer, "clear_vis_x"):
