@@ -12,6 +12,18 @@ REF = "/root/reference/CXPMRG_Bench_MambaXray_VL"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists only in the build container")
 
 
+@pytest.fixture(autouse=True)
+def _restore_sys_modules():
+    """The drop-in and the timm stand-ins register modules under third-party names; later tests (transformers probes
+    `find_spec("timm")`) must not see them."""
+    before = dict(sys.modules)
+    yield
+    for k in list(sys.modules):
+        if k not in before:
+            del sys.modules[k]
+    sys.modules.update({k: v for k, v in before.items() if sys.modules.get(k) is not v})
+
+
 def _load_reference(path, name):
     import medical_image_analysis_amd.dropin as dropin
     dropin.install()
