@@ -135,8 +135,14 @@ class MaskedAutoencoderViT(nn.Module):
                  norm_pix_loss=False, mask_ratio=0.75, use_learnable_pos_emb=True, new_depth=6):
         super().__init__()
         # the reference hard-codes SmallPatchEmbed(1, 1024, 1024) whatever embed_dim is (mae.py:57): only the
-        # embed_dim = 1024 factories can run there; here the embedding follows embed_dim so every factory runs
-        self.patch_embed = SmallPatchEmbed(in_chans, embed_dim, 1024)
+        # embed_dim = 1024 factories can run there; here the embedding follows embed_dim so every factory runs.
+        # Any other geometry (BASELINE configs[0]: ViT-Base, 224 x 224, patch 16) takes the generic one-conv PatchEmbed of
+        # the same code base (finetune/DP/models/vit.py:186-221) -- SURVEY.md section 8 row A7.
+        if (img_size, patch_size) == (1280, 64):
+            self.patch_embed = SmallPatchEmbed(in_chans, embed_dim, 1024)
+        else:
+            self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, stride_size=patch_size,
+                                          in_chans=in_chans, embed_dim=embed_dim)
         num_patches = self.patch_embed.num_patches
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
@@ -292,6 +298,14 @@ def mae_vit_large_patch16_dec512d8b(**kwargs):
 def mae_vit_huge_patch14_dec512d8b(**kwargs):
     return MaskedAutoencoderViT(patch_size=64, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512,
                                 decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_base_patch16_224(**kwargs):
+    """BASELINE configs[0]: ViT-Base encoder (vit.py:361-366: 768 x 12 x 12 heads) at 224 x 224 / patch 16, 1 channel,
+    with the reference factories' decoder (512 x 8 x 16 heads)."""
+    return MaskedAutoencoderViT(img_size=224, patch_size=16, in_chans=1, embed_dim=768, depth=12, num_heads=12,
+                                decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
 

@@ -73,6 +73,14 @@ def np_(t):
     return None if t is None else t.detach().cpu().float().numpy().copy()
 
 
+# MXVL_GOLDEN_ONLY=name1,name2 regenerates only those generators (the module set-up always runs)
+_ONLY = {x for x in os.environ.get("MXVL_GOLDEN_ONLY", "").split(",") if x}
+
+
+def want(name):
+    return not _ONLY or name in _ONLY
+
+
 def save(name, **arrs):
     arrs = {k: v for k, v in arrs.items() if v is not None}
     path = os.path.join(HERE, name + ".npz")
@@ -496,6 +504,244 @@ def gen_decode():
     save("decode_tiny_llama", inputs_embeds=np_(emb), attention_mask=att.numpy().copy(), **out)
 
 
+
+def keyed_fill_(module, scale=1.0):
+    """Deterministic weights from the parameter NAMES (tests/golden/keyed_fill.py): models too large to store
+    (ViT-Base) are re-filled identically by the generator and by the test."""
+    from keyed_fill import keyed_fill_ as kf
+    return kf(module, scale)
+
+
+def _ref_functions(path, class_name, names, extra_globals):
+    """Compile selected top-level classes / methods of a reference file WITHOUT importing the file (its Lightning / peft /
+    tokenizer imports are third-party wheels absent here): the source is parsed where it lies and only the named
+    definitions are executed.  Returns {name: object}."""
+    import ast
+    tree = ast.parse(open(path).read())
+    picked = []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            body = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in names]
+            node.body = body
+            node.bases = []
+            node.keywords = []
+            picked.append(node)
+        elif isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in names:
+            picked.append(node)
+    mod = ast.Module(body=picked, type_ignores=[])
+    ns = dict(extra_globals)
+    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def gen_lora_x(models_mamba):
+    """EMRRG `lora_X` (EMRRG/models/MambaXrayVL_DownStream.py:33-46 Adapter, :272-306 _apply_lora_X_to_model) applied BY THE
+    REFERENCE'S OWN CODE to the reference ARM encoder (depth 2).  The up-projections (zero-initialised) are randomised so
+    the adapter contributes.  Note the reference's late binding of `original_forward` (:285-287): every patched mixer runs
+    the LAST mixer's original forward -- the golden records what the reference computes."""
+    import math as _math
+    import types as _types
+    ns = _ref_functions(os.path.join(REF, "EMRRG/models/MambaXrayVL_DownStream.py"), "MambaXrayVLDownStream",
+                        {"Adapter", "_apply_lora_X_to_model"}, dict(nn=torch.nn, torch=torch, math=_math, types=_types))
+    torch.manual_seed(0)
+    m = models_mamba.ARM(img_size=48, patch_size=16, depth=2, embed_dim=64, if_cls_token=True, if_abs_pos_embed=True,
+                         bimamba_type="v3", use_middle_cls_token=True, if_devide_out=True, drop_path_rate=0.0)
+    _randomize(m)
+    host = ns["MambaXrayVLDownStream"]()
+    host.dim_X, host.s_X = 4, 0.5
+    torch.manual_seed(1)
+    host._apply_lora_X_to_model(m)
+    patched = [n for n, mod in m.named_modules() if hasattr(mod, "lora_X")]
+    assert patched == ["layers.0.mixer", "layers.1.mixer"], patched
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n in patched:
+            up = m.get_submodule(n).lora_X.adapter_up.weight
+            up.copy_(0.2 * torch.randn(up.shape, generator=g))
+    m.eval()
+    img = torch.randn(2, 3, 48, 48, generator=g)
+    with torch.no_grad():
+        out = m(img)
+        # the mixer-level effect, on the first patched mixer alone
+        hid = torch.randn(2, 10, 64, generator=g)
+        mix_out = m.layers[0].mixer(hid)
+    sd = {("p_" + k): np_(v) for k, v in m.state_dict().items()}
+    save("lora_x_arm_d2", img=np_(img), out=np_(out), mixer_hidden=np_(hid), mixer_out=np_(mix_out),
+         dim_X=np.array(4), s_X=np.array(0.5), **sd)
+
+
+def gen_clip_loss(models_mamba):
+    """Stage-2 contrastive step: the reference's own `MambaXrayVLCLIP.forward / encode_img / encode_txt`
+    (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_CLIP.py:106-150) executed on the reference ARM (depth 2) with toy
+    tokenizer / text encoder stand-ins for the third-party HF pieces.  Loss + gradients."""
+    import torch.nn.functional as F
+    from toy_text import ToyText as _ToyText, ToyTokenizer as _ToyTokenizer
+    ns = _ref_functions(os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_CLIP.py"), "MambaXrayVLCLIP",
+                        {"forward", "encode_img", "encode_txt"}, dict(torch=torch, F=F))
+    Ref = ns["MambaXrayVLCLIP"]
+    torch.manual_seed(0)
+    host = Ref()
+    host.visual_encoder = models_mamba.ARM(img_size=48, patch_size=16, depth=2, embed_dim=64, if_cls_token=True,
+                                           if_abs_pos_embed=True, bimamba_type="v3", use_middle_cls_token=True,
+                                           if_devide_out=True, drop_path_rate=0.0)
+    _randomize(host.visual_encoder)
+    host.visual_encoder.eval()
+    host.text_encoder_type = "Bio_ClinicalBERT"
+    host.text_encoder = _ToyText(32)
+    host.tokenizer = _ToyTokenizer()
+    host.vision_proj = torch.nn.Linear(64, 16)
+    host.text_proj = torch.nn.Linear(32, 16)
+    host.logit_scale = torch.nn.Parameter(torch.ones([]) * float(np.log(1 / 0.07)))
+    g = torch.Generator().manual_seed(11)
+    texts = ["no acute cardiopulmonary process", "small left pleural effusion is seen", "heart size is normal",
+             "right lower lobe opacity concerning for pneumonia"]
+    images = [torch.randn(4, 3, 48, 48, generator=g), torch.randn(4, 3, 48, 48, generator=g)]   # two views per study
+    loss = host.forward({"image": images, "input_text": texts})["loss"]
+    loss.backward()
+    with torch.no_grad():
+        img_f = host.encode_img(images)
+        txt_f = host.encode_txt(host.tokenizer(texts, max_length=128))
+    out = {("p_visual_encoder." + k): np_(v) for k, v in host.visual_encoder.state_dict().items()}
+    out.update({("p_text_encoder." + k): np_(v) for k, v in host.text_encoder.state_dict().items()})
+    for n in ("vision_proj", "text_proj"):
+        out.update({f"p_{n}.{k}": np_(v) for k, v in getattr(host, n).state_dict().items()})
+    out["p_logit_scale"] = np_(host.logit_scale)
+    grads = {"g_logit_scale": np_(host.logit_scale.grad), "g_vision_proj.weight": np_(host.vision_proj.weight.grad),
+             "g_text_proj.weight": np_(host.text_proj.weight.grad),
+             "g_visual_encoder.patch_embed.proj.weight": np_(host.visual_encoder.patch_embed.proj.weight.grad)}
+    save("clip_loss_arm_d2", image0=np_(images[0]), image1=np_(images[1]), texts=np.array(texts), loss=np_(loss),
+         image_features=np_(img_f), text_features=np_(txt_f), **out, **grads)
+
+
+def gen_mae_vitb_224():
+    """BASELINE configs[0]: 'HD_Xray_Pretrain_MAE ViT-Base 224x224, 75% mask, batch=4'.  The reference's
+    MaskedAutoencoderViT (pretrain/models/mae.py) run with its hard-coded SmallPatchEmbed (:57, 1280 px / 64) replaced by
+    the reference's own generic PatchEmbed (finetune/DP/models/vit.py:186-221) at 224 / patch 16 / 1 channel, ViT-Base
+    encoder (768 x 12 x 12 heads, vit.py:361-366) and the factory's decoder (512 x 8 x 16 heads); random masking 75 %
+    (mae.py:157-182), batch 4.  86 M + 26 M weights are not stored: keyed_fill_ regenerates them from the key names."""
+    mae_root = os.path.join(REF, "HD_Xray_Pretrain_MAE")
+    vit = sys.modules.get("vit_ref") or _load(os.path.join(mae_root, "finetune/DP/models/vit.py"), "vit_ref")
+    install_timm_stubs()
+    vt = sys.modules["timm.models.vision_transformer"]
+    vt.Block = vit.Block
+    vt.PatchEmbed = vit.PatchEmbed
+    pdir = os.path.join(mae_root, "pretrain")
+    if pdir not in sys.path:
+        sys.path.insert(0, pdir)
+    for k in ("pos_embed", "patch_embed"):
+        sys.modules.pop(k, None)
+    mae = _load(os.path.join(pdir, "models/mae.py"), "mae_ref224")
+    import math as _math
+    from functools import partial
+    mae.math = _math
+    mae.SmallPatchEmbed = lambda *a, **k: vit.PatchEmbed(img_size=224, patch_size=16, stride_size=16, in_chans=1, embed_dim=768)
+    torch.manual_seed(0)
+    m = mae.MaskedAutoencoderViT(img_size=224, patch_size=16, in_chans=1, embed_dim=768, depth=12, num_heads=12,
+                                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                 norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), norm_pix_loss=True)
+    assert m.patch_embed.num_patches == 196 and m.pos_embed.shape == (1, 197, 768)
+    sincos = dict(sincos_pos_embed_sub=np_(m.pos_embed[:, ::7, ::13]), sincos_dec_pos_embed_sub=np_(m.decoder_pos_embed[:, ::7, ::13]))
+    keyed_fill_(m)
+    m.eval()
+    img_seed, noise_seed = 31, 9
+    img = torch.randn(4, 1, 224, 224, generator=torch.Generator().manual_seed(img_seed))
+    with torch.no_grad():
+        torch.manual_seed(noise_seed)
+        loss, mask = m(img, 0, 0.75, 0.0)
+        torch.manual_seed(noise_seed)
+        noise = torch.rand(4, 196)           # the draw random_masking makes (mae.py:167)
+        torch.manual_seed(noise_seed)
+        latent, mask2, ids = m.forward_encoder(img, 0, 0.75, 0.0)
+        pred, _ = m.forward_decoder(latent, ids)
+    assert torch.equal(mask, mask2) and latent.shape == (4, 50, 768) and pred.shape == (4, 196, 256)
+    save("mae_vitb_224", img_seed=np.array(img_seed), noise=np_(noise), img_checksum=np_(img.double().sum().float()),
+         loss=np_(loss), mask=np_(mask), ids_restore=ids.numpy().copy(), latent_sub=np_(latent[:, ::7, ::13]),
+         pred_sub=np_(pred[:, ::5, ::9]), patchify_sub=np_(m.patchify(img)[:, ::11, ::7]),
+         n_params=np.array(sum(p.numel() for p in m.parameters())), **sincos)
+
+
+def gen_decode_hd64():
+    """HF LlamaForCausalLM with head_dim 64 -- a configuration the HIP decode kernels (csrc/decode.hip) support -- and
+    bf16-REPRESENTABLE weights (rounded to bf16, computed by HF in fp32): prompt logits, greedy decoding with the raw
+    logits of every step (teacher-forced check of the kernels), beam-3 tokens.  bf16 arithmetic perturbs logits of scale
+    ~25 by ~0.1, so the seed is chosen such that the token streams do not hinge on near-ties: they must be identical
+    (a) when HF itself runs in bf16, (b) when this package's torch decode path runs in bf16 on the CPU and (c) under 4 draws
+    of N(0, 0.06) noise added to every step's scores; the greedy top-2 margin is recorded and must exceed 0.25."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import LlamaConfig, LlamaForCausalLM, LogitsProcessor, LogitsProcessorList
+
+    class Noise(LogitsProcessor):
+        def __init__(self, seed):
+            self.g = torch.Generator().manual_seed(seed)
+
+        def __call__(self, input_ids, scores):
+            return scores + 0.06 * torch.randn(scores.shape, generator=self.g)
+
+    cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=1, max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1,
+                      eos_token_id=2, pad_token_id=0, attention_bias=False, tie_word_embeddings=False)
+    kw_g = dict(num_beams=1, min_new_tokens=4, max_new_tokens=12)
+    kw_b = dict(num_beams=3, min_new_tokens=6, max_new_tokens=12)
+    for seed in range(400):
+        torch.manual_seed(seed)
+        m = LlamaForCausalLM(cfg).eval()
+        with torch.no_grad():
+            for n_, p_ in m.named_parameters():
+                p_.mul_(9.0 if n_.startswith("lm_head") else 3.0)      # sharper distributions
+                p_.copy_(p_.to(torch.bfloat16).float())
+        g = torch.Generator().manual_seed(100 + seed)
+        emb = (0.5 * torch.randn(2, 9, 128, generator=g)).to(torch.bfloat16).float()
+        att = torch.ones(2, 9, dtype=torch.long)
+        att[1, :3] = 0
+        common = dict(inputs_embeds=emb, attention_mask=att, do_sample=False, repetition_penalty=2.0, length_penalty=2.0,
+                      pad_token_id=0, eos_token_id=2)
+        with torch.no_grad():
+            gr = m.generate(output_logits=True, return_dict_in_generate=True, **kw_g, **common)
+            step_logits = torch.stack(gr.logits, dim=1)     # (B, steps, V) raw logits
+            top2 = step_logits.topk(2, dim=-1).values
+            margin = float((top2[..., 0] - top2[..., 1]).min())
+            if margin <= 0.25:
+                continue
+            b3 = m.generate(**kw_b, **common)
+            mb = LlamaForCausalLM(cfg).eval()
+            mb.load_state_dict(m.state_dict())
+            mb = mb.to(torch.bfloat16)
+            cb = dict(common, inputs_embeds=emb.to(torch.bfloat16))
+            gr_b = mb.generate(**kw_g, **cb)
+            b3_b = mb.generate(**kw_b, **cb)
+            eq = lambda x, y: x.shape == y.shape and torch.equal(x, y)
+            same = eq(gr.sequences, gr_b) and eq(b3, b3_b)
+            if same:
+                sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+                from medical_image_analysis_amd.report_decoder import ReportDecoder
+                rd = ReportDecoder(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2,
+                                   num_attention_heads=2, num_key_value_heads=1, rms_norm_eps=1e-6, max_position_embeddings=128)
+                rd.load_hf_state_dict(m.state_dict())
+                rd = rd.to(torch.bfloat16).eval()
+                kw = dict(attention_mask=att, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+                same = eq(rd.generate(emb.to(torch.bfloat16), **kw_g, **kw), gr.sequences) and \
+                    eq(rd.generate(emb.to(torch.bfloat16), **kw_b, **kw), b3)
+            for t in range(4):
+                if not same:
+                    break
+                lp = lambda: LogitsProcessorList([Noise(1000 * seed + t)])
+                same = eq(m.generate(logits_processor=lp(), **kw_g, **common), gr.sequences) and \
+                    eq(m.generate(logits_processor=lp(), **kw_b, **common), b3)
+        print(f"decode_hd64 seed {seed}: robust={same} min greedy top-2 margin {margin:.3f}")
+        if same:
+            break
+    else:
+        raise RuntimeError("no robust seed found")
+    out = {("p_" + k): m.state_dict()[k].to(torch.bfloat16).view(torch.int16).numpy().copy() for k in m.state_dict()}
+    with torch.no_grad():
+        logits_prompt = m(inputs_embeds=emb, attention_mask=att).logits
+    print({"greedy": gr.sequences.tolist(), "beam3": b3.tolist()})
+    save("decode_llama_hd64", seed=np.array(seed), margin=np.array(margin), inputs_embeds=np_(emb),
+         attention_mask=att.numpy().copy(), logits_prompt=np_(logits_prompt), greedy=gr.sequences.numpy().copy(),
+         greedy_step_logits=np_(step_logits), beam3=b3.numpy().copy(), **out)
+
+
 def gen_vmamba(scan_ref):
     """VMamba / SS2D (R2GenCSR/VMamba/classification/models/vmamba.py) on CPU.  The vendored CUDA extension
     `selective_scan_cuda_oflex` is replaced by a stub that evaluates the reference's own selective_scan_ref (forward)
@@ -581,45 +827,71 @@ def gen_handoff():
 
 def main():
     torch.set_num_threads(8)
+    sys.path.insert(0, HERE)      # keyed_fill.py
     scan_ref = load_scan_ref()
-    gen_scan(scan_ref)
+    if want("scan"):
+        gen_scan(scan_ref)
     install_mamba_stubs(scan_ref)
     ft_dir = os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/arm/Finetuning")
     sys.path.insert(0, ft_dir)
     mamba_mod = _load(os.path.join(ft_dir, "mamba_simple.py"), "mamba_simple")
-    gen_conv1d(mamba_mod)
-    gen_mamba_slow(mamba_mod)
-    gen_mamba_step(mamba_mod)
+    if want("conv1d"):
+        gen_conv1d(mamba_mod)
+    if want("mamba_slow"):
+        gen_mamba_slow(mamba_mod)
+    if want("mamba_step"):
+        gen_mamba_step(mamba_mod)
     # ---- fast paths: inject the restated fused functions, then the reference's own modules run on CPU
     no_out, with_out = make_inner_stub(scan_ref)
     mamba_mod.mamba_inner_fn_no_out_proj = no_out
     mamba_mod.mamba_inner_fn = with_out
-    gen_mamba_v3(mamba_mod)
-    gen_mamba_v4(mamba_mod)
+    if want("mamba_v3"):
+        gen_mamba_v3(mamba_mod)
+    if want("mamba_v4"):
+        gen_mamba_v4(mamba_mod)
     install_timm_stubs()
     models_mamba = _load(os.path.join(ft_dir, "models_mamba.py"), "models_mamba_ref")
-    gen_arm(models_mamba)
+    if want("arm"):
+        gen_arm(models_mamba)
+    if want("lora_x"):
+        gen_lora_x(models_mamba)
+    if want("clip_loss"):
+        gen_clip_loss(models_mamba)
     # stage-1 pre-training model lives next to its own (uni-directional) mamba_simple.py
     pt_dir = os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/pretrain")
     sys.path.remove(ft_dir)
     sys.path.insert(0, pt_dir)
     for k in ("mamba_simple", "utils", "utils.pos_embed"):
         sys.modules.pop(k, None)
-    pt_mamba = _load(os.path.join(pt_dir, "mamba_simple.py"), "mamba_simple")
-    pt_mamba.mamba_inner_fn_no_out_proj = no_out
-    pt_mamba.mamba_inner_fn = with_out
-    models_pretrain = _load(os.path.join(pt_dir, "models_pretrain.py"), "models_pretrain_ref")
-    gen_pretrain(models_pretrain)
+    if want("pretrain"):
+        pt_mamba = _load(os.path.join(pt_dir, "mamba_simple.py"), "mamba_simple")
+        pt_mamba.mamba_inner_fn_no_out_proj = no_out
+        pt_mamba.mamba_inner_fn = with_out
+        models_pretrain = _load(os.path.join(pt_dir, "models_pretrain.py"), "models_pretrain_ref")
+        gen_pretrain(models_pretrain)
     sys.path.remove(pt_dir)
-    gen_vmamba(scan_ref)
-    gen_handoff()
-    gen_vit_mae()
-    gen_hybrid_decoder()
-    gen_decode()
-    gen_image_preprocess()
-    gen_report_metrics()
-    gen_clean_report()
-    gen_qformer()
+    if want("vmamba"):
+        gen_vmamba(scan_ref)
+    if want("handoff"):
+        gen_handoff()
+    if want("vit_mae"):
+        gen_vit_mae()
+    if want("mae_vitb_224"):
+        gen_mae_vitb_224()
+    if want("hybrid_decoder"):
+        gen_hybrid_decoder()
+    if want("decode"):
+        gen_decode()
+    if want("decode_hd64"):
+        gen_decode_hd64()
+    if want("image_preprocess"):
+        gen_image_preprocess()
+    if want("report_metrics"):
+        gen_report_metrics()
+    if want("clean_report"):
+        gen_clean_report()
+    if want("qformer"):
+        gen_qformer()
 
 
 # cases of tests/golden/image_preprocess.npz: (name, in_h, in_w, out_h, out_w, PIL resample, seed)

@@ -73,8 +73,9 @@ def test_generation_with_conditioned_hybrid_layers_runs_and_depends_on_image():
 @pytest.mark.gpu
 def test_hip_decode_step_matches_torch_step_bf16():
     """csrc/decode.hip (fused RMSNorm+GEMV, RoPE+cache+attention, SwiGLU) against the torch/SDPA decode step on the
-    same bf16 weights, teacher-forced over several tokens with beam re-ordering.  Both compute in bf16 with fp32
-    accumulation; logits agree to bf16 rounding noise, and the greedy/beam token streams are identical here."""
+    same bf16 weights, teacher-forced over several tokens with RANDOM beam re-ordering at a larger width than the HF
+    goldens (which pin the kernels themselves: test_hip_decode_kernels_* below).  Both sides compute in bf16 with fp32
+    accumulation; logits agree to bf16 rounding noise."""
     from medical_image_analysis_amd.report_decoder import ReportDecoder, _GraphStepper, _KernelStepper, KVCache
     dev = "cuda:0"
     torch.manual_seed(0)
@@ -102,13 +103,89 @@ def test_hip_decode_step_matches_torch_step_bf16():
             lt = ts.step(tok, beam, k).float().clone()
             scale = float(lt.abs().max())
             assert_close(lk, lt, 0.03 * scale, 0.03, f"logits at step {k}")
-    kw = dict(min_new_tokens=4, max_new_tokens=8, repetition_penalty=2.0, length_penalty=2.0, eos_token_id=2, pad_token_id=0)
-    for beams in (1, 3):
-        a = m.generate(emb, attention_mask=mask, num_beams=beams, use_graph=True, **kw)
-        b = m.generate(emb, attention_mask=mask, num_beams=beams, use_graph="torch", **kw)
-        assert a.shape == b.shape
-        agree = (a == b).float().mean().item()
-        assert agree >= 0.75, f"beams={beams}: only {agree:.2f} of the tokens agree between the HIP and torch decode paths"
+
+
+# ---- HF-pinned checks of the HIP decode kernels (tests/golden/decode_llama_hd64.npz: head_dim 64, bf16 weights) --------
+HD64 = dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+            num_key_value_heads=1, rms_norm_eps=1e-6, max_position_embeddings=128)
+HD64_GEN = dict(do_sample=False, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+HD64_GREEDY = dict(num_beams=1, min_new_tokens=4, max_new_tokens=12)
+HD64_BEAM = dict(num_beams=3, min_new_tokens=6, max_new_tokens=12)
+
+
+def _model_hd64(g, dev, dtype):
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    m = ReportDecoder(**HD64)
+    sd = {k[2:]: v.view(torch.bfloat16).float() for k, v in g.items() if k.startswith("p_")}   # stored as bf16 bit patterns
+    m.load_hf_state_dict(sd)
+    return m.to(dev).to(dtype).eval()
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_hd64_fp32_path_matches_hf(dev):
+    """The fp32 torch path on the head_dim-64 golden: prompt logits, greedy and beam-3 token streams equal HF's."""
+    g = load_golden("decode_llama_hd64")
+    m = _model_hd64(g, dev, torch.float32)
+    emb, att = g["inputs_embeds"].to(dev), g["attention_mask"].to(dev)
+    with torch.no_grad():
+        logits = m(emb, attention_mask=att)
+    real = g["attention_mask"].bool()
+    scale = float(g["logits_prompt"].abs().max())
+    assert_close(logits[real.to(dev)], g["logits_prompt"][real], 2e-5 * scale, 1e-4, "prompt logits")
+    for name, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
+        out = m.generate(emb, attention_mask=att, use_graph=False, **kw, **HD64_GEN)
+        assert torch.equal(out.cpu(), g[name]), f"{name}: {out.cpu().tolist()} vs HF {g[name].tolist()}"
+
+
+@pytest.mark.gpu
+def test_hip_decode_kernels_match_hf_logits_teacher_forced():
+    """gemv_bf16_kernel (+RMSNorm prologue, +residual, SwiGLU, fp32 logits) and decode_attn_kernel (RoPE, cache append,
+    one-query attention) against HF's OWN per-step logits: the HIP stepper is fed HF's greedy tokens and must reproduce
+    the raw logits HF recorded for the next position, to bf16 tolerance (weights are bf16-exact in the golden; the
+    activations are bf16 here and fp32 in HF).  Where HF's top-2 margin exceeds that tolerance the arg-max must agree."""
+    from medical_image_analysis_amd.report_decoder import KVCache, _KernelStepper
+    dev = "cuda:0"
+    g = load_golden("decode_llama_hd64")
+    m = _model_hd64(g, dev, torch.bfloat16)
+    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    want = g["greedy_step_logits"]                      # (B, steps, V): [:, 0] = after the prompt
+    toks = g["greedy"].to(dev)
+    B, steps, V = want.shape
+    assert _KernelStepper.supported(m, B, torch.bfloat16, dev), "head_dim 64 / bf16 must take the HIP kernels"
+    scale = float(want.abs().max())
+    tol = 0.02 * scale
+    with torch.no_grad():
+        cache = KVCache()
+        pre = m(emb, attention_mask=att, past_key_values=cache)[:, -1].float()
+        assert_close(pre, want[:, 0], tol, 0.02, "prefill logits (torch bf16 path)")
+        ks = _KernelStepper(m, B, att, cache, steps, torch.bfloat16)
+        ident = torch.arange(B, device=dev)
+        worst = 0.0
+        for k in range(steps - 1):
+            got = ks.step(toks[:, k], ident, k).float().cpu()
+            ref = want[:, k + 1]
+            worst = max(worst, float((got - ref).abs().max()))
+            assert_close(got, ref, tol, 0.02, f"HIP logits after token {k} vs HF")
+            top2 = ref.topk(2, dim=-1)
+            clear = (top2.values[:, 0] - top2.values[:, 1]) > 2 * tol
+            assert torch.equal(got.argmax(-1)[clear], top2.indices[:, 0][clear]), f"arg-max after token {k}"
+    assert worst > 0.0, "the stepper produced HF's logits bit for bit: it did not run in bf16"
+
+
+@pytest.mark.gpu
+def test_hip_decode_generate_tokens_match_hf():
+    """End to end on the HIP path (graph-captured stepper + beam_step kernel + slot-table re-ordering): greedy and beam-3
+    token streams equal HF's.  The golden's seed was selected so that no decision sits on a near-tie (make_golden.py
+    gen_decode_hd64: identical streams under HF-bf16, this package's bf16 CPU path and injected logit noise)."""
+    dev = "cuda:0"
+    g = load_golden("decode_llama_hd64")
+    m = _model_hd64(g, dev, torch.bfloat16)
+    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    for name, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
+        out = m.generate(emb, attention_mask=att, use_graph=True, **kw, **HD64_GEN)
+        key = [k for k in m._steppers if k[0] == emb.shape[0] * kw["num_beams"]][-1]
+        assert type(m._steppers[key]).__name__ == "_KernelStepper", "generate() must have taken the HIP kernels"
+        assert torch.equal(out.cpu(), g[name]), f"{name}: {out.cpu().tolist()} vs HF {g[name].tolist()}"
 
 
 @pytest.mark.gpu

@@ -120,6 +120,81 @@ def test_scan_fwd_mamba_like_unit_scale():
     assert_close(out, ref, 1e-4, 1e-5, "out")
 
 
+def test_scan_fwd_unit_scale_groups_and_single_state():
+    """Second flat-1e-4 case (north_star's fp32 atol, no scaling): VMamba's configuration -- 4 B/C groups, dstate 1, no z
+    (vmamba.py:406-408) -- and a grouped N = 8 case, Mamba-like magnitudes so outputs are O(1)."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    for (B, D, L, N, G, has_z) in [(2, 64, 3136, 1, 4, False), (3, 48, 1000, 8, 2, True)]:
+        gen = torch.Generator().manual_seed(11 + N)
+        A = -(0.5 + torch.rand(D, N, generator=gen))
+        u = torch.randn(B, D, L, generator=gen)
+        delta = 0.1 * torch.randn(B, D, L, generator=gen)
+        bias = -2.0 + 0.5 * torch.rand(D, generator=gen)
+        Bm, Cm = torch.randn(B, G, N, L, generator=gen), torch.randn(B, G, N, L, generator=gen)
+        z = torch.randn(B, D, L, generator=gen) if has_z else None
+        Dv = torch.ones(D)
+        ref = orc.selective_scan_ref(u, delta, A, Bm, Cm, Dv, z, bias, True)
+        assert float(ref.abs().max()) < 32.0
+        out = selective_scan_fn(u.to(dev), delta.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), Dv.to(dev),
+                                z=None if z is None else z.to(dev), delta_bias=bias.to(dev), delta_softplus=True)
+        assert_close(out, ref, 1e-4, 1e-5, f"out (G={G}, N={N})")
+
+
+def test_scan_north_star_shape_rows_vs_oracle_and_linearity():
+    """The roofline shape of north_star / SURVEY 8-d (B=8, L=4096, D=1536, N=16, fp32 io, z/D/bias/softplus on) at FULL size:
+    (1) forward and every row-local gradient (du, ddelta, dz) plus dA/dD/ddelta_bias of 8 sampled channels x all 8 batch
+        elements (64 rows) against the CPU oracle run on exactly those rows (rows are independent given B, C);
+    (2) dB/dC are sums over all 1536 channels: checked through linearity in dout, as are out(u) and the row gradients."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    B, D, L, N = 8, 1536, 4096, 16
+    gen = torch.Generator(device=dev).manual_seed(5)
+    r = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    A = -0.5 * torch.rand(D, N, device=dev, generator=gen) - 0.05
+    u, z = r(B, D, L), r(B, D, L)
+    delta = 0.5 * torch.rand(B, D, L, device=dev, generator=gen)
+    Bm, Cm = r(B, N, L), r(B, N, L)
+    Dv, bias = r(D), 0.5 * torch.rand(D, device=dev, generator=gen)
+    dout, dout2 = r(B, D, L), r(B, D, L)
+    rows = torch.tensor([0, 15, 16, 511, 777, 1024, 1500, 1535], device=dev)
+
+    def run(uu, go):
+        x = [t.clone().requires_grad_(True) for t in (uu, delta, A, Bm, Cm, Dv, z, bias)]
+        out = selective_scan_fn(x[0], x[1], x[2], x[3], x[4], x[5], z=x[6], delta_bias=x[7], delta_softplus=True)
+        out.backward(go)
+        return out.detach(), dict(zip(("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias"), [t.grad for t in x]))
+
+    out, g = run(u, dout)
+    assert _abi.load().mxvl_last_scan_kernel().decode().startswith("scan_fwd_stream"), "the roofline kernel must serve this shape"
+    c = lambda t: t.detach().cpu()
+    sub = dict(u=c(u[:, rows]), delta=c(delta[:, rows]), A=c(A[rows]), B=c(Bm), C=c(Cm), D=c(Dv[rows]), z=c(z[:, rows]),
+               delta_bias=c(bias[rows]))
+    ref = orc.selective_scan_ref(sub["u"], sub["delta"], sub["A"], sub["B"], sub["C"], sub["D"], sub["z"], sub["delta_bias"], True)
+    assert_close(out[:, rows], ref, _atol(ref), 1e-5, "out rows")
+    rg = orc.selective_scan_ref_bwd(sub["u"], sub["delta"], sub["A"], sub["B"], sub["C"], sub["D"], sub["z"], sub["delta_bias"],
+                                    True, c(dout[:, rows]))
+    for k, got in (("du", g["du"][:, rows]), ("ddelta", g["ddelta"][:, rows]), ("dz", g["dz"][:, rows]), ("dA", g["dA"][rows]),
+                   ("dD", g["dD"][rows]), ("ddelta_bias", g["ddelta_bias"][rows])):
+        scale = max(1.0, float(rg[k].abs().max()))
+        assert_close(got, rg[k], 5e-5 * scale, 2e-4, k + " rows")
+    # linearity in dout (gradients) and in u (forward), full tensors
+    _, g2 = run(u, dout2)
+    _, g3 = run(u, dout + 2.0 * dout2)
+    for k in g:
+        want = g[k] + 2.0 * g2[k]
+        scale = max(1.0, float(want.abs().max()))
+        assert_close(g3[k], want, 1e-4 * scale, 2e-4, "linearity " + k)
+    u2 = r(B, D, L)
+    o2, _ = run(u2, dout)
+    o3, _ = run(u + 2.0 * u2, dout)
+    want = out + 2.0 * o2
+    assert_close(o3, want, 1e-4 * max(1.0, float(want.abs().max()) / 32), 1e-4, "out is linear in u")
+
+
 def test_scan_rejects_bad_arguments():
     from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
     dev = _dev()
