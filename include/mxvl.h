@@ -324,7 +324,10 @@ int mxvl_image_preprocess(const mxvl_image_desc *desc, void *hip_stream);
 
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
-/* kernel-variant override for A/B measurements (bench.py only); 0 = automatic */
+/* Forward-scan kernel selection for tests / A-B measurements: 0 = automatic, 1..255 = force one of the (equally correct)
+ * kernel shapes; unknown ids fall back to automatic.  Thread-local: it affects only mxvl_scan_fwd calls made by the calling
+ * thread.  The product library ignores every bit above the low 8 (measurement builds, -DMXVL_ABLATE, read ablation
+ * switches there). */
 void mxvl_set_scan_variant(int variant);
 /* name of the kernel the last mxvl_scan_fwd on this thread dispatched to (static string) */
 const char *mxvl_last_scan_kernel(void);

@@ -29,7 +29,14 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+ABLATE_LIB = os.path.join(PKG, "build", "libmxvl_ablate.so")
+
+
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """ablate=True: a SEPARATE measurement library (build/libmxvl_ablate.so, -DMXVL_ABLATE) whose kernels honour the
+    MXVL_*_ABLATE / MXVL_BWD_WAVES environment switches; the product library has none of that code (mxvl_common.h)."""
+    if ablate:
+        return _build_ablate(verbose)
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -58,5 +65,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def _build_ablate(verbose: bool) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
+           "-DMXVL_ABLATE", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-shared", "-o", ABLATE_LIB] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ABLATE_LIB
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate="--ablate" in sys.argv))

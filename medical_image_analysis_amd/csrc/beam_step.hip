@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
       }
       __syncthreads();
     }
-    if (p.ablate == 1) continue;
+    if (MXVL_ABL(p.ablate == 1)) continue;
     // ---- (2) every thread keeps its TWO best penalised, score-shifted candidates (branch-free insertion) ---------------
     // A sorted `keep`-deep list per thread costs a wave-wide insertion for almost every element (some lane always
     // inserts): 100 us.  Two entries per thread are exact unless one thread owns three of the final `keep` -- detected
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
         }
       }
     }
-    if (p.ablate == 2) continue;
+    if (MXVL_ABL(p.ablate == 2)) continue;
     // ---- (3) `keep` rounds of block arg-max over the thread-local heads --------------------------------------------------
     int head = 0;
     for (int round = 0; round < keep; ++round) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
       }
       __syncthreads();
     }
-    if (p.ablate == 3) continue;
+    if (MXVL_ABL(p.ablate == 3)) continue;
     // ---- (4) bookkeeping on the survivors (one lane; everything here is `keep` <= 8 wide) -----------------------------
     if (tid == 0) {
       float* top_lp = s_bk_f;                      // dynamically indexed: LDS, not private (scratch) arrays
@@ -367,7 +367,7 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   BeamArgs a;
   a.batch = d->batch; a.nb = d->beams; a.V = d->vocab; a.max_new = d->max_new; a.min_new = d->min_new; a.n_eos = d->n_eos;
   a.early = d->early_stopping; a.keep = d->keep; a.rep_pen = d->repetition_penalty;
-  { const char* e = getenv("MXVL_BEAM_ABLATE"); a.ablate = e ? atoi(e) : 0; }   // measurement only
+  a.ablate = MXVL_ABL_ENV("MXVL_BEAM_ABLATE");
   a.logits = (const float*)d->logits; a.run_seq = (long long*)d->run_seq; a.fin_seq = (long long*)d->fin_seq;
   a.run_score = (float*)d->run_score; a.fin_score = (float*)d->fin_score; a.fin_done = (unsigned char*)d->fin_done;
   a.heur_open = (unsigned char*)d->heur_open; a.cur = (long long*)d->cur; a.eos = (const long long*)d->eos;

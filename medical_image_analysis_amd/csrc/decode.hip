@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   __shared__ float s_part[kMaxRows][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = p.K, N = p.N;
-  if (p.ablate == 1) return;
+  if (MXVL_ABL(p.ablate == 1)) return;
   const int S = p.swiglu ? 2 : 1;
   const int TW = gridDim.x * NW;                      // waves in the launch
   const int n_first = blockIdx.x * NW + wave;
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   // Stage x (or RMSNorm(x)*g, Qwen2RMSNorm hybrid_decoder_layer.py:193-198: bf16(bf16(x*rstd) * g)) in LDS.  One
   // 16-byte global load per thread per (row, 8192-column block), ALL issued before the first use: the prologue costs
   // one L2 round trip, not one per element.
-  if (p.ablate == 2) return;
-  if (p.ablate != 3)
+  if (MXVL_ABL(p.ablate == 2)) return;
+  if (!MXVL_ABL(p.ablate == 3))
   for (int c0 = 0; c0 < K; c0 += 8192) {
     const int kk = c0 + tid * 8;
     const bool on = kk < K;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
   }
   __syncthreads();
 
-  if (p.ablate == 4) return;
+  if (MXVL_ABL(p.ablate == 4)) return;
   float gate[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) gate[m] = 0.0f;
@@ -365,8 +365,7 @@ int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
   GemvArgs a;
-  static const int ablate = getenv("MXVL_GEMV_ABLATE") ? atoi(getenv("MXVL_GEMV_ABLATE")) : 0;
-  a.ablate = ablate;
+  a.ablate = MXVL_ABL_ENV("MXVL_GEMV_ABLATE");
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32; a.eps = d->eps;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->norm_weight; a.W = (const uint16_t*)d->W;
   a.W2 = (const uint16_t*)d->W2; a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;

@@ -7,6 +7,18 @@
 
 #include "mxvl.h"
 
+// Measurement-only ablation switches (tools/*_bench.py).  They exist ONLY in builds made with -DMXVL_ABLATE
+// (`python -m medical_image_analysis_amd.build --ablate` -> build/libmxvl_ablate.so); in the product library every
+// MXVL_ABL(...) condition is the constant false, no environment variable is read and no ablation code is emitted.
+#ifdef MXVL_ABLATE
+#include <stdlib.h>
+#define MXVL_ABL(cond) (cond)
+#define MXVL_ABL_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define MXVL_ABL(cond) (false)
+#define MXVL_ABL_ENV(name) (0)
+#endif
+
 namespace mxvl {
 
 constexpr int kWave = 64;

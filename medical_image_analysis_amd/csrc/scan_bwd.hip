@@ -16,7 +16,6 @@
 //   * dA, dD, ddelta_bias are reduced over lanes with DPP and over chunks in LDS/registers: one global
 //     atomic per (row,n) / row per workgroup.
 // du, ddelta, dz are fully written; dA, dB, dC, dD, ddelta_bias are accumulated into caller-zeroed fp32.
-#include <stdlib.h>
 
 #include "mxvl_common.h"
 
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     float* aB = sAcc + (row * 2 + 0) * NG * CH + j * T;
     float* aC = sAcc + (row * 2 + 1) * NG * CH + j * T;
 
-    for (int n = 0; n < ((p.ablate & 4) ? 0 : N); ++n) {
+    for (int n = 0; n < (MXVL_ABL(p.ablate & 4) ? 0 : N); ++n) {
       const float A2 = ac[n].x;
       const float hin = ac_in[n].y;
       float a[T], bb[T], cv[T], h[T];
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         dA_part = fmaf(gha, dl[i], dA_part);
         gg = ga;
       }
-      if (!(p.ablate & 1)) {
+      if (!MXVL_ABL(p.ablate & 1)) {
         float4* wB = (float4*)(aB + (n % NG) * CH);
         float4* wC = (float4*)(aC + (n % NG) * CH);
         wB[0] = make_float4(vB[0], vB[1], vB[2], vB[3]); wB[1] = make_float4(vB[4], vB[5], vB[6], vB[7]);
@@ -392,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
           float v = 0.0f;
 #pragma unroll
           for (int rr = 0; rr < DT; ++rr) v += sAcc[(rr * 2 + which) * NG * CH + rem];
-          if (n0 + nn <= n && t0 + e < L && !(p.ablate & 2)) {
+          if (n0 + nn <= n && t0 + e < L && !MXVL_ABL(p.ablate & 2)) {
             float* dst = which ? dCp + (int64_t)(n0 + nn) * p.dC_ns : dBp + (int64_t)(n0 + nn) * p.dB_ns;
             unsafeAtomicAdd(dst + t0 + e, v);
           }
@@ -467,7 +466,7 @@ static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it goes out as global
   // atomics (the atomics are ~1/3 of the kernel at 16 rows) at the same 8 waves per CU.  Used when 32-row tiles still
   // give every CU a workgroup.
-  static const int forced = getenv("MXVL_BWD_WAVES") ? atoi(getenv("MXVL_BWD_WAVES")) : 0;
+  static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
   const long tiles32 = (long)a.batch * a.G * ((a.dim / a.G + 31) / 32);
   const bool wide = forced ? forced == 8 : ((a.dim / a.G) % 32 == 0 && tiles32 >= 256);
   if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
@@ -507,7 +506,7 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.dl_ratio = f->delta_group_ratio > 1 ? f->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
-  { const char* e = getenv("MXVL_BWD_ABLATE"); a.ablate = e ? atoi(e) : 0; }  // measurement only
+  a.ablate = MXVL_ABL_ENV("MXVL_BWD_ABLATE");
   {
     const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
     const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     const bool full = t0 + CH <= L;
     __syncthreads();  // every wave is done with the previous B/C tile (first pass: sAC visible)
     // ---- stage the shared B/C tile -------------------------------------------------------------
-    if (p.ablate & 2) {
+    if (MXVL_ABL(p.ablate & 2)) {
     } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;                 // float4 columns per row
       constexpr int RSTEP = NT / CQ;             // rows covered per pass
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
       }
     }
     // ---- stage this wave's own rows of u / delta / z -------------------------------------------
-    if (p.ablate & 4) {
+    if (MXVL_ABL(p.ablate & 4)) {
     } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;  // float4 columns per row; a wave owns RPW*CQ = 16*T of them
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     float* ckpt_row = p.ckpt ? p.ckpt + (((int64_t)b * p.dim + d) * p.n_ckpt + (t0 + j * T) / kCkptLen) * N : nullptr;
     float2* ac = sAC + row * N;
 
-    for (int n0 = 0; n0 < ((p.ablate & 1) ? 0 : N); n0 += NU) {
+    for (int n0 = 0; n0 < (MXVL_ABL(p.ablate & 1) ? 0 : N); n0 += NU) {
       float a[NU][T], bb[NU][T], cv[NU][T], hl[NU], P[NU], x[NU];
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (p.ablate & 8) {
+    if (MXVL_ABL(p.ablate & 8)) {
     } else if (vec_ok && full) {
       constexpr int CQ = CH / 4;
 #pragma unroll
@@ -361,7 +361,7 @@ namespace mxvl {
 // ---------------------------------------------------------------------------------------------
 static thread_local int g_last_hip_error = 0;
 static thread_local const char* g_last_kernel = "none";
-static int g_variant = 0;
+static thread_local int g_variant = 0;   // per calling thread: a test / bench hook, not process-global state
 
 template <typename io_t, int T, int LPR, int NWAVES, int NU, int MINW = 1>
 static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
@@ -457,7 +457,7 @@ int mxvl_abi_version(void) { return MXVL_ABI_VERSION; }
 int mxvl_scan_chunk_len(int, int) { return kCkptLen; }
 int mxvl_scan_n_chunks(int seqlen, int) { return (seqlen + kCkptLen - 1) / kCkptLen; }
 int mxvl_last_hip_error(void) { return g_last_hip_error; }
-void mxvl_set_scan_variant(int v) { g_variant = v; }
+void mxvl_set_scan_variant(int v) { g_variant = MXVL_ABL(true) ? v : (v & 0xff); }
 const char* mxvl_last_scan_kernel(void) { return g_last_kernel; }
 
 int mxvl_scan_check(const mxvl_scan_desc* d) {
@@ -494,7 +494,7 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
   a.dl_ratio = d->delta_group_ratio > 1 ? d->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
-  a.ablate = (g_variant >> 8) & 0xff;  // measurement-only knobs (tools/scan_bench.py); 0 in production
+  a.ablate = MXVL_ABL(true) ? (g_variant >> 8) & 0xff : 0;
   // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
   {
     const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2;

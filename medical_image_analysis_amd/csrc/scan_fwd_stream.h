@@ -182,7 +182,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   };
 
   const int nchunks = (L + CH - 1) / CH;
+#ifdef MXVL_ABLATE
   const long long clk0 = clock64(), wall0 = wall_clock64();   // (ablate & 16) measurement: shader clock vs 100 MHz wall
+#else
+  const long long clk0 = 0, wall0 = 0;
+#endif
   float un[T], dn[T];
   bc_fetch(0);
   row_fetch(pu, 0, un);
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     const float* cC = cB + N * CH;
 
 #pragma unroll 4
-    for (int n = 0; n < ((p.ablate & 1) ? 0 : (p.ablate & 2) ? N / 2 : N); ++n) {
+    for (int n = 0; n < (MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N); ++n) {
       const float A2 = ac[n].x;
       const float car = ac_in[n].y;                           // state entering the chunk (lane 0), 0 elsewhere
       float a[T], bb[T], cv[T];
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
       for (int i = 0; i < T; ++i) y[i] *= silu(zz[i]);
     }
-    if (p.ablate & 8) continue;
+    if (MXVL_ABL(p.ablate & 8)) continue;
     if (VEC && full) {
       if (row_ok) {
 #pragma unroll
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
   }
 
-  if ((p.ablate & 16) && tid == 0) {   // per-workgroup start / end wall ticks (use with ablate & 8: no out stores)
+  if (MXVL_ABL(p.ablate & 16) && tid == 0) {   // per-workgroup start / end wall ticks (use with ablate & 8: no out stores)
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     ((float*)p.out)[4 * wg] = (float)(wall0 & 0xffffff);
     ((float*)p.out)[4 * wg + 1] = (float)(wall_clock64() & 0xffffff);

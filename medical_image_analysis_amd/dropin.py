@@ -49,6 +49,42 @@ def _oflex_module(name):
     return m
 
 
+def _mamba_ssm_cuda_module(name):
+    """`selective_scan_cuda` of the mamba-ssm wheel, as the reference's SelectiveScanMamba calls it
+    (R2GenCSR/VMamba/classification/models/vmamba.py:255, 266-269) -- NOT the oflex argument order:
+    fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus) -> [out, x] (+ [out_z] when z is given)
+    bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, dz, delta_softplus, recompute_out_z)
+        -> [du, ddelta, dA, dB, dC, dD, ddelta_bias] (+ [dz] when z is given)."""
+    from . import selective_scan_interface as ssi
+    m = _mod(name)
+
+    def fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False):
+        _, u_, d_, A_, B_, C_, D_, z_, b_ = ssi._prep(u, delta, A, B, C, D, z, delta_bias)
+        x = lambda ck: ck if ck is not None else torch.empty(0, device=u.device)
+        if z_ is None:
+            out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, bool(delta_softplus), want_ckpt=True)
+            return [out, x(ckpt)]
+        # the wheel returns the ungated scan output AND the gated one (selective_scan.cpp: out, x, out_z)
+        out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, bool(delta_softplus), want_ckpt=True)
+        out_z, _, _ = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, z_, b_, bool(delta_softplus))
+        return [out, x(ckpt), out_z]
+
+    def bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out=None, dz=None, delta_softplus=False, recompute_out_z=False):
+        _, u_, d_, A_, B_, C_, D_, z_, b_ = ssi._prep(u, delta, A, B, C, D, z, delta_bias)
+        ckpt = x if (x is not None and x.numel() > 0) else None
+        du, dd, dA, dB, dC, dD, dz_, dbias = ssi.scan_bwd_raw(u_, d_, A_, B_, C_, D_, z_, b_, bool(delta_softplus), ckpt,
+                                                            dout.to(u_.dtype))
+        res = [du, dd, dA, dB.to(B.dtype), dC.to(C.dtype), dD, dbias]
+        if z_ is not None:
+            res.append(dz_)
+            if recompute_out_z:
+                res.append(ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, z_, b_, bool(delta_softplus))[0])
+        return res
+
+    m.fwd, m.bwd = fwd, bwd
+    return m
+
+
 def install(force: bool = False) -> None:
     """Idempotent.  Refuses to shadow a real `mamba_ssm` / `causal_conv1d` install unless force=True."""
     for real in ("mamba_ssm", "causal_conv1d"):
@@ -75,5 +111,6 @@ def install(force: bool = False) -> None:
     _mod("mamba_ssm.utils.generation").GenerationMixin = object
     hf = _mod("mamba_ssm.utils.hf")
     hf.load_config_hf = hf.load_state_dict_hf = None
-    for name in ("selective_scan_cuda_oflex", "selective_scan_cuda_core", "selective_scan_cuda"):
+    for name in ("selective_scan_cuda_oflex", "selective_scan_cuda_core"):
         _oflex_module(name)
+    _mamba_ssm_cuda_module("selective_scan_cuda")

@@ -366,8 +366,8 @@ class Mamba(nn.Module):
                 ssm_state.copy_(last)
                 out = self.out_proj(y.transpose(1, 2))
         if self.init_layer_scale is not None:
-            if isinstance(out, tuple):
-                out = tuple(o * self.gamma for o in out)
+            if isinstance(out, tuple):   # v4: the reference scales `out` only, `out_d` leaves unscaled (mamba_simple.py:710-713)
+                out = (out[0] * self.gamma,) + tuple(out[1:])
             else:
                 out = out * self.gamma
         return out

@@ -91,6 +91,18 @@ def _build_encoder(args, large):
     return enc
 
 
+def _wants_checkpoint(vision_model: str) -> bool:
+    """The reference loads `args.vision_model` unconditionally unless it is the string 'None' (MambaXrayVL_DownStream.py:
+    33-42, MambaXrayVL_CLIP.py:32-66) and so fails loudly on a wrong path.  Same here: a missing file raises instead of
+    leaving a randomly initialised (then frozen) encoder behind.  'None' -- and '<anything>-None', e.g. 'Base-None', which
+    only selects the architecture through the reference's `'B' in vision_model` test -- mean "no checkpoint"."""
+    if vision_model == "None" or vision_model.endswith("-None"):
+        return False
+    if not os.path.exists(vision_model):
+        raise FileNotFoundError(f"vision_model checkpoint {vision_model!r} does not exist (use 'None' to train from scratch)")
+    return True
+
+
 class MambaXrayVLDownStream(nn.Module):
     """Stage 3: ARM encoder -> llama_proj -> LayerNorm -> [bos, prompt, image tokens, prompt] -> frozen LLM."""
 
@@ -102,7 +114,7 @@ class MambaXrayVLDownStream(nn.Module):
         vision_model = str(_get(args, "vision_model", "None"))
         self.visual_encoder = _build_encoder(args, large="B" not in vision_model)   # the reference's test (:28-31)
         ckpt = None
-        if vision_model != "None" and os.path.exists(vision_model):
+        if _wants_checkpoint(vision_model):
             ckpt = torch.load(vision_model, map_location="cpu")
             compat.load_visual_encoder(self.visual_encoder, ckpt, strict=True)
         # EMRRG (EMRRG/models/MambaXrayVL_DownStream.py:59-89): lora_X adapters go on every mixer BEFORE the freeze, so
@@ -287,7 +299,7 @@ class MambaXrayVLCLIP(nn.Module):
         self.text_encoder_type = _get(args, "text_encoder_type", "Bio_ClinicalBERT")
         self.visual_encoder = _build_encoder(args, large=_get(args, "type") != "base")
         vision_model = str(_get(args, "vision_model", "None"))
-        if vision_model != "None" and os.path.exists(vision_model):
+        if _wants_checkpoint(vision_model):
             compat.load_stage1_into_arm(self.visual_encoder, vision_model)
         if _get(args, "freeze_vm", False):
             for p in self.visual_encoder.parameters():

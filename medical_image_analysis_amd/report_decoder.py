@@ -568,7 +568,16 @@ class ReportDecoder(nn.Module):
         stepper = None
         if use_graph:
             # the captured graph is reused by later calls with the same shapes (capture costs ~a hundred ms for 32 layers)
-            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph))
+            # A captured graph bakes in weight addresses and the (un)conditioned layer structure: a later .to()/.half()
+            # (new parameter storage) or condition_vis_x() must not replay it.  The weight identity is part of the cache
+            # (stale steppers are dropped), the conditioning state is part of the key.
+            conditioned = any(self.model.layers[i].vis_x is not None for i in self.hybrid_layers)
+            ident = tuple((w.data_ptr(), w.dtype) for w in (self.lm_head.weight, self.model.embed_tokens.weight,
+                                                            self.model.layers[-1].mlp.down_proj.weight))
+            if self.__dict__.get("_stepper_weights") != ident:
+                self.__dict__["_steppers"] = {}
+                self.__dict__["_stepper_weights"] = ident
+            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph), conditioned)
             stepper = getattr(self, "_steppers", {}).get(key)
             if stepper is None:
                 cls = _KernelStepper if (use_graph != "torch" and _KernelStepper.supported(

@@ -193,7 +193,9 @@ class SelectiveScanFn(torch.autograd.Function):
     def forward(ctx, u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state):
         B_was_3d, C_was_3d = B.dim() == 3, C.dim() == 3
         dev, u, delta, A, B, C, D, z, delta_bias = _prep(u, delta, A, B, C, D, z, delta_bias)
-        needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        # grad mode is off inside Function.forward: the copies _prep makes (.contiguous() / .float()) never require grad, so
+        # ask autograd about the ORIGINAL arguments
+        needs_grad = any(ctx.needs_input_grad[:8])
         out, last, ckpt = scan_fwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus,
                                        want_last_state=return_last_state, want_ckpt=needs_grad)
         ctx.delta_softplus = delta_softplus

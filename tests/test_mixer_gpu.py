@@ -3,7 +3,7 @@ against the reference goldens (tests/golden/conv1d_*, mamba_slow_*, mamba_step) 
 import pytest
 import torch
 
-from conftest import assert_close, golden_names, load_golden
+from conftest import assert_close, golden_names, load_golden, scan_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -168,3 +168,58 @@ def test_dir_merge_gate_equals_torch_restatement(dtype):
     with torch.no_grad():                                                   # inference: no `pre` buffer is written
         out2 = _DirMergeGate.apply(y.to(DEV), z.to(DEV), i32, p32, L, 0.25)
     assert torch.equal(out2, out)
+
+
+def test_v4_layer_scale_scales_out_only():
+    """bimamba v4 + init_layer_scale: the reference multiplies `out` by gamma and returns `out_d` unscaled
+    (arm/Finetuning/mamba_simple.py:710-713)."""
+    from medical_image_analysis_amd.mamba_simple import Mamba
+    torch.manual_seed(0)
+    a = Mamba(d_model=32, expand=1, bimamba_type="v4", if_devide_out=True).to(DEV)
+    b = Mamba(d_model=32, expand=1, bimamba_type="v4", if_devide_out=True, init_layer_scale=0.5).to(DEV)
+    b.load_state_dict(a.state_dict(), strict=False)
+    x, seg = torch.randn(2, 10, 32, device=DEV), torch.randn(2, 10, 32, device=DEV)
+    oa, da = a(x, segmenttation_features=seg)
+    ob, db = b(x, segmenttation_features=seg)
+    assert_close(ob, 0.5 * oa, 1e-6, 1e-6, "out * gamma")
+    assert_close(db, da, 1e-6, 1e-6, "out_d stays unscaled")
+
+
+def test_scan_backward_when_only_a_copied_input_needs_grad():
+    """Only u requires grad and it is non-contiguous (so the op works on a copy), A/D frozen, L > one chunk: the
+    checkpoints must still be written (needs_input_grad, not requires_grad of the copies)."""
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    x = scan_inputs(2, 32, 300, 16, 1, True, True, True, seed=4, device=DEV)
+    u = x["u"].transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)     # (B, D, L) view with stride(-1) != 1
+    assert u.stride(-1) != 1
+    out = selective_scan_fn(u, x["delta"], x["A"], x["B"], x["C"], x["D"], z=x["z"], delta_bias=x["delta_bias"], delta_softplus=True)
+    out.sum().backward()
+    ref_u = x["u"].clone().requires_grad_(True)
+    selective_scan_fn(ref_u, x["delta"], x["A"], x["B"], x["C"], x["D"], z=x["z"], delta_bias=x["delta_bias"],
+                      delta_softplus=True).sum().backward()
+    assert_close(u.grad, ref_u.grad, 1e-5, 1e-5, "du through the copied input")
+
+
+def test_dropin_selective_scan_cuda_has_the_mamba_ssm_signature():
+    """The reference's SelectiveScanMamba calls `selective_scan_cuda.fwd(u, delta, A, B, C, D, None, delta_bias, softplus)`
+    and a 14-argument bwd (R2GenCSR/VMamba/classification/models/vmamba.py:255, 266-269); the oflex / core modules take
+    (…, D, delta_bias, softplus, nrows).  Both must give the same numbers through the drop-in."""
+    import sys
+    import medical_image_analysis_amd.dropin as dropin
+    dropin.install()
+    cuda, oflex = sys.modules["selective_scan_cuda"], sys.modules["selective_scan_cuda_oflex"]
+    x = scan_inputs(2, 32, 300, 4, 2, False, True, True, seed=6, device=DEV)
+    out, ck, *rest = cuda.fwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], None, x["delta_bias"], True)
+    out2, ck2 = oflex.fwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["delta_bias"], True, 1)
+    assert rest == [] and torch.equal(out, out2) and torch.equal(ck, ck2)
+    dout = torch.randn_like(out)
+    g1 = cuda.bwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], None, x["delta_bias"], dout, ck, None, None, True, False)
+    g2 = oflex.bwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["delta_bias"], dout, ck2, True, 1)
+    assert len(g1) == 7
+    for a, b, k in zip(g1, g2, ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"]):
+        assert_close(a, b, 1e-5 * max(1.0, float(b.abs().max())), 1e-5, k)
+    # with a gate: fwd also returns out_z, bwd also returns dz
+    z = torch.randn_like(x["u"])
+    o, ckz, oz = cuda.fwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], z, x["delta_bias"], True)
+    assert_close(oz, o * torch.nn.functional.silu(z), 1e-5 * max(1.0, float(oz.abs().max())), 1e-5, "out_z = out * silu(z)")
+    assert len(cuda.bwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], z, x["delta_bias"], dout, ckz, o, None, True, False)) == 8

@@ -189,6 +189,25 @@ def test_hip_decode_generate_tokens_match_hf():
 
 
 @pytest.mark.gpu
+def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning():
+    """A captured decode graph holds weight addresses and the unconditioned layer structure: after the parameters move
+    (.to() re-creates their storage) generate() must capture anew -- and still give the same tokens --, and a
+    conditioned decoder must not replay the unconditioned kernel path."""
+    dev = "cuda:0"
+    g = load_golden("decode_llama_hd64")
+    m = _model_hd64(g, dev, torch.bfloat16)
+    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    a = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
+    first = list(m._steppers.values())[0]
+    b = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
+    assert list(m._steppers.values())[0] is first and torch.equal(a, b), "same weights, same shapes: the graph is reused"
+    m = m.to(torch.float32).to(torch.bfloat16)            # new parameter storage
+    c = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
+    assert list(m._steppers.values())[0] is not first, "stale graph over freed weight buffers must not be replayed"
+    assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [dict(B=1, nb=3, V=32000, max_new=24, min_new=6, rep=2.0, lp=2.0, early=False),
                                  dict(B=2, nb=2, V=997, max_new=12, min_new=0, rep=1.0, lp=1.0, early=True),
                                  dict(B=3, nb=4, V=5000, max_new=16, min_new=3, rep=1.3, lp=0.5, early="never")])

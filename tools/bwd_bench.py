@@ -1,6 +1,11 @@
 """Dev tool: time mxvl_scan_bwd alone (set MXVL_BWD_ABLATE=bits to skip parts: 1 LDS atomics, 2 global atomics, 4 state loop)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+# ablation switches live only in the measurement build (csrc/mxvl_common.h): point the binding at it when one is requested
+if any(os.environ.get(k) for k in ['MXVL_BWD_ABLATE', 'MXVL_BWD_WAVES']):
+    from medical_image_analysis_amd import _abi as _abi_sel, build as _build_sel
+    _abi_sel.LIB_PATH = _build_sel.build(ablate=True)
 import torch
 from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw, scan_bwd_raw, scan_algorithmic_bytes
 
