@@ -50,8 +50,21 @@ def pmc_traffic(workload):
         except (OSError, ValueError):
             continue
         if rec:
-            return {"bytes": rec["bytes"], "source": os.path.basename(path), "fetch_kb": rec["fetch_kb"], "write_kb": rec["write_kb"]}
+            return {"bytes": rec["bytes"], "source": os.path.basename(path), "fetch_kb": rec["fetch_kb"], "write_kb": rec["write_kb"],
+                    "kernel": rec.get("kernel")}
     return None
+
+
+def attach_traffic(roofline, workload):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel.  It is NOT re-measured by this process (PMC needs
+    rocprofv3 around the command): the number is read from the committed PMC record of the same command and labelled so."""
+    pmc = pmc_traffic(workload)
+    if pmc is None:
+        return
+    roofline["traffic"] = pmc["bytes"]
+    roofline["traffic_from_profile"] = (f"profiles/{pmc['source']} ({pmc.get('kernel')}): FETCH_SIZE {pmc['fetch_kb']} KB x2 (gfx950 "
+                                        f"correction) + WRITE_SIZE {pmc['write_kb']} KB per launch, separate rocprofv3 --pmc passes of "
+                                        f"`bench.py --workload {workload}`; copied from the profile, not re-measured in this run")
 
 WORKLOADS = {
     # name: (B, D, L, N, torch dtype name, description)
@@ -149,18 +162,17 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
     }
 
 
-def run_decode(args, rank, world, dev, dist):
+def measure_decode(workload, steps, warmup, rank, world, dev, dist):
     """Autoregressive report decoding: one 'step' = one full generate() of `new_tokens` tokens per sample.
-    Replicas only across GPUs (the reference decodes on a single device, MambaXrayVL_DownStream.py:407)."""
+    Replicas only across GPUs (the reference decodes on a single device, MambaXrayVL_DownStream.py:407).
+    Returns the result dict on rank 0 (None elsewhere)."""
     from medical_image_analysis_amd.report_decoder import ReportDecoder
-    vocab, hidden, inter, layers, heads, kvh, plen, new, beams, B, desc = DECODE_WORKLOADS[args.workload]
+    vocab, hidden, inter, layers, heads, kvh, plen, new, beams, B, desc = DECODE_WORKLOADS[workload]
     torch.manual_seed(0)
     with torch.device(dev):
         m = ReportDecoder(vocab, hidden, inter, layers, heads, kvh).to(torch.bfloat16).eval()
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     emb = (0.02 * torch.randn(B, plen, hidden, generator=g)).to(dev, torch.bfloat16)
-    steps = args.steps if args.steps > 0 else 3
-    warmup = args.warmup if args.warmup >= 0 else 1
     kw = dict(num_beams=beams, min_new_tokens=new, max_new_tokens=new, repetition_penalty=2.0, length_penalty=2.0,
               eos_token_id=2, pad_token_id=0)
     for _ in range(warmup):
@@ -179,23 +191,35 @@ def run_decode(args, rank, world, dev, dist):
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
-    if rank != 0:
-        return
+    stepper = type(next(iter(m._steppers.values()))).__name__ if getattr(m, "_steppers", None) else "eager"
     n_params = sum(p.numel() for p in m.parameters())
-    tokens = B * world * steps * out.shape[1]
+    n_out = int(out.shape[1])
+    del m
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    tokens = B * world * steps * n_out
     wbytes = 2 * n_params                                   # every decode step streams the bf16 weights once
-    step_s = wall / (steps * out.shape[1])                  # per generated token (beam batch of `beams` rows)
+    step_s = wall / (steps * n_out)                         # per generated token (beam batch of `beams` rows)
     achieved = wbytes / step_s / 1e9
-    print(json.dumps({
+    return {
         "metric": "report-generation decode tokens/sec (returned tokens; each step advances all beams)",
         "value": tokens / wall, "unit": "tokens/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic prompt embeddings (seed 1000+rank), random-init weights (seed 0)",
-        "config": {"workload": f"{args.workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
-                   "new_tokens": int(out.shape[1]), "parallelism": f"replicas x{world} (no collective)"},
+        "config": {"workload": f"{workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
+                   "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step = 161 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)",
-                     "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}))
+                     "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}
+
+
+def run_decode(args, rank, world, dev, dist):
+    steps = args.steps if args.steps > 0 else 3
+    warmup = args.warmup if args.warmup >= 0 else 1
+    res = measure_decode(args.workload, steps, warmup, rank, world, dev, dist)
+    if res is not None:
+        print(json.dumps(res))
 
 
 def host_physical_cores():
@@ -213,7 +237,7 @@ def host_physical_cores():
     return len(pairs) or max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline_pretrain(model, img, patch, depth, budget_s=25.0):
+def cpu_baseline_pretrain(sd, img, patch, depth, budget_s=25.0):
     """FORWARD pass of the same model on the host: oracle/models_ref.py (functional restatement of the reference's
     VisionMamba.forward over the C scan/conv oracles), fp32, all cores.  The reference's own training step cannot
     run without its CUDA wheels; forward-only is what the CPU oracle offers, and the sample says so."""
@@ -224,7 +248,6 @@ def cpu_baseline_pretrain(model, img, patch, depth, budget_s=25.0):
     cores = min(host_physical_cores(), 64)
     orc.set_threads(cores)
     torch.set_num_threads(cores)
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0))
     n, elapsed = 0, 0.0
     while elapsed < budget_s and n < 8:
@@ -284,6 +307,17 @@ def run_pretrain(args, rank, world, dev, dist):
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
+    final_loss = float(loss)
+    cpu_sd = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    secondary = None
+    if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
+        # second half of BASELINE.json's metric ("MAE pretrain images/sec + report-gen decode tokens/sec"): the report
+        # decoder of configs[3], measured by the same process right after the training steps (replicas on every rank)
+        del eng, model, batches
+        torch.cuda.empty_cache()
+        secondary = measure_decode("decode_llama7b_128", 2, 1, rank, world, dev, dist)
     if rank != 0:
         return
     stats = {}
@@ -304,15 +338,20 @@ def run_pretrain(args, rank, world, dev, dist):
         "dtype": "bf16", "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world,
                    "seq_len": L, "params": n_params, "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)",
-                   "final_loss": float(loss)},
+                   "final_loss": final_loss,
+                   "timed_step": "forward + backward (DDP bucketed grad all-reduce overlapped) + loss all-reduce + clip + fused AdamW"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kind,
                      "kernel_ms": tot_ms / calls, "launches_timed": calls,
                      "algorithmic_bytes_per_launch": tot_bytes // calls,
                      "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}},
     }
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_pretrain(model, img, patch, depth)
+    attach_traffic(out["roofline"], args.workload)
+    if secondary is not None:
+        out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                      "dtype", "config", "roofline")}
+    if cpu_sd is not None:
+        out["cpu_baseline"] = cpu_baseline_pretrain(cpu_sd, img, patch, depth)
     print(json.dumps(out))
 
 
@@ -475,7 +514,19 @@ def main():
                     choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS) + sorted(MAE_WORKLOADS) + sorted(VMAMBA_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves, exactly the way the driver does
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -566,11 +617,7 @@ def main():
                          "kernel": "scan_fwd_stream_kernel", "algorithmic_bytes_per_launch": nbytes,
                          "kernel_ms": kern_ms},
         }
-        pmc = pmc_traffic(args.workload)
-        if pmc is not None:
-            out["roofline"]["traffic"] = pmc["bytes"]
-            out["roofline"]["traffic_source"] = (f"profiles/{pmc['source']}: FETCH_SIZE {pmc['fetch_kb']} KB x2 + WRITE_SIZE "
-                                                 f"{pmc['write_kb']} KB per launch (separate rocprofv3 --pmc passes of this command)")
+        attach_traffic(out["roofline"], args.workload)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_scan(B, D, L, N)
         print(json.dumps(out))
