@@ -38,10 +38,14 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     model = VisionMamba(**MODEL_KW).to("cuda:0")
     eng = PretrainEngine(model, lr=1e-3, amp_dtype=None, device="cuda:0", bucket_cap_mb=1)   # several buckets on a small model
-    losses = [float(eng.step(_batch(rank, s).to("cuda:0"))) for s in range(STEPS)]
+    losses, grads = [], None
+    for s in range(STEPS):
+        losses.append(float(eng.step(_batch(rank, s).to("cuda:0"))))
+        if s == 0:   # the (rank-averaged) gradients of the first step are still in .grad
+            grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
     torch.cuda.synchronize()
     sd = {k: v.detach().float().cpu().numpy().copy() for k, v in model.state_dict().items()}
-    out.put((rank, losses, sd))
+    out.put((rank, losses, sd, grads))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,7 +62,7 @@ def test_real_model_ddp_two_ranks_equals_single_process():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, sd0), (_, l1, sd1) = results
+    (_, l0, sd0, g0), (_, l1, sd1, g1) = results
     assert l0 == l1, "the in-step all_reduce_mean(loss) must agree on every rank"
     for k in sd0:
         assert (sd0[k] == sd1[k]).all(), f"replicas diverged at {k}"
@@ -71,14 +75,17 @@ def test_real_model_ddp_two_ranks_equals_single_process():
     for s in range(STEPS):
         x = torch.cat([_batch(r, s) for r in range(world)], dim=0).to("cuda:0")
         loss = float(eng.step(x))
-        assert abs(loss - l0[s]) <= 2e-5 * max(1.0, abs(loss)), f"step {s}: loss {loss} vs DDP {l0[s]}"
-    worst = 0.0
-    for k, v in model.state_dict().items():
-        ref = torch.from_numpy(sd0[k])
-        err = float((v.float().cpu() - ref).abs().max())
-        scale = max(1e-3, float(ref.abs().max()))
-        worst = max(worst, err / scale)
-        # AdamW's first steps move every weight by ~lr whatever the gradient scale: sign flips of ~0 gradients are the only
-        # place float re-association (fp32 atomics, bucket order) can show, hence the lr-sized absolute term
-        assert err <= 2.5e-3 + 1e-3 * scale, f"{k}: max |diff| {err} (scale {scale})"
-    print(f"DDP(2 ranks) vs single process: worst relative parameter difference {worst:.2e}")
+        # step 0 starts from identical weights: only float re-association (fp32 atomics, bucket order) separates the two runs.
+        # Step 1 starts from weights that may differ by 2*lr where AdamW normalised a ~0 gradient of opposite sign.
+        tol = 2e-5 if s == 0 else 2e-3
+        assert abs(loss - l0[s]) <= tol * max(1.0, abs(loss)), f"step {s}: loss {loss} vs DDP {l0[s]}"
+        if s == 0:
+            worst = 0.0
+            for k, p in model.named_parameters():
+                ref = torch.from_numpy(g0[k])
+                err = float((p.grad.float().cpu() - ref).abs().max())
+                scale = max(1e-6, float(ref.abs().max()))
+                worst = max(worst, err / scale)
+                assert err <= 2e-4 * scale + 1e-7, f"grad {k}: max |diff| {err} (scale {scale})"
+                assert (g0[k] == g1[k]).all(), f"ranks hold different averaged gradients at {k}"
+            print(f"DDP(2 ranks) vs single process: worst relative gradient difference {worst:.2e}")
