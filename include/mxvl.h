@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 1
+#define MXVL_ABI_VERSION 2
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -115,6 +115,13 @@ typedef struct mxvl_scan_bwd_desc {
   void *du, *ddelta, *dz;   /* dz required iff fwd.z */
   void *dA, *dB, *dC;       /* fp32 accumulate */
   void *dD, *ddelta_bias;   /* fp32 accumulate; optional like their forward twins */
+  /* Optional scratch of >= mxvl_scan_bwd_workspace_bytes(&fwd) bytes (16-byte aligned, contents irrelevant).  dB / dC are
+   * sums over all channels of a group: with the scratch every workgroup stores its channel tile's share with plain
+   * coalesced stores and a second small kernel adds the tiles into dB / dC (deterministic, no atomics); without it (NULL
+   * or too small) the shares go out as fp32 global atomics, which the reference does too (selective_scan_bwd_kernel.cuh:
+   * 215-221) and which cost 16-22 % of the kernel on MI355X. */
+  void *workspace;
+  int64_t workspace_bytes;
 } mxvl_scan_bwd_desc;
 
 /* depthwise causal conv1d (+ optional SiLU): y[b,d,t] = act(bias[d] + sum_k w[d,k] * x[b,d,t-W+1+k]) */
@@ -189,6 +196,8 @@ int mxvl_scan_n_chunks(int seqlen, int dstate);
 
 int mxvl_scan_fwd(const mxvl_scan_desc *desc, void *hip_stream);
 int mxvl_scan_bwd(const mxvl_scan_bwd_desc *desc, void *hip_stream);
+/* bytes of mxvl_scan_bwd_desc.workspace that make the backward atomics-free for this problem; 0 = no scratch is useful */
+int64_t mxvl_scan_bwd_workspace_bytes(const mxvl_scan_desc *fwd);
 
 int mxvl_conv1d_fwd(const mxvl_conv1d_desc *desc, void *hip_stream);
 int mxvl_conv1d_bwd(const mxvl_conv1d_bwd_desc *desc, void *hip_stream);

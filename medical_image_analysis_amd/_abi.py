@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -28,6 +28,7 @@ STATUS = {
 # every symbol include/mxvl.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
     "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fwd", "mxvl_scan_bwd",
+    "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
@@ -62,6 +63,7 @@ class ScanBwdDesc(ctypes.Structure):
         ("dC_bs", c_int64), ("dC_gs", c_int64), ("dC_ns", c_int64),
         ("dout", c_void_p), ("du", c_void_p), ("ddelta", c_void_p), ("dz", c_void_p),
         ("dA", c_void_p), ("dB", c_void_p), ("dC", c_void_p), ("dD", c_void_p), ("ddelta_bias", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -166,6 +168,7 @@ def load() -> ctypes.CDLL:
     if lib.mxvl_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libmxvl.so ABI {lib.mxvl_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
+    lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
     for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

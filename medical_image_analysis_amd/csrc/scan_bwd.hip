@@ -35,6 +35,7 @@ struct ScanBwdArgs {
   const float *A, *D, *bias, *ckpt;
   void *du, *ddelta, *dz;
   float *dA, *dB, *dC, *dD, *dbias;
+  float* ws;   // optional dB/dC partials: [batch][gridDim.x][2 (dB, dC)][N][L] fp32, fully written (no atomics); see below
 };
 
 // forward inclusive scan + exclusive shift over a 16-lane DPP row (see scan_fwd.hip)
@@ -82,7 +83,7 @@ __device__ inline float row_sum_to_lane15(float v) {
   return v;
 }
 
-template <typename io_t, int NWAVES, bool VEC>
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NG = 2;
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
@@ -388,12 +389,27 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         for (int i = tid; i < 2 * NG * CH; i += NT) {
           const int which = i / (NG * CH), rem = i - which * (NG * CH);
           const int nn = rem / CH, e = rem - nn * CH;
-          float v = 0.0f;
+          // all DT row shares first (independent LDS reads in flight together), then a pairwise tree: the serial
+          // read-add chain this replaces was LDS-latency bound (5 reads in flight, 32 dependent adds)
+          float part[DT];
 #pragma unroll
-          for (int rr = 0; rr < DT; ++rr) v += sAcc[(rr * 2 + which) * NG * CH + rem];
+          for (int rr = 0; rr < DT; ++rr) part[rr] = sAcc[(rr * 2 + which) * NG * CH + rem];
+#pragma unroll
+          for (int w = DT / 2; w > 0; w >>= 1) {
+#pragma unroll
+            for (int rr = 0; rr < w; ++rr) part[rr] += part[rr + w];
+          }
+          const float v = part[0];
           if (n0 + nn <= n && t0 + e < L && !MXVL_ABL(p.ablate & 2)) {
-            float* dst = which ? dCp + (int64_t)(n0 + nn) * p.dC_ns : dBp + (int64_t)(n0 + nn) * p.dB_ns;
-            unsafeAtomicAdd(dst + t0 + e, v);
+            if constexpr (PARTIAL) {
+              // one plain coalesced store per (tile, n, t): the cross-tile sum is mxvl's second, tiny kernel
+              // (scan_bwd_reduce_kernel).  fp32 global atomics to the 32 tiles' shared (n, t) cells were 16-22 % of this kernel.
+              float* dst = p.ws + ((((int64_t)b * gridDim.x + blockIdx.x) * 2 + which) * N + (n0 + nn)) * (int64_t)L;
+              __builtin_nontemporal_store(v, dst + t0 + e);
+            } else {
+              float* dst = which ? dCp + (int64_t)(n0 + nn) * p.dC_ns : dBp + (int64_t)(n0 + nn) * p.dB_ns;
+              unsafeAtomicAdd(dst + t0 + e, v);
+            }
           }
         }
         __syncthreads();
@@ -441,14 +457,50 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   }
 }
 
+// dB/dC (batch, G, N, L) += sum over the `tiles` channel tiles of a group of the partials scan_bwd_kernel<PARTIAL> wrote.
+// One thread per 4 consecutive steps; the tile loop reads `tiles` coalesced slabs.
+struct ScanBwdReduceArgs {
+  int G, N, L, tiles, vec;
+  int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
+  const float* ws;
+  float *dB, *dC;
+};
+__global__ __launch_bounds__(256) void scan_bwd_reduce_kernel(const ScanBwdReduceArgs p) {
+  const int bg = blockIdx.z, b = bg / p.G, g = bg - b * p.G;
+  const int which = blockIdx.y / p.N, n = blockIdx.y - which * p.N;
+  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (t >= p.L) return;
+  const int64_t slab = (int64_t)2 * p.N * p.L;   // one tile's partials
+  const float* src = p.ws + ((int64_t)b * p.G * p.tiles + (int64_t)g * p.tiles) * slab + ((int64_t)which * p.N + n) * p.L + t;
+  float* dst = which ? p.dC + (int64_t)b * p.dC_bs + (int64_t)g * p.dC_gs + (int64_t)n * p.dC_ns + t
+                     : p.dB + (int64_t)b * p.dB_bs + (int64_t)g * p.dB_gs + (int64_t)n * p.dB_ns + t;
+  if (p.vec && t + 4 <= p.L) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < p.tiles; ++k) {
+      const float4 v = *(const float4*)(src + (int64_t)k * slab);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 o = *(float4*)dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *(float4*)dst = o;
+  } else {
+    for (int e = 0; e < 4 && t + e < p.L; ++e) {
+      float acc = 0.f;
+      for (int k = 0; k < p.tiles; ++k) acc += src[(int64_t)k * slab + e];
+      dst[e] += acc;
+    }
+  }
+}
+
 static thread_local int g_bwd_hip_error = 0;
 
-template <typename io_t, int NWAVES, bool VEC>
-static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
+static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)DT * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
@@ -458,17 +510,38 @@ static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  if constexpr (PARTIAL) {
+    ScanBwdReduceArgs r;
+    r.G = a.G; r.N = a.N; r.L = a.L; r.tiles = (dpg + DT - 1) / DT;
+    r.dB_bs = a.dB_bs; r.dB_gs = a.dB_gs; r.dB_ns = a.dB_ns; r.dC_bs = a.dC_bs; r.dC_gs = a.dC_gs; r.dC_ns = a.dC_ns;
+    r.ws = a.ws; r.dB = a.dB; r.dC = a.dC;
+    const int64_t ss[] = {a.dB_bs, a.dB_gs, a.dB_ns, a.dC_bs, a.dC_gs, a.dC_ns};
+    bool v = (a.L % 4 == 0) && ((uintptr_t)a.dB % 16 == 0) && ((uintptr_t)a.dC % 16 == 0) && ((uintptr_t)a.ws % 16 == 0);
+    for (int64_t x : ss) v = v && (x % 4 == 0);
+    r.vec = v ? 1 : 0;
+    dim3 rg((a.L + 1023) / 1024, 2 * a.N, a.batch * a.G);
+    hipLaunchKernelGGL(scan_bwd_reduce_kernel, rg, dim3(256), 0, stream, r);
+    e = hipGetLastError();
+    if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  }
   return MXVL_OK;
+}
+template <typename io_t, int NWAVES, bool VEC>
+static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false>(a, stream);
+}
+
+// 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it leaves the workgroup
+// at the same 8 waves per CU.  Used when 32-row tiles still give every CU a workgroup.
+static bool bwd_wide(int batch, int dim, int G) {
+  static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
+  const long tiles32 = (long)batch * G * ((dim / G + 31) / 32);
+  return forced ? forced == 8 : ((dim / G) % 32 == 0 && tiles32 >= 256);
 }
 
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
-  // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it goes out as global
-  // atomics (the atomics are ~1/3 of the kernel at 16 rows) at the same 8 waves per CU.  Used when 32-row tiles still
-  // give every CU a workgroup.
-  static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
-  const long tiles32 = (long)a.batch * a.G * ((a.dim / a.G + 31) / 32);
-  const bool wide = forced ? forced == 8 : ((a.dim / a.G) % 32 == 0 && tiles32 >= 256);
+  const bool wide = bwd_wide(a.batch, a.dim, a.G);
   if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
   return a.vec_ok ? launch_bwd<io_t, 4, true>(a, stream) : launch_bwd<io_t, 4, false>(a, stream);
 }
@@ -478,6 +551,15 @@ static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
 using namespace mxvl;
 
 extern "C" int mxvl_scan_check(const mxvl_scan_desc* d);
+
+extern "C" int64_t mxvl_scan_bwd_workspace_bytes(const mxvl_scan_desc* f) {
+  if (mxvl_scan_check(f) != MXVL_OK || f->dstate > 64) return 0;
+  const int DT = bwd_wide(f->batch, f->dim, f->n_groups) ? 32 : 16;
+  const int64_t tiles = (f->dim / f->n_groups + DT - 1) / DT;
+  if (tiles < 2) return 0;   // one tile per group: nothing to reduce across workgroups
+  const int64_t bytes = (int64_t)f->batch * f->n_groups * tiles * 2 * f->dstate * (int64_t)f->seqlen * 4;
+  return bytes <= ((int64_t)4 << 30) ? bytes : 0;
+}
 
 extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   if (!d) return MXVL_ERR_NULL;
@@ -503,6 +585,10 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.A = (const float*)f->A; a.D = (const float*)f->D; a.bias = (const float*)f->delta_bias; a.ckpt = (const float*)f->ckpt;
   a.du = d->du; a.ddelta = d->ddelta; a.dz = d->dz;
   a.dA = (float*)d->dA; a.dB = (float*)d->dB; a.dC = (float*)d->dC; a.dD = (float*)d->dD; a.dbias = (float*)d->ddelta_bias;
+  {
+    const int64_t need = mxvl_scan_bwd_workspace_bytes(f);
+    a.ws = (d->workspace && need > 0 && d->workspace_bytes >= need) ? (float*)d->workspace : nullptr;
+  }
   a.dl_ratio = f->delta_group_ratio > 1 ? f->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;

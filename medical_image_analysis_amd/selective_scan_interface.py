@@ -139,6 +139,9 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
     return out, last, ckpt
 
 
+USE_BWD_WORKSPACE = True   # tools / tests flip this to exercise the atomic path of mxvl_scan_bwd
+
+
 def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout):
     """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C)."""
     lib = _abi.load()
@@ -167,6 +170,10 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     desc.dout, desc.du, desc.ddelta, desc.dz = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), _abi.ptr(dz)
     desc.dA, desc.dB, desc.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     desc.dD, desc.ddelta_bias = _abi.ptr(dD), _abi.ptr(dbias)
+    # scratch for the per-tile dB / dC shares (plain stores + a second small kernel instead of fp32 global atomics)
+    ws_bytes = int(lib.mxvl_scan_bwd_workspace_bytes(ctypes.byref(desc.fwd))) if USE_BWD_WORKSPACE else 0
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=u.device) if ws_bytes > 0 else None
+    desc.workspace, desc.workspace_bytes = _abi.ptr(ws), ws_bytes
     timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
         if timers is not None:

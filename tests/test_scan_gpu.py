@@ -279,6 +279,40 @@ def test_scan_bwd_half_io():
         assert_close(got[k], r, 5e-2 * scale * 0.2, 6e-2, k)
 
 
+def test_scan_bwd_workspace_and_atomic_paths_agree():
+    """mxvl_scan_bwd with the dB/dC scratch (plain per-tile stores + scan_bwd_reduce_kernel) and without it (fp32 global
+    atomics) on a multi-tile, grouped, ragged-length problem: same gradients, and both equal the oracle."""
+    import medical_image_analysis_amd.selective_scan_interface as ssi
+    from oracle import oracle as orc
+    dev = _dev()
+    B, D, L, N, G = 2, 192, 333, 8, 2
+    cpu = scan_inputs(B, D, L, N, G, True, True, True, seed=21)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(22))
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], True, dout)
+    x = _to(cpu, dev)
+    got = {}
+    for flag in (True, False):
+        ssi.USE_BWD_WORKSPACE = flag
+        try:
+            got[flag] = _grads_via_autograd(x, True, dout.to(dev))
+        finally:
+            ssi.USE_BWD_WORKSPACE = True
+    from medical_image_analysis_amd import _abi
+    import ctypes
+    desc = _abi.ScanDesc()
+    ssi._fill_fwd(desc, x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, None, None, None)
+    need = int(_abi.load().mxvl_scan_bwd_workspace_bytes(ctypes.byref(desc)))
+    assert need == B * G * (D // G // 16) * 2 * N * L * 4, "16-row tiles here: 6 tiles per group"
+    for k, r in ref.items():
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(got[True][k], r, 2e-5 * scale, 1e-4, k + " (workspace path)")
+        assert_close(got[False][k], r, 2e-5 * scale, 1e-4, k + " (atomic path)")
+    # the workspace path sums in a fixed order: bit-reproducible dB / dC
+    again = _grads_via_autograd(x, True, dout.to(dev))
+    assert torch.equal(again["dB"], got[True]["dB"]) and torch.equal(again["dC"], got[True]["dC"])
+
+
 def test_scan_bwd_linearity_full_size():
     """Size-independent property at BASELINE configs[1] full size: the gradient is linear in dout."""
     dev = _dev()
