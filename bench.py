@@ -74,6 +74,10 @@ WORKLOADS = {
                         "north_star roofline shape: selective-scan forward B=8 L=4096 D=1536 N=16 (z, D, delta_bias, softplus)"),
     "scan_fwd_target_bf16": (8, 1536, 4096, 16, "bfloat16",
                              "north_star roofline shape with bf16 io: B=8 L=4096 D=1536 N=16"),
+    # the dominant hand-written kernel of the default workload, alone: same shape, dtype and entry point (mxvl_scan_bwd) as the
+    # 24 launches per step of arm_pretrain_large_1024 at per-GPU batch 16 -- what the PMC traffic passes are taken on
+    "scan_bwd_pretrain": (16, 1024, 4080, 16, "bfloat16",
+                          "selective-scan BACKWARD of the ARM-large 1024x1024 pre-training step: B=16 L=4080 D=1024 N=16 bf16 io"),
 }
 PRETRAIN_WORKLOADS = {
     # name: (img, patch, embed_dim, depth, dec_dim, per-GPU batch, description)
@@ -346,7 +350,8 @@ def run_pretrain(args, rank, world, dev, dist):
                      "algorithmic_bytes_per_launch": tot_bytes // calls,
                      "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}},
     }
-    attach_traffic(out["roofline"], args.workload)
+    attach_traffic(out["roofline"], "scan_bwd_pretrain" if (kind == "scan_bwd" and args.workload == DEFAULT_WORKLOAD and B == 16)
+                   else args.workload)
     if secondary is not None:
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                       "dtype", "config", "roofline")}
@@ -574,6 +579,12 @@ def main():
     dtype = getattr(torch, dtname)
     x = make_scan_inputs(B, D, L, N, dtype, dev, seed=rank)
     step = lambda: scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True)
+    backward = args.workload.startswith("scan_bwd")
+    if backward:
+        from medical_image_analysis_amd.selective_scan_interface import scan_algorithmic_bytes, scan_bwd_raw
+        _, _, ckpt = scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, want_ckpt=True)
+        dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(7 + rank)).to(dev, dtype)
+        step = lambda: scan_bwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, ckpt, dout)
 
     for _ in range(args.warmup):
         step()
@@ -602,6 +613,8 @@ def main():
         images = B * world * args.steps
         elt = torch.empty((), dtype=dtype).element_size()
         nbytes = scan_bytes(B, D, L, N, 1, elt)
+        if backward:
+            nbytes = scan_algorithmic_bytes(B, D, L, N, 1, elt, True, True, ckpt.shape[2])
         achieved = nbytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "images/sec (one image = one (D x L) patch-token sequence through the selective scan)",
@@ -614,11 +627,12 @@ def main():
                        "kernel": _abi.load().mxvl_last_scan_kernel().decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scan_fwd_stream_kernel", "algorithmic_bytes_per_launch": nbytes,
-                         "kernel_ms": kern_ms},
+                         "kernel": ("scan_bwd_kernel + scan_bwd_reduce_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
+                                    if backward else "scan_fwd_stream_kernel"),
+                         "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms},
         }
         attach_traffic(out["roofline"], args.workload)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not backward:
             out["cpu_baseline"] = cpu_baseline_scan(B, D, L, N)
         print(json.dumps(out))
     if dist is not None:
