@@ -139,7 +139,10 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
     return out, last, ckpt
 
 
-USE_BWD_WORKSPACE = True   # tools / tests flip this to exercise the atomic path of mxvl_scan_bwd
+# dB / dC across channel tiles: False = fp32 global atomics (default: measured FASTER on MI355X -- 1.34 ms vs 1.47 ms at the
+# pre-training shape, profiles/r02_bwd_workspace_ab.txt: the atomics are asynchronous and the 267 MB of partials are not free);
+# True = per-tile plain stores into a scratch + scan_bwd_reduce_kernel (bit-reproducible dB / dC, no atomics).
+USE_BWD_WORKSPACE = False
 
 
 def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout):

@@ -297,7 +297,7 @@ def test_scan_bwd_workspace_and_atomic_paths_agree():
         try:
             got[flag] = _grads_via_autograd(x, True, dout.to(dev))
         finally:
-            ssi.USE_BWD_WORKSPACE = True
+            ssi.USE_BWD_WORKSPACE = False
     from medical_image_analysis_amd import _abi
     import ctypes
     desc = _abi.ScanDesc()
@@ -309,7 +309,11 @@ def test_scan_bwd_workspace_and_atomic_paths_agree():
         assert_close(got[True][k], r, 2e-5 * scale, 1e-4, k + " (workspace path)")
         assert_close(got[False][k], r, 2e-5 * scale, 1e-4, k + " (atomic path)")
     # the workspace path sums in a fixed order: bit-reproducible dB / dC
-    again = _grads_via_autograd(x, True, dout.to(dev))
+    ssi.USE_BWD_WORKSPACE = True
+    try:
+        again = _grads_via_autograd(x, True, dout.to(dev))
+    finally:
+        ssi.USE_BWD_WORKSPACE = False
     assert torch.equal(again["dB"], got[True]["dB"]) and torch.equal(again["dC"], got[True]["dC"])
 
 
