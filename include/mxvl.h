@@ -331,6 +331,48 @@ int mxvl_resample_ksize(int in_size, int out_size, int filter);
 int mxvl_resample_coeffs(int in_size, int out_size, int filter, int32_t *bounds, int32_t *kk);
 int mxvl_image_preprocess(const mxvl_image_desc *desc, void *hip_stream);
 
+/* Fused multi-head attention, forward and backward, on the matrix cores (csrc/attn.hip): out = softmax(q k^T * scale + mask) v
+ * without materialising the (seqlen_q x seqlen_k) scores.  Replaces the score-matrix attention of
+ *   CXPMRG_Bench_MambaXray_VL/pretrain/models_pretrain.py:55-83 (CrossAttention + the block-causal mask of :395-400),
+ *   HD_Xray_Pretrain_MAE/finetune/DP/models/vit.py:141-163 (ViT / MAE blocks),
+ *   EMRRG/models/hybrid_decoder_layer.py:25-77 (text -> image cross-attention, boolean key mask) and :392-457 (causal GQA).
+ * q (batch, n_heads, seqlen_q, head_dim), k / v (batch, n_kv_heads, seqlen_k, head_dim), out like q: element strides for
+ * batch / head / token, head_dim contiguous, every row 16-byte aligned (so any (B, L, H, D) / (B, H, L, D) view works without
+ * a copy).  head_dim 32 / 64 (forward and backward) or 128 (forward only); io dtype fp32 (exact fp32 MFMA) / bf16 / fp16.
+ * mask_mode: 0 none; 1 causal: key j visible to query i iff j <= i + seqlen_k - seqlen_q; 2 block-causal: iff
+ * j / cluster <= i / cluster (mask_generate's block-lower-triangular mask with 16-token clusters).  key_mask: optional
+ * (batch, seqlen_k) bytes, nonzero = may be attended.  bias: optional additive fp32 (seqlen_q, seqlen_k), broadcast over
+ * batch and heads (generic slow path for masks that are none of the above).
+ * lse: (batch, n_heads, seqlen_q) fp32 log2-domain log-sum-exp of the scaled logits (+inf for a row with no visible key, whose
+ * output is 0); optional for inference, required for mxvl_attn_bwd, which also needs `delta` scratch of the same shape. */
+typedef struct mxvl_attn_desc {
+  int32_t batch, n_heads, n_kv_heads, seqlen_q, seqlen_k, head_dim;
+  int32_t io_dtype;  /* mxvl_dtype */
+  int32_t mask_mode, cluster;
+  float scale;
+  int64_t q_bs, q_hs, q_ts;
+  int64_t k_bs, k_hs, k_ts;
+  int64_t v_bs, v_hs, v_ts;
+  int64_t o_bs, o_hs, o_ts;
+  const void *q, *k, *v;
+  void *out;
+  void *lse;
+  const void *key_mask;
+  const void *bias;
+} mxvl_attn_desc;
+typedef struct mxvl_attn_bwd_desc {
+  mxvl_attn_desc fwd;   /* fwd.out and fwd.lse as the forward call left them */
+  int64_t dout_bs, dout_hs, dout_ts;
+  int64_t dq_bs, dq_hs, dq_ts;
+  int64_t dk_bs, dk_hs, dk_ts;
+  int64_t dv_bs, dv_hs, dv_ts;
+  const void *dout;
+  void *dq, *dk, *dv;   /* io dtype, fully written; dk / dv are (batch, n_kv_heads, seqlen_k, head_dim): summed over the group */
+  void *delta;          /* (batch, n_heads, seqlen_q) fp32 scratch */
+} mxvl_attn_bwd_desc;
+int mxvl_attn_fwd(const mxvl_attn_desc *desc, void *hip_stream);
+int mxvl_attn_bwd(const mxvl_attn_bwd_desc *desc, void *hip_stream);
+
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
 /* Forward-scan kernel selection for tests / A-B measurements: 0 = automatic, 1..255 = force one of the (equally correct)

@@ -35,7 +35,7 @@ SYMBOLS = [
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
-    "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess",
+    "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd",
 ]
 
 
@@ -64,6 +64,26 @@ class ScanBwdDesc(ctypes.Structure):
         ("dout", c_void_p), ("du", c_void_p), ("ddelta", c_void_p), ("dz", c_void_p),
         ("dA", c_void_p), ("dB", c_void_p), ("dC", c_void_p), ("dD", c_void_p), ("ddelta_bias", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+    ]
+
+
+class AttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("seqlen_q", c_int32), ("seqlen_k", c_int32),
+        ("head_dim", c_int32), ("io_dtype", c_int32), ("mask_mode", c_int32), ("cluster", c_int32), ("scale", ctypes.c_float),
+        ("q_bs", c_int64), ("q_hs", c_int64), ("q_ts", c_int64), ("k_bs", c_int64), ("k_hs", c_int64), ("k_ts", c_int64),
+        ("v_bs", c_int64), ("v_hs", c_int64), ("v_ts", c_int64), ("o_bs", c_int64), ("o_hs", c_int64), ("o_ts", c_int64),
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("key_mask", c_void_p),
+        ("bias", c_void_p),
+    ]
+
+
+class AttnBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("fwd", AttnDesc),
+        ("dout_bs", c_int64), ("dout_hs", c_int64), ("dout_ts", c_int64), ("dq_bs", c_int64), ("dq_hs", c_int64), ("dq_ts", c_int64),
+        ("dk_bs", c_int64), ("dk_hs", c_int64), ("dk_ts", c_int64), ("dv_bs", c_int64), ("dv_hs", c_int64), ("dv_ts", c_int64),
+        ("dout", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p), ("delta", c_void_p),
     ]
 
 
@@ -169,7 +189,8 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(f"libmxvl.so ABI {lib.mxvl_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
     lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
-    for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn"):
+    for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn",
+                 "mxvl_attn_fwd", "mxvl_attn_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_conv1d_update.restype = c_int

@@ -1,0 +1,584 @@
+// attn.hip -- fused (flash-style) multi-head attention forward + backward on the gfx950 matrix cores.
+//
+// Replaces, for every attention on the MambaXray-VL hot path, the score-matrix implementations of the reference:
+//   CXPMRG_Bench_MambaXray_VL/pretrain/models_pretrain.py:55-83   CrossAttention (softmax(q k^T * scale + mask) v) with the
+//                                                                 block-lower-triangular mask of mask_generate (:395-400,
+//                                                                 16-token clusters) -- 4 decoder blocks, 4080 tokens
+//   HD_Xray_Pretrain_MAE/finetune/DP/models/vit.py:141-163        ViT / MAE self-attention (dense)
+//   EMRRG/models/hybrid_decoder_layer.py:25-77, 392-457           causal self-attention (GQA) and text->image cross-attention
+//                                                                 with a boolean key mask
+// No (Lq x Lk) matrix ever reaches HBM: one workgroup owns 128 query rows (4 waves x 32), walks the key/value sequence in
+// 64-key tiles staged in LDS, keeps the running (max, sum) of the online softmax and the output accumulator in registers.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_{bf16,f16}; v_mfma_f32_32x32x2_f32 for fp32 inputs -- exact fp32, used by the fp32
+// parity tests).  Everything is computed TRANSPOSED so that a lane owns one query (forward, dQ) or one key (dK/dV):
+//   S^T[key][q]  = sum_d K[key][d] Q[q][d]      A = K rows from LDS (16-byte reads, XOR-swizzled), B = Q fragments in registers
+//   O^T[d][q]   += sum_key V[key][d] P[q][key]  A = V^T through ds_read_b64_tr_b16 (hardware transpose read of the row-major
+//                                               V tile), B = P straight from the S^T accumulator registers
+// C/D layout of the 32x32 MFMA: lane l, register r holds row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 -- so lane l and
+// lane l^32 together hold the 32 scores of query (l&31) against a 32-key half tile; row max / sum are 16 in-register ops
+// plus one exchange with lane l^32, and the rescale of O by exp2(m_old - m_new) is lane-local.  The B operand of the
+// second product needs, for k-slot (l>>5, e), the score of "some" key: the accumulator registers are used as they are
+// (slot e of step s <-> register 8s+e) and the V^T operand is simply read at the key rows those registers belong to,
+// which removes the cvt/permlane shuffle a row-major P would need.
+//
+// Backward (no atomics, two kernels over the same primitives; P is recomputed from the saved log-sum-exp):
+//   attn_bwd_dq_kernel   per query tile:  delta = rowsum(dO * O);  dS^T = P^T * (V dO^T - delta);  dQ^T += K^T dS^T
+//   attn_bwd_dkv_kernel  per key tile (loops over the query heads of its KV group and their query tiles):
+//                        dV^T += dO^T P,  dS = P * (dO V^T - delta),  dK^T += Q^T dS
+// Masks: none, causal (key <= query + Lk - Lq), block-causal (key cluster <= query cluster), optional (batch, Lk) key
+// mask and optional additive (Lq, Lk) fp32 bias (generic slow path).  Tiles wholly above the diagonal are never visited.
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct AttnArgs {
+  int batch, H, Hkv, Lq, Lk, mask_mode, cluster;
+  float scale;
+  int64_t q_bs, q_hs, q_ts, k_bs, k_hs, k_ts, v_bs, v_hs, v_ts, o_bs, o_hs, o_ts;
+  int64_t do_bs, do_hs, do_ts, dq_bs, dq_hs, dq_ts, dk_bs, dk_hs, dk_ts, dv_bs, dv_hs, dv_ts;
+  const void *q, *k, *v, *o, *dout;
+  void *out, *dq, *dk, *dv;
+  float *lse, *delta;          // (batch, H, Lq)
+  const uint8_t* kmask;        // (batch, Lk), nonzero = attend
+  const float* bias;           // (Lq, Lk) additive, broadcast over batch and heads
+};
+
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+constexpr float kNegInf = -__builtin_inff();
+
+// ---- operand policies -------------------------------------------------------------------------------------------------
+template <typename E> struct Pol16 {
+  static constexpr int KSTEP = 16, ESZ = 2;
+  typedef uint4 Frag;
+  static __device__ __forceinline__ Frag zero() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
+    if constexpr (sizeof(E) == 2 && __is_same(E, bf16_t))
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static constexpr int tile_bytes(int rows, int D) { return rows * D * 2; }
+  // byte offset of 16-byte unit u of a row: XOR swizzle so that 32 rows read at one unit spread over the LDS banks
+  template <int D> static __device__ __forceinline__ int unit_off(int row, int u) {
+    constexpr int UPR = D / 8, M = (UPR < 8 ? UPR : 8) - 1;
+    return row * (D * 2) + ((u ^ (row & M)) << 4);
+  }
+  // A operand, row-major rows: lane (row, hi) takes elements [16 ks + 8 hi, +8) of its row
+  template <int D> static __device__ __forceinline__ Frag a_row(const char* tile, int row, int ks, int hi) {
+    return *(const uint4*)(tile + unit_off<D>(row, 2 * ks + hi));
+  }
+  // A operand, TRANSPOSED: lane (c = lane & 31, hi) takes column dbase + c of the 8 rows that accumulator registers
+  // 8 ks .. 8 ks + 7 of lane half `hi` stand for: rbase + 16 ks + 4 hi + {0..3} and the same + 8.
+  // ds_read_b64_tr_b16: within each 16-lane group lane t' supplies the address of row (t' >> 2), columns 4 (t' & 3) .. + 3 of
+  // a [4][16] block and receives column t' of its 4 rows.
+  template <int D> static __device__ __forceinline__ Frag a_tr(const char* tile, int rbase, int ks, int hi, int dbase, int lane) {
+    const int t = lane & 15, g = (lane >> 4) & 1;
+    const int col = dbase + 16 * g + 4 * (t & 3);
+    const int r0 = rbase + 16 * ks + 4 * hi + (t >> 2);
+    const int inner = (col & 7) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(tile + unit_off<D>(r0, col >> 3) + inner));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(tile + unit_off<D>(r0 + 8, col >> 3) + inner));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi4);
+    return make_uint4(a.x, a.y, b.x, b.y);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (__is_same(E, bf16_t)) return cvt_pk_bf16(a, b);
+    else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      return __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b});
+    }
+  }
+  // B operand from accumulator registers 8 ks .. 8 ks + 7
+  static __device__ __forceinline__ Frag b_from_acc(const f32x16& a, int ks) {
+    const int o = 8 * ks;
+    return make_uint4(pack2(a[o], a[o + 1]), pack2(a[o + 2], a[o + 3]), pack2(a[o + 4], a[o + 5]), pack2(a[o + 6], a[o + 7]));
+  }
+  static __device__ __forceinline__ Frag ldg(const E* row, int ks, int hi) { return *(const uint4*)(row + 16 * ks + 8 * hi); }
+  static __device__ __forceinline__ float el(uint32_t w, int i) {
+    if constexpr (__is_same(E, bf16_t)) return __builtin_bit_cast(float, i ? (w & 0xffff0000u) : (w << 16));
+    else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 v = __builtin_bit_cast(h2, w);
+      return (float)(i ? v.y : v.x);
+    }
+  }
+  static __device__ __forceinline__ float dot(Frag a, Frag b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = fmaf(el(x[i], 0), el(y[i], 0), fmaf(el(x[i], 1), el(y[i], 1), s));
+    return s;
+  }
+  // global [rows x D] (row stride ts elements) -> swizzled LDS tile; rows >= nvalid are zero-filled
+  template <int D, int ROWS, int NT> static __device__ __forceinline__ void stage(char* tile, const E* base, int64_t ts, int nvalid, int tid) {
+    constexpr int UPR = D / 8;
+#pragma unroll
+    for (int c = tid; c < ROWS * UPR; c += NT) {
+      const int row = c / UPR, u = c % UPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < nvalid) v = *(const uint4*)(base + (int64_t)row * ts + u * 8);
+      *(uint4*)(tile + unit_off<D>(row, u)) = v;
+    }
+  }
+  // 4 consecutive output elements
+  static __device__ __forceinline__ void st4(E* p, float a, float b, float c, float d) { *(uint2*)p = make_uint2(pack2(a, b), pack2(c, d)); }
+};
+
+struct Pol32 {
+  static constexpr int KSTEP = 2, ESZ = 4;
+  typedef float Frag;
+  static __device__ __forceinline__ Frag zero() { return 0.f; }
+  static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  static constexpr int tile_bytes(int rows, int D) { return rows * (D + 1) * 4; }   // +1 float: column reads hit 32 banks
+  template <int D> static __device__ __forceinline__ Frag a_row(const char* tile, int row, int ks, int hi) {
+    return ((const float*)tile)[row * (D + 1) + 2 * ks + hi];
+  }
+  template <int D> static __device__ __forceinline__ Frag a_tr(const char* tile, int rbase, int ks, int hi, int dbase, int lane) {
+    return ((const float*)tile)[(rbase + crow(ks, hi)) * (D + 1) + dbase + (lane & 31)];
+  }
+  static __device__ __forceinline__ Frag b_from_acc(const f32x16& a, int ks) { return a[ks]; }
+  static __device__ __forceinline__ Frag ldg(const float* row, int ks, int hi) { return row[2 * ks + hi]; }
+  static __device__ __forceinline__ float dot(Frag a, Frag b) { return a * b; }
+  template <int D, int ROWS, int NT> static __device__ __forceinline__ void stage(char* tile, const float* base, int64_t ts, int nvalid, int tid) {
+    constexpr int QPR = D / 4;
+    float* t = (float*)tile;
+#pragma unroll
+    for (int c = tid; c < ROWS * QPR; c += NT) {
+      const int row = c / QPR, u = c % QPR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nvalid) v = *(const float4*)(base + (int64_t)row * ts + u * 4);
+      float* d = t + row * (D + 1) + u * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
+};
+
+template <typename E> struct PolOf { typedef Pol16<E> type; };
+template <> struct PolOf<float> { typedef Pol32 type; };
+
+__device__ __forceinline__ float xchg32(float v) { return __shfl_xor(v, 32, 64); }
+
+// key limit of a query row: keys [0, klim) may be attended (before the optional key mask / bias)
+__device__ __forceinline__ int key_limit(const AttnArgs& p, int qrow) {
+  if (qrow >= p.Lq) return 0;
+  int lim = p.Lk;
+  if (p.mask_mode == 1) lim = qrow + (p.Lk - p.Lq) + 1;
+  else if (p.mask_mode == 2) lim = (qrow / p.cluster + 1) * p.cluster;
+  return lim < 0 ? 0 : (lim > p.Lk ? p.Lk : lim);
+}
+
+constexpr int kKT = 64;   // keys per staged tile (forward, dQ) / queries per staged tile (dK/dV)
+
+// ---- forward ----------------------------------------------------------------------------------------------------------
+// DQ = false: O, lse.   DQ = true: the dQ pass of the backward (same walk over the key tiles).
+template <typename E, int D, int NW, bool DQ>
+__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
+  typedef typename PolOf<E>::type Pol;
+  typedef typename Pol::Frag Frag;
+  constexpr int QT = NW * 32, KT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + Pol::tile_bytes(KT, D);
+  float* sMask = (float*)(sV + Pol::tile_bytes(KT, D));   // [KT] 0 / -inf from the key mask
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.H / p.Hkv);
+  const int qt = p.mask_mode ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // long rows first
+  const int q0 = qt * QT, qrow = q0 + wave * 32 + j;
+  const bool qv = qrow < p.Lq;
+  const int64_t qr = qv ? qrow : 0;
+  const float c = p.scale * kLog2e;
+
+  const E* qp = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + qr * p.q_ts;
+  Frag qf[NKD];
+#pragma unroll
+  for (int ks = 0; ks < NKD; ++ks) qf[ks] = qv ? Pol::ldg(qp, ks, hi) : Pol::zero();
+  Frag dof[DQ ? NKD : 1];
+  float lse = 0.f, delta = 0.f;
+  if constexpr (DQ) {
+    const E* dop = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)h * p.do_hs + qr * p.do_ts;
+    const E* op = (const E*)p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + qr * p.o_ts;
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) {
+      dof[ks] = qv ? Pol::ldg(dop, ks, hi) : Pol::zero();
+      const Frag of = qv ? Pol::ldg(op, ks, hi) : Pol::zero();
+      delta += Pol::dot(dof[ks], of);
+    }
+    delta += xchg32(delta);
+    const int64_t ro = ((int64_t)b * p.H + h) * p.Lq + qr;
+    lse = qv ? p.lse[ro] : __builtin_inff();
+    if (qv && hi == 0) p.delta[ro] = delta;
+  }
+
+  const int klim = key_limit(p, qrow);
+  const int qlast = (q0 + QT < p.Lq ? q0 + QT : p.Lq) - 1;
+  const int kend = key_limit(p, qlast);            // limits grow with the row index in every mask mode
+  const int kfull = key_limit(p, q0);              // keys below this are visible to every row of the workgroup
+  const bool extra = p.kmask != nullptr || p.bias != nullptr;
+  const int ntiles = (kend + KT - 1) / KT;
+
+  const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+
+  f32x16 acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  float m = kNegInf, l = 0.f;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();
+    Pol::template stage<D, KT, NT>(sK, kb + (int64_t)k0 * p.k_ts, p.k_ts, p.Lk - k0, tid);
+    Pol::template stage<D, KT, NT>(sV, vb + (int64_t)k0 * p.v_ts, p.v_ts, p.Lk - k0, tid);
+    if (p.kmask && tid < KT) sMask[tid] = (k0 + tid < p.Lk && p.kmask[(int64_t)b * p.Lk + k0 + tid]) ? 0.f : kNegInf;
+    __syncthreads();
+
+    f32x16 s[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[h2][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKD; ++ks) s[h2] = Pol::mma(Pol::template a_row<D>(sK, 32 * h2 + j, ks, hi), qf[ks], s[h2]);
+    }
+    // logits in the log2 domain
+    const bool masked = extra || (k0 + KT > kfull);
+    if (masked) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = 32 * h2 + crow(r, hi), key = k0 + kl;
+          float x = s[h2][r] * c;
+          if (p.bias && qv && key < p.Lk) x = fmaf(p.bias[qr * p.Lk + key], kLog2e, x);
+          if (p.kmask) x += sMask[kl];
+          s[h2][r] = key < klim ? x : kNegInf;
+        }
+    } else {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[h2][r] *= c;
+    }
+
+    if constexpr (!DQ) {
+      float mx = kNegInf;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[h2][r]);
+      mx = fmaxf(mx, xchg32(mx));
+      const float mn = fmaxf(m, mx);
+      const float mu = (mn == kNegInf) ? 0.f : mn;
+      const float alpha = fast_exp2(m - mu);
+      float rs = 0.f;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(s[h2][r] - mu);
+          s[h2][r] = pv;
+          rs += pv;
+        }
+      rs += xchg32(rs);
+      l = fmaf(l, alpha, rs);
+      m = mn;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+      }
+      // O^T += V^T P^T
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int ks = 0; ks < NKR; ++ks) {
+          const Frag pb = Pol::b_from_acc(s[h2], ks);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+            acc[dt] = Pol::mma(Pol::template a_tr<D>(sV, 32 * h2, ks, hi, 32 * dt, lane), pb, acc[dt]);
+        }
+    } else {
+      // P^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        f32x16 dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) dp = Pol::mma(Pol::template a_row<D>(sV, 32 * h2 + j, ks, hi), dof[ks], dp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(s[h2][r] - lse);     // masked: exp2(-inf) = 0; rows without keys: lse = +inf
+          s[h2][r] = pv * (dp[r] - delta);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKR; ++ks) {
+          const Frag db = Pol::b_from_acc(s[h2], ks);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+            acc[dt] = Pol::mma(Pol::template a_tr<D>(sK, 32 * h2, ks, hi, 32 * dt, lane), db, acc[dt]);
+        }
+      }
+    }
+  }
+
+  if (!qv) return;
+  if constexpr (!DQ) {
+    const float inv = l > 0.f ? fast_rcp(l) : 0.f;
+    E* op = (E*)p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + qr * p.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        Pol::st4(op + 32 * dt + 8 * g + 4 * hi, acc[dt][4 * g] * inv, acc[dt][4 * g + 1] * inv, acc[dt][4 * g + 2] * inv, acc[dt][4 * g + 3] * inv);
+    if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qr] = l > 0.f ? m + fast_log2(l) : __builtin_inff();
+  } else {
+    E* dqp = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)h * p.dq_hs + qr * p.dq_ts;
+    const float sc = p.scale;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        Pol::st4(dqp + 32 * dt + 8 * g + 4 * hi, acc[dt][4 * g] * sc, acc[dt][4 * g + 1] * sc, acc[dt][4 * g + 2] * sc, acc[dt][4 * g + 3] * sc);
+  }
+}
+
+// ---- dK / dV ----------------------------------------------------------------------------------------------------------
+template <typename E, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  typedef typename PolOf<E>::type Pol;
+  typedef typename Pol::Frag Frag;
+  constexpr int KTW = NW * 32, QT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sdO = smem + Pol::tile_bytes(QT, D);
+  float* sLse = (float*)(sdO + Pol::tile_bytes(QT, D));   // [QT]
+  float* sDelta = sLse + QT;                               // [QT]
+  int* sKlim = (int*)(sDelta + QT);                        // [QT] key limit of every staged query row (0: row not valid)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, hk = blockIdx.y, grp = p.H / p.Hkv;
+  const int kk0 = blockIdx.x * KTW, krow = kk0 + wave * 32 + j;
+  const bool kv = krow < p.Lk;
+  const int64_t kr = kv ? krow : 0;
+  const float c = p.scale * kLog2e;
+  const bool key_on = kv && (!p.kmask || p.kmask[(int64_t)b * p.Lk + kr] != 0);
+
+  const E* kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs + kr * p.k_ts;
+  const E* vp = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs + kr * p.v_ts;
+  Frag kf[NKD], vf[NKD];
+#pragma unroll
+  for (int ks = 0; ks < NKD; ++ks) {
+    kf[ks] = kv ? Pol::ldg(kp, ks, hi) : Pol::zero();
+    vf[ks] = kv ? Pol::ldg(vp, ks, hi) : Pol::zero();
+  }
+  f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+
+  // first query row that can see a key of this tile (its own first key kk0)
+  int qfirst = 0;
+  if (p.mask_mode == 1) qfirst = kk0 - (p.Lk - p.Lq);
+  else if (p.mask_mode == 2) qfirst = (kk0 / p.cluster) * p.cluster;
+  if (qfirst < 0) qfirst = 0;
+  const int qt0 = qfirst / QT, nqt = (p.Lq + QT - 1) / QT;
+
+  for (int hq = hk * grp; hq < (hk + 1) * grp; ++hq) {
+    const E* qb = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)hq * p.q_hs;
+    const E* dob = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)hq * p.do_hs;
+    const int64_t ro = ((int64_t)b * p.H + hq) * p.Lq;
+    for (int qt = qt0; qt < nqt; ++qt) {
+      const int q0 = qt * QT;
+      __syncthreads();
+      Pol::template stage<D, QT, NT>(sQ, qb + (int64_t)q0 * p.q_ts, p.q_ts, p.Lq - q0, tid);
+      Pol::template stage<D, QT, NT>(sdO, dob + (int64_t)q0 * p.do_ts, p.do_ts, p.Lq - q0, tid);
+      if (tid < QT) {
+        const int q = q0 + tid;
+        const bool ok = q < p.Lq;
+        sLse[tid] = ok ? p.lse[ro + q] : __builtin_inff();
+        sDelta[tid] = ok ? p.delta[ro + q] : 0.f;
+        sKlim[tid] = key_limit(p, q);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) {
+          s = Pol::mma(Pol::template a_row<D>(sQ, 32 * h2 + j, ks, hi), kf[ks], s);
+          dp = Pol::mma(Pol::template a_row<D>(sdO, 32 * h2 + j, ks, hi), vf[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = 32 * h2 + crow(r, hi);
+          float x = s[r] * c;
+          if (p.bias && q0 + ql < p.Lq && kv) x = fmaf(p.bias[(int64_t)(q0 + ql) * p.Lk + kr], kLog2e, x);
+          const bool on = key_on && krow < sKlim[ql];
+          const float pv = on ? fast_exp2(x - sLse[ql]) : 0.f;
+          s[r] = pv;
+          dp[r] = pv * (dp[r] - sDelta[ql]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKR; ++ks) {
+          const Frag pb = Pol::b_from_acc(s, ks), db = Pol::b_from_acc(dp, ks);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) {
+            dv[dt] = Pol::mma(Pol::template a_tr<D>(sdO, 32 * h2, ks, hi, 32 * dt, lane), pb, dv[dt]);
+            dk[dt] = Pol::mma(Pol::template a_tr<D>(sQ, 32 * h2, ks, hi, 32 * dt, lane), db, dk[dt]);
+          }
+        }
+      }
+    }
+  }
+  if (!kv) return;
+  E* dkp = (E*)p.dk + (int64_t)b * p.dk_bs + (int64_t)hk * p.dk_hs + kr * p.dk_ts;
+  E* dvp = (E*)p.dv + (int64_t)b * p.dv_bs + (int64_t)hk * p.dv_hs + kr * p.dv_ts;
+  const float sc = p.scale;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * dt + 8 * g + 4 * hi;
+      Pol::st4(dkp + d, dk[dt][4 * g] * sc, dk[dt][4 * g + 1] * sc, dk[dt][4 * g + 2] * sc, dk[dt][4 * g + 3] * sc);
+      Pol::st4(dvp + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------
+static thread_local int g_attn_hip_error = 0;
+
+static int attn_launch_check() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_attn_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
+template <typename K>
+static int raise_lds(K kern, size_t lds) {
+  if (lds > 64 * 1024) {
+    if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MXVL_ERR_LAUNCH;
+  }
+  return MXVL_OK;
+}
+
+template <typename E, int D, bool DQ>
+static int launch_q(const AttnArgs& a, hipStream_t s) {
+  typedef typename PolOf<E>::type Pol;
+  constexpr int NW = 4;
+  const size_t lds = 2 * (size_t)Pol::tile_bytes(kKT, D) + kKT * sizeof(float);
+  auto kern = attn_q_kernel<E, D, NW, DQ>;
+  int rc = raise_lds(kern, lds);
+  if (rc != MXVL_OK) return rc;
+  dim3 grid((a.Lq + NW * 32 - 1) / (NW * 32), a.H, a.batch);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+  return attn_launch_check();
+}
+
+template <typename E, int D>
+static int launch_dkv(const AttnArgs& a, hipStream_t s) {
+  typedef typename PolOf<E>::type Pol;
+  constexpr int NW = 4;
+  const size_t lds = 2 * (size_t)Pol::tile_bytes(kKT, D) + 3 * kKT * sizeof(float);
+  auto kern = attn_bwd_dkv_kernel<E, D, NW>;
+  int rc = raise_lds(kern, lds);
+  if (rc != MXVL_OK) return rc;
+  dim3 grid((a.Lk + NW * 32 - 1) / (NW * 32), a.Hkv, a.batch);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+  return attn_launch_check();
+}
+
+template <typename E>
+static int dispatch_attn(const AttnArgs& a, int D, int what, hipStream_t s) {   // what: 0 fwd, 1 dq, 2 dkv
+  switch (D) {
+    case 32: return what == 0 ? launch_q<E, 32, false>(a, s) : what == 1 ? launch_q<E, 32, true>(a, s) : launch_dkv<E, 32>(a, s);
+    case 64: return what == 0 ? launch_q<E, 64, false>(a, s) : what == 1 ? launch_q<E, 64, true>(a, s) : launch_dkv<E, 64>(a, s);
+    case 128: return what == 0 ? launch_q<E, 128, false>(a, s) : MXVL_ERR_UNSUPPORTED;   // D = 128 is decode-side: forward only
+    default: return MXVL_ERR_UNSUPPORTED;
+  }
+}
+
+static int fill_args(const mxvl_attn_desc* d, AttnArgs& a) {
+  if (!d || !d->q || !d->k || !d->v) return MXVL_ERR_NULL;
+  if (d->io_dtype != MXVL_F32 && d->io_dtype != MXVL_BF16 && d->io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  if (d->batch <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->seqlen_q <= 0 || d->seqlen_k <= 0) return MXVL_ERR_SHAPE;
+  if (d->n_heads % d->n_kv_heads != 0) return MXVL_ERR_SHAPE;
+  if (d->mask_mode < 0 || d->mask_mode > 2 || (d->mask_mode == 2 && d->cluster <= 0)) return MXVL_ERR_SHAPE;
+  const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2, al = 16 / esz;   // rows must start on 16-byte boundaries
+  const int64_t st[] = {d->q_bs, d->q_hs, d->q_ts, d->k_bs, d->k_hs, d->k_ts, d->v_bs, d->v_hs, d->v_ts};
+  for (int64_t x : st) if (x < 0 || x % al != 0) return MXVL_ERR_STRIDE;
+  const void* ps[] = {d->q, d->k, d->v};
+  for (const void* q : ps) if ((uintptr_t)q % 16 != 0) return MXVL_ERR_STRIDE;
+  a.batch = d->batch; a.H = d->n_heads; a.Hkv = d->n_kv_heads; a.Lq = d->seqlen_q; a.Lk = d->seqlen_k;
+  a.mask_mode = d->mask_mode; a.cluster = d->cluster > 0 ? d->cluster : 1; a.scale = d->scale;
+  a.q_bs = d->q_bs; a.q_hs = d->q_hs; a.q_ts = d->q_ts; a.k_bs = d->k_bs; a.k_hs = d->k_hs; a.k_ts = d->k_ts;
+  a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_ts = d->o_ts;
+  a.q = d->q; a.k = d->k; a.v = d->v; a.out = d->out; a.o = d->out; a.lse = (float*)d->lse;
+  a.kmask = (const uint8_t*)d->key_mask; a.bias = (const float*)d->bias;
+  a.dout = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
+  a.do_bs = a.do_hs = a.do_ts = a.dq_bs = a.dq_hs = a.dq_ts = a.dk_bs = a.dk_hs = a.dk_ts = a.dv_bs = a.dv_hs = a.dv_ts = 0;
+  return MXVL_OK;
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" int mxvl_attn_fwd(const mxvl_attn_desc* d, void* hip_stream) {
+  AttnArgs a;
+  int rc = fill_args(d, a);
+  if (rc != MXVL_OK) return rc;
+  if (!d->out) return MXVL_ERR_NULL;
+  const int64_t al = d->io_dtype == MXVL_F32 ? 4 : 8;
+  if (d->o_bs % al || d->o_hs % al || d->o_ts % al || (uintptr_t)d->out % 16) return MXVL_ERR_STRIDE;
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (d->io_dtype) {
+    case MXVL_F32: return dispatch_attn<float>(a, d->head_dim, 0, s);
+    case MXVL_BF16: return dispatch_attn<bf16_t>(a, d->head_dim, 0, s);
+    default: return dispatch_attn<f16_t>(a, d->head_dim, 0, s);
+  }
+}
+
+extern "C" int mxvl_attn_bwd(const mxvl_attn_bwd_desc* d, void* hip_stream) {
+  if (!d) return MXVL_ERR_NULL;
+  AttnArgs a;
+  int rc = fill_args(&d->fwd, a);
+  if (rc != MXVL_OK) return rc;
+  if (!d->fwd.out || !d->fwd.lse || !d->dout || !d->dq || !d->dk || !d->dv || !d->delta) return MXVL_ERR_NULL;
+  const int64_t al = d->fwd.io_dtype == MXVL_F32 ? 4 : 8;
+  const int64_t st[] = {d->fwd.o_bs, d->fwd.o_hs, d->fwd.o_ts, d->dout_bs, d->dout_hs, d->dout_ts, d->dq_bs, d->dq_hs, d->dq_ts,
+                        d->dk_bs, d->dk_hs, d->dk_ts, d->dv_bs, d->dv_hs, d->dv_ts};
+  for (int64_t x : st) if (x < 0 || x % al != 0) return MXVL_ERR_STRIDE;
+  const void* ps[] = {d->fwd.out, d->dout, d->dq, d->dk, d->dv};
+  for (const void* q : ps) if ((uintptr_t)q % 16 != 0) return MXVL_ERR_STRIDE;
+  a.dout = d->dout; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv; a.delta = (float*)d->delta;
+  a.do_bs = d->dout_bs; a.do_hs = d->dout_hs; a.do_ts = d->dout_ts; a.dq_bs = d->dq_bs; a.dq_hs = d->dq_hs; a.dq_ts = d->dq_ts;
+  a.dk_bs = d->dk_bs; a.dk_hs = d->dk_hs; a.dk_ts = d->dk_ts; a.dv_bs = d->dv_bs; a.dv_hs = d->dv_hs; a.dv_ts = d->dv_ts;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int D = d->fwd.head_dim;
+  for (int what = 1; what <= 2; ++what) {   // dQ (also writes delta) first, dK/dV second: same stream, in order
+    switch (d->fwd.io_dtype) {
+      case MXVL_F32: rc = dispatch_attn<float>(a, D, what, s); break;
+      case MXVL_BF16: rc = dispatch_attn<bf16_t>(a, D, what, s); break;
+      default: rc = dispatch_attn<f16_t>(a, D, what, s); break;
+    }
+    if (rc != MXVL_OK) return rc;
+  }
+  return MXVL_OK;
+}

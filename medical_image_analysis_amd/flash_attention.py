@@ -1,0 +1,220 @@
+"""Fused multi-head attention on the MI355X matrix cores: autograd binding of mxvl_attn_fwd / mxvl_attn_bwd (csrc/attn.hip).
+
+    out = attention(q, k, v, scale=None, mask="none" | "causal" | "block_causal", cluster=16, key_mask=None, bias=None)
+
+q (B, H, Lq, D), k / v (B, Hkv, Lk, D) in any batch / head / token strides with D contiguous -- the (B, L, H, D) layout a
+`Linear(...).reshape(B, L, H, D).transpose(1, 2)` produces is consumed in place.  The result is returned as a (B, H, Lq, D)
+view of a (B, Lq, H, D) buffer, so the usual `.transpose(1, 2).reshape(B, L, H * D)` after it is free.
+Replaces F.scaled_dot_product_attention (AOTriton kernels on ROCm) everywhere on the hot path; the reference sites are listed
+in include/mxvl.h.  There is no fallback: CPU tensors raise (tests compare against an fp32 masked-softmax reference).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _abi
+
+MASKS = {"none": 0, "causal": 1, "block_causal": 2}
+
+
+def _rows_ok(t: torch.Tensor) -> bool:
+    al = 16 // t.element_size()
+    return (t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % al == 0 for s in t.stride()[:-1]))
+
+
+def _prep(t: torch.Tensor) -> torch.Tensor:
+    """(B, H, L, D) with unit last stride and 16-byte aligned rows; otherwise one token-major copy."""
+    if _rows_ok(t):
+        return t
+    return t.transpose(1, 2).contiguous().transpose(1, 2)
+
+
+def _token_major(B, H, L, D, like):
+    return torch.empty(B, L, H, D, dtype=like.dtype, device=like.device).transpose(1, 2)
+
+
+def _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias):
+    B, H, Lq, D = q.shape
+    desc.batch, desc.n_heads, desc.n_kv_heads, desc.seqlen_q, desc.seqlen_k, desc.head_dim = B, H, k.shape[1], Lq, k.shape[2], D
+    desc.io_dtype = _abi.dtype_code(q.dtype)
+    desc.mask_mode, desc.cluster, desc.scale = mask_mode, cluster, scale
+    desc.q_bs, desc.q_hs, desc.q_ts = q.stride(0), q.stride(1), q.stride(2)
+    desc.k_bs, desc.k_hs, desc.k_ts = k.stride(0), k.stride(1), k.stride(2)
+    desc.v_bs, desc.v_hs, desc.v_ts = v.stride(0), v.stride(1), v.stride(2)
+    desc.o_bs, desc.o_hs, desc.o_ts = out.stride(0), out.stride(1), out.stride(2)
+    desc.q, desc.k, desc.v, desc.out, desc.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _abi.ptr(lse)
+    desc.key_mask, desc.bias = _abi.ptr(key_mask), _abi.ptr(bias)
+
+
+def attn_fwd_raw(q, k, v, scale, mask_mode=0, cluster=16, key_mask=None, bias=None, want_lse=True):
+    lib = _abi.load()
+    _abi.require_gpu(q, k, v)
+    B, H, Lq, D = q.shape
+    if k.shape[0] != B or v.shape != k.shape or k.shape[3] != D or H % k.shape[1] != 0:
+        raise RuntimeError(f"attention: inconsistent shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise RuntimeError("attention: q, k, v must share one dtype")
+    if D not in (32, 64, 128):
+        raise RuntimeError(f"attention: head_dim must be 32, 64 or 128, got {D}")
+    q, k, v = _prep(q), _prep(k), _prep(v)
+    if key_mask is not None:
+        key_mask = key_mask.to(torch.uint8).contiguous()
+        assert key_mask.shape == (B, k.shape[2])
+    if bias is not None:
+        bias = bias.float().contiguous()
+        assert bias.shape == (Lq, k.shape[2])
+    out = _token_major(B, H, Lq, D, q)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device) if want_lse else None
+    desc = _abi.AttnDesc()
+    _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias)
+    with torch.cuda.device(q.device):
+        _abi.check(lib.mxvl_attn_fwd(ctypes.byref(desc), _abi.stream_ptr(q.device)), "mxvl_attn_fwd")
+    return out, lse, (q, k, v, key_mask, bias)
+
+
+def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=None, dv=None):
+    lib = _abi.load()
+    q, k, v, key_mask, bias = saved
+    B, H, Lq, D = q.shape
+    if D == 128:
+        raise RuntimeError("attention backward supports head_dim 32 / 64 (128 is the decode-side forward)")
+    dout = _prep(dout.to(q.dtype))
+    dq = _token_major(B, H, Lq, D, q) if dq is None else dq
+    dk = _token_major(B, k.shape[1], k.shape[2], D, q) if dk is None else dk
+    dv = _token_major(B, k.shape[1], k.shape[2], D, q) if dv is None else dv
+    delta = torch.empty_like(lse)
+    desc = _abi.AttnBwdDesc()
+    _fill(desc.fwd, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias)
+    desc.dout_bs, desc.dout_hs, desc.dout_ts = dout.stride(0), dout.stride(1), dout.stride(2)
+    desc.dq_bs, desc.dq_hs, desc.dq_ts = dq.stride(0), dq.stride(1), dq.stride(2)
+    desc.dk_bs, desc.dk_hs, desc.dk_ts = dk.stride(0), dk.stride(1), dk.stride(2)
+    desc.dv_bs, desc.dv_hs, desc.dv_ts = dv.stride(0), dv.stride(1), dv.stride(2)
+    desc.dout, desc.dq, desc.dk, desc.dv, desc.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+    with torch.cuda.device(q.device):
+        _abi.check(lib.mxvl_attn_bwd(ctypes.byref(desc), _abi.stream_ptr(q.device)), "mxvl_attn_bwd")
+    return dq, dk, dv
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale, mask_mode, cluster, key_mask, bias):
+        need = any(ctx.needs_input_grad[:3])
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, key_mask, bias, want_lse=need)
+        if need:
+            ctx.save_for_backward(saved[0], saved[1], saved[2], out, lse,
+                                  *( [saved[3]] if saved[3] is not None else []), *([saved[4]] if saved[4] is not None else []))
+            ctx.cfg = (scale, mask_mode, cluster, saved[3] is not None, saved[4] is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        scale, mask_mode, cluster, has_km, has_bias = ctx.cfg
+        t = list(ctx.saved_tensors)
+        q, k, v, out, lse = t[:5]
+        rest = t[5:]
+        km = rest.pop(0) if has_km else None
+        bias = rest.pop(0) if has_bias else None
+        dq, dk, dv = attn_bwd_raw((q, k, v, km, bias), out, lse, dout, scale, mask_mode, cluster)
+        return dq, dk, dv, None, None, None, None, None
+
+
+class _AttentionKVPacked(torch.autograd.Function):
+    """kv given as ONE (B, Lk, 2, Hkv, D) tensor (what `Linear(dim, 2 * dim)(x).reshape(B, L, 2, H, D)` is): the gradient comes
+    back as one tensor of the same layout -- autograd's select-backward would zero-fill and copy two full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale, mask_mode, cluster):
+        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need)
+        if need:
+            ctx.save_for_backward(saved[0], kv, out, lse)
+            ctx.cfg = (scale, mask_mode, cluster)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        scale, mask_mode, cluster = ctx.cfg
+        k, v = _prep(kv[:, :, 0].transpose(1, 2)), _prep(kv[:, :, 1].transpose(1, 2))
+        dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)
+        dq, _, _ = attn_bwd_raw((q, k, v, None, None), out, lse, dout, scale, mask_mode, cluster,
+                                dk=dkv[:, :, 0].transpose(1, 2), dv=dkv[:, :, 1].transpose(1, 2))
+        return dq, dkv, None, None, None
+
+
+class _AttentionQKVPacked(torch.autograd.Function):
+    """Self-attention over ONE (B, L, 3, H, D) tensor (`Linear(dim, 3 * dim)(x).reshape(B, L, 3, H, D)`, vit.py:152-153);
+    the gradient is written into one tensor of the same layout."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, mask_mode, cluster):
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        need = ctx.needs_input_grad[0]
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need)
+        if need:
+            ctx.save_for_backward(qkv, out, lse)
+            ctx.cfg = (scale, mask_mode, cluster)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        scale, mask_mode, cluster = ctx.cfg
+        q, k, v = (_prep(qkv[:, :, i].transpose(1, 2)) for i in range(3))
+        dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
+        attn_bwd_raw((q, k, v, None, None), out, lse, dout, scale, mask_mode, cluster, dq=dqkv[:, :, 0].transpose(1, 2),
+                     dk=dqkv[:, :, 1].transpose(1, 2), dv=dqkv[:, :, 2].transpose(1, 2))
+        return dqkv, None, None, None
+
+
+def attention(q, k, v, scale=None, mask="none", cluster=16, key_mask=None, bias=None):
+    """softmax(q k^T * scale + mask) v.  mask: "none", "causal" (key j <= query i + Lk - Lq) or "block_causal" (key cluster <=
+    query cluster, cluster tokens each); key_mask (B, Lk) bool: True = may be attended; bias (Lq, Lk) additive fp32."""
+    scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
+    return _Attention.apply(q, k, v, scale, MASKS[mask], int(cluster), key_mask, bias)
+
+
+def attention_kvpacked(q, kv, scale=None, mask="none", cluster=16):
+    """q (B, H, Lq, D) view, kv (B, Lk, 2, Hkv, D)."""
+    scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
+    return _AttentionKVPacked.apply(q, kv, scale, MASKS[mask], int(cluster))
+
+
+def attention_qkvpacked(qkv, scale=None, mask="none", cluster=16):
+    """qkv (B, L, 3, H, D) -> (B, H, L, D) view of a (B, L, H, D) buffer."""
+    scale = float(qkv.shape[-1] ** -0.5 if scale is None else scale)
+    return _AttentionQKVPacked.apply(qkv, scale, MASKS[mask], int(cluster))
+
+
+_BLOCK_MASK_CACHE = {}
+
+
+def is_block_causal_mask(mask: torch.Tensor, cluster: int = 16) -> bool:
+    """True when the additive (L, L) mask is exactly mask_generate's pattern (models_pretrain.py:395-400): 0 where
+    key cluster <= query cluster, -inf elsewhere.  Checked once per mask storage (the model registers it as a buffer)."""
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), cluster, str(mask.device))
+    hit = _BLOCK_MASK_CACHE.get(key)
+    if hit is None:
+        L = mask.shape[-1]
+        ok = mask.dim() == 2 and mask.shape[0] == L
+        if ok:
+            i = torch.arange(L, device=mask.device) // cluster
+            want = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")).to(mask.dtype)
+            ok = bool(torch.equal(mask, want))
+        if len(_BLOCK_MASK_CACHE) > 64:
+            _BLOCK_MASK_CACHE.clear()
+        _BLOCK_MASK_CACHE[key] = hit = ok
+    return hit
+
+
+def supported(q, *others) -> bool:
+    """HIP tensors of a supported dtype / head_dim.  head_dim 128 has a forward kernel only (the decode side): when a gradient
+    is going to be asked for, the caller keeps its library path."""
+    if not (q.is_cuda and q.dtype in (torch.float32, torch.bfloat16, torch.float16) and q.shape[-1] in (32, 64, 128)):
+        return False
+    if q.shape[-1] == 128 and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q,) + others):
+        return False
+    return True

@@ -28,6 +28,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import flash_attention as flash
+
 
 class Qwen2RMSNorm(nn.Module):
     def __init__(self, hidden_size, eps=1e-6):
@@ -117,10 +119,22 @@ class ScaleDotProductCrossAttention(nn.Module):
         self.softmax_scale = softmax_scale
         self.dropout_p = attention_dropout
 
-    def forward(self, q, k, v, attn_mask=None):
+    def forward(self, q, k, v, attn_mask=None, key_mask=None):
+        """attn_mask (B, Lq, Lk) bool as in the reference; key_mask (B, Lk) bool when the mask does not depend on the query
+        (both cross-attention variants build it that way): then the MFMA flash kernel runs, image K/V tiles staged in LDS,
+        grouped-query heads served without repeat_kv."""
+        p = self.dropout_p if self.training else 0.0
+        if p == 0.0 and attn_mask is None and flash.supported(q, k, v):
+            o = flash.attention(q, k, v, scale=self.softmax_scale, key_mask=key_mask)
+            B, H, L, D = o.shape
+            return o.transpose(1, 2).reshape(B, L, H * D)
+        if key_mask is not None and attn_mask is None:
+            attn_mask = key_mask[:, None, :].expand(-1, q.shape[2], -1)
+        if k.shape[1] != q.shape[1]:
+            k, v = repeat_kv(k, q.shape[1] // k.shape[1]), repeat_kv(v, q.shape[1] // v.shape[1])
         if attn_mask is not None:
             attn_mask = attn_mask[:, None, :, :].expand(-1, q.shape[1], -1, -1)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=self.dropout_p if self.training else 0.0,
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=p,
                                            is_causal=False, scale=self.softmax_scale)
         B, H, L, D = o.shape
         return o.transpose(1, 2).reshape(B, L, H * D)
@@ -170,9 +184,7 @@ class Qwen2HybridAttention(nn.Module):
         kv = self.cross_attn_kv_proj(vision_features.contiguous())
         B, Lv, _ = kv.shape
         kv = kv.view(B, Lv, self.num_key_value_heads, 2, self.head_dim)   # '(H KV D)' packing of the reference (:683)
-        k = repeat_kv(kv[:, :, :, 0].transpose(1, 2), self.num_key_value_groups)
-        v = repeat_kv(kv[:, :, :, 1].transpose(1, 2), self.num_key_value_groups)
-        return k, v
+        return kv[:, :, :, 0].transpose(1, 2), kv[:, :, :, 1].transpose(1, 2)   # (B, Hkv, Lv, D): the attention op handles GQA
 
     def _require_gate(self):
         if not hasattr(self, "cross_attn_gate_proj"):
@@ -191,8 +203,7 @@ class Qwen2HybridAttention(nn.Module):
             gate = gate * self.cross_attn_warm_up_gate
         k, v = self._vision_kv(vision_features)
         q = text_query.permute(1, 2, 0, 3)                                    # (B, H, L, D)
-        mask = text2vision_cross_attn_mask[:, None, :].expand(-1, text_state.shape[0], -1)
-        ctx = self.cross_attn_core_attention(q, k, v, attn_mask=mask).transpose(0, 1)   # (L, B, hidden)
+        ctx = self.cross_attn_core_attention(q, k, v, key_mask=text2vision_cross_attn_mask).transpose(0, 1)   # (L, B, hidden)
         ctx = all_text_mask[None, :, None] * ctx
         return text_state + ctx * gate
 
@@ -221,8 +232,7 @@ class Qwen2HybridAttention(nn.Module):
         if "warmup" in self.gating_type:
             gate = gate * self.cross_attn_warm_up_gate.tanh()
         k, v = self._vision_kv(vision_features)
-        mask = text2vision_cross_attn_mask[:, None, :].expand(-1, Lq, -1)
-        ctx = self.cross_attn_core_attention(q.transpose(1, 2), k, v, attn_mask=mask)         # (B, Lq, hidden)
+        ctx = self.cross_attn_core_attention(q.transpose(1, 2), k, v, key_mask=text2vision_cross_attn_mask)   # (B, Lq, hidden)
         ctx = all_text_mask[:, None, None] * ctx
         ext = torch.zeros_like(text_state)
         ext[text_mask] = ctx[valid] * gate
@@ -246,6 +256,14 @@ class Qwen2HybridAttention(nn.Module):
         if past_key_value is not None:
             k, v = past_key_value.update(k, v, self.layer_idx, {"sin": sin, "cos": cos, "cache_position": cache_position})
         kv_len = k.shape[-2]
+        p_drop = self.attention_dropout if self.training else 0.0
+        if p_drop == 0.0 and flash.supported(q, k, v) and (attention_mask is None or attention_mask.dim() == 2):
+            # MFMA flash attention: causal aligned to the END of the key sequence (decode with a cache) + the (B, kv_len)
+            # padding mask as a key mask; grouped-query heads without repeat_kv
+            km = None if attention_mask is None else attention_mask[:, :kv_len].bool()
+            attn = flash.attention(q, k, v, mask="causal", key_mask=km)
+            attn_output = attn.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
+            return self._finish(attn_output, q, visual_hidden_states, token_type, text2visual_attention_mask, past_key_value)
         kf, vf = repeat_kv(k, self.num_key_value_groups), repeat_kv(v, self.num_key_value_groups)
         # causal mask aligned to the END of the key sequence (decode with a cache), AND the (B, kv_len) padding mask
         causal = torch.ones(q_len, kv_len, dtype=torch.bool, device=q.device).tril(kv_len - q_len)
@@ -255,9 +273,11 @@ class Qwen2HybridAttention(nn.Module):
                 mask = mask & attention_mask[:, None, None, :kv_len].bool()
             else:  # additive 4-D mask from HF: 0 = keep
                 mask = mask & (attention_mask[:, :, :, :kv_len] == 0)
-        attn = F.scaled_dot_product_attention(q, kf, vf, attn_mask=mask,
-                                              dropout_p=self.attention_dropout if self.training else 0.0)
+        attn = F.scaled_dot_product_attention(q, kf, vf, attn_mask=mask, dropout_p=p_drop)
         attn_output = attn.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
+        return self._finish(attn_output, q, visual_hidden_states, token_type, text2visual_attention_mask, past_key_value)
+
+    def _finish(self, attn_output, q, visual_hidden_states, token_type, text2visual_attention_mask, past_key_value):
         if self.is_hyper_enabled and visual_hidden_states is not None:
             all_text_mask = (token_type == 3).sum(dim=-1).bool()  # False: the sample carries no image
             qh = q.transpose(1, 2)                                # (B, T, H, D), the RoPE'd queries

@@ -9,7 +9,7 @@ State-dict keys follow the reference (timm Block naming: blocks.{i}.{norm1,attn.
 MI355X-first differences:
   * every patch-embedding convolution has kernel == stride, i.e. it is a GEMM over non-overlapping patches: done as
     unfold-by-view + linear (MIOpen falls back to a naive direct convolution for these shapes on gfx950);
-  * attention goes through the fused flash kernel behind F.scaled_dot_product_attention (no L x L score matrix);
+  * attention is the hand-written MFMA flash kernel (flash_attention.py / csrc/attn.hip; no L x L score matrix);
   * the context-aware masking (`random_masking_yiliao`, mae.py:184-253) is vectorised index arithmetic with the same
     result as the reference's per-element Python loops; masks/ids are index ops and are reproduced bit-exactly.
 The reference calls torch.rand inside the masking functions; pass `noise=` to make a call reproducible (tests).
@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import flash_attention as flash
 from . import fused_ops
 from .models_mamba import DropPath, run_blocks, to_2tuple, trunc_normal_
 from .models_pretrain import get_2d_sincos_pos_embed as _sincos_no_cls
@@ -76,9 +77,13 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         p = self.attn_drop.p if self.training else 0.0
-        x = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p, scale=self.scale)
+        if p == 0.0 and flash.supported(qkv):
+            x = flash.attention_qkvpacked(qkv, scale=self.scale)      # MFMA flash attention over the packed projection
+        else:   # CPU tensors / attention dropout
+            qkv = qkv.permute(2, 0, 3, 1, 4)
+            x = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p, scale=self.scale)
         return self.proj_drop(self.proj(x.transpose(1, 2).reshape(B, N, C)))
 
 

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import flash_attention as flash
 from .models_mamba import Block as _FtBlock  # noqa: F401  (same Block arithmetic; kept for isinstance checks)
 from .models_mamba import DropPath, PatchEmbed, SwiGLU, _init_weights, run_blocks, segm_init_weights, trunc_normal_
 from .mamba_simple import Mamba
@@ -104,10 +105,19 @@ class CrossAttention(nn.Module):
     def forward(self, q, kv, mask):
         B, N, C = q.shape
         H = self.num_heads
-        q = self.q(q).reshape(B, N, H, C // H).transpose(1, 2)                 # (B, H, N, dh)
-        kv = self.kv(kv).reshape(B, N, 2, H, C // H).permute(2, 0, 3, 1, 4)    # (2, B, H, N, dh)
         p = self.attn_drop.p if self.training else 0.0
-        x = block_causal_attention(q, kv[0], kv[1], mask.to(q.dtype), p, self.scale)
+        q = self.q(q).reshape(B, N, H, C // H).transpose(1, 2)                 # (B, H, N, dh) view, no copy
+        kv = self.kv(kv).reshape(B, N, 2, H, C // H)                           # packed (B, N, 2, H, dh)
+        if p == 0.0 and flash.supported(q):
+            # hand-written MFMA flash attention (csrc/attn.hip): the block-lower-triangular mask of mask_generate is a kernel
+            # mode that never visits the tiles above the diagonal; any other mask tensor goes in as an additive bias
+            if flash.is_block_causal_mask(mask, 16):
+                x = flash.attention_kvpacked(q, kv, scale=self.scale, mask="block_causal", cluster=16)
+            else:
+                x = flash.attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale=self.scale, bias=mask)
+        else:   # CPU tensors / attention dropout: the library path
+            kvp = kv.permute(2, 0, 3, 1, 4)
+            x = block_causal_attention(q, kvp[0], kvp[1], mask.to(q.dtype), p, self.scale)
         x = x.transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 

@@ -17,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import flash_attention as flash
+
 
 class _Attention(nn.Module):
     """`attention` (query/key/value) of HF's Blip2QFormerMultiHeadAttention."""
@@ -32,6 +34,10 @@ class _Attention(nn.Module):
     def forward(self, x, kv, mask):
         B, Lq, H = x.shape
         split = lambda t: t.view(B, t.shape[1], self.heads, H // self.heads).transpose(1, 2)
+        p = self.dropout if self.training else 0.0
+        if mask is None and p == 0.0 and flash.supported(x) and H // self.heads in (32, 64, 128):
+            out = flash.attention(split(self.query(x)), split(self.key(kv)), split(self.value(kv)))
+            return out.transpose(1, 2).reshape(B, Lq, H)
         out = F.scaled_dot_product_attention(split(self.query(x)), split(self.key(kv)), split(self.value(kv)), attn_mask=mask,
                                              dropout_p=self.dropout if self.training else 0.0)
         return out.transpose(1, 2).reshape(B, Lq, H)
