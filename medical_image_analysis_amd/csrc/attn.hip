@@ -65,9 +65,11 @@ template <typename E> struct Pol16 {
   }
   static constexpr int tile_bytes(int rows, int D) { return rows * D * 2; }
   // byte offset of 16-byte unit u of a row: XOR swizzle so that 32 rows read at one unit spread over the LDS banks
+  // A 16-lane group of ds_read_b128 must hit 16 different (256-byte bank row offset, 16-byte unit) pairs.  A row is D * 2
+  // bytes = UPR units, 16 / UPR rows share one 256-byte bank row: XOR the unit with the index of the row's bank row.
   template <int D> static __device__ __forceinline__ int unit_off(int row, int u) {
-    constexpr int UPR = D / 8, M = (UPR < 8 ? UPR : 8) - 1;
-    return row * (D * 2) + ((u ^ (row & M)) << 4);
+    constexpr int UPR = D / 8, SH = UPR >= 16 ? 0 : (UPR == 8 ? 1 : 2);
+    return row * (D * 2) + ((u ^ ((row >> SH) & (UPR - 1))) << 4);
   }
   // A operand, row-major rows: lane (row, hi) takes elements [16 ks + 8 hi, +8) of its row
   template <int D> static __device__ __forceinline__ Frag a_row(const char* tile, int row, int ks, int hi) {
@@ -116,17 +118,27 @@ template <typename E> struct Pol16 {
     for (int i = 0; i < 4; ++i) s = fmaf(el(x[i], 0), el(y[i], 0), fmaf(el(x[i], 1), el(y[i], 1), s));
     return s;
   }
-  // global [rows x D] (row stride ts elements) -> swizzled LDS tile; rows >= nvalid are zero-filled
-  template <int D, int ROWS, int NT> static __device__ __forceinline__ void stage(char* tile, const E* base, int64_t ts, int nvalid, int tid) {
-    constexpr int UPR = D / 8;
+  // global [rows x D] (row stride ts elements) -> registers -> swizzled LDS tile; rows >= nvalid are zero-filled.  Split in two
+  // so that the loads of tile t + 1 are in flight while tile t is being multiplied (the write happens after it).
+  template <int D, int ROWS, int NT> struct Stage {
+    static constexpr int UPR = D / 8, N = ROWS * UPR / NT;
+    uint4 v[N];
+    __device__ __forceinline__ void load(const E* base, int64_t ts, int nvalid, int tid) {
 #pragma unroll
-    for (int c = tid; c < ROWS * UPR; c += NT) {
-      const int row = c / UPR, u = c % UPR;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < nvalid) v = *(const uint4*)(base + (int64_t)row * ts + u * 8);
-      *(uint4*)(tile + unit_off<D>(row, u)) = v;
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / UPR, u = c % UPR;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (row < nvalid) v[i] = *(const uint4*)(base + (int64_t)row * ts + u * 8);
+      }
     }
-  }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / UPR, u = c % UPR;
+        *(uint4*)(tile + unit_off<D>(row, u)) = v[i];
+      }
+    }
+  };
   // 4 consecutive output elements
   static __device__ __forceinline__ void st4(E* p, float a, float b, float c, float d) { *(uint2*)p = make_uint2(pack2(a, b), pack2(c, d)); }
 };
@@ -146,25 +158,50 @@ struct Pol32 {
   static __device__ __forceinline__ Frag b_from_acc(const f32x16& a, int ks) { return a[ks]; }
   static __device__ __forceinline__ Frag ldg(const float* row, int ks, int hi) { return row[2 * ks + hi]; }
   static __device__ __forceinline__ float dot(Frag a, Frag b) { return a * b; }
-  template <int D, int ROWS, int NT> static __device__ __forceinline__ void stage(char* tile, const float* base, int64_t ts, int nvalid, int tid) {
-    constexpr int QPR = D / 4;
-    float* t = (float*)tile;
+  template <int D, int ROWS, int NT> struct Stage {
+    static constexpr int QPR = D / 4, N = ROWS * QPR / NT;
+    float4 v[N];
+    __device__ __forceinline__ void load(const float* base, int64_t ts, int nvalid, int tid) {
 #pragma unroll
-    for (int c = tid; c < ROWS * QPR; c += NT) {
-      const int row = c / QPR, u = c % QPR;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < nvalid) v = *(const float4*)(base + (int64_t)row * ts + u * 4);
-      float* d = t + row * (D + 1) + u * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / QPR, u = c % QPR;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nvalid) v[i] = *(const float4*)(base + (int64_t)row * ts + u * 4);
+      }
     }
-  }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+      float* t = (float*)tile;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT, row = c / QPR, u = c % QPR;
+        float* d = t + row * (D + 1) + u * 4;
+        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+      }
+    }
+  };
   static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *(float4*)p = make_float4(a, b, c, d); }
 };
 
 template <typename E> struct PolOf { typedef Pol16<E> type; };
 template <> struct PolOf<float> { typedef Pol32 type; };
 
-__device__ __forceinline__ float xchg32(float v) { return __shfl_xor(v, 32, 64); }
+// Reductions over the lane pair (l, l ^ 32) that shares an MFMA column: v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second -- one VALU op, no LDS round trip.  Inline asm: this toolchain's
+// __builtin_amdgcn_permlane32_swap returns its FIRST result in both vector elements (clang emits extractvalue 0 twice).
+// The two v_nop-equivalent wait states the swap needs after a VALU write of its operands are inside the string.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float pair_max(float v) {
+  float a = v, b = v;
+  swap32(a, b);      // a = {lo, lo}, b = {hi, hi}
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float pair_sum(float v) {
+  float a = v, b = v;
+  swap32(a, b);
+  return a + b;
+}
 
 // key limit of a query row: keys [0, klim) may be attended (before the optional key mask / bias)
 __device__ __forceinline__ int key_limit(const AttnArgs& p, int qrow) {
@@ -177,17 +214,19 @@ __device__ __forceinline__ int key_limit(const AttnArgs& p, int qrow) {
 
 constexpr int kKT = 64;   // keys per staged tile (forward, dQ) / queries per staged tile (dK/dV)
 
-// ---- forward ----------------------------------------------------------------------------------------------------------
+// ---- forward / dQ -------------------------------------------------------------------------------------------------------
 // DQ = false: O, lse.   DQ = true: the dQ pass of the backward (same walk over the key tiles).
+// K / V tiles are double-buffered in LDS: the global loads of tile t + 1 are issued before tile t is multiplied and land in
+// registers; they are written to the other buffer after the products, one barrier per tile.
 template <typename E, int D, int NW, bool DQ>
-__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void attn_q_kernel(const AttnArgs p) {
   typedef typename PolOf<E>::type Pol;
   typedef typename Pol::Frag Frag;
   constexpr int QT = NW * 32, KT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
+  constexpr int TB = Pol::tile_bytes(KT, D);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + Pol::tile_bytes(KT, D);
-  float* sMask = (float*)(sV + Pol::tile_bytes(KT, D));   // [KT] 0 / -inf from the key mask
+  // [buf][K | V] tiles, then [buf][KT] key-mask addends
+  float* sMaskAll = (float*)(smem + 4 * TB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.H / p.Hkv);
@@ -196,6 +235,30 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
   const bool qv = qrow < p.Lq;
   const int64_t qr = qv ? qrow : 0;
   const float c = p.scale * kLog2e;
+
+  const int klim = key_limit(p, qrow);
+  const int qlast = (q0 + QT < p.Lq ? q0 + QT : p.Lq) - 1;
+  const int kend = key_limit(p, qlast);            // limits grow with the row index in every mask mode
+  const int kfull = key_limit(p, q0);              // keys below this are visible to every row of the workgroup
+  const bool extra = p.kmask != nullptr || p.bias != nullptr;
+  const int ntiles = (kend + KT - 1) / KT;
+
+  const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+  typename Pol::template Stage<D, KT, NT> stK, stV;
+  float mreg = 0.f;
+  auto fetch = [&](int kt) {
+    const int k0 = kt * KT;
+    stK.load(kb + (int64_t)k0 * p.k_ts, p.k_ts, p.Lk - k0, tid);
+    stV.load(vb + (int64_t)k0 * p.v_ts, p.v_ts, p.Lk - k0, tid);
+    if (p.kmask && tid < KT) mreg = (k0 + tid < p.Lk && p.kmask[(int64_t)b * p.Lk + k0 + tid]) ? 0.f : kNegInf;
+  };
+  auto commit = [&](int buf) {
+    stK.store(smem + (2 * buf) * TB, tid);
+    stV.store(smem + (2 * buf + 1) * TB, tid);
+    if (p.kmask && tid < KT) sMaskAll[buf * KT + tid] = mreg;
+  };
+  if (ntiles > 0) fetch(0);
 
   const E* qp = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + qr * p.q_ts;
   Frag qf[NKD];
@@ -212,21 +275,11 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
       const Frag of = qv ? Pol::ldg(op, ks, hi) : Pol::zero();
       delta += Pol::dot(dof[ks], of);
     }
-    delta += xchg32(delta);
+    delta = pair_sum(delta);
     const int64_t ro = ((int64_t)b * p.H + h) * p.Lq + qr;
     lse = qv ? p.lse[ro] : __builtin_inff();
     if (qv && hi == 0) p.delta[ro] = delta;
   }
-
-  const int klim = key_limit(p, qrow);
-  const int qlast = (q0 + QT < p.Lq ? q0 + QT : p.Lq) - 1;
-  const int kend = key_limit(p, qlast);            // limits grow with the row index in every mask mode
-  const int kfull = key_limit(p, q0);              // keys below this are visible to every row of the workgroup
-  const bool extra = p.kmask != nullptr || p.bias != nullptr;
-  const int ntiles = (kend + KT - 1) / KT;
-
-  const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
-  const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
 
   f32x16 acc[NDT];
 #pragma unroll
@@ -235,13 +288,16 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   float m = kNegInf, l = 0.f;
 
+  if (ntiles > 0) commit(0);
+  __syncthreads();
+
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int k0 = kt * KT;
-    __syncthreads();
-    Pol::template stage<D, KT, NT>(sK, kb + (int64_t)k0 * p.k_ts, p.k_ts, p.Lk - k0, tid);
-    Pol::template stage<D, KT, NT>(sV, vb + (int64_t)k0 * p.v_ts, p.v_ts, p.Lk - k0, tid);
-    if (p.kmask && tid < KT) sMask[tid] = (k0 + tid < p.Lk && p.kmask[(int64_t)b * p.Lk + k0 + tid]) ? 0.f : kNegInf;
-    __syncthreads();
+    const int k0 = kt * KT, buf = kt & 1;
+    const char* sK = smem + (2 * buf) * TB;
+    const char* sV = smem + (2 * buf + 1) * TB;
+    const float* sMask = sMaskAll + buf * KT;
+    const bool more = kt + 1 < ntiles;
+    if (more) fetch(kt + 1);
 
     f32x16 s[2];
 #pragma unroll
@@ -277,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[h2][r]);
-      mx = fmaxf(mx, xchg32(mx));
+      mx = pair_max(mx);
       const float mn = fmaxf(m, mx);
       const float mu = (mn == kNegInf) ? 0.f : mn;
       const float alpha = fast_exp2(m - mu);
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
           s[h2][r] = pv;
           rs += pv;
         }
-      rs += xchg32(rs);
+      rs = pair_sum(rs);
       l = fmaf(l, alpha, rs);
       m = mn;
       if (!__all(alpha == 1.0f)) {
@@ -332,6 +388,8 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
         }
       }
     }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
   }
 
   if (!qv) return;
@@ -356,17 +414,15 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const AttnArgs p) {
 }
 
 // ---- dK / dV ----------------------------------------------------------------------------------------------------------
+// One workgroup per 128-key tile (a lane owns a key); walks the query tiles that can see it, Q / dO tiles double-buffered.
 template <typename E, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, sizeof(E) == 4 ? 1 : 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
   typedef typename PolOf<E>::type Pol;
   typedef typename Pol::Frag Frag;
   constexpr int KTW = NW * 32, QT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
+  constexpr int TB = Pol::tile_bytes(QT, D);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;
-  char* sdO = smem + Pol::tile_bytes(QT, D);
-  float* sLse = (float*)(sdO + Pol::tile_bytes(QT, D));   // [QT]
-  float* sDelta = sLse + QT;                               // [QT]
-  int* sKlim = (int*)(sDelta + QT);                        // [QT] key limit of every staged query row (0: row not valid)
+  float* sRow = (float*)(smem + 4 * TB);      // [buf][3][QT]: lse, delta, key limit (int bits)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, hk = blockIdx.y, grp = p.H / p.Hkv;
@@ -375,6 +431,42 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs p)
   const int64_t kr = kv ? krow : 0;
   const float c = p.scale * kLog2e;
   const bool key_on = kv && (!p.kmask || p.kmask[(int64_t)b * p.Lk + kr] != 0);
+
+  // first query row that can see a key of this tile (its own first key kk0)
+  int qfirst = 0;
+  if (p.mask_mode == 1) qfirst = kk0 - (p.Lk - p.Lq);
+  else if (p.mask_mode == 2) qfirst = (kk0 / p.cluster) * p.cluster;
+  if (qfirst < 0) qfirst = 0;
+  const int qt0 = qfirst / QT, nqt = (p.Lq + QT - 1) / QT;
+  const int per_head = nqt > qt0 ? nqt - qt0 : 0, nit = per_head * grp;
+
+  typename Pol::template Stage<D, QT, NT> stQ, stO;
+  float r_lse = 0.f, r_delta = 0.f;
+  int r_klim = 0;
+  auto fetch = [&](int it) {
+    const int hq = hk * grp + it / per_head, q0 = (qt0 + it % per_head) * QT;
+    stQ.load((const E*)p.q + (int64_t)b * p.q_bs + (int64_t)hq * p.q_hs + (int64_t)q0 * p.q_ts, p.q_ts, p.Lq - q0, tid);
+    stO.load((const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)hq * p.do_hs + (int64_t)q0 * p.do_ts, p.do_ts, p.Lq - q0, tid);
+    if (tid < QT) {
+      const int q = q0 + tid;
+      const bool ok = q < p.Lq;
+      const int64_t ro = ((int64_t)b * p.H + hq) * p.Lq;
+      r_lse = ok ? p.lse[ro + q] : __builtin_inff();
+      r_delta = ok ? p.delta[ro + q] : 0.f;
+      r_klim = key_limit(p, q);
+    }
+  };
+  auto commit = [&](int buf) {
+    stQ.store(smem + (2 * buf) * TB, tid);
+    stO.store(smem + (2 * buf + 1) * TB, tid);
+    if (tid < QT) {
+      float* r = sRow + buf * 3 * QT;
+      r[tid] = r_lse;
+      r[QT + tid] = r_delta;
+      ((int*)r)[2 * QT + tid] = r_klim;
+    }
+  };
+  if (nit > 0) fetch(0);
 
   const E* kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs + kr * p.k_ts;
   const E* vp = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs + kr * p.v_ts;
@@ -390,61 +482,50 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  // first query row that can see a key of this tile (its own first key kk0)
-  int qfirst = 0;
-  if (p.mask_mode == 1) qfirst = kk0 - (p.Lk - p.Lq);
-  else if (p.mask_mode == 2) qfirst = (kk0 / p.cluster) * p.cluster;
-  if (qfirst < 0) qfirst = 0;
-  const int qt0 = qfirst / QT, nqt = (p.Lq + QT - 1) / QT;
+  if (nit > 0) commit(0);
+  __syncthreads();
 
-  for (int hq = hk * grp; hq < (hk + 1) * grp; ++hq) {
-    const E* qb = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)hq * p.q_hs;
-    const E* dob = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)hq * p.do_hs;
-    const int64_t ro = ((int64_t)b * p.H + hq) * p.Lq;
-    for (int qt = qt0; qt < nqt; ++qt) {
-      const int q0 = qt * QT;
-      __syncthreads();
-      Pol::template stage<D, QT, NT>(sQ, qb + (int64_t)q0 * p.q_ts, p.q_ts, p.Lq - q0, tid);
-      Pol::template stage<D, QT, NT>(sdO, dob + (int64_t)q0 * p.do_ts, p.do_ts, p.Lq - q0, tid);
-      if (tid < QT) {
-        const int q = q0 + tid;
-        const bool ok = q < p.Lq;
-        sLse[tid] = ok ? p.lse[ro + q] : __builtin_inff();
-        sDelta[tid] = ok ? p.delta[ro + q] : 0.f;
-        sKlim[tid] = key_limit(p, q);
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1, q0 = (qt0 + it % per_head) * QT;
+    const char* sQ = smem + (2 * buf) * TB;
+    const char* sdO = smem + (2 * buf + 1) * TB;
+    const float* sLse = sRow + buf * 3 * QT;
+    const float* sDelta = sLse + QT;
+    const int* sKlim = (const int*)(sLse + 2 * QT);
+    const bool more = it + 1 < nit;
+    if (more) fetch(it + 1);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < NKD; ++ks) {
+        s = Pol::mma(Pol::template a_row<D>(sQ, 32 * h2 + j, ks, hi), kf[ks], s);
+        dp = Pol::mma(Pol::template a_row<D>(sdO, 32 * h2 + j, ks, hi), vf[ks], dp);
       }
-      __syncthreads();
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        f32x16 s, dp;
+      for (int r = 0; r < 16; ++r) {
+        const int ql = 32 * h2 + crow(r, hi);
+        float x = s[r] * c;
+        if (p.bias && q0 + ql < p.Lq && kv) x = fmaf(p.bias[(int64_t)(q0 + ql) * p.Lk + kr], kLog2e, x);
+        const bool on = key_on && krow < sKlim[ql];
+        const float pv = on ? fast_exp2(x - sLse[ql]) : 0.f;
+        s[r] = pv;
+        dp[r] = pv * (dp[r] - sDelta[ql]);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int ks = 0; ks < NKR; ++ks) {
+        const Frag pb = Pol::b_from_acc(s, ks), db = Pol::b_from_acc(dp, ks);
 #pragma unroll
-        for (int ks = 0; ks < NKD; ++ks) {
-          s = Pol::mma(Pol::template a_row<D>(sQ, 32 * h2 + j, ks, hi), kf[ks], s);
-          dp = Pol::mma(Pol::template a_row<D>(sdO, 32 * h2 + j, ks, hi), vf[ks], dp);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ql = 32 * h2 + crow(r, hi);
-          float x = s[r] * c;
-          if (p.bias && q0 + ql < p.Lq && kv) x = fmaf(p.bias[(int64_t)(q0 + ql) * p.Lk + kr], kLog2e, x);
-          const bool on = key_on && krow < sKlim[ql];
-          const float pv = on ? fast_exp2(x - sLse[ql]) : 0.f;
-          s[r] = pv;
-          dp[r] = pv * (dp[r] - sDelta[ql]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKR; ++ks) {
-          const Frag pb = Pol::b_from_acc(s, ks), db = Pol::b_from_acc(dp, ks);
-#pragma unroll
-          for (int dt = 0; dt < NDT; ++dt) {
-            dv[dt] = Pol::mma(Pol::template a_tr<D>(sdO, 32 * h2, ks, hi, 32 * dt, lane), pb, dv[dt]);
-            dk[dt] = Pol::mma(Pol::template a_tr<D>(sQ, 32 * h2, ks, hi, 32 * dt, lane), db, dk[dt]);
-          }
+        for (int dt = 0; dt < NDT; ++dt) {
+          dv[dt] = Pol::mma(Pol::template a_tr<D>(sdO, 32 * h2, ks, hi, 32 * dt, lane), pb, dv[dt]);
+          dk[dt] = Pol::mma(Pol::template a_tr<D>(sQ, 32 * h2, ks, hi, 32 * dt, lane), db, dk[dt]);
         }
       }
     }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
   }
   if (!kv) return;
   E* dkp = (E*)p.dk + (int64_t)b * p.dk_bs + (int64_t)hk * p.dk_hs + kr * p.dk_ts;
@@ -482,7 +563,7 @@ template <typename E, int D, bool DQ>
 static int launch_q(const AttnArgs& a, hipStream_t s) {
   typedef typename PolOf<E>::type Pol;
   constexpr int NW = 4;
-  const size_t lds = 2 * (size_t)Pol::tile_bytes(kKT, D) + kKT * sizeof(float);
+  const size_t lds = 4 * (size_t)Pol::tile_bytes(kKT, D) + 2 * kKT * sizeof(float);
   auto kern = attn_q_kernel<E, D, NW, DQ>;
   int rc = raise_lds(kern, lds);
   if (rc != MXVL_OK) return rc;
@@ -495,7 +576,7 @@ template <typename E, int D>
 static int launch_dkv(const AttnArgs& a, hipStream_t s) {
   typedef typename PolOf<E>::type Pol;
   constexpr int NW = 4;
-  const size_t lds = 2 * (size_t)Pol::tile_bytes(kKT, D) + 3 * kKT * sizeof(float);
+  const size_t lds = 4 * (size_t)Pol::tile_bytes(kKT, D) + 6 * kKT * sizeof(float);
   auto kern = attn_bwd_dkv_kernel<E, D, NW>;
   int rc = raise_lds(kern, lds);
   if (rc != MXVL_OK) return rc;

@@ -1,35 +1,57 @@
-import sys, os, torch, torch.nn.functional as F
-sys.path.insert(0, os.getcwd())
-from medical_image_analysis_amd.models_pretrain import block_causal_attention
-dev = "cuda:0"
-B, H, N, d = 8, 8, 4080, 64
-torch.manual_seed(0)
-q, k, v = (torch.randn(B, H, N, d, device=dev, dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
-seg = N // 16
-m = torch.tril(torch.ones(seg, seg, device=dev))
-m = m.masked_fill(m == 0, float("-inf")).masked_fill(m == 1, 0).repeat_interleave(16, 0).repeat_interleave(16, 1).to(torch.bfloat16)
-def t(fn, n=5):
-    for _ in range(2): fn()
+"""Dev tool: time the MFMA flash-attention kernels (fwd / dq / dkv) at the pre-training decoder's shape and the library path
+beside them.  usage: python tools/attn_bench.py [B H L D] [--sdpa]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from medical_image_analysis_amd import flash_attention as fa
+
+
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n): fn()
+    for _ in range(iters):
+        fn()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
-def full(): return F.scaled_dot_product_attention(q, k, v, attn_mask=m, scale=d ** -0.5)
-def nomask(): return F.scaled_dot_product_attention(q, k, v, scale=d ** -0.5)
-def causal(): return F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=d ** -0.5)
-g = torch.randn(B, H, N, d, device=dev, dtype=torch.bfloat16)
-for name, fn in (("masked full", full), ("no mask", nomask), ("is_causal", causal)):
-    print(f"{name:14s} fwd {t(fn):.3f} ms   fwd+bwd {t(lambda: fn().backward(g)):.3f} ms")
-for ch in (256, 512, 1024, 2048):
-    fn = lambda: block_causal_attention(q, k, v, m, 0.0, d ** -0.5, chunk=ch)
-    print(f"chunk {ch:5d}    fwd {t(fn):.3f} ms   fwd+bwd {t(lambda: fn().backward(g)):.3f} ms")
-a, b_ = full(), block_causal_attention(q, k, v, m, 0.0, d ** -0.5, chunk=512)
-print("max diff chunked vs full:", float((a.float() - b_.float()).abs().max()))
-with torch.no_grad():
-    qf, kf, vf = q[:2].float(), k[:2].float(), v[:2].float()
-    ref = torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5 + m.float(), dim=-1) @ vf
-    for name, o in (("full", a[:2]), ("chunk512", b_[:2]), ("chunk1024", block_causal_attention(q, k, v, m, 0.0, d ** -0.5, chunk=1024)[:2])):
-        e = (o.float() - ref).abs()
-        print(f"{name}: max err vs fp32 reference {float(e.max()):.4f}, mean {float(e.mean()):.5f}, ref max {float(ref.abs().max()):.3f}")
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B, H, L, D = (int(x) for x in args[:4]) if len(args) >= 4 else (16, 8, 4080, 64)
+    mask = args[4] if len(args) > 4 else "block_causal"
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, L, H, D, generator=g).to(dev, torch.bfloat16).transpose(1, 2)
+    kv = torch.randn(B, L, 2, H, D, generator=g).to(dev, torch.bfloat16)
+    k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+    do = torch.randn(B, L, H, D, generator=g).to(dev, torch.bfloat16).transpose(1, 2)
+    mm = fa.MASKS[mask]
+    scale = D ** -0.5
+    out, lse, saved = fa.attn_fwd_raw(q, k, v, scale, mm, 16)
+    frac = {"none": 1.0, "causal": 0.5, "block_causal": 0.5}[mask]
+    flops_f = 4.0 * B * H * L * L * D * frac
+    t_f = timeit(lambda: fa.attn_fwd_raw(q, k, v, scale, mm, 16))
+    t_b = timeit(lambda: fa.attn_bwd_raw(saved, out, lse, do, scale, mm, 16))
+    print(f"mxvl attention B={B} H={H} L={L} D={D} {mask}: fwd {t_f:8.1f} us ({flops_f / t_f * 1e-6:6.1f} TFLOP/s)   "
+          f"bwd {t_b:8.1f} us ({2.5 * flops_f / t_b * 1e-6:6.1f} TFLOP/s, 5 GEMMs of useful work)")
+    if "--sdpa" in sys.argv:
+        from medical_image_analysis_amd.models_pretrain import block_causal_attention
+        i = torch.arange(L, device=dev) // 16
+        bias = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")).to(torch.bfloat16) if mask == "block_causal" else None
+        ql, kl, vl = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+        def f():
+            if bias is not None:
+                return block_causal_attention(ql, kl, vl, bias, 0.0, scale)
+            return torch.nn.functional.scaled_dot_product_attention(ql, kl, vl, is_causal=(mask == "causal"), scale=scale)
+        t_sf = timeit(lambda: f())
+        def fb():
+            o = f(); o.backward(do)
+        t_sfb = timeit(fb)
+        print(f"library SDPA (chunked for block_causal): fwd {t_sf:8.1f} us   fwd+bwd {t_sfb:8.1f} us")
+
+
+if __name__ == "__main__":
+    main()
