@@ -375,10 +375,11 @@ int mxvl_attn_bwd(const mxvl_attn_bwd_desc *desc, void *hip_stream);
 
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
-/* Forward-scan kernel selection for tests / A-B measurements: 0 = automatic, 1..255 = force one of the (equally correct)
- * kernel shapes; unknown ids fall back to automatic.  Thread-local: it affects only mxvl_scan_fwd calls made by the calling
- * thread.  The product library ignores every bit above the low 8 (measurement builds, -DMXVL_ABLATE, read ablation
- * switches there). */
+/* Scan kernel selection for tests / A-B measurements.  Bits 0..7: forward kernel shape (0 = automatic, unknown ids fall
+ * back to automatic); bits 8..15: backward (0 automatic, 1 = 32-row / 8-wave workgroups, 2 = 16-row / 4-wave, 3 = 16-row at
+ * 3 waves per SIMD).  Every choice is a correct kernel.  Thread-local: it affects only calls made by the calling thread --
+ * note that autograd runs backward on its own thread.  The product library ignores bits >= 16 (measurement builds,
+ * -DMXVL_ABLATE, read ablation switches there). */
 void mxvl_set_scan_variant(int variant);
 /* name of the kernel the last mxvl_scan_fwd on this thread dispatched to (static string) */
 const char *mxvl_last_scan_kernel(void);

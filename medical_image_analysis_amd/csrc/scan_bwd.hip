@@ -83,8 +83,11 @@ __device__ inline float row_sum_to_lane15(float v) {
   return v;
 }
 
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
-__global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
+// MINW = waves per SIMD the register allocation is held to: 2 (<= 256 VGPR, no spill) or 3 (<= 168 VGPR: the per-chunk row
+// state is spilled to scratch once per chunk -- 1 scratch access inside the state loop, 117 outside -- and three 4-wave
+// workgroups share a CU; the kernel sits in s_waitcnt / barriers 36 % of its wave-cycles at 2 waves per SIMD).
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL, int MINW>
+__global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NG = 2;
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
   using io = Io<io_t>;
@@ -97,8 +100,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   // plain 16-byte LDS stores, then a tree-less 16-way sum at the group flush.  (ds_add_f32 measured 7x the
   // whole rest of the kernel, with or without same-address conflicts: LDS float atomics are not usable here.)
   float* sAcc = sC + N * CH;               // [DT][2 (dB,dC)][NG][CH]
-  float* sO = sAcc + DT * 2 * NG * CH;     // [DT][CH] store transpose tile (unaligned rows)
-  float2* sAC = (float2*)(sO + DT * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
+  float* sO = sAcc;                        // [DT][CH] store transpose tile of unaligned rows: aliases sAcc (idle between the
+                                           // last flush barrier of a chunk and the barrier that opens the next one)
+  float2* sAC = (float2*)(sAcc + DT * 2 * NG * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
   float* sG = (float*)(sAC + (DT + 1) * N);  // [DT+1][N] adjoint entering the chunk from the right; row DT = 0
   float* sdA = sG + (DT + 1) * N;          // [DT][N] dA accumulated over the chunks
 
@@ -495,12 +499,12 @@ __global__ __launch_bounds__(256) void scan_bwd_reduce_kernel(const ScanBwdReduc
 
 static thread_local int g_bwd_hip_error = 0;
 
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL, int MINW>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)DT * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL, MINW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
@@ -526,22 +530,28 @@ static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   }
   return MXVL_OK;
 }
-template <typename io_t, int NWAVES, bool VEC>
+template <typename io_t, int NWAVES, bool VEC, int MINW = 2>
 static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
-  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false>(a, stream);
+  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true, MINW>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false, MINW>(a, stream);
 }
 
 // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it leaves the workgroup
 // at the same 8 waves per CU.  Used when 32-row tiles still give every CU a workgroup.
-static bool bwd_wide(int batch, int dim, int G) {
+extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
+
+static bool bwd_wide(int batch, int dim, int G, int L) {
   static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
   const long tiles32 = (long)batch * G * ((dim / G + 31) / 32);
-  return forced ? forced == 8 : ((dim / G) % 32 == 0 && tiles32 >= 256);
+  // one- and two-chunk sequences (the 197-token encoders) run 8 % faster on 16-row workgroups: 1.44 vs 1.58 ms at
+  // B 64 x D 4096 x L 200 (profiles/r02_bwd_variants.txt); long sequences prefer the 32-row pre-sum of dB / dC
+  return forced ? forced == 8 : ((dim / G) % 32 == 0 && tiles32 >= 256 && L > 256);
 }
 
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
-  const bool wide = bwd_wide(a.batch, a.dim, a.G);
+  const int variant = mxvl_scan_bwd_variant();   // tests / A-B measurements: 0 automatic
+  if (variant == 3 && sizeof(io_t) == 2) return a.vec_ok ? launch_bwd<io_t, 4, true, 3>(a, stream) : launch_bwd<io_t, 4, false, 3>(a, stream);
+  const bool wide = variant == 1 ? true : variant == 2 || variant == 3 ? false : bwd_wide(a.batch, a.dim, a.G, a.L);
   if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
   return a.vec_ok ? launch_bwd<io_t, 4, true>(a, stream) : launch_bwd<io_t, 4, false>(a, stream);
 }
@@ -554,7 +564,8 @@ extern "C" int mxvl_scan_check(const mxvl_scan_desc* d);
 
 extern "C" int64_t mxvl_scan_bwd_workspace_bytes(const mxvl_scan_desc* f) {
   if (mxvl_scan_check(f) != MXVL_OK || f->dstate > 64) return 0;
-  const int DT = bwd_wide(f->batch, f->dim, f->n_groups) ? 32 : 16;
+  const int bv = mxvl_scan_bwd_variant();
+  const int DT = (bv == 1 || (bv == 0 && bwd_wide(f->batch, f->dim, f->n_groups, f->seqlen))) ? 32 : 16;
   const int64_t tiles = (f->dim / f->n_groups + DT - 1) / DT;
   if (tiles < 2) return 0;   // one tile per group: nothing to reduce across workgroups
   const int64_t bytes = (int64_t)f->batch * f->n_groups * tiles * 2 * f->dstate * (int64_t)f->seqlen * 4;

@@ -457,7 +457,8 @@ int mxvl_abi_version(void) { return MXVL_ABI_VERSION; }
 int mxvl_scan_chunk_len(int, int) { return kCkptLen; }
 int mxvl_scan_n_chunks(int seqlen, int) { return (seqlen + kCkptLen - 1) / kCkptLen; }
 int mxvl_last_hip_error(void) { return g_last_hip_error; }
-void mxvl_set_scan_variant(int v) { g_variant = MXVL_ABL(true) ? v : (v & 0xff); }
+void mxvl_set_scan_variant(int v) { g_variant = MXVL_ABL(true) ? v : (v & 0xffff); }
+int mxvl_scan_bwd_variant(void) { return (g_variant >> 8) & 0xff; }
 const char* mxvl_last_scan_kernel(void) { return g_last_kernel; }
 
 int mxvl_scan_check(const mxvl_scan_desc* d) {
@@ -494,7 +495,7 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
   a.dl_ratio = d->delta_group_ratio > 1 ? d->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
-  a.ablate = MXVL_ABL(true) ? (g_variant >> 8) & 0xff : 0;
+  a.ablate = MXVL_ABL(true) ? (g_variant >> 16) & 0xff : 0;
   // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
   {
     const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2;

@@ -152,22 +152,31 @@ class Block(nn.Module):
         return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)
 
 
-def run_blocks(layers, hidden_states, inference_params=None, taps=None):
-    """Run a stack of Blocks; `taps` (1-based layer counts) -> list of the hidden states after those layers."""
+def run_blocks(layers, hidden_states, inference_params=None, taps=None, tap_norms=None):
+    """Run a stack of Blocks; `taps` (1-based layer counts) -> list of the hidden states after those layers.
+    tap_norms (one nn.LayerNorm per tap, optional): the list holds LayerNorm_k(hidden state) instead -- on the fused path
+    the tap's residual add and its LayerNorm are the same HIP kernel (the stage-1 model normalises every tap,
+    pretrain/models_pretrain.py:448-452)."""
     feats = []
     if len(layers) and hidden_states.is_contiguous() and all(hasattr(l, "fusable") and l.fusable(hidden_states) for l in layers):
         h, pending = hidden_states, None
         for count, layer in enumerate(layers, start=1):
             h, pending = layer.forward_fused(h, pending, inference_params)
             if taps and count in taps:
-                h, pending = h + pending, None
-                feats.append(h)
+                if tap_norms is not None:
+                    ln = tap_norms[len(feats)]
+                    h, nt = fused_ops.add_layer_norm(h, pending, ln.weight, ln.bias, ln.eps)
+                    pending = None
+                    feats.append(nt)
+                else:
+                    h, pending = h + pending, None
+                    feats.append(h)
         hidden_states = h if pending is None else h + pending
     else:
         for count, layer in enumerate(layers, start=1):
             hidden_states = layer(hidden_states) if inference_params is None else layer(hidden_states, inference_params=inference_params)
             if taps and count in taps:
-                feats.append(hidden_states)
+                feats.append(hidden_states if tap_norms is None else tap_norms[len(feats)](hidden_states))
     return (hidden_states, feats) if taps else hidden_states
 
 

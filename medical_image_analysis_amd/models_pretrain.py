@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import flash_attention as flash
+from . import fused_ops
 from .models_mamba import Block as _FtBlock  # noqa: F401  (same Block arithmetic; kept for isinstance checks)
 from .models_mamba import DropPath, PatchEmbed, SwiGLU, _init_weights, run_blocks, segm_init_weights, trunc_normal_
 from .mamba_simple import Mamba
@@ -257,15 +258,25 @@ class VisionMamba(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "cls_token", "dist_token", "cls_token_head", "cls_token_tail"}
 
-    def forward_features(self, x, inference_params=None):
+    def forward_features(self, x, inference_params=None, per_tap=False):
         x = self.patch_embed(x)
         B, N, C = x.shape
         x = self.pos_drop(x + self.pos_embed)
         hw = int(math.isqrt(N))
         x = cluster_order(x, hw)
         hidden_states = x[:, :-1].reshape(B, -1, C)  # the last cluster is only ever a target
-        hidden_states, feats = run_blocks(self.layers, hidden_states.contiguous(), inference_params, taps=self.skip)
-        feats = torch.cat([self.norm_1(feats[0]), self.norm_2(feats[1]), self.norm_3(feats[2]), self.norm_4(feats[3])], dim=-1)
+        hidden_states, feats = run_blocks(self.layers, hidden_states.contiguous(), inference_params, taps=self.skip,
+                                          tap_norms=[self.norm_1, self.norm_2, self.norm_3, self.norm_4])
+        feats = torch.cat(feats, dim=-1)
+        if per_tap:
+            # decoder block k reads output channels {4 c + k} of enc2dec (`latent_ar[:, :, :, k]`, :465-470): compute them as
+            # four contiguous (B, N, C/4) tensors -- the weight rows are re-ordered (8 M elements), not the activations
+            C4 = self.enc2dec.out_features // 4
+            w = self.enc2dec.weight.view(C4, 4, -1).transpose(0, 1).reshape(4 * C4, -1)
+            b = self.enc2dec.bias.view(C4, 4).t().reshape(-1)
+            y = F.linear(feats, w, b)
+            assert y.shape[1] == 16 * self.cluster_num
+            return y.view(y.shape[0], y.shape[1], 4, C4).permute(2, 0, 1, 3).contiguous()
         feats = self.enc2dec(feats)
         B, N, C = feats.shape
         assert N == 16 * self.cluster_num
@@ -280,6 +291,29 @@ class VisionMamba(nn.Module):
         for count, blk in enumerate(self.dec_block):
             ar_token = blk(ar_token, latent_ar[:, :, :, count], self.mask)
         return self.ar_pred(self.ar_norm(ar_token))
+
+    def _decoder_fusable(self, x):
+        C = self.dec_embed_dim
+        plain = all(type(n) is nn.LayerNorm for blk in self.dec_block for n in (blk.norm2_1, blk.norm2_2, blk.norm2))
+        no_drop = all(isinstance(blk.drop_path, nn.Identity) for blk in self.dec_block)
+        return plain and no_drop and type(self.ar_norm) is nn.LayerNorm and fused_ops.add_layer_norm_supported(x, C)
+
+    def forward_decoder_fused(self, taps, decoder_pos_embed):
+        """forward_decoder with every residual add riding in the following LayerNorm kernel (csrc/fused_norm_act.hip) and
+        contiguous per-block K/V inputs: taps (4, B, N, C).  Same arithmetic as DecoderBlock.forward (:86-104)."""
+        _, B, N, C = taps.shape
+        ar_token = self.ar_token + decoder_pos_embed
+        hw = int(math.isqrt(ar_token.shape[1]))
+        ar_token = cluster_order(ar_token, hw)[:, 1:].reshape(1, -1, C)
+        stream, pending = ar_token.repeat(B, 1, 1), None
+        for k, blk in enumerate(self.dec_block):
+            stream, nq = fused_ops.add_layer_norm(stream, pending, blk.norm2_1.weight, blk.norm2_1.bias, blk.norm2_1.eps)
+            _, nkv = fused_ops.add_layer_norm(taps[k], None, blk.norm2_2.weight, blk.norm2_2.bias, blk.norm2_2.eps)
+            a = blk.attn2(nq, nkv, self.mask)
+            stream, n2 = fused_ops.add_layer_norm(stream, a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            pending = blk.mlp(n2)
+        _, out = fused_ops.add_layer_norm(stream, pending, self.ar_norm.weight, self.ar_norm.bias, self.ar_norm.eps)
+        return self.ar_pred(out)
 
     def patchify(self, imgs):
         """(N, 3, H, W) -> (N, L, p*p*3), channel fastest: einsum 'nchpwq->nhwpqc' (:481-493). Index op, bit-exact."""
@@ -300,8 +334,10 @@ class VisionMamba(nn.Module):
 
     def forward(self, x, inference_params=None):
         labels = x
-        x = self.forward_features(x, inference_params)
-        x = self.forward_decoder(x, self.dec_pos_embed)
+        if x.is_cuda and self._decoder_fusable(x):
+            x = self.forward_decoder_fused(self.forward_features(x, inference_params, per_tap=True), self.dec_pos_embed)
+        else:
+            x = self.forward_decoder(self.forward_features(x, inference_params), self.dec_pos_embed)
         loss = self.forward_loss(labels, x)
         return loss.mean(-1).mean(0)
 

@@ -96,6 +96,38 @@ def test_pretrain_visionmamba_matches_reference():
     _check_grads(m, g, atol_scale=2e-4, rtol=5e-3)
 
 
+def test_pretrain_fused_decoder_path_matches_oracle_and_unfused_path():
+    """At widths the add+LayerNorm kernel serves (multiples of 256) forward() takes the fused route: tap LayerNorms inside
+    the tap's residual-add kernel, enc2dec computed per decoder block, decoder adds inside the LayerNorm kernels, MFMA
+    block-causal attention.  Checked against the CPU oracle (oracle/models_ref.py, itself pinned to the reference golden)
+    and against the module-by-module route on the same weights, loss and parameter gradients."""
+    from medical_image_analysis_amd.models_pretrain import VisionMamba
+    from oracle import models_ref
+    torch.manual_seed(0)
+    m = VisionMamba(img_size=128, patch_size=16, depth=12, embed_dim=256, dec_embed_dim=256, if_abs_pos_embed=True,
+                    bimamba_type="None", drop_path_rate=0.0).to(DEV)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.requires_grad and p.dim() <= 1 and "A_log" not in n and not n.endswith(".D"):
+                p.add_(0.1 * torch.randn_like(p))          # move biases / norm weights off their trivial init
+    img = torch.randn(2, 3, 128, 128, device=DEV)
+    assert m._decoder_fusable(img)
+    loss = m(img)
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref_loss, _, _ = models_ref.visionmamba_forward_ref(sd, img.cpu(), patch=16)
+    assert_close(loss, ref_loss, 1e-4, 1e-3, "fused route vs CPU oracle")
+    loss.mean().backward()
+    fused = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    plain = m.forward_loss(img, m.forward_decoder(m.forward_features(img), m.dec_pos_embed)).mean(-1).mean(0)
+    assert_close(loss, plain, 2e-5, 1e-4, "fused route vs module-by-module route")
+    plain.mean().backward()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            scale = max(1e-4, float(p.grad.abs().max()))
+            assert_close(fused[k], p.grad, 2e-3 * scale, 2e-3, "grad " + k)
+
+
 def test_reference_style_import_through_dropin():
     """`from mamba_ssm.ops.selective_scan_interface import ...` resolves to the HIP path after dropin.install()."""
     import medical_image_analysis_amd.dropin as dropin

@@ -12,8 +12,10 @@ from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw, sc
 import medical_image_analysis_amd.selective_scan_interface as ssi
 
 
-def run(B, D, L, N, dtype, iters=10, workspace=True):
+def run(B, D, L, N, dtype, iters=10, workspace=False, variant=0):
     ssi.USE_BWD_WORKSPACE = workspace
+    from medical_image_analysis_amd import _abi
+    _abi.load().mxvl_set_scan_variant(variant << 8)
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
@@ -32,15 +34,16 @@ def run(B, D, L, N, dtype, iters=10, workspace=True):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     nb = scan_algorithmic_bytes(B, D, L, N, 1, u.element_size(), True, True, ckpt.shape[2])
-    print(f"bwd B={B} D={D} L={L} N={N} {str(dtype)[6:]} ablate={os.environ.get('MXVL_BWD_ABLATE','0')} dBdC={'workspace+reduce' if workspace else 'atomics'}: {us:9.1f} us  {nb/us*1e-6:6.3f} TB/s (incl. torch.zeros of the accumulators)")
+    print(f"bwd B={B} D={D} L={L} N={N} {str(dtype)[6:]} ablate={os.environ.get('MXVL_BWD_ABLATE','0')} dBdC={'workspace+reduce' if workspace else 'atomics'} variant={variant}: {us:9.1f} us  {nb/us*1e-6:6.3f} TB/s (incl. torch.zeros of the accumulators)")
 
 if __name__ == "__main__":
     if len(sys.argv) > 4:
         run(*map(int, sys.argv[1:5]), getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32)
         sys.exit(0)
-    for ws in (True, False, True, False):
-        run(16, 1024, 4080, 16, torch.bfloat16, workspace=ws)
-    for ws in (True, False):
-        run(8, 1024, 4080, 16, torch.bfloat16, workspace=ws)
-        run(8, 1536, 4096, 16, torch.float32, workspace=ws)
-        run(64, 4096, 200, 16, torch.bfloat16, workspace=ws)   # arm_encoder_large_224: 4 directions stacked, L = 197 -> 200
+    for rep in range(2):
+        for v in (1, 2, 3):
+            run(16, 1024, 4080, 16, torch.bfloat16, variant=v)
+    for v in (1, 2, 3):
+        run(8, 1024, 4080, 16, torch.bfloat16, variant=v)
+        run(64, 4096, 200, 16, torch.bfloat16, variant=v)   # arm_encoder_large_224: 4 directions stacked, L = 197 -> 200
+        run(32, 768, 196, 16, torch.bfloat16, variant=v)

@@ -14,7 +14,7 @@ Dv = torch.randn(D, generator=g).to(dev); bias = (0.5 * torch.rand(D, generator=
 lib = _abi.load()
 nwg = (D // 16) * B
 for ab in (24, 24 | 1):
-    lib.mxvl_set_scan_variant(10 | (ab << 8))
+    lib.mxvl_set_scan_variant(10 | (ab << 16))
     for it in range(3):
         out = scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True)[0]
         torch.cuda.synchronize()

@@ -43,7 +43,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         for ab in (0, 1, 2, 4, 8, 1 | 4, 1 | 4 | 8):
             print("ablate bits", ab, "(1=no n-loop 2=half n-loop 4=no softplus/silu 8=no out store)")
-            run(8, 1536, 4096, 16, torch.float32, variants=[10 | (ab << 8)], rounds=3)
+            run(8, 1536, 4096, 16, torch.float32, variants=[10 | (ab << 16)], rounds=3)
     elif len(sys.argv) > 1:
         B, D, L, N = map(int, sys.argv[1:5]); dt = getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32
         run(B, D, L, N, dt)
