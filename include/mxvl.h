@@ -373,6 +373,13 @@ typedef struct mxvl_attn_bwd_desc {
 int mxvl_attn_fwd(const mxvl_attn_desc *desc, void *hip_stream);
 int mxvl_attn_bwd(const mxvl_attn_bwd_desc *desc, void *hip_stream);
 
+/* Stage-2 contrastive step (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_CLIP.py:133-148) as one kernel: L2-normalise both
+ * feature sets, logits = exp(logit_scale) * img_n @ txt_n^T, loss = (CE(logits, arange) + CE(logits^T, arange)) / 2, plus the
+ * gradients for d(loss) = 1.  Features fp32 (batch, dim) contiguous; logit_scale (device
+ * scalar) is the parameter, i.e. the log of the multiplier; loss and d_logit_scale are device scalars.  batch <= 89. */
+int mxvl_clip_loss(const float *image_features, const float *text_features, const float *logit_scale, int batch, int dim,
+                   float *loss, float *d_image, float *d_text, float *d_logit_scale, void *hip_stream);
+
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
 /* Scan kernel selection for tests / A-B measurements.  Bits 0..7: forward kernel shape (0 = automatic, unknown ids fall

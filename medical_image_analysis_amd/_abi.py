@@ -35,7 +35,7 @@ SYMBOLS = [
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
-    "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd",
+    "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
 ]
 
 
@@ -228,6 +228,8 @@ def load() -> ctypes.CDLL:
     lib.mxvl_resample_coeffs.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p]
     lib.mxvl_image_preprocess.restype = c_int
     lib.mxvl_image_preprocess.argtypes = [c_void_p, c_void_p]
+    lib.mxvl_clip_loss.restype = c_int
+    lib.mxvl_clip_loss.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int
     lib.mxvl_scan_n_chunks.restype = c_int
     lib.mxvl_set_scan_variant.argtypes = [c_int]

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from .selective_scan_interface import _SplitHalves, mamba_inner_fn, proj_in, selective_scan_fn
+from .selective_scan_interface import _SplitHalves, bimamba_inner_fn, mamba_inner_fn, proj_in, selective_scan_fn
 from .selective_state_update import selective_state_update
 
 _SUFFIXES = {"v2": ["_b"], "v3": ["_b", "_c", "_c_b"], "v4": ["_b", "_c", "_c_b", "_d", "_d_b"]}
@@ -191,8 +191,6 @@ class Mamba(nn.Module):
         self.bimamba_type = bimamba_type
         self.if_devide_out = if_devide_out
         self.init_layer_scale = init_layer_scale
-        if bimamba_type == "v1":
-            raise NotImplementedError("bimamba_type='v1' (bimamba_inner_fn) is not built; no shipped factory uses it")
         if init_layer_scale is not None:
             self.gamma = nn.Parameter(init_layer_scale * torch.ones(d_model), requires_grad=True)
 
@@ -203,6 +201,10 @@ class Mamba(nn.Module):
         self._make_direction("", conv_bias, device, factory_kwargs)
         for sfx in _SUFFIXES.get(bimamba_type, []):
             self._make_direction(sfx, conv_bias, device, factory_kwargs)
+        if bimamba_type == "v1":   # shared conv / projections, its own decay matrix for the reversed scan (:132-140)
+            A_b_log = torch.log(torch.arange(1, self.d_state + 1, dtype=torch.float32, device=device)).repeat(self.d_inner, 1)
+            self.A_b_log = nn.Parameter(A_b_log.contiguous())
+            self.A_b_log._no_weight_decay = True
         self.out_proj = nn.Linear(self.d_inner, self.d_model, bias=bias, **factory_kwargs)
         self._perm_cache = {}
 
@@ -349,7 +351,11 @@ class Mamba(nn.Module):
             out = self._multi_direction(xz, xd if self.bimamba_type == "v4" else None)
         else:
             A = -torch.exp(self.A_log.float())
-            if inference_params is None:
+            if inference_params is None and self.bimamba_type == "v1":
+                out = bimamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
+                                       self.out_proj.weight, self.out_proj.bias, A, -torch.exp(self.A_b_log.float()), None, None,
+                                       self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+            elif inference_params is None:
                 out = mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                                      self.out_proj.weight, self.out_proj.bias, A, None, None, self.D.float(),
                                      delta_bias=self.dt_proj.bias.float(), delta_softplus=True)

@@ -288,6 +288,37 @@ class MambaXrayVLDownStream(nn.Module):
         return {"optimizer": opt, "lr_scheduler": sched}
 
 
+class _ClipLoss(torch.autograd.Function):
+    """normalise -> cosine logits * exp(logit_scale) -> symmetric cross-entropy (MambaXrayVL_CLIP.py:133-148); loss and all
+    three gradients come out of ONE launch of mxvl_clip_loss."""
+
+    @staticmethod
+    def forward(ctx, img, txt, logit_scale):
+        from . import _abi
+        lib = _abi.load()
+        img, txt = img.contiguous(), txt.contiguous()
+        ls = logit_scale.detach().float().reshape(1).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=img.device)
+        dimg, dtxt = torch.empty_like(img), torch.empty_like(txt)
+        dsc = torch.empty((), dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            _abi.check(lib.mxvl_clip_loss(img.data_ptr(), txt.data_ptr(), ls.data_ptr(), img.shape[0],
+                                          img.shape[1], loss.data_ptr(), dimg.data_ptr(), dtxt.data_ptr(), dsc.data_ptr(),
+                                          _abi.stream_ptr(img.device)), "mxvl_clip_loss")
+        ctx.save_for_backward(dimg, dtxt, dsc)
+        ctx.scale_dtype = logit_scale.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dimg, dtxt, dsc = ctx.saved_tensors
+        return dimg * g, dtxt * g, (dsc * g).to(ctx.scale_dtype)
+
+
+def clip_contrastive_loss(image_features, text_features, logit_scale):
+    return _ClipLoss.apply(image_features.float(), text_features.float(), logit_scale)
+
+
 class MambaXrayVLCLIP(nn.Module):
     """Stage 2: image/report contrastive alignment (MambaXrayVL_CLIP.py:106-150).  `text_encoder` is any module that
     returns `.last_hidden_state` / ["last_hidden_state"] (the reference: HF Bio_ClinicalBERT, third-party)."""
@@ -336,8 +367,10 @@ class MambaXrayVLCLIP(nn.Module):
     def forward(self, samples):
         image = samples["image"]
         toks = self.tokenizer(samples["input_text"], padding="max_length", truncation=True, return_tensors="pt", max_length=128).to(image[0].device)
-        img = F.normalize(self.encode_img(image).float(), dim=1)
-        txt = F.normalize(self.encode_txt(toks).float(), dim=1)
+        img, txt = self.encode_img(image).float(), self.encode_txt(toks).float()
+        if img.is_cuda and img.shape[0] <= 89:
+            return {"loss": clip_contrastive_loss(img, txt, self.logit_scale)}       # one HIP kernel (csrc/clip_loss.hip)
+        img, txt = F.normalize(img, dim=1), F.normalize(txt, dim=1)
         logits = self.logit_scale.exp() * img @ txt.t()
         labels = torch.arange(logits.shape[0], device=logits.device)
         return {"loss": (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2}

@@ -484,6 +484,35 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     return proj_out(y, out_proj_weight, out_proj_bias)
 
 
-def bimamba_inner_fn(*args, **kwargs):
-    raise NotImplementedError("bimamba_inner_fn (bimamba_type='v1') is not used by any shipped factory "
-                              "(models_mamba.py:398-436 build 'v3'); not built")
+def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                     A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """bimamba_type "v1" (call site arm/Finetuning/mamba_simple.py:429-444).  The function itself lives in the patched
+    third-party `mamba_ssm` the reference imports (absent from /root/reference, unpinned -- SURVEY.md 8-c); restated from the
+    Vim project's BiMambaInnerFn, which that fork carries: ONE conv1d / x_proj / dt_proj, a forward scan with A and a scan of
+    the time-reversed (x, delta, B, C, z) with A_b, `out_z = out_z_f + out_z_b.flip(-1)`, then out_proj."""
+    from .causal_conv1d import causal_conv1d_fn
+    if B is not None or C is not None:
+        raise NotImplementedError("bimamba_inner_fn: only input-dependent B and C (the reference passes None, mamba_simple.py:439-440)")
+    if xz.dim() != 3 or xz.shape[1] % 2 != 0:
+        raise RuntimeError("bimamba_inner_fn: xz must be (batch, 2*d_inner, seqlen)")
+    batch, two_d, L = xz.shape
+    d_inner = two_d // 2
+    N = A.shape[1]
+    R = delta_proj_weight.shape[1]
+    x, z = _SplitHalves.apply(xz) if xz.requires_grad else (xz[:, :d_inner], xz[:, d_inner:])
+    xc = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")
+    xc2 = _dmajor_2d(xc)
+    x_dbl = torch.matmul(x_proj_weight.to(xc.dtype), xc2)
+    dt = _from_2d(torch.matmul(delta_proj_weight.to(xc.dtype), x_dbl[:R]), batch, L)
+    Bm = _from_2d(x_dbl[R:R + N], batch, L)
+    Cm = _from_2d(x_dbl[R + N:R + 2 * N], batch, L)
+    if B_proj_bias is not None:
+        Bm = Bm + B_proj_bias.to(Bm.dtype)[None, :, None]
+    if C_proj_bias is not None:
+        Cm = Cm + C_proj_bias.to(Cm.dtype)[None, :, None]
+    io = xc.dtype
+    dt, Bm, Cm, zz = dt.to(io), Bm.to(io), Cm.to(io), z.to(io)
+    y_f = selective_scan_fn(xc, dt, A, Bm, Cm, D, z=zz, delta_bias=delta_bias, delta_softplus=delta_softplus)
+    y_b = selective_scan_fn(xc.flip(-1), dt.flip(-1), A_b, Bm.flip(-1), Cm.flip(-1), D, z=zz.flip(-1), delta_bias=delta_bias,
+                            delta_softplus=delta_softplus)
+    return proj_out(y_f + y_b.flip(-1), out_proj_weight, out_proj_bias)

@@ -201,6 +201,31 @@ def mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_we
                     None if out_proj_bias is None else out_proj_bias.float())
 
 
+def bimamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias, A, A_b,
+                      D=None, delta_bias=None, delta_softplus=True):
+    """bimamba_type "v1" (call site arm/Finetuning/mamba_simple.py:429-444; the function belongs to the patched third-party
+    mamba_ssm, restated from Vim's BiMambaInnerFn -- PARITY UNPINNED at this boundary, like the other fused inner functions):
+    shared conv / projections, forward scan with A plus the scan of the time-reversed sequence with A_b, flipped back."""
+    xz = xz.float()
+    L = xz.shape[-1]
+    R = delta_proj_weight.shape[1]
+    N = A.shape[1]
+    x, z = xz.chunk(2, dim=1)
+    x = causal_conv1d_ref(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
+    b, d, _ = x.shape
+    x_dbl = F.linear(x.permute(0, 2, 1).reshape(b * L, d), x_proj_weight.float())
+    dt, Bm, Cm = torch.split(x_dbl, [R, N, N], dim=-1)
+    dt = (delta_proj_weight.float() @ dt.t()).reshape(d, b, L).permute(1, 0, 2).contiguous()
+    Bm = Bm.reshape(b, L, N).permute(0, 2, 1).contiguous()
+    Cm = Cm.reshape(b, L, N).permute(0, 2, 1).contiguous()
+    z = z.contiguous()
+    fl = lambda t: t.flip(-1).contiguous()
+    y_f = selective_scan_ref(x, dt, A, Bm, Cm, D, z, delta_bias, delta_softplus)
+    y_b = selective_scan_ref(fl(x), fl(dt), A_b, fl(Bm), fl(Cm), D, fl(z), delta_bias, delta_softplus)
+    y = y_f + y_b.flip(-1)
+    return F.linear(y.permute(0, 2, 1), out_proj_weight.float(), None if out_proj_bias is None else out_proj_bias.float())
+
+
 def cross_scan_ref(x):
     """vmamba.py:25-35 CrossScan.forward: (B,C,H,W) -> (B,4,C,H*W).  fp32 through the C loops; other dtypes are pure
     data movement, so they round-trip through fp32 exactly."""

@@ -102,3 +102,27 @@ def g_texts():
     import numpy as np
     import os
     return np.load(os.path.join(GOLDEN, "clip_loss_arm_d2.npz"))["texts"].tolist()
+
+
+@pytest.mark.gpu
+def test_clip_loss_kernel_matches_torch_at_training_size():
+    """mxvl_clip_loss at the reference's stage-2 batch (48 x 512 projections): loss and the three gradients against the eager
+    fp32 statement of MambaXrayVL_CLIP.py:133-148."""
+    import torch.nn.functional as F
+    from medical_image_analysis_amd.mambaxray_vl import clip_contrastive_loss
+    g = torch.Generator().manual_seed(4)
+    for n, P in ((48, 512), (7, 96), (89, 64)):
+        img = torch.randn(n, P, generator=g).to(DEV).requires_grad_(True)
+        txt = torch.randn(n, P, generator=g).to(DEV).requires_grad_(True)
+        ls = torch.tensor(2.3, device=DEV, requires_grad=True)
+        loss = clip_contrastive_loss(img, txt, ls)
+        (loss * 1.7).backward()
+        ri, rt, rs = [t.detach().clone().requires_grad_(True) for t in (img, txt, ls)]
+        a, b = F.normalize(ri, dim=1), F.normalize(rt, dim=1)
+        logits = rs.exp() * a @ b.t()
+        lab = torch.arange(n, device=DEV)
+        ref = (F.cross_entropy(logits, lab) + F.cross_entropy(logits.t(), lab)) / 2
+        (ref * 1.7).backward()
+        assert_close(loss, ref, 1e-5, 1e-5, f"loss n={n}")
+        for got, want, nm in ((img.grad, ri.grad, "dimg"), (txt.grad, rt.grad, "dtxt"), (ls.grad, rs.grad, "dscale")):
+            assert_close(got, want, 1e-6 + 2e-5 * float(want.abs().max()), 1e-4, f"{nm} n={n}")

@@ -223,3 +223,28 @@ def test_dropin_selective_scan_cuda_has_the_mamba_ssm_signature():
     o, ckz, oz = cuda.fwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], z, x["delta_bias"], True)
     assert_close(oz, o * torch.nn.functional.silu(z), 1e-5 * max(1.0, float(oz.abs().max())), 1e-5, "out_z = out * silu(z)")
     assert len(cuda.bwd(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], z, x["delta_bias"], dout, ckz, o, None, True, False)) == 8
+
+
+def test_bimamba_v1_mixer_matches_oracle():
+    """bimamba_type "v1": `bimamba_inner_fn` through the Mamba module (state_dict adds A_b_log only, as the reference's
+    constructor :132-140) against the CPU restatement -- third-party function, unpinned; forward + input gradient."""
+    from medical_image_analysis_amd.mamba_simple import Mamba
+    from oracle import oracle as orc
+    torch.manual_seed(0)
+    m = Mamba(d_model=64, expand=1, bimamba_type="v1").to(DEV)
+    assert "A_b_log" in m.state_dict() and "conv1d_b.weight" not in m.state_dict()
+    with torch.no_grad():
+        m.A_b_log.add_(0.3 * torch.randn_like(m.A_b_log))
+        m.D.add_(0.2 * torch.randn_like(m.D))
+    x = torch.randn(2, 150, 64, device=DEV, requires_grad=True)
+    out = m(x)
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    xc = x.detach().cpu().requires_grad_(True)
+    xz = (xc @ sd["in_proj.weight"].t()).permute(0, 2, 1)
+    ref = orc.bimamba_inner_ref(xz, sd["conv1d.weight"].squeeze(1), sd["conv1d.bias"], sd["x_proj.weight"], sd["dt_proj.weight"],
+                                sd["out_proj.weight"], None, -torch.exp(sd["A_log"]), -torch.exp(sd["A_b_log"]), sd["D"],
+                                delta_bias=sd["dt_proj.bias"], delta_softplus=True)
+    assert_close(out, ref.detach(), 2e-5, 1e-4, "bimamba v1 out")
+    g = torch.randn_like(out)
+    out.backward(g)
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
