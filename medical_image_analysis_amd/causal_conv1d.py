@@ -46,12 +46,15 @@ def conv1d_fwd_raw(x, w32, b32, silu):
     return y
 
 
-def conv1d_bwd_raw(x, w32, b32, silu, dy):
+def conv1d_bwd_raw(x, w32, b32, silu, dy, dx=None):
+    """dx may be passed in (x's dtype, seqlen-contiguous, any batch/channel strides): the fused mixer backward has the
+    kernel write the x half of d(xz) in place."""
     lib = _abi.load()
     batch, dim, L = x.shape
     if dy.stride(-1) != 1:
         dy = dy.contiguous()
-    dx = torch.empty_like(x)
+    if dx is None:
+        dx = torch.empty_like(x)
     dw = torch.zeros_like(w32)
     db = torch.zeros_like(b32) if b32 is not None else None
     d = _abi.Conv1dBwdDesc()

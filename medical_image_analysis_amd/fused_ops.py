@@ -78,8 +78,8 @@ class _AddLayerNorm(torch.autograd.Function):
         dx = torch.empty_like(h)
         dbr = torch.empty((rows, C), dtype=br_dtype, device=h.device) if has_br and br_dtype != h.dtype else None
         n_part = lib.mxvl_add_layernorm_partials(rows)
-        pg = torch.empty((n_part, C), dtype=torch.float32, device=h.device)
-        pb = torch.empty_like(pg)
+        pgb = torch.empty((2, n_part, C), dtype=torch.float32, device=h.device)     # dgamma | dbeta partials: ONE reduction below
+        pg, pb = pgb[0], pgb[1]
         d = _abi.AddLnBwdDesc()
         d.rows, d.cols, d.n_partials = rows, C, n_part
         d.res_dtype, d.branch_dtype, d.out_dtype = _abi.dtype_code(h.dtype), _abi.dtype_code(br_dtype), _abi.dtype_code(out_dtype)
@@ -87,8 +87,9 @@ class _AddLayerNorm(torch.autograd.Function):
         d.dx, d.dbranch, d.partial_dgamma, d.partial_dbeta = dx.data_ptr(), _abi.ptr(dbr), pg.data_ptr(), pb.data_ptr()
         with torch.cuda.device(h.device):
             _abi.check(lib.mxvl_add_layernorm_bwd(ctypes.byref(d), _abi.stream_ptr(h.device)), "mxvl_add_layernorm_bwd")
-        dgamma = pg.sum(0).to(w_dtype)
-        dbeta = pb.sum(0).to(b_dtype) if has_bias else None
+        gb = pgb.sum(1)
+        dgamma = gb[0].to(w_dtype)
+        dbeta = gb[1].to(b_dtype) if has_bias else None
         dx_v = dx.view(shape)
         dbranch = None
         if has_br:

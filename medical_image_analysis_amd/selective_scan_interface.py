@@ -145,20 +145,26 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
 USE_BWD_WORKSPACE = False
 
 
-def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout):
-    """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C)."""
+def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout, du=None, dz=None, dB=None, dC=None):
+    """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C).
+    du / dz (io dtype, seqlen-contiguous, any batch/channel strides) and dB / dC (fp32, ZEROED by the caller) may be passed
+    in: the fused mixer backward lets the kernel write straight into the buffers the next GEMM reads."""
     lib = _abi.load()
     batch, dim, L = u.shape
     dout = _last_contig(dout)
-    du = torch.empty_like(u)
+    if du is None:
+        du = torch.empty_like(u)
     ratio = dim // delta.shape[1]
     # the kernel writes ddelta / ddelta_bias per channel; grouped delta (ratio > 1) is reduced over each group below
     ddelta = torch.empty_like(delta) if ratio == 1 else torch.empty_like(u)
-    dz = torch.empty_like(z) if z is not None else None
+    if dz is None and z is not None:
+        dz = torch.empty_like(z)
     # accumulated-into buffers start at zero (reference contract, selective_scan.cpp:321-327)
     dA = torch.zeros_like(A)
-    dB = torch.zeros(B.shape, dtype=torch.float32, device=u.device)
-    dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
+    if dB is None:
+        dB = torch.zeros(B.shape, dtype=torch.float32, device=u.device)
+    if dC is None:
+        dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
     dD = torch.zeros_like(D) if D is not None else None
     dbias = torch.zeros(dim, dtype=torch.float32, device=u.device) if delta_bias is not None else None
     desc = _abi.ScanBwdDesc()
@@ -289,10 +295,16 @@ def _bmm_f32(a, b):
     return torch.bmm(a, b, out_dtype=torch.float32) if _BMM_F32 else torch.bmm(a, b)
 
 
+# measured exceptions to the rule below (tools/wgrad_bench.py on an MI355X, profiles/r02_wgrad_bench.txt): (M, N, K) -> slices
+_WGRAD_SPLITS = {(5460, 1024, 65280): 16}     # SwiGLU w1|w2 at per-GPU batch 16: 995 us at 4 slices, 816 us at 16
+
+
 def wgrad_splits(K, M, N):
     """Number of token slices: enough (slices x 256^2 output tiles) to give every CU work, a power of two dividing K."""
     if K < 4096 or os.environ.get("MXVL_WGRAD_SPLITS") == "0":
         return 1
+    if (M, N, K) in _WGRAD_SPLITS and K % _WGRAD_SPLITS[(M, N, K)] == 0:
+        return _WGRAD_SPLITS[(M, N, K)]
     tiles = -(-M // 256) * -(-N // 256)
     S = 1
     while S < 16 and S * tiles < 256 and K % (2 * S) == 0:
@@ -449,6 +461,88 @@ class _SplitHalves(torch.autograd.Function):
         return g
 
 
+class _MambaInnerFn(torch.autograd.Function):
+    """conv1d+SiLU -> x_proj -> dt_proj -> selective scan as ONE autograd node over the same HIP kernels and library GEMMs
+    as the composed path below.  What the node buys is the BACKWARD's data movement: scan_bwd writes dz and conv1d_bwd
+    writes dx straight into the two halves of the channel-major d(xz) buffer (no _SplitHalves copies), x_proj's data
+    gradient is accumulated into du by the GEMM itself (beta = 1, no add pass), d(x_dbl) is assembled once instead of by
+    three zero-filled slice gradients, and both skinny weight gradients (96 x 1024 and 1024 x 64 over 65k tokens) take the
+    split-K path.  7.6 ms of 242 at the pre-training step.  (The reference's counterpart is the patched mamba_ssm's
+    MambaInnerFn, third-party and absent; semantics from mamba_simple.py:665-709 as above.)"""
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus):
+        from .causal_conv1d import conv1d_fwd_raw, _w2
+        _abi.require_gpu(xz, conv_w, x_proj_w, dt_proj_w, A)
+        batch, two_d, L = xz.shape
+        d = two_d // 2
+        N, R = A.shape[1], dt_proj_w.shape[1]
+        if xz.stride(-1) != 1 and L != 1:
+            xz = xz.contiguous()
+        x, z = xz[:, :d], xz[:, d:]
+        w32 = _w2(conv_w).detach().float().contiguous()
+        if w32.shape[0] != d:
+            raise RuntimeError("causal_conv1d: weight.shape[0] must equal dim")
+        b32 = conv_b.detach().float().contiguous() if conv_b is not None else None
+        xc = conv1d_fwd_raw(x, w32, b32, 1)
+        io = xc.dtype
+        xc2 = _dmajor_2d(xc)
+        wx, wdt = x_proj_w.to(io), dt_proj_w.to(io)
+        x_dbl = torch.matmul(wx, xc2)                                            # (R+2N, B*L)
+        dt = _from_2d(torch.matmul(wdt, x_dbl[:R]), batch, L)
+        Bm, Cm = _from_2d(x_dbl[R:R + N], batch, L), _from_2d(x_dbl[R + N:R + 2 * N], batch, L)
+        if B_proj_bias is not None:
+            Bm = Bm + B_proj_bias.to(io)[None, :, None]
+        if C_proj_bias is not None:
+            Cm = Cm + C_proj_bias.to(io)[None, :, None]
+        _, u_, dt_, A_, B_, C_, D_, z_, bias_ = _prep(xc, dt, A, Bm, Cm, D, z, delta_bias)
+        needs_grad = any(ctx.needs_input_grad[:10])
+        out, _, ckpt = scan_fwd_raw(u_, dt_, A_, B_, C_, D_, z_, bias_, delta_softplus, want_ckpt=needs_grad)
+        ctx.meta = (delta_softplus, conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
+                    dt_proj_w.dtype, A.dtype, None if D is None else D.dtype, None if delta_bias is None else delta_bias.dtype,
+                    None if B_proj_bias is None else B_proj_bias.dtype, None if C_proj_bias is None else C_proj_bias.dtype)
+        ctx.save_for_backward(xz, w32, b32, u_, x_dbl, dt_, wx, wdt, A_, B_, C_, D_, bias_, ckpt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .causal_conv1d import conv1d_bwd_raw
+        xz, w32, b32, xc, x_dbl, dt, wx, wdt, A, Bm, Cm, D, bias, ckpt = ctx.saved_tensors
+        softplus, cw_shape, cw_dt, cb_dt, wx_dt, wdt_dt, A_dt, D_dt, bias_dt, Bb_dt, Cb_dt = ctx.meta
+        batch, two_d, L = xz.shape
+        d = two_d // 2
+        N, R = A.shape[1], wdt.shape[1]
+        io = xc.dtype
+        T = batch * L
+        dxz = torch.empty((two_d, batch, L), dtype=io, device=xz.device).permute(1, 0, 2)   # (B, 2D, L), stored channel-major
+        du = torch.empty((d, batch, L), dtype=io, device=xz.device).permute(1, 0, 2)
+        dBC = torch.zeros((2 * N, batch, L), dtype=torch.float32, device=xz.device)         # dB | dC rows, fp32 accumulators
+        dB = dBC[:N].permute(1, 0, 2).unsqueeze(1)
+        dC = dBC[N:].permute(1, 0, 2).unsqueeze(1)
+        _, ddelta, dA, _, _, dD, _, dbias = scan_bwd_raw(xc, dt, A, Bm, Cm, D, xz[:, d:], bias, softplus, ckpt,
+                                                          dout.to(io), du=du, dz=dxz[:, d:], dB=dB, dC=dC)
+        dd2 = _dmajor_2d(ddelta)                                                 # (D, T), free view
+        dx_dbl = torch.empty((R + 2 * N, T), dtype=io, device=xz.device)
+        torch.matmul(wdt.t(), dd2, out=dx_dbl[:R])
+        dx_dbl[R:].copy_(dBC.view(2 * N, T))                                     # the cast selective_scan.cpp:347 makes
+        dwdt = splitk_wgrad_cm(dd2, x_dbl[:R].t(), wdt_dt)
+        xc2 = _dmajor_2d(xc)
+        dwx = splitk_wgrad_cm(dx_dbl, xc2.t(), wx_dt)
+        du2 = du.permute(1, 0, 2).view(d, T)
+        du2.addmm_(wx.t(), dx_dbl)                                               # du += Wx^T @ d(x_dbl), in the GEMM epilogue
+        _, dcw, dcb = conv1d_bwd_raw(xz[:, :d], w32, b32, 1, du, dx=dxz[:, :d])
+        dBb = dBC[:N].sum((1, 2)).to(Bb_dt) if Bb_dt is not None else None
+        dCb = dBC[N:].sum((1, 2)).to(Cb_dt) if Cb_dt is not None else None
+        return (dxz, dcw.reshape(cw_shape).to(cw_dt), dcb.to(cb_dt) if dcb is not None else None, dwx, dwdt, dA.to(A_dt),
+                dD.to(D_dt) if dD is not None else None, dbias.to(bias_dt) if dbias is not None else None, dBb, dCb, None)
+
+
+# The single-node mixer (above) is the default on the GPU; MXVL_MIXER_NODE=0 keeps the composition of separate autograd nodes
+# (same kernels), which the tests hold against it.
+def _use_mixer_node(xz):
+    return xz.is_cuda and os.environ.get("MXVL_MIXER_NODE") != "0"
+
+
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,
                                D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     from .causal_conv1d import causal_conv1d_fn
@@ -460,6 +554,9 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
     d_inner = two_d // 2
     N = A.shape[1]
     R = delta_proj_weight.shape[1]
+    if _use_mixer_node(xz):
+        return _MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+                                   B_proj_bias, C_proj_bias, delta_softplus)
     x, z = _SplitHalves.apply(xz) if xz.requires_grad else (xz[:, :d_inner], xz[:, d_inner:])   # views: strided rows
     xc = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")  # (b, d, l)
     # x_proj / dt_proj as single 2-D GEMMs on the channel-major matrix (D, B*L); B and C are row blocks of x_dbl
