@@ -10,9 +10,11 @@
 //   * the adjoint recurrence g_t = C_t dy_t + a_{t+1} g_{t+1} is the mirror image: a Horner fold from the
 //     lane's last step, a REVERSE prefix scan over the lanes (DPP row_shl fused into v_fmac/v_mul), and a
 //     second pass that produces every gradient contribution of the step;
-//   * dB/dC (summed over the rows of a B/C group) are reduced over the workgroup's 16 rows in an LDS
-//     tile with ds_add_f32 and leave as ONE fp32 global atomic per (n,t) per workgroup -- the CUDA kernel
-//     issues one global atomic per (row,n,t) (bwd_kernel.cuh:215-221);
+//   * dB/dC (summed over the rows of a B/C group): a wave sums the shares of its 4 rows in registers
+//     (v_permlane32_swap / v_permlane16_swap), the workgroup's waves meet in an LDS tile flushed in groups of 4 states one
+//     group behind the computation, and each (n,t) leaves as ONE fp32 global atomic per workgroup (or a plain store into the
+//     caller's workspace + a reduce kernel) -- the CUDA kernel issues one global atomic per (row,n,t)
+//     (bwd_kernel.cuh:215-221);
 //   * dA, dD, ddelta_bias are reduced over lanes with DPP and over chunks in LDS/registers: one global
 //     atomic per (row,n) / row per workgroup.
 // du, ddelta, dz are fully written; dA, dB, dC, dD, ddelta_bias are accumulated into caller-zeroed fp32.
@@ -83,12 +85,35 @@ __device__ inline float row_sum_to_lane15(float v) {
   return v;
 }
 
-// MINW = waves per SIMD the register allocation is held to: 2 (<= 256 VGPR, no spill) or 3 (<= 168 VGPR: the per-chunk row
-// state is spilled to scratch once per chunk -- 1 scratch access inside the state loop, 117 outside -- and three 4-wave
-// workgroups share a CU; the kernel sits in s_waitcnt / barriers 36 % of its wave-cycles at 2 waves per SIMD).
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL, int MINW>
-__global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanBwdArgs p) {
-  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64, NG = 2;
+// lanes l <-> l+32 / 16-lane rows 1 <-> 0, 3 <-> 2 exchanged between two registers: the building blocks of the in-register
+// sum over the 4 rows of a wave.  Inline asm: this toolchain's __builtin_amdgcn_permlane32_swap returns its first
+// result twice.  A swap needs two wait states after a VALU write of its operands: one s_nop 1 opens each block, the swaps
+// that follow (independent registers) cover each other.
+__device__ __forceinline__ void lane32_swap_x8(float (&x)[8], float (&y)[8]) {   // (x[i], x[i+4]) and (y[i], y[i+4]), i < 4
+  asm volatile(
+      "s_nop 1\n"
+      "v_permlane32_swap_b32 %0, %4\n v_permlane32_swap_b32 %8, %12\n"
+      "v_permlane32_swap_b32 %1, %5\n v_permlane32_swap_b32 %9, %13\n"
+      "v_permlane32_swap_b32 %2, %6\n v_permlane32_swap_b32 %10, %14\n"
+      "v_permlane32_swap_b32 %3, %7\n v_permlane32_swap_b32 %11, %15\n"
+      : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+        "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]));
+}
+__device__ __forceinline__ void lane16_swap_x4(float (&s)[8]) {                   // (s[0], s[1]) (s[2], s[3]) (s[4], s[5]) (s[6], s[7])
+  asm volatile(
+      "s_nop 1\n"
+      "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n"
+      "v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+      : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]));
+}
+
+// Registers are held to 2 waves per SIMD (<= 256 VGPR, no spill).  A 3-waves/SIMD build (<= 168 VGPR, the per-chunk row state
+// spilled once per chunk) measured 1.80 ms against 1.34 ms at the pre-training shape (profiles/r02_bwd_variants.txt) and was
+// dropped.
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
+__global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
+  constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
+  constexpr int FG = 4;                    // states per dB/dC flush group
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
   using io = Io<io_t>;
 
@@ -96,15 +121,19 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanB
   const int N = p.N, L = p.L;
   float* sB = smem;                        // [N][CH]  lane-major halves (see scan_fwd_stream.h)
   float* sC = sB + N * CH;                 // [N][CH]
-  // dB/dC contributions of the current group of NG states, one PRIVATE tile per row of the workgroup:
-  // plain 16-byte LDS stores, then a tree-less 16-way sum at the group flush.  (ds_add_f32 measured 7x the
-  // whole rest of the kernel, with or without same-address conflicts: LDS float atomics are not usable here.)
-  float* sAcc = sC + N * CH;               // [DT][2 (dB,dC)][NG][CH]
+  // dB/dC shares of a group of FG states, one tile per WAVE (its 4 rows summed in registers first), double-buffered:
+  // plain LDS stores, then a NWAVES-way tree sum one group behind.  (ds_add_f32 measured 7x the whole rest of the kernel,
+  // with or without same-address conflicts: LDS float atomics are not usable here.)
+  float* sAcc = sC + N * CH;               // [2 buffers][FG][NWAVES][2 (dB,dC)][CH]
   float* sO = sAcc;                        // [DT][CH] store transpose tile of unaligned rows: aliases sAcc (idle between the
                                            // last flush barrier of a chunk and the barrier that opens the next one)
-  float2* sAC = (float2*)(sAcc + DT * 2 * NG * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
+  float2* sAC = (float2*)(sAcc + 2 * FG * NWAVES * 2 * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
   float* sG = (float*)(sAC + (DT + 1) * N);  // [DT+1][N] adjoint entering the chunk from the right; row DT = 0
   float* sdA = sG + (DT + 1) * N;          // [DT][N] dA accumulated over the chunks
+  // u, delta, z, dout of the chunk as loaded, parked here across the state loop.  They are only needed again for the
+  // per-step outputs; in registers (32 VGPRs) they push the loop to the 256-VGPR limit, where the compiler re-computes the 8
+  // v_exp_f32 of a_t in the second pass instead of keeping them (17 instead of 9 transcendentals per state).
+  io_t* sPark = (io_t*)(smem + (((sdA + DT * N) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane >> 4, j = lane & 15;
@@ -273,6 +302,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanB
       }
     }
 
+    {
+      auto park = [&](int arr, const float (&v)[T]) {
+        io_t* q = sPark + ((size_t)arr * NT + tid) * T;
+        st4<io_t>(q, make_float4(v[0], v[1], v[2], v[3]));
+        st4<io_t>(q + 4, make_float4(v[4], v[5], v[6], v[7]));
+      };
+      park(0, uu);
+      park(1, dl);
+      park(3, go);
+      if (has_z) park(2, zz);
+    }
     float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
     // uniform flag tests outside the per-step loops (a branch per step serialises the transcendental chains)
 #pragma unroll
@@ -302,7 +342,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanB
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       du[i] = dl[i] * uu[i];
-      y[i] = Dv * uu[i];
+      y[i] = 0.0f;                       // D * u joins after the state loop (u is parked)
       sgB[i] = 0.0f;
       sAh[i] = 0.0f;
     }
@@ -316,13 +356,55 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanB
     const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * N;
     const float* cB = sB + j * 4;
     const float* cC = sC + j * 4;
-    float* aB = sAcc + (row * 2 + 0) * NG * CH + j * T;
-    float* aC = sAcc + (row * 2 + 1) * NG * CH + j * T;
+    // A wave first sums the dB / dC shares of its 4 rows in registers (v_permlane{32,16}_swap), so only ONE
+    // share per wave goes to LDS; states are flushed in groups of FG, one group behind -- sAcc is two buffers of
+    // [FG][NWAVES][2][CH] -- so the sums of group g run while group g+1 is computed and one barrier per FG states separates a
+    // buffer's writers from its readers.  (History, profiles/r02_bwd_ablation.txt: per-row tiles + a two-barrier flush every 2
+    // states cost 30 % of the kernel in LDS stores, flush reads and barriers; per-wave global atomics without LDS, 8x the
+    // atomics, ran 4x slower.)
+    constexpr int FK = FG * 2 * CH / NT;          // elements of a group per thread: 2 (8 waves) / 4 (4 waves)
+    float* wAcc = sAcc + wave * (2 * CH) + j * T + (r & 1) + (r >> 1) * 4;   // lane (r, j) holds step 8 j + {0, 1, 4, 5}[r] (and +2)
+    auto flush_load = [&](int g, float (&part)[FK * NWAVES]) {
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+        // element x = tid + NT k of the group: state slot x / (2 CH), dB|dC (x / CH) & 1, step x % CH
+        const int x = tid + NT * k;
+        const float* qq = sAcc + (g & 1) * (FG * NWAVES * 2 * CH) + (x / (2 * CH)) * (NWAVES * 2 * CH) + (x % (2 * CH));
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) part[k * NWAVES + w] = qq[w * 2 * CH];
+      }
+    };
+    auto flush_add = [&](int g, float (&part)[FK * NWAVES]) {
+#pragma unroll
+      for (int k = 0; k < FK; ++k) {
+#pragma unroll
+        for (int w = NWAVES / 2; w > 0; w >>= 1) {
+#pragma unroll
+          for (int rr = 0; rr < w; ++rr) part[k * NWAVES + rr] += part[k * NWAVES + rr + w];
+        }
+        const int x = tid + NT * k;
+        const int nn = g * FG + x / (2 * CH), which = (x / CH) & 1, e = x % CH;
+        if (g >= 0 && nn < N && t0 + e < L && !MXVL_ABL(p.ablate & 2)) {
+          const float v = part[k * NWAVES];
+          if constexpr (PARTIAL) {
+            // one plain coalesced store per (tile, n, t): the cross-tile sum is mxvl's second, tiny kernel (scan_bwd_reduce_kernel)
+            float* dst = p.ws + ((((int64_t)b * gridDim.x + blockIdx.x) * 2 + which) * N + nn) * (int64_t)L;
+            __builtin_nontemporal_store(v, dst + t0 + e);
+          } else {
+            float* dst = which ? dCp + (int64_t)nn * p.dC_ns : dBp + (int64_t)nn * p.dB_ns;
+            unsafeAtomicAdd(dst + t0 + e, v);
+          }
+        }
+      }
+    };
 
     for (int n = 0; n < (MXVL_ABL(p.ablate & 4) ? 0 : N); ++n) {
       const float A2 = ac[n].x;
       const float hin = ac_in[n].y;
       float a[T], bb[T], cv[T], h[T];
+      float fpart[FK * NWAVES];
+      const bool f_first = (n % FG) == 0;                  // the previous group's shares are summed during this state
+      if (f_first && !MXVL_ABL(p.ablate & 16)) flush_load(n / FG - 1, fpart);   // group -1: stale LDS, discarded
       {
         const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 64);
         const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 64);
@@ -377,49 +459,52 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_bwd_kernel(const ScanB
         dA_part = fmaf(gha, dl[i], dA_part);
         gg = ga;
       }
-      if (!MXVL_ABL(p.ablate & 1)) {
-        float4* wB = (float4*)(aB + (n % NG) * CH);
-        float4* wC = (float4*)(aC + (n % NG) * CH);
-        wB[0] = make_float4(vB[0], vB[1], vB[2], vB[3]); wB[1] = make_float4(vB[4], vB[5], vB[6], vB[7]);
-        wC[0] = make_float4(vC[0], vC[1], vC[2], vC[3]); wC[1] = make_float4(vC[4], vC[5], vC[6], vC[7]);
-      }
-      dA_part = row_sum_to_lane15(dA_part);
-      if (j == LPR - 1) sdA[row * N + n] += dA_part;
-
-      if ((n % NG) == NG - 1 || n == N - 1) {
-        // flush the group: every row of the workgroup has added its share of states n0..n
-        const int n0 = n - (n % NG);
-        __syncthreads();
-        for (int i = tid; i < 2 * NG * CH; i += NT) {
-          const int which = i / (NG * CH), rem = i - which * (NG * CH);
-          const int nn = rem / CH, e = rem - nn * CH;
-          // all DT row shares first (independent LDS reads in flight together), then a pairwise tree: the serial
-          // read-add chain this replaces was LDS-latency bound (5 reads in flight, 32 dependent adds)
-          float part[DT];
+      {
+        dA_part = row_sum_to_lane15(dA_part);
+        if (j == LPR - 1) sdA[row * N + n] += dA_part;
+        if (!MXVL_ABL(p.ablate & 1)) {
+          // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
+          // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
+          // steps {i, i+1, i+4, i+5}
+          float sr[8];
+          lane32_swap_x8(vB, vC);
 #pragma unroll
-          for (int rr = 0; rr < DT; ++rr) part[rr] = sAcc[(rr * 2 + which) * NG * CH + rem];
-#pragma unroll
-          for (int w = DT / 2; w > 0; w >>= 1) {
-#pragma unroll
-            for (int rr = 0; rr < w; ++rr) part[rr] += part[rr + w];
-          }
-          const float v = part[0];
-          if (n0 + nn <= n && t0 + e < L && !MXVL_ABL(p.ablate & 2)) {
-            if constexpr (PARTIAL) {
-              // one plain coalesced store per (tile, n, t): the cross-tile sum is mxvl's second, tiny kernel
-              // (scan_bwd_reduce_kernel).  fp32 global atomics to the 32 tiles' shared (n, t) cells were 16-22 % of this kernel.
-              float* dst = p.ws + ((((int64_t)b * gridDim.x + blockIdx.x) * 2 + which) * N + (n0 + nn)) * (int64_t)L;
-              __builtin_nontemporal_store(v, dst + t0 + e);
-            } else {
-              float* dst = which ? dCp + (int64_t)(n0 + nn) * p.dC_ns : dBp + (int64_t)(n0 + nn) * p.dB_ns;
-              unsafeAtomicAdd(dst + t0 + e, v);
-            }
-          }
+          for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
+          lane16_swap_x4(sr);
+          float* w = wAcc + (((n / FG) & 1) * FG + (n % FG)) * (NWAVES * 2 * CH);
+          w[0] = sr[0] + sr[1]; w[2] = sr[2] + sr[3];
+          w[CH] = sr[4] + sr[5]; w[CH + 2] = sr[6] + sr[7];
         }
-        __syncthreads();
+        if (f_first && !MXVL_ABL(p.ablate & 16)) flush_add(n / FG - 1, fpart);
+        if (((n % FG) == FG - 1 || n == N - 1) && !MXVL_ABL(p.ablate & 8)) __syncthreads();
       }
     }
 
+    {
+      if (!MXVL_ABL(p.ablate & 4)) {     // the last group's shares
+        float fpart[FK * NWAVES];
+        flush_load((N - 1) / FG, fpart);
+        flush_add((N - 1) / FG, fpart);
+        if (!VEC) __syncthreads();       // unaligned rows: the store transpose tile sO aliases buffer 0
+      }
+      auto unpark = [&](int arr, float (&v)[T]) {
+        const io_t* q = sPark + ((size_t)arr * NT + tid) * T;
+        const float4 a0 = ld4<io_t>(q), a1 = ld4<io_t>(q + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      };
+      float raw[T];
+      unpark(0, uu);
+      unpark(1, raw);
+      unpark(3, go);
+      if (has_z) unpark(2, zz);
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const float rb = raw[i] + bias;
+        dsp[i] = (p.softplus && !(rb > 20.0f)) ? sigmoid(rb) : 1.0f;
+        if (!full && !(t0 + j * T + i < L)) dsp[i] = 0.0f;
+        y[i] = fmaf(Dv, uu[i], y[i]);
+      }
+    }
     // ---- per-step outputs --------------------------------------------------------------------------------
     float o_du[T], o_dd[T], o_dz[T];
 #pragma unroll
@@ -498,13 +583,15 @@ __global__ __launch_bounds__(256) void scan_bwd_reduce_kernel(const ScanBwdReduc
 }
 
 static thread_local int g_bwd_hip_error = 0;
+extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL, int MINW>
+template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N);
+  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N) +
+                     16 + (size_t)4 * NWAVES * 64 * 8 * sizeof(io_t);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL, MINW>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
@@ -530,14 +617,13 @@ static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   }
   return MXVL_OK;
 }
-template <typename io_t, int NWAVES, bool VEC, int MINW = 2>
+template <typename io_t, int NWAVES, bool VEC>
 static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
-  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true, MINW>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false, MINW>(a, stream);
+  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false>(a, stream);
 }
 
 // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it leaves the workgroup
 // at the same 8 waves per CU.  Used when 32-row tiles still give every CU a workgroup.
-extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
 static bool bwd_wide(int batch, int dim, int G, int L) {
   static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
@@ -550,8 +636,7 @@ static bool bwd_wide(int batch, int dim, int G, int L) {
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   const int variant = mxvl_scan_bwd_variant();   // tests / A-B measurements: 0 automatic
-  if (variant == 3 && sizeof(io_t) == 2) return a.vec_ok ? launch_bwd<io_t, 4, true, 3>(a, stream) : launch_bwd<io_t, 4, false, 3>(a, stream);
-  const bool wide = variant == 1 ? true : variant == 2 || variant == 3 ? false : bwd_wide(a.batch, a.dim, a.G, a.L);
+  const bool wide = variant == 1 ? true : variant == 2 ? false : bwd_wide(a.batch, a.dim, a.G, a.L);
   if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
   return a.vec_ok ? launch_bwd<io_t, 4, true>(a, stream) : launch_bwd<io_t, 4, false>(a, stream);
 }

@@ -317,6 +317,50 @@ def test_scan_bwd_workspace_and_atomic_paths_agree():
     assert torch.equal(again["dB"], got[True]["dB"]) and torch.equal(again["dC"], got[True]["dC"])
 
 
+@pytest.mark.parametrize("shape", [(2, 192, 333, 8, 2, torch.float32),      # ragged last chunk, unaligned rows (scalar tile path)
+                                   (8, 1024, 1032, 16, 1, torch.float32),  # 32-row workgroups (8 waves), aligned rows
+                                   (8, 1024, 1032, 16, 1, torch.bfloat16),
+                                   (2, 64, 522, 3, 1, torch.float32),      # odd state count, ragged rows of an aligned tensor
+                                   (3, 80, 200, 6, 1, torch.float16)])
+def test_scan_bwd_workgroup_shapes_and_dBdC_paths_agree(shape):
+    """mxvl_scan_bwd in its workgroup shapes (variant 1: 8 waves x 32 rows, 2: 4 waves x 16 rows) and dB / dC paths (fp32 global atomics, or the per-tile workspace + reduce kernel).  In the default
+    kernels a wave sums its 4 rows' shares in registers (v_permlane{32,16}_swap) before they reach LDS, and groups of 4 states
+    are flushed one group behind.  Same per-element arithmetic everywhere, so all gradients agree to summation order -- and in
+    fp32 equal the oracle."""
+    import medical_image_analysis_amd.selective_scan_interface as ssi
+    from medical_image_analysis_amd import _abi
+    from oracle import oracle as orc
+    B, D, L, N, G, dtype = shape
+    dev = _dev()
+    cpu = scan_inputs(B, D, L, N, G, True, True, True, seed=31, dtype=dtype)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(32)).to(dtype)
+    x = _to(cpu, dev)
+    lib = _abi.load()
+    got = {}
+    try:
+        for v in (0, 1, 2):
+            lib.mxvl_set_scan_variant(v << 8)
+            got[v] = _grads_via_autograd(x, True, dout.to(dev))
+        ssi.USE_BWD_WORKSPACE = True
+        for v in (1, 2):
+            lib.mxvl_set_scan_variant(v << 8)
+            got[v + 10] = _grads_via_autograd(x, True, dout.to(dev))
+    finally:
+        ssi.USE_BWD_WORKSPACE = False
+        lib.mxvl_set_scan_variant(0)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for v in (1, 2, 11, 12):
+        for k in got[v]:
+            r = got[0][k].float()
+            scale = max(1.0, float(r.abs().max()))
+            assert_close(got[v][k].float(), r, tol * scale, tol, f"{k} (variant {v} vs automatic)")
+    if dtype == torch.float32 and B * D * L <= 200000:
+        ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                         cpu["delta_bias"], True, dout)
+        for v in (1, 2, 12):
+            _check_grads(got[v], ref, f"variant {v}: ")
+
+
 def test_scan_bwd_linearity_full_size():
     """Size-independent property at BASELINE configs[1] full size: the gradient is linear in dout."""
     dev = _dev()

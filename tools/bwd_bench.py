@@ -40,10 +40,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 4:
         run(*map(int, sys.argv[1:5]), getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32)
         sys.exit(0)
+    # variant: 1 = 8-wave (32-row) workgroups, 2 = 4-wave
     for rep in range(2):
-        for v in (1, 2, 3):
+        for v in (1, 2):
             run(16, 1024, 4080, 16, torch.bfloat16, variant=v)
-    for v in (1, 2, 3):
+    run(16, 1024, 4080, 16, torch.float32, variant=1)
+    for v in (1, 2):
         run(8, 1024, 4080, 16, torch.bfloat16, variant=v)
         run(64, 4096, 200, 16, torch.bfloat16, variant=v)   # arm_encoder_large_224: 4 directions stacked, L = 197 -> 200
         run(32, 768, 196, 16, torch.bfloat16, variant=v)
