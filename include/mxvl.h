@@ -57,6 +57,10 @@ typedef enum mxvl_dtype { MXVL_F32 = 0, MXVL_BF16 = 1, MXVL_F16 = 2 } mxvl_dtype
 
 /* flag bits of mxvl_scan_desc.flags */
 #define MXVL_SCAN_DELTA_SOFTPLUS 1u
+/* `out` (mxvl_scan_fwd) and `dout` (mxvl_scan_bwd) are fp32 whatever io_dtype says; their strides count fp32 elements.
+ * The vendored VMamba extension's "oflex" i16o32 mode (cusoflex/selective_scan_oflex.cpp:150,207): half-precision inputs,
+ * the fp32 accumulator stored unrounded. */
+#define MXVL_SCAN_OUT_F32 2u
 
 /*
  * Forward selective scan.

@@ -19,6 +19,7 @@ ABI_VERSION = 2
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
+SCAN_OUT_F32 = 2          # out / dout fp32 whatever io_dtype is (the oflex i16o32 mode)
 
 STATUS = {
     0: "MXVL_OK", -1: "MXVL_ERR_NULL", -2: "MXVL_ERR_DTYPE", -3: "MXVL_ERR_SHAPE", -4: "MXVL_ERR_DSTATE",

@@ -102,6 +102,22 @@ template <> __device__ inline void st4<f16_t>(f16_t* p, float4 v) {
   *(h4*)p = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
 }
 
+// `out` (forward) / `dout` (backward) of the scan: io dtype, or fp32 for any io dtype when the caller set MXVL_SCAN_OUT_F32
+// (the reference's "oflex" i16o32 mode, cusoflex/selective_scan_oflex.cpp:150,207).  `off` is an element offset; the flag is
+// uniform, so the branch costs one scalar compare per store site.
+template <typename io_t> __device__ inline void st4_out(void* base, int64_t off, float4 v, bool f32) {
+  if (f32) *(float4*)((float*)base + off) = v; else st4<io_t>((io_t*)base + off, v);
+}
+template <typename io_t> __device__ inline void st_out(void* base, int64_t off, float v, bool f32) {
+  if (f32) ((float*)base)[off] = v; else Io<io_t>::st((io_t*)base + off, v);
+}
+template <typename io_t> __device__ inline float4 ld4_out(const void* base, int64_t off, bool f32) {
+  return f32 ? *(const float4*)((const float*)base + off) : ld4<io_t>((const io_t*)base + off);
+}
+template <typename io_t> __device__ inline float ld_out(const void* base, int64_t off, bool f32) {
+  return f32 ? ((const float*)base)[off] : Io<io_t>::ld((const io_t*)base + off);
+}
+
 // ---- DPP cross-lane moves (gfx9 encodings) -------------------------------------------------------
 // Lanes whose source is outside the row / disabled by row_mask keep `old` (bound_ctrl = 0).
 constexpr int DPP_ROW_SHR(int n) { return 0x110 + n; }

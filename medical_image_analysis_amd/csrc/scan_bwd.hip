@@ -27,7 +27,7 @@ constexpr int kCkptLenB = 128;
 
 struct ScanBwdArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok, ablate, dl_ratio;
+  int softplus, vec_ok, ablate, dl_ratio, out_f32;
   uint32_t dl_magic;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, do_bs, do_ds;
   int64_t du_bs, du_ds, dd_bs, dd_ds, dz_bs, dz_ds;
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   const io_t* __restrict__ pu = (const io_t*)p.u + (int64_t)b * p.u_bs + (int64_t)dc * p.u_ds + j * T;
   const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dr * p.dl_ds + j * T;
   const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
-  const io_t* __restrict__ pg = (const io_t*)p.dout + (int64_t)b * p.do_bs + (int64_t)dc * p.do_ds + j * T;
+  const int64_t pg_off = (int64_t)b * p.do_bs + (int64_t)dc * p.do_ds + j * T;   // element offset into dout (io dtype, or fp32)
+  const io_t* __restrict__ pg = (const io_t*)p.dout + pg_off;                       // io-dtype view (not used when dout is fp32)
+  const bool of32 = p.out_f32 != 0;
   io_t* __restrict__ qdu = (io_t*)p.du + (int64_t)b * p.du_bs + (int64_t)dc * p.du_ds + j * T;
   io_t* __restrict__ qdd = (io_t*)p.ddelta + (int64_t)b * p.dd_bs + (int64_t)dc * p.dd_ds + j * T;
   io_t* __restrict__ qdz = p.dz ? (io_t*)p.dz + (int64_t)b * p.dz_bs + (int64_t)dc * p.dz_ds + j * T : nullptr;
@@ -188,6 +190,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     } else {
 #pragma unroll
       for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
+    }
+  };
+  // dout: io dtype through row_fetch, or fp32 (MXVL_SCAN_OUT_F32: oflex i16o32) with the same masks
+  auto dout_fetch = [&](int t0, float (&v)[T]) {
+    if (!of32) { row_fetch(pg, t0, v); return; }
+    const bool whole = VEC && (t0 + CH <= L || t0 + j * T + T <= L);
+    if (whole) {
+      const float4 a0 = ld4_out<io_t>(p.dout, pg_off + t0, true), a1 = ld4_out<io_t>(p.dout, pg_off + t0 + 4, true);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? ld_out<io_t>(p.dout, pg_off + t0 + i, true) : 0.0f;
     }
   };
   auto row_store = [&](io_t* q, const void* base, int64_t bs, int64_t ds, int t0, const float (&v)[T]) {
@@ -251,12 +265,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     if (PF && have_pf) {
       unpack(ru, uu);
       unpack(rd, dl);
-      unpack(rg, go);
+      if (of32) dout_fetch(t0, go); else unpack(rg, go);
       if (has_z) unpack(rz, zz);
     } else {
       row_fetch(pu, t0, uu);
       row_fetch(pd, t0, dl);
-      row_fetch(pg, t0, go);
+      dout_fetch(t0, go);
       if (has_z) row_fetch(pz, t0, zz);
     }
     // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         const int tn = t0 - CH;
         ru = *(const uint4*)(pu + tn);
         rd = *(const uint4*)(pd + tn);
-        rg = *(const uint4*)(pg + tn);
+        if (!of32) rg = *(const uint4*)(pg + tn);
         if (has_z) rz = *(const uint4*)(pz + tn);
       }
     }
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       };
       park(0, uu);
       park(1, dl);
-      park(3, go);
+      if (!of32) park(3, go);       // an fp32 dout is re-read after the loop instead (parking would round it to the io dtype)
       if (has_z) park(2, zz);
     }
     float du[T], dy[T], y[T], dsp[T], sgB[T], sAh[T];
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       float raw[T];
       unpark(0, uu);
       unpark(1, raw);
-      unpark(3, go);
+      if (of32) dout_fetch(t0, go); else unpark(3, go);
       if (has_z) unpark(2, zz);
 #pragma unroll
       for (int i = 0; i < T; ++i) {
@@ -671,6 +685,7 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   ScanBwdArgs a;
   a.batch = f->batch; a.dim = f->dim; a.L = f->seqlen; a.N = f->dstate; a.G = f->n_groups; a.n_ckpt = n_ckpt;
   a.softplus = (f->flags & MXVL_SCAN_DELTA_SOFTPLUS) ? 1 : 0;
+  a.out_f32 = (f->flags & MXVL_SCAN_OUT_F32) ? 1 : 0;
   a.u_bs = f->u_bs; a.u_ds = f->u_ds; a.dl_bs = f->delta_bs; a.dl_ds = f->delta_ds; a.z_bs = f->z_bs; a.z_ds = f->z_ds;
   a.do_bs = d->dout_bs; a.do_ds = d->dout_ds; a.du_bs = d->du_bs; a.du_ds = d->du_ds;
   a.dd_bs = d->ddelta_bs; a.dd_ds = d->ddelta_ds; a.dz_bs = d->dz_bs; a.dz_ds = d->dz_ds;
@@ -697,8 +712,9 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
                                f->B_bs, f->B_gs, f->B_ns, f->C_bs, f->C_gs, f->C_ns};
     bool ok = true;
     for (int64_t s : strides) ok = ok && (s % 4 == 0);
-    const void* ptrs[] = {f->u, f->delta, f->z, d->dout, d->du, d->ddelta, d->dz, f->B, f->C};
+    const void* ptrs[] = {f->u, f->delta, f->z, d->du, d->ddelta, d->dz, f->B, f->C};
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
+    ok = ok && (((uintptr_t)d->dout) % (4 * (a.out_f32 ? 4 : esz)) == 0);
     a.vec_ok = ok ? 1 : 0;
   }
   hipStream_t stream = (hipStream_t)hip_stream;

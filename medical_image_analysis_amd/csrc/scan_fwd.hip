@@ -30,7 +30,7 @@ constexpr int kCkptLen = 128;  // checkpoint spacing in time steps (mxvl_scan_ch
 
 struct ScanArgs {
   int batch, dim, L, N, G, n_ckpt;
-  int softplus, vec_ok, ablate, dl_ratio;
+  int softplus, vec_ok, ablate, dl_ratio, out_f32;
   uint32_t dl_magic;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, o_bs, o_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
   const io_t* __restrict__ up = (const io_t*)p.u + (int64_t)b * p.u_bs;
   const io_t* __restrict__ dp = (const io_t*)p.delta + (int64_t)b * p.dl_bs;
   const io_t* __restrict__ zp = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs : nullptr;
-  io_t* __restrict__ op = (io_t*)p.out + (int64_t)b * p.o_bs;
+  const int64_t op = (int64_t)b * p.o_bs;     // element offset into p.out (io dtype, or fp32 with MXVL_SCAN_OUT_F32)
+  const bool of32 = p.out_f32 != 0;
   const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
   const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
   const bool has_z = zp != nullptr;
@@ -327,17 +328,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
         const int rr = q / CQ, e4 = (q % CQ) * 4;
         const int wrow = wave * RPW + rr;
         const int dd = d0 + wrow;
-        if (dd < d_end) st4<io_t>(op + (int64_t)dd * p.o_ds + t0 + e4, *(const float4*)(sU + wrow * CH + e4));
+        if (dd < d_end) st4_out<io_t>(p.out, op + (int64_t)dd * p.o_ds + t0 + e4, *(const float4*)(sU + wrow * CH + e4), of32);
       }
     } else {
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
         const int wrow = wave * RPW + rr;
         const int dd = d0 + wrow;
-        io_t* po = op + (int64_t)dd * p.o_ds + t0;
+        const int64_t po = op + (int64_t)dd * p.o_ds + t0;
 #pragma unroll
         for (int e = lane; e < CH; e += 64)
-          if (dd < d_end && t0 + e < L) io::st(po + e, sU[wrow * CH + e]);
+          if (dd < d_end && t0 + e < L) st_out<io_t>(p.out, po + e, sU[wrow * CH + e], of32);
       }
     }
   }
@@ -486,6 +487,7 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.batch = d->batch; a.dim = d->dim; a.L = d->seqlen; a.N = d->dstate; a.G = d->n_groups;
   a.n_ckpt = (d->seqlen + kCkptLen - 1) / kCkptLen;
   a.softplus = (d->flags & MXVL_SCAN_DELTA_SOFTPLUS) ? 1 : 0;
+  a.out_f32 = (d->flags & MXVL_SCAN_OUT_F32) ? 1 : 0;
   a.u_bs = d->u_bs; a.u_ds = d->u_ds; a.dl_bs = d->delta_bs; a.dl_ds = d->delta_ds;
   a.z_bs = d->z_bs; a.z_ds = d->z_ds; a.o_bs = d->out_bs; a.o_ds = d->out_ds;
   a.B_bs = d->B_bs; a.B_gs = d->B_gs; a.B_ns = d->B_ns;
@@ -504,8 +506,9 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
                                d->z ? d->z_bs : 0, d->z ? d->z_ds : 0};
     bool ok = true;
     for (int64_t s : strides) ok = ok && (s % 4 == 0);
-    const void* ptrs[] = {d->u, d->delta, d->out, d->B, d->C, d->z};
+    const void* ptrs[] = {d->u, d->delta, d->B, d->C, d->z};
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
+    ok = ok && (((uintptr_t)d->out) % (4 * (a.out_f32 ? 4 : esz)) == 0);
     a.vec_ok = ok ? 1 : 0;
   }
   hipStream_t stream = (hipStream_t)hip_stream;

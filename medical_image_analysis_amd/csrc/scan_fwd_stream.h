@@ -67,7 +67,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const io_t* __restrict__ pu = (const io_t*)p.u + (int64_t)b * p.u_bs + (int64_t)dc * p.u_ds + j * T;
   const io_t* __restrict__ pd = (const io_t*)p.delta + (int64_t)b * p.dl_bs + (int64_t)dr * p.dl_ds + j * T;
   const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
-  io_t* __restrict__ po = (io_t*)p.out + (int64_t)b * p.o_bs + (int64_t)dc * p.o_ds + j * T;
+  const int64_t po = (int64_t)b * p.o_bs + (int64_t)dc * p.o_ds + j * T;   // element offset into p.out (io dtype, or fp32)
+  const bool of32 = p.out_f32 != 0;
   const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
   const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
   const bool has_z = pz != nullptr;
@@ -290,18 +291,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       if (row_ok) {
 #pragma unroll
         for (int k = 0; k < TQ; ++k)
-          st4<io_t>(po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]));
+          st4_out<io_t>(p.out, po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]), of32);
       }
     } else if (VEC) {   // ragged last chunk of aligned rows: whole lane groups as vectors, the boundary lane element-wise
       if (row_ok) {
         if (t0 + j * T + T <= L) {
 #pragma unroll
           for (int k = 0; k < TQ; ++k)
-            st4<io_t>(po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]));
+            st4_out<io_t>(p.out, po + t0 + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]), of32);
         } else {
 #pragma unroll
           for (int i = 0; i < T; ++i)
-            if (t0 + j * T + i < L) io::st(po + t0 + i, y[i]);
+            if (t0 + j * T + i < L) st_out<io_t>(p.out, po + t0 + i, y[i], of32);
         }
       }
     } else {
@@ -315,10 +316,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int rr = 0; rr < RPW; ++rr) {
         const int wrow = wave * RPW + rr;
         const int dd = d0 + wrow;
-        io_t* q = (io_t*)p.out + (int64_t)b * p.o_bs + (int64_t)dd * p.o_ds + t0;
+        const int64_t q = (int64_t)b * p.o_bs + (int64_t)dd * p.o_ds + t0;
 #pragma unroll
         for (int e = lane; e < CH; e += 64)
-          if (dd < d_end && t0 + e < L) io::st(q + e, sO[wrow * CH + e]);
+          if (dd < d_end && t0 + e < L) st_out<io_t>(p.out, q + e, sO[wrow * CH + e], of32);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

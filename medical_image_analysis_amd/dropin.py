@@ -33,16 +33,17 @@ def _oflex_module(name):
 
     def fwd(u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1, out_float=False):
         _, u_, d_, A_, B_, C_, D_, _, b_ = ssi._prep(u, delta, A, B, C, D, None, delta_bias)
-        out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus, want_ckpt=True)
-        if out_float:
-            out = out.float()
+        # out_float: the fp32 accumulator stored unrounded by the kernel (selective_scan_oflex.cpp:150)
+        out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus, want_ckpt=True, out_f32=bool(out_float))
         return [out, ckpt if ckpt is not None else torch.empty(0, device=u.device)]
 
     def bwd(u, delta, A, B, C, D, delta_bias, dout, x, delta_softplus, nrows=1):
         _, u_, d_, A_, B_, C_, D_, _, b_ = ssi._prep(u, delta, A, B, C, D, None, delta_bias)
         ckpt = x if (x is not None and x.numel() > 0) else None
+        # dout arrives in out's dtype: fp32 for half inputs in the i16o32 mode (:207), read as it is
+        f32 = dout.dtype == torch.float32 and u_.dtype != torch.float32
         du, dd, dA, dB, dC, dD, _, dbias = ssi.scan_bwd_raw(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus, ckpt,
-                                                          dout.to(u_.dtype))
+                                                          dout if f32 else dout.to(u_.dtype), dout_f32=f32)
         return [du, dd, dA, dB.to(B.dtype), dC.to(C.dtype), dD, dbias]
 
     m.fwd, m.bwd = fwd, bwd

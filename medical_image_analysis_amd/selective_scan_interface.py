@@ -89,11 +89,11 @@ def _prep(u, delta, A, B, C, D, z, delta_bias):
     return dev, u, delta, A, B, C, D, z, delta_bias
 
 
-def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last_state, ckpt):
+def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last_state, ckpt, out_f32=False):
     batch, dim, L = u.shape
     desc.batch, desc.dim, desc.seqlen, desc.dstate, desc.n_groups = batch, dim, L, A.shape[1], B.shape[1]
     desc.io_dtype = _abi.dtype_code(u.dtype)
-    desc.flags = _abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0
+    desc.flags = (_abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0) | (_abi.SCAN_OUT_F32 if out_f32 else 0)
     desc.delta_group_ratio = dim // delta.shape[1]
     desc.u_bs, desc.u_ds = u.stride(0), u.stride(1)
     desc.delta_bs, desc.delta_ds = delta.stride(0), delta.stride(1)
@@ -110,12 +110,15 @@ def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, la
 
 
 def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
-                 want_last_state=False, want_ckpt=False):
-    """One mxvl_scan_fwd call on already-validated tensors; returns (out, last_state|None, ckpt|None)."""
+                 want_last_state=False, want_ckpt=False, out_f32=False):
+    """One mxvl_scan_fwd call on already-validated tensors; returns (out, last_state|None, ckpt|None).
+    out_f32: the kernel stores its fp32 accumulator unrounded whatever the io dtype (oflex i16o32)."""
     lib = _abi.load()
     batch, dim, L = u.shape
     N = A.shape[1]
-    out = torch.empty_like(u)  # keeps a channel-major (D, B, L) memory layout when u has one
+    out_f32 = bool(out_f32) and u.dtype != torch.float32
+    # keeps a channel-major (D, B, L) memory layout when u has one
+    out = torch.empty_like(u, dtype=torch.float32) if out_f32 else torch.empty_like(u)
     last = torch.empty((batch, dim, N), dtype=torch.float32, device=u.device) if want_last_state else None
     ckpt = None
     if want_ckpt:
@@ -123,7 +126,7 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
         if n_chunks > 1:
             ckpt = torch.empty((batch, dim, n_chunks, N), dtype=torch.float32, device=u.device)
     desc = _abi.ScanDesc()
-    _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt)
+    _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt, out_f32)
     timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
         if timers is not None:
@@ -145,12 +148,16 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
 USE_BWD_WORKSPACE = False
 
 
-def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout, du=None, dz=None, dB=None, dC=None):
+def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout, du=None, dz=None, dB=None, dC=None,
+                 dout_f32=False):
     """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C).
     du / dz (io dtype, seqlen-contiguous, any batch/channel strides) and dB / dC (fp32, ZEROED by the caller) may be passed
     in: the fused mixer backward lets the kernel write straight into the buffers the next GEMM reads."""
     lib = _abi.load()
     batch, dim, L = u.shape
+    dout_f32 = bool(dout_f32) and u.dtype != torch.float32      # dout read as fp32 by the kernel (oflex i16o32)
+    if dout.dtype != (torch.float32 if dout_f32 else u.dtype):
+        raise RuntimeError("selective_scan backward: dout must be fp32 with dout_f32, else u's dtype")
     dout = _last_contig(dout)
     if du is None:
         du = torch.empty_like(u)
@@ -168,7 +175,7 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     dD = torch.zeros_like(D) if D is not None else None
     dbias = torch.zeros(dim, dtype=torch.float32, device=u.device) if delta_bias is not None else None
     desc = _abi.ScanBwdDesc()
-    _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt)
+    _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt, dout_f32)
     desc.dout_bs, desc.dout_ds = dout.stride(0), dout.stride(1)
     desc.du_bs, desc.du_ds = du.stride(0), du.stride(1)
     desc.ddelta_bs, desc.ddelta_ds = ddelta.stride(0), ddelta.stride(1)

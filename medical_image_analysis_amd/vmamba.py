@@ -128,24 +128,33 @@ def dwconv3x3_act(x, conv: nn.Conv2d, act: nn.Module):
 class SelectiveScanOflex(torch.autograd.Function):
     """forward(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows, backnrows, oflex) (vmamba.py:294-312).
     nrows / backnrows are tuning knobs of the CUDA kernel and are ignored; oflex=True returns fp32 out for
-    half-precision inputs (cusoflex/selective_scan_oflex.cpp:144-151)."""
+    half-precision inputs (cusoflex/selective_scan_oflex.cpp:144-151) -- the kernel's fp32 accumulator stored unrounded
+    (MXVL_SCAN_OUT_F32), and the backward reads the fp32 dout as it is (:207, i16o32)."""
 
     @staticmethod
     def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, nrows=1, backnrows=1, oflex=True):
         ctx.delta_softplus = delta_softplus
         _, u_, d_, A_, B_, C_, D_, _, b_ = ssi._prep(u, delta, A, B, C, D, None, delta_bias)
-        out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus, want_ckpt=True)
+        out, _, ckpt = ssi.scan_fwd_raw(u_, d_, A_, B_, C_, D_, None, b_, delta_softplus, want_ckpt=True, out_f32=bool(oflex))
         ctx.save_for_backward(u_, d_, A_, B_, C_, D_, b_, ckpt)
         ctx.in_dtypes = (u.dtype, delta.dtype, B.dtype, C.dtype)
-        return out.float() if oflex else out
+        ctx.bc_3d = (B.dim() == 3, C.dim() == 3)
+        ctx.out_f32 = out.dtype == torch.float32 and u_.dtype != torch.float32
+        return out
 
     @staticmethod
     def backward(ctx, dout, *args):
         u, delta, A, B, C, D, bias, ckpt = ctx.saved_tensors
         du, dd, dA, dB, dC, dD, _, dbias = ssi.scan_bwd_raw(u, delta, A, B, C, D, None, bias, ctx.delta_softplus, ckpt,
-                                                          dout.to(u.dtype))
+                                                          dout.float() if ctx.out_f32 else dout.to(u.dtype),
+                                                          dout_f32=ctx.out_f32)
         tu, td, tb, tc = ctx.in_dtypes
-        return (du.to(tu), dd.to(td), dA, dB.to(tb), dC.to(tc), dD, dbias, None, None, None, None)
+        dB, dC = dB.to(tb), dC.to(tc)
+        if ctx.bc_3d[0]:
+            dB = dB.squeeze(1)
+        if ctx.bc_3d[1]:
+            dC = dC.squeeze(1)
+        return (du.to(tu), dd.to(td), dA, dB, dC, dD, dbias, None, None, None, None)
 
 
 class SelectiveScanCore(SelectiveScanOflex):

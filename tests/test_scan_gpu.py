@@ -442,3 +442,42 @@ def test_scan_delta_channel_groups_rejects_bad_shapes():
         selective_scan_fn(x["u"], x["delta"][:, :5].contiguous(), x["A"], x["B"], x["C"])
     with pytest.raises(RuntimeError):   # delta_bias follows delta's channel count
         selective_scan_fn(x["u"], x["delta"][:, :12].contiguous(), x["A"], x["B"], x["C"], delta_bias=torch.zeros(48, device=dev))
+
+
+# ---------------------------------------------------------------------------------------------------
+# oflex i16o32 (cusoflex/selective_scan_oflex.cpp:150,207): half-precision inputs, fp32 out stored unrounded by the kernel and
+# an fp32 dout read as it is (MXVL_SCAN_OUT_F32) -- not an io-dtype store followed by a cast
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,D,L,N,G,dtype", [(2, 96, 197, 16, 4, torch.bfloat16),      # VMamba-like: 4 groups, unaligned rows
+                                             (4, 256, 1024, 16, 1, torch.float16),    # streaming kernel, aligned rows
+                                             (2, 64, 333, 8, 2, torch.bfloat16)])
+def test_oflex_fp32_out_is_the_unrounded_accumulator(B, D, L, N, G, dtype):
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.vmamba import SelectiveScanOflex, SelectiveScanCore
+    dev = _dev()
+    cpu = scan_inputs(B, D, L, N, G, False, True, True, seed=41, dtype=dtype)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(42))          # fp32, NOT representable in the io dtype
+    args = lambda: [cpu[k].to(dev).requires_grad_(cpu[k].is_floating_point()) for k in ("u", "delta", "A", "B", "C", "D", "delta_bias")]
+    # the oracle on the (exactly representable) half-precision inputs, in fp32
+    f = {k: (v.float() if v is not None else None) for k, v in cpu.items()}
+    ref = orc.selective_scan_ref(f["u"], f["delta"], f["A"], f["B"], f["C"], f["D"], None, f["delta_bias"], True)
+    rg = orc.selective_scan_ref_bwd(f["u"], f["delta"], f["A"], f["B"], f["C"], f["D"], None, f["delta_bias"], True, dout)
+    a = args()
+    out = SelectiveScanOflex.apply(*a, True, 1, 1, True)
+    assert out.dtype == torch.float32
+    scale = max(1.0, float(ref.abs().max()) / 32)
+    assert_close(out, ref, 1e-4 * scale, 1e-5, "oflex fp32 out")                    # fp32-level agreement: no io-dtype rounding
+    core = SelectiveScanCore.apply(*args(), True, 1, 1, True)
+    assert core.dtype == dtype
+    assert torch.equal(core, out.to(dtype)), "the io-dtype output is the same accumulator rounded once"
+    assert float((out.detach() - core.detach().float()).abs().max()) > 1e-4 * scale, "fp32 out must carry the bits the io dtype drops"
+    out.backward(dout.to(dev))
+    # row-local gradients leave in the io dtype (rounded once from the fp32 result computed with the UNROUNDED dout)
+    for k, t in (("du", a[0]), ("ddelta", a[1])):
+        want = rg[k].to(dtype).float()
+        ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+        err = (t.grad.float().cpu() - want).abs()
+        assert float((err > 2 * ulp * want.abs() + 1e-4 * max(1.0, float(want.abs().max()) / 32)).float().mean()) < 1e-3, k
+    for k, t in (("dA", a[2]), ("dD", a[5]), ("ddelta_bias", a[6])):                # fp32 accumulators
+        r = rg[k]
+        assert_close(t.grad, r, 2e-5 * max(1.0, float(r.abs().max())), 1e-4, k)
