@@ -55,6 +55,12 @@ def pmc_traffic(workload):
     return None
 
 
+def _dp_label(world):
+    if os.environ.get("MXVL_BENCH_ONE_GPU") == "1" and world > 1:
+        return f"dp{world} (DEV CHECK: all ranks on cuda:0, gloo all-reduce -- not a scaling number)"
+    return f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)"
+
+
 def attach_traffic(roofline, workload):
     """roofline.traffic = HBM bytes per launch of the dominant kernel.  It is NOT re-measured by this process (PMC needs
     rocprofv3 around the command): the number is read from the committed PMC record of the same command and labelled so."""
@@ -341,7 +347,7 @@ def run_pretrain(args, rank, world, dev, dist):
         "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world,
-                   "seq_len": L, "params": n_params, "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)",
+                   "seq_len": L, "params": n_params, "parallelism": _dp_label(world),
                    "final_loss": final_loss,
                    "timed_step": "forward + backward (DDP bucketed grad all-reduce overlapped) + loss all-reduce + clip + fused AdamW"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -422,7 +428,7 @@ def run_mae(args, rank, world, dev, dist):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic N(0,1) 1-channel images (seed 1000+rank), random-init weights (seed 0)",
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world, "visible_tokens": kept,
-                   "params": n_params, "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)",
+                   "params": n_params, "parallelism": _dp_label(world),
                    "final_loss": float(loss)},
         "roofline": {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": flops / step_s / 1e12 / 2500.0, "traffic": None,
@@ -502,7 +508,7 @@ def run_vmamba(args, rank, world, dev, dist):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world, "params": n_params,
-                   "parallelism": f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)", "final_loss": float(loss.mean())},
+                   "parallelism": _dp_label(world), "final_loss": float(loss.mean())},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": kind + (" (4 directions stacked: one launch, n_groups 4, L = 197)" if args.workload.startswith("arm_")
                                                          else " (all SS2D stages: L = 3136 / 784 / 196 / 49, 4 direction groups, d_state 1)"),

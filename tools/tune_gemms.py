@@ -23,7 +23,7 @@ for w in workloads:
     for f in glob.glob(base.replace(".csv", "*.csv")):
         os.remove(f)
     env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=base,
-               PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS="15", PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS="10", MXVL_TUNED_GEMMS="0")
+               PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=os.environ.get("MXVL_TUNE_MS", "15"), PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS=os.environ.get("MXVL_TUNE_ITERS", "10"), MXVL_TUNED_GEMMS="0")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", "2", "--warmup", "1",
                            "--no-cpu-baseline"] + batch, env=env, cwd=ROOT)
     for f in glob.glob(base.replace(".csv", "*.csv")):
