@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = p.N, L = p.L;
-  float* sB = smem;                        // [N][CH]  lane-major halves (see scan_fwd_stream.h)
+  float* sB = smem;                        // [N][CH]  quarter-major, odd quarter bank-swizzled (see scan_fwd_stream.h qpos)
   float* sC = sB + N * CH;                 // [N][CH]
   // dB/dC shares of a group of FG states, one tile per WAVE (its 4 rows summed in registers first), double-buffered:
   // plain LDS stores, then a NWAVES-way tree sum one group behind.  (ds_add_f32 measured 7x the whole rest of the kernel,
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
         const float4 bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e);
         const float4 cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e);
-        const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4;
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4) ^ (((e >> 2) & 1) * 32));   // odd quarter bank-swizzled: conflict-free staging writes
         *(float4*)(sB + pos) = bv;
         *(float4*)(sC + pos) = cv;
       }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
           bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
           cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
         }
-        const int pos = n * CH + ((e >> 2) & 1) * 64 + (e >> 3) * 4 + (e & 3);
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4) ^ (((e >> 2) & 1) * 32)) + (e & 3);
         sB[pos] = bv;
         sC[pos] = cv;
       }
@@ -368,8 +368,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;
     float* gq = sG + row * N;
     const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * N;
-    const float* cB = sB + j * 4;
+    const float* cB = sB + j * 4;                   // even quarter (steps 8j..8j+3) at word 4j, odd quarter at 64 + (4j ^ 32)
     const float* cC = sC + j * 4;
+    const int q1 = 64 + ((j * 4) ^ 32) - j * 4;     // word offset of the odd quarter relative to cB / cC
     // A wave first sums the dB / dC shares of its 4 rows in registers (v_permlane{32,16}_swap), so only ONE
     // share per wave goes to LDS; states are flushed in groups of FG, one group behind -- sAcc is two buffers of
     // [FG][NWAVES][2][CH] -- so the sums of group g run while group g+1 is computed and one barrier per FG states separates a
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       const bool f_first = (n % FG) == 0;                  // the previous group's shares are summed during this state
       if (f_first && !MXVL_ABL(p.ablate & 16)) flush_load(n / FG - 1, fpart);   // group -1: stale LDS, discarded
       {
-        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + 64);
-        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + 64);
+        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
+        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
         bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
         cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
       }

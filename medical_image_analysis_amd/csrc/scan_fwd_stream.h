@@ -7,7 +7,8 @@
 //     chunk c is requested before the state loop and consumed after it;
 //   * the B/C tile of chunk c+1 is fetched by the whole workgroup during chunk c and written into the other half
 //     of a double-buffered LDS tile after the state loop: one barrier per chunk.  The tile is stored
-//     "quarter-major" ([T/4][LPR][4] per row) so the per-lane 16-byte reads of a DPP row are conflict-free;
+//     "quarter-major" ([T/4][LPR][4] per row) so the per-lane 16-byte reads of a DPP row are conflict-free, with the odd
+//     quarter bank-swizzled so the staging writes are too (see qpos);
 //   * the prefix scan over the LPR lanes is fused-DPP (v_fmac/v_mul with row_shr).  For LPR = 8 two rows share a
 //     16-lane DPP row: the first lane of every row scans with P = 0 (after absorbing the incoming state), which
 //     cuts every contribution that would cross the row boundary -- no exec masking needed;
@@ -81,8 +82,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
 
-  // element e = jj*T + i of a tile row lives at quarter-major position (i/4)*(LPR*4) + jj*4 + i%4
-  auto qpos = [](int e) { return ((e % T) >> 2) * (LPR * 4) + (e / T) * 4 + (e & 3); };
+  // element e = jj*T + i of a tile row lives at quarter-major position (i/4)*(LPR*4) + jj*4 + i%4.  For 16-lane rows the odd
+  // quarter is stored with bit 5 of the word offset flipped (SWZ): the 16 lanes of one ds_write_b128 pass of the staging
+  // (8 even + 8 odd quarters) then cover 64 different banks -- unswizzled, the two quarters sit 64 words apart and every
+  // staging write was a 2-way conflict (29 % of the LDS-active cycles in profiles/r01_scan_sq.txt).  The reads stay one
+  // contiguous 256-byte run per quarter, in a lane order that does not matter.
+  constexpr int SWZ = (LPR == 16) ? 32 : 0;
+  auto qpos = [](int e) { const int q = (e % T) >> 2; return q * (LPR * 4) + (((e / T) * 4) ^ ((q & 1) * SWZ)) + (e & 3); };
 
   // ---- B/C tile fetch (global -> registers) and commit (registers -> LDS buffer) ------------------
   float4 bq[VEC ? BCV : 1], cq[VEC ? BCV : 1];
@@ -239,8 +245,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
     float2* ac = sAC + row * N;
     const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;  // only lane 0 sees the state entering the chunk
-    const float* cB = sBC + (c & 1) * 2 * N * CH + j * 4;
+    const float* cB = sBC + (c & 1) * 2 * N * CH;
     const float* cC = cB + N * CH;
+    int rq[TQ];                                               // this lane's word offset inside a tile row, per quarter
+#pragma unroll
+    for (int k = 0; k < TQ; ++k) rq[k] = k * (LPR * 4) + ((j * 4) ^ ((k & 1) * SWZ));
 
 #pragma unroll 4
     for (int n = 0; n < (MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N); ++n) {
@@ -249,8 +258,8 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       float a[T], bb[T], cv[T];
 #pragma unroll
       for (int k = 0; k < TQ; ++k) {
-        const float4 b4 = *(const float4*)(cB + n * CH + k * (LPR * 4));
-        const float4 c4 = *(const float4*)(cC + n * CH + k * (LPR * 4));
+        const float4 b4 = *(const float4*)(cB + n * CH + rq[k]);
+        const float4 c4 = *(const float4*)(cC + n * CH + rq[k]);
         bb[4 * k] = b4.x; bb[4 * k + 1] = b4.y; bb[4 * k + 2] = b4.z; bb[4 * k + 3] = b4.w;
         cv[4 * k] = c4.x; cv[4 * k + 1] = c4.y; cv[4 * k + 2] = c4.z; cv[4 * k + 3] = c4.w;
       }
