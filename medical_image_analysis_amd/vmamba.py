@@ -225,7 +225,17 @@ class Linear2d(nn.Linear):
     """1x1 convolution with nn.Linear's parameters (vmamba.py:441-448)."""
 
     def forward(self, x):
-        return F.conv2d(x, self.weight[:, :, None, None], self.bias)
+        # W @ x over the channel axis as one batched library GEMM (not F.conv2d: MIOpen's 1x1 path compiles / searches
+        # solutions on first use, and its backward aborted sporadically on fresh boxes)
+        B, C, H, W = x.shape
+        w = self.weight.view(self.weight.shape[0], C)
+        if torch.is_autocast_enabled("cuda"):
+            cd = torch.get_autocast_dtype("cuda")
+            x, w = x.to(cd), w.to(cd)
+        y = torch.matmul(w, x.reshape(B, C, H * W))
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype)[None, :, None]
+        return y.view(B, -1, H, W)
 
     def _load_from_state_dict(self, state_dict, prefix, *args):
         state_dict[prefix + "weight"] = state_dict[prefix + "weight"].view(self.weight.shape)
