@@ -247,23 +247,33 @@ def host_physical_cores():
     return len(pairs) or max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline_pretrain(sd, img, patch, depth, budget_s=25.0):
-    """FORWARD pass of the same model on the host: oracle/models_ref.py (functional restatement of the reference's
-    VisionMamba.forward over the C scan/conv oracles), fp32, all cores.  The reference's own training step cannot
-    run without its CUDA wheels; forward-only is what the CPU oracle offers, and the sample says so."""
+def cpu_baseline_pretrain(sd, img, patch, depth, trainable, budget_s=20.0):
+    """The SAME unit of work as the GPU value -- forward + backward + grad-clip + AdamW of the same model on one image -- on
+    the host: oracle/models_ref.py (functional restatement of the reference's VisionMamba.forward over the C scan / conv
+    oracles and their C gradients, wrapped as autograd functions in oracle/oracle.py), fp32, one socket's cores.  The
+    reference's own training step cannot run without its CUDA wheels, so this is kind "port"."""
     from oracle import models_ref
     from oracle import oracle as orc
     # one socket's worth of physical cores: with every hardware thread of a 2-socket host (256 on the pool's EPYC 9575F
-    # boxes) torch's intra-op pools oversubscribe and this forward ran 5x slower than on 8 cores
+    # boxes) torch's intra-op pools oversubscribe and the forward ran 5x slower than on 8 cores
     cores = min(host_physical_cores(), 64)
     orc.set_threads(cores)
     torch.set_num_threads(cores)
+    trainable = set(trainable)
+    params = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for k, v in params.items() if k in trainable], lr=1e-4, weight_decay=0.05)
     x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(0))
-    n, elapsed = 0, 0.0
+    n, elapsed, fwd_s = 0, 0.0, 0.0
     while elapsed < budget_s and n < 8:
         t0 = time.perf_counter()
-        models_ref.visionmamba_forward_ref(sd, x, patch=patch, depth=depth)
+        loss, _, _ = models_ref.visionmamba_forward_ref(params, x, patch=patch, depth=depth)
+        t1 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss.mean().backward()
+        torch.nn.utils.clip_grad_norm_([v for k, v in params.items() if k in trainable], 3.0)
+        opt.step()
         elapsed += time.perf_counter() - t0
+        fwd_s += t1 - t0
         n += 1
     cpu_model = "unknown"
     try:
@@ -275,9 +285,9 @@ def cpu_baseline_pretrain(sd, img, patch, depth, budget_s=25.0):
     except OSError:
         pass
     return {"value": n / elapsed, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model,
-            "sample": f"{n} x forward+loss of the same model on one {img}x{img} image (oracle/models_ref.py over "
-                      f"oracle/mxvl_oracle.c, fp32, torch intra-op + OpenMP threads = {cores}); FORWARD ONLY -- the GPU "
-                      f"value is forward+backward+optimizer, {elapsed:.1f} s of CPU work"}
+            "sample": f"{n} x (forward + backward + grad-clip + AdamW) of the same model on one {img}x{img} image, fp32 "
+                      f"(oracle/models_ref.py over oracle/mxvl_oracle.c and its C gradients, torch intra-op + OpenMP threads = "
+                      f"{cores}); {elapsed:.1f} s of CPU work, of which forward {fwd_s:.1f} s"}
 
 
 def run_pretrain(args, rank, world, dev, dist):
@@ -321,6 +331,7 @@ def run_pretrain(args, rank, world, dev, dist):
     cpu_sd = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        cpu_trainable = [n for n, p in model.named_parameters() if p.requires_grad]
     secondary = None
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
         # second half of BASELINE.json's metric ("MAE pretrain images/sec + report-gen decode tokens/sec"): the report
@@ -362,7 +373,7 @@ def run_pretrain(args, rank, world, dev, dist):
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                       "dtype", "config", "roofline")}
     if cpu_sd is not None:
-        out["cpu_baseline"] = cpu_baseline_pretrain(cpu_sd, img, patch, depth)
+        out["cpu_baseline"] = cpu_baseline_pretrain(cpu_sd, img, patch, depth, cpu_trainable)
     print(json.dumps(out))
 
 

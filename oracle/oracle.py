@@ -174,6 +174,41 @@ def selective_state_update_ref(state, x, dt, A, B, C, D=None, z=None, dt_bias=No
 # "parity unpinned" at this boundary: no reference test or golden covers the fused functions
 # themselves; the goldens pin the slow path they must equal.
 # ---------------------------------------------------------------------------------------------
+# ---- autograd views of the C oracle (fp32 CPU): the gradient routines above as torch.autograd.Functions, so the model-level
+# oracle (oracle/models_ref.py) can run a whole TRAINING step on the host -- used by tests (oracle gradients of the model vs the
+# reference's) and by bench.py's cpu_baseline leg.  Still test infrastructure only.
+class _ScanRefFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, z, delta_bias, delta_softplus):
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias)
+        ctx.softplus = bool(delta_softplus)
+        return selective_scan_ref(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, A, B, C, D, z, delta_bias = ctx.saved_tensors
+        g = selective_scan_ref_bwd(u, delta, A, B, C, D, z, delta_bias, ctx.softplus, dout)
+        return g["du"], g["ddelta"], g["dA"], g["dB"], g["dC"], g["dD"], g["dz"], g["ddelta_bias"], None
+
+
+class _ConvRefFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, activation):
+        ctx.save_for_backward(x, weight, bias)
+        ctx.activation = activation
+        return causal_conv1d_ref(x, weight, bias, activation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        g = causal_conv1d_ref_bwd(x, weight, bias, ctx.activation, dy)
+        return g["dx"], g["dweight"], g["dbias"], None
+
+
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def mamba_inner_ref_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                 A, B=None, C=None, D=None, delta_bias=None, delta_softplus=True):
     assert B is None and C is None, "input-dependent B/C only (reference passes None, :456-457)"
@@ -182,13 +217,19 @@ def mamba_inner_ref_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, d
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
     x, z = xz.chunk(2, dim=1)
-    x = causal_conv1d_ref(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
+    ad = _wants_grad(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)
+    if ad:
+        x = _ConvRefFn.apply(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
+    else:
+        x = causal_conv1d_ref(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
     b, d, _ = x.shape
     x_dbl = F.linear(x.permute(0, 2, 1).reshape(b * L, d), x_proj_weight.float())  # (bl, R+2N)
     dt, Bm, Cm = torch.split(x_dbl, [R, N, N], dim=-1)
     dt = (delta_proj_weight.float() @ dt.t()).reshape(d, b, L).permute(1, 0, 2).contiguous()
     Bm = Bm.reshape(b, L, N).permute(0, 2, 1).contiguous()
     Cm = Cm.reshape(b, L, N).permute(0, 2, 1).contiguous()
+    if ad:
+        return _ScanRefFn.apply(x, dt, A, Bm, Cm, D, z.contiguous(), delta_bias, delta_softplus)
     return selective_scan_ref(x, dt, A, Bm, Cm, D, z=z.contiguous(), delta_bias=delta_bias,
                               delta_softplus=delta_softplus)
 
@@ -211,7 +252,11 @@ def bimamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_
     R = delta_proj_weight.shape[1]
     N = A.shape[1]
     x, z = xz.chunk(2, dim=1)
-    x = causal_conv1d_ref(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
+    ad = _wants_grad(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias)
+    if ad:
+        x = _ConvRefFn.apply(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
+    else:
+        x = causal_conv1d_ref(x.contiguous(), conv1d_weight, conv1d_bias, "silu")
     b, d, _ = x.shape
     x_dbl = F.linear(x.permute(0, 2, 1).reshape(b * L, d), x_proj_weight.float())
     dt, Bm, Cm = torch.split(x_dbl, [R, N, N], dim=-1)

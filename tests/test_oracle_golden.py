@@ -127,3 +127,20 @@ def test_vssm_oracle_matches_reference():
     pooled = models_ref.vssm_forward_ref(sd, g["img"], [1, 1, 2, 1], global_features=True)
     assert float((feat - g["feat"]).abs().max()) <= 1e-2 * float(g["feat"].abs().max())
     assert float((pooled - g["pooled"]).abs().max()) <= 1e-2 * float(g["pooled"].abs().max())
+
+
+def test_model_level_oracle_gradients_match_reference_visionmamba():
+    """The C gradient routines behind torch.autograd (oracle._ScanRefFn / _ConvRefFn) give the model-level oracle a backward:
+    d(loss.mean())/d(parameter) against the gradients the reference's own VisionMamba produced (9 parameters spread over the
+    patch embedding, first / last mixer, the tap norms, enc2dec and the decoder).  This is the training step bench.py times as
+    `cpu_baseline`."""
+    from oracle import models_ref
+    g = load_golden("pretrain_d12_128")
+    want = {k[2:]: v for k, v in g.items() if k.startswith("g_")}
+    sd = {k[2:]: (v.clone().requires_grad_(True) if k[2:] in want else v) for k, v in g.items() if k.startswith("p_")}
+    loss, _, _ = models_ref.visionmamba_forward_ref(sd, g["img"], patch=16)
+    loss.mean().backward()
+    assert len(want) >= 9
+    for k, ref in want.items():
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close(sd[k].grad, ref, 2e-5 * scale, 1e-3, "grad " + k)
