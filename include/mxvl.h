@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 2
+#define MXVL_ABI_VERSION 3
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -188,10 +188,39 @@ typedef struct mxvl_decode_attn_desc {
   const void *pos;          /* device int64 scalar: position being written */
   const void *mask;         /* (rows, max_len) int64, nonzero = may attend */
   void *out;                /* (rows, n_heads * head_dim) bf16 */
+  void *q_rope;             /* ABI v3, optional: (rows, n_heads * head_dim) bf16, the rotated (unscaled) query -- the input of
+                               mxvl_decode_cross_attn for hybrid layers conditioned on image tokens */
 } mxvl_decode_attn_desc;
+
+/*
+ * mxvl_decode_cross_attn (ABI v3): the gated image cross-attention of a hybrid decoder layer for one new token per row --
+ * `all2media_cross_attn`, EMRRG/models/hybrid_decoder_layer.py:653-697 (attention :25-77, gate construction :631-640):
+ *   ctx = softmax(q_rope K_img^T * scale, masked by key_mask) V_img      per (row, head), grouped-query heads
+ *   out = text_state + (row_on ? ctx : 0) * gate,   gate = [tanh](gate_weight . text_state + gate_bias) * [tanh](warm_up_gate)
+ * with bf16 roundings where the reference's bf16 tensor ops round.  K_img / V_img are the layer's `cross_attn_kv_proj` of the
+ * (input-normed) image tokens, constant over a generation; rows of one sample (beams) share them through kv_rows_div.
+ */
+#define MXVL_GATE_TANH 1        /* nn.Tanh after the gate projection ("...-tanh..." gating types) */
+#define MXVL_GATE_WARM_TANH 2   /* warm_up_gate enters through tanh() (the text-only variant, :745) instead of raw (:690) */
+typedef struct mxvl_decode_cross_attn_desc {
+  int32_t rows, n_heads, n_kv_heads, head_dim, n_keys;
+  int32_t kv_rows_div;      /* rows per image sample (num_beams); K/V, key_mask, row_on are indexed by row / kv_rows_div */
+  int32_t gate_flags;       /* MXVL_GATE_* */
+  float scale;
+  const void *q_rope;       /* (rows, n_heads * head_dim) bf16, from mxvl_decode_attn */
+  const void *k, *v;        /* (rows / kv_rows_div, n_kv_heads, n_keys, head_dim) bf16 */
+  const void *key_mask;     /* optional (rows / kv_rows_div, n_keys) uint8, nonzero = may attend */
+  const void *row_on;       /* optional (rows / kv_rows_div) uint8, 0 = sample without an image: context zeroed (:693) */
+  const void *text_state;   /* (rows, n_heads * head_dim) bf16: the self-attention output (mxvl_decode_attn's out) */
+  const void *gate_weight;  /* (n_heads * head_dim) bf16 */
+  const void *gate_bias;    /* (1) bf16 */
+  const void *warm_up_gate; /* optional (1) bf16 */
+  void *out;                /* (rows, n_heads * head_dim) bf16, must not alias text_state */
+} mxvl_decode_cross_attn_desc;
 
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);
 int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
+int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc *desc, void *hip_stream);
 
 int mxvl_abi_version(void);
 /* time steps covered by one checkpoint chunk for a sequence of `seqlen` steps and `dstate` states */

@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -32,6 +32,7 @@ SYMBOLS = [
     "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
+    "mxvl_decode_cross_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum",
@@ -119,7 +120,20 @@ class DecodeAttnDesc(ctypes.Structure):
         ("rows", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32), ("max_len", c_int32),
         ("scale", ctypes.c_float),
         ("qkv", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p),
-        ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p), ("out", c_void_p),
+        ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p), ("out", c_void_p), ("q_rope", c_void_p),
+    ]
+
+
+GATE_TANH, GATE_WARM_TANH = 1, 2
+
+
+class DecodeCrossAttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32), ("n_keys", c_int32),
+        ("kv_rows_div", c_int32), ("gate_flags", c_int32), ("scale", ctypes.c_float),
+        ("q_rope", c_void_p), ("k", c_void_p), ("v", c_void_p), ("key_mask", c_void_p), ("row_on", c_void_p),
+        ("text_state", c_void_p), ("gate_weight", c_void_p), ("gate_bias", c_void_p), ("warm_up_gate", c_void_p),
+        ("out", c_void_p),
     ]
 
 
@@ -191,7 +205,7 @@ def load() -> ctypes.CDLL:
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
     lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
     for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn",
-                 "mxvl_attn_fwd", "mxvl_attn_bwd"):
+                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_conv1d_update.restype = c_int

@@ -207,6 +207,19 @@ struct AttnArgs {
   const int64_t* pos;        // device scalar
   const int64_t* mask;       // (rows, max_len), nonzero = attend
   uint16_t* out;             // (rows, H * D)
+  uint16_t* q_rope;          // optional (rows, H * D): the rotated, UNscaled query (what the hybrid layers' image cross-attention reads)
+};
+
+struct CrossAttnArgs {
+  int rows, H, Hkv, D, n_keys, kv_rows_div, gate_flags;
+  float scale;
+  const uint16_t* q_rope;      // (rows, H * D) rotated query (decode_attn_kernel wrote it)
+  const uint16_t *k, *v;       // (rows / kv_rows_div, Hkv, n_keys, D) image keys / values
+  const uint8_t* key_mask;     // optional (rows / kv_rows_div, n_keys), nonzero = may attend
+  const uint8_t* row_on;       // optional (rows / kv_rows_div): 0 = this sample carries no image (its context is zeroed)
+  const uint16_t* text_state;  // (rows, H * D) the self-attention output the gate reads and the context is added to
+  const uint16_t *gate_w, *gate_b, *warm;   // Linear(hidden, 1) weight (hidden), bias (1), warm-up gate (1, optional)
+  uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
 constexpr int kAttnWaves = 8;
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
     const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * s))));
     const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * s))));
     sq[d] = qr * p.scale;
+    if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
     sk[d] = kr;
     sv[d] = bf2f(vn[d]);
     if (h % group == 0) {  // one head of the group appends to the cache (slot m owns position pos of beam m)
@@ -330,6 +344,115 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
   }
 }
 
+// Image cross-attention of a hybrid decoder layer for ONE new token per row (EMRRG/models/hybrid_decoder_layer.py:653-697,
+// `all2media_cross_attn`): ctx = softmax(q K_img^T * scale + mask) V_img from the layer's RoPE'd query to the image keys /
+// values (constant over a generation: projected once when the layer is conditioned), then
+//     out = text_state + (row_on * ctx) * gate,   gate = tanh?(w_g . text_state + b_g) * warm_up?,
+// every product / sum rounded to bf16 where the reference's bf16 tensor ops round.  One workgroup per (head, row), same
+// lane mapping and one-pass softmax as decode_attn_kernel; the gate (a hidden-wide dot product per row) is recomputed by
+// every head's workgroup -- 8 KB from L2 -- instead of costing a launch of its own.
+template <int D>
+__global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(const CrossAttnArgs p) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = kAttnWaves * RPW, NT = kAttnWaves * 64;
+  extern __shared__ float sm[];
+  float* sq = sm;                 // [D] scaled query
+  float* gm = sq + D;             // [NG]
+  float* gl = gm + NG;            // [NG]
+  float* go = gl + NG;            // [NG][D]
+  float* sred = go + NG * D;      // [kAttnWaves] gate partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, m = blockIdx.y;
+  const int group = p.H / p.Hkv, hk = h / group;
+  const int ms = m / p.kv_rows_div;            // image sample of this row (beams of a sample share it)
+  const int hidden = p.H * D;
+  // ---- gate -------------------------------------------------------------------------------------------------------
+  float part = 0.0f;
+  for (int c = tid * 8; c < hidden; c += NT * 8) {
+    const uint4 xv = *(const uint4*)(p.text_state + (size_t)m * hidden + c);
+    const uint4 wv = *(const uint4*)(p.gate_w + c);
+    part = dot2(xv.x, wv.x, part); part = dot2(xv.y, wv.y, part); part = dot2(xv.z, wv.z, part); part = dot2(xv.w, wv.w, part);
+  }
+  part = wave_sum(part);
+  if (lane == 0) sred[wave] = part;
+  if (tid < D) sq[tid] = bf2f(p.q_rope[(size_t)m * hidden + (size_t)h * D + tid]) * p.scale;
+  __syncthreads();
+  float gate = 0.0f;
+#pragma unroll
+  for (int w = 0; w < kAttnWaves; ++w) gate += sred[w];
+  gate = bf2f(f2bf(gate + bf2f(p.gate_b[0])));                                  // Linear output, bf16
+  if (p.gate_flags & 1) gate = bf2f(f2bf(tanhf(gate)));                          // nn.Tanh in bf16
+  if (p.warm) {
+    float wu = bf2f(p.warm[0]);
+    if (p.gate_flags & 2) wu = bf2f(f2bf(tanhf(wu)));                            // text-only variant: gate * warm.tanh()
+    gate = bf2f(f2bf(gate * wu));
+  }
+  // ---- one-query attention over the image tokens ----------------------------------------------------------------------
+  const int sub = lane % LPR, g = wave * RPW + lane / LPR;
+  float qv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qv[j] = sq[sub * 8 + j];
+  float mx = -1e30f, l = 0.0f, o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+  const uint16_t* kb = p.k + ((size_t)ms * p.Hkv + hk) * p.n_keys * D + sub * 8;
+  const uint16_t* vb = p.v + ((size_t)ms * p.Hkv + hk) * p.n_keys * D + sub * 8;
+  const uint8_t* km = p.key_mask ? p.key_mask + (size_t)ms * p.n_keys : nullptr;
+  constexpr int U = 4;
+  for (int t0 = g; t0 < p.n_keys; t0 += NG * U) {
+    uint4 kq[U], vq[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      live[u] = t < p.n_keys && (!km || km[t] != 0);
+      kq[u] = make_uint4(0, 0, 0, 0);
+      vq[u] = kq[u];
+      if (live[u]) {
+        kq[u] = *(const uint4*)(kb + (size_t)t * D);
+        vq[u] = *(const uint4*)(vb + (size_t)t * D);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t kw[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, vw[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
+      float s = 0.0f, vf[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s = fmaf(qv[2 * j], __builtin_bit_cast(float, kw[j] << 16), s);
+        s = fmaf(qv[2 * j + 1], __builtin_bit_cast(float, kw[j] & 0xffff0000u), s);
+        vf[2 * j] = __builtin_bit_cast(float, vw[j] << 16);
+        vf[2 * j + 1] = __builtin_bit_cast(float, vw[j] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+      const float mn = live[u] ? fmaxf(mx, s) : mx;
+      const float corr = fast_exp(mx - mn), pr = live[u] ? fast_exp(s - mn) : 0.0f;
+      mx = mn;
+      l = fmaf(l, corr, pr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaf(o[j], corr, pr * vf[j]);
+    }
+  }
+  if (sub == 0) { gm[g] = mx; gl[g] = l; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) go[g * D + sub * 8 + j] = o[j];
+  __syncthreads();
+  if (tid < D) {
+    float gmax = -1e30f;
+    for (int i = 0; i < NG; ++i) gmax = fmaxf(gmax, gm[i]);
+    float num = 0.0f, den = 0.0f;
+    for (int i = 0; i < NG; ++i) {
+      const float w = fast_exp(gm[i] - gmax);
+      num = fmaf(w, go[i * D + tid], num);
+      den = fmaf(w, gl[i], den);
+    }
+    float ctx = den > 0.0f ? bf2f(f2bf(num / den)) : 0.0f;                       // attention output, bf16
+    if (p.row_on && p.row_on[ms] == 0) ctx = 0.0f;
+    const size_t o_idx = (size_t)m * hidden + (size_t)h * D + tid;
+    p.out[o_idx] = f2bf(bf2f(p.text_state[o_idx]) + bf2f(f2bf(ctx * gate)));
+  }
+}
+
 static int dec_check() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
@@ -394,6 +517,7 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   a.scale = d->scale; a.qkv = (const uint16_t*)d->qkv; a.cosv = (const float*)d->cos; a.sinv = (const float*)d->sin;
   a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
   a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
+  a.q_rope = (uint16_t*)d->q_rope;
   const int NG = kAttnWaves * 64 / (a.D / 8);
   const size_t lds = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
   if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
@@ -403,6 +527,33 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
     case 64: hipLaunchKernelGGL(decode_attn_kernel<64>, grid, block, lds, s, a); break;
     case 128: hipLaunchKernelGGL(decode_attn_kernel<128>, grid, block, lds, s, a); break;
     case 256: hipLaunchKernelGGL(decode_attn_kernel<256>, grid, block, lds, s, a); break;
+    default: return MXVL_ERR_UNSUPPORTED;
+  }
+  return dec_check();
+}
+
+int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc* d, void* hip_stream) {
+  if (!d || !d->q_rope || !d->k || !d->v || !d->text_state || !d->gate_weight || !d->gate_bias || !d->out) return MXVL_ERR_NULL;
+  if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0 || d->n_keys <= 0) return MXVL_ERR_SHAPE;
+  if (d->kv_rows_div <= 0 || d->rows % d->kv_rows_div != 0) return MXVL_ERR_SHAPE;
+  if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;
+  if (d->out == d->text_state) return MXVL_ERR_UNSUPPORTED;   // every head's workgroup reads the whole row for the gate
+  CrossAttnArgs a;
+  a.rows = d->rows; a.H = d->n_heads; a.Hkv = d->n_kv_heads; a.D = d->head_dim; a.n_keys = d->n_keys;
+  a.kv_rows_div = d->kv_rows_div; a.gate_flags = d->gate_flags; a.scale = d->scale;
+  a.q_rope = (const uint16_t*)d->q_rope; a.k = (const uint16_t*)d->k; a.v = (const uint16_t*)d->v;
+  a.key_mask = (const uint8_t*)d->key_mask; a.row_on = (const uint8_t*)d->row_on; a.text_state = (const uint16_t*)d->text_state;
+  a.gate_w = (const uint16_t*)d->gate_weight; a.gate_b = (const uint16_t*)d->gate_bias; a.warm = (const uint16_t*)d->warm_up_gate;
+  a.out = (uint16_t*)d->out;
+  const int NG = kAttnWaves * 64 / (a.D / 8);
+  const size_t lds = sizeof(float) * ((size_t)a.D + 2 * NG + (size_t)NG * a.D + kAttnWaves);
+  if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
+  const dim3 grid(a.H, a.rows), block(kAttnWaves * 64);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (a.D) {
+    case 64: hipLaunchKernelGGL(decode_cross_attn_kernel<64>, grid, block, lds, s, a); break;
+    case 128: hipLaunchKernelGGL(decode_cross_attn_kernel<128>, grid, block, lds, s, a); break;
+    case 256: hipLaunchKernelGGL(decode_cross_attn_kernel<256>, grid, block, lds, s, a); break;
     default: return MXVL_ERR_UNSUPPORTED;
   }
   return dec_check();

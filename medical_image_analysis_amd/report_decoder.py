@@ -314,7 +314,20 @@ class _KernelStepper(_SearchFusion):
     """One decode step on the hand-written HIP kernels (csrc/decode.hip): per layer a fused RMSNorm+QKV GEMV, the
     RoPE/cache-append/attention kernel, o_proj GEMV (+residual), fused RMSNorm + gate/up GEMV + SwiGLU, down GEMV
     (+residual); then RMSNorm + lm_head.  161 launches per token for 32 layers, captured once in a hipGraph.
-    Beam re-ordering permutes a (rows, max_len) int32 slot table; cache lines never move."""
+    Beam re-ordering permutes a (rows, max_len) int32 slot table; cache lines never move.
+    Hybrid layers conditioned on image tokens (`condition_vis_x`, "vanilla" cross-attention: every token attends,
+    hybrid_decoder_layer.py:653-697) add one launch: the image K / V are projected once per generation and
+    mxvl_decode_cross_attn adds the gated single-query attention to the self-attention output before o_proj."""
+
+    @staticmethod
+    def _cond_layers(model):
+        return [i for i in model.hybrid_layers if model.model.layers[i].vis_x is not None]
+
+    @staticmethod
+    def cond_signature(model):
+        """Shapes the captured graph depends on: part of the stepper cache key."""
+        return tuple((i, tuple(model.model.layers[i].vis_x.shape), model.model.layers[i].cross_attn_mask is not None)
+                     for i in _KernelStepper._cond_layers(model))
 
     @staticmethod
     def supported(model, rows, dtype, device):
@@ -323,9 +336,16 @@ class _KernelStepper(_SearchFusion):
             _abi.load()          # a missing libmxvl.so is an error on a GPU box, never a silent torch path
         cfg = model.config
         D = cfg.hidden_size // cfg.num_attention_heads
-        conditioned = any(model.model.layers[i].vis_x is not None for i in model.hybrid_layers)
+        for i in _KernelStepper._cond_layers(model):
+            lay = model.model.layers[i]
+            at = lay.self_attn
+            # the decode step of the reference is only defined for the all-token ("vanilla") cross-attention with a
+            # scalar gate projection; anything else stays on the module path (which raises where the reference does)
+            if not (at.cross_attention_implementation.startswith("vanilla") and hasattr(at, "cross_attn_gate_proj")
+                    and lay.media_locations is not None and lay.vis_x.dim() == 3 and rows % lay.vis_x.shape[0] == 0):
+                return False
         return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and D in (64, 128, 256)
-                and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and not conditioned
+                and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
                 and rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024)
 
     def __init__(self, model, rows, prompt_mask, dyn_cache, max_new, dtype):
@@ -350,6 +370,9 @@ class _KernelStepper(_SearchFusion):
         self.x2 = torch.zeros(rows, self.hidden, **bf)
         self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
         self.att = torch.zeros(rows, self.H * self.D, **bf)
+        self.att2 = torch.zeros(rows, self.H * self.D, **bf)      # self-attention output + gated image context
+        self.q_rope = torch.zeros(rows, self.H * self.D, **bf)    # rotated query of the current layer
+        self.cond = {}                                            # layer -> image K / V, masks, gate flags (filled by reset)
         self.act = torch.zeros(rows, self.inter, **bf)
         self.logits = torch.zeros(rows, self.V, dtype=torch.float32, device=dev)
         self.cos = torch.zeros(rows, self.D, dtype=torch.float32, device=dev)
@@ -375,6 +398,51 @@ class _KernelStepper(_SearchFusion):
         self.mask[:, :self.P] = prompt_mask.repeat_interleave(rep, dim=0)
         self.n_real.copy_(self.mask[:, :self.P].sum(-1, keepdim=True))
         self.slot.copy_(self.own.expand(-1, self.max_len))
+        self._project_image_tokens()
+
+    @torch.no_grad()
+    def _project_image_tokens(self):
+        """K_img / V_img of every conditioned hybrid layer: `cross_attn_kv_proj(input_layernorm(vis_x))`, constant over the
+        generation (hybrid_decoder_layer.py:1428, :683).  Written into persistent buffers so a captured graph stays valid."""
+        for i in self._cond_layers(self.model):
+            lay = self.model.model.layers[i]
+            at = lay.self_attn
+            k, v = at._vision_kv(lay.input_layernorm(lay.vis_x.to(self.x.dtype)))           # (Bv, Hkv, Lv, D) views
+            km = lay.cross_attn_mask
+            on = (lay.media_locations == 3).sum(dim=-1).bool()
+            flags = self._abi.GATE_TANH if any(isinstance(mod, nn.Tanh) for mod in at.cross_attn_gate_proj) else 0
+            lin = at.cross_attn_gate_proj[0]
+            c = self.cond.get(i)
+            if c is None or c["k"].shape != k.shape:
+                c = dict(k=torch.empty(k.shape, dtype=self.x.dtype, device=self.x.device),
+                         v=torch.empty(v.shape, dtype=self.x.dtype, device=self.x.device),
+                         km=None if km is None else torch.empty(km.shape, dtype=torch.uint8, device=self.x.device),
+                         on=torch.empty(on.shape, dtype=torch.uint8, device=self.x.device))
+                self.cond[i] = c
+                self.graph = None                       # new buffers: a captured graph no longer describes this step
+            c["k"].copy_(k)
+            c["v"].copy_(v)
+            if km is not None:
+                c["km"].copy_(km.to(torch.uint8))
+            c["on"].copy_(on.to(torch.uint8))
+            c["flags"] = flags
+            c["gate_w"], c["gate_b"] = lin.weight.reshape(-1), lin.bias
+            c["warm"] = getattr(at, "cross_attn_warm_up_gate", None) if "warmup" in at.gating_type else None
+            c["div"] = self.rows // k.shape[0]
+        for i in [i for i in self.cond if i not in self._cond_layers(self.model)]:
+            del self.cond[i]
+            self.graph = None
+
+    def _cross_attn(self, i, sp):
+        c = self.cond[i]
+        d = self._abi.DecodeCrossAttnDesc()
+        d.rows, d.n_heads, d.n_kv_heads, d.head_dim, d.n_keys = self.rows, self.H, self.Hkv, self.D, c["k"].shape[2]
+        d.kv_rows_div, d.gate_flags, d.scale = c["div"], c["flags"], self.D ** -0.5
+        d.q_rope, d.k, d.v = self.q_rope.data_ptr(), c["k"].data_ptr(), c["v"].data_ptr()
+        d.key_mask, d.row_on = self._abi.ptr(c["km"]), c["on"].data_ptr()
+        d.text_state, d.out = self.att.data_ptr(), self.att2.data_ptr()
+        d.gate_weight, d.gate_bias, d.warm_up_gate = c["gate_w"].data_ptr(), c["gate_b"].data_ptr(), self._abi.ptr(c["warm"])
+        self._abi.check(self.lib.mxvl_decode_cross_attn(self._ct.byref(d), sp), "mxvl_decode_cross_attn")
 
     def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False):
         d = self._abi.GemvDesc()
@@ -404,8 +472,13 @@ class _KernelStepper(_SearchFusion):
             self._gemv(self.x, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], norm=layer.input_layernorm.weight,
                        eps=layer.input_layernorm.variance_epsilon, bias=at.qkv_bias)
             a.k_cache, a.v_cache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
+            a.q_rope = self.q_rope.data_ptr() if i in self.cond else None
             self._abi.check(self.lib.mxvl_decode_attn(self._ct.byref(a), sp), "mxvl_decode_attn")
-            self._gemv(self.att, at.o_proj.weight, self.x2, self.H * self.D, self.hidden, res=self.x)
+            att = self.att
+            if i in self.cond:                       # gated image cross-attention on the rotated query, before o_proj
+                self._cross_attn(i, sp)
+                att = self.att2
+            self._gemv(att, at.o_proj.weight, self.x2, self.H * self.D, self.hidden, res=self.x)
             self._gemv(self.x2, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter,
                        norm=layer.post_attention_layernorm.weight, eps=layer.post_attention_layernorm.variance_epsilon,
                        W2=layer.mlp.up_proj.weight)
@@ -577,7 +650,8 @@ class ReportDecoder(nn.Module):
             if self.__dict__.get("_stepper_weights") != ident:
                 self.__dict__["_steppers"] = {}
                 self.__dict__["_stepper_weights"] = ident
-            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph), conditioned)
+            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph), conditioned,
+                   _KernelStepper.cond_signature(self))
             stepper = getattr(self, "_steppers", {}).get(key)
             if stepper is None:
                 cls = _KernelStepper if (use_graph != "torch" and _KernelStepper.supported(

@@ -105,6 +105,74 @@ def test_hip_decode_step_matches_torch_step_bf16():
             assert_close(lk, lt, 0.03 * scale, 0.03, f"logits at step {k}")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gating", ["whole-dynamic-tanh-warmup", "whole-dynamic"])
+def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_path(gating):
+    """Hybrid layers conditioned on image tokens (`condition_vis_x`, "vanilla" = every token attends,
+    hybrid_decoder_layer.py:653-697): the kernel stepper (mxvl_decode_attn -> mxvl_decode_cross_attn: single-query attention over
+    the image K / V, scalar gate, added before o_proj) against the module path (the torch stepper calling the layers' forward,
+    which is pinned to the reference by tests/golden/hybrid_decoder.npz), teacher-forced.  One sample carries no image
+    (token_type has no 3: its context is zeroed, :693), some image tokens are masked, grouped-query heads."""
+    from medical_image_analysis_amd.report_decoder import ReportDecoder, _GraphStepper, _KernelStepper, KVCache
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=256, hybrid_layers=(0, 2), cross_attn_implementation="vanilla",
+                      cross_attn_gating_type=gating).to(dev).to(torch.bfloat16).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)
+        for i in (0, 2):
+            at = m.model.layers[i].self_attn
+            if hasattr(at, "cross_attn_warm_up_gate"):
+                at.cross_attn_warm_up_gate.fill_(0.75)
+            at.cross_attn_gate_proj[0].bias.fill_(0.5)
+    B, P, new, Lv = 3, 9, 5, 37
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    mask = torch.ones(B, P, dtype=torch.long, device=dev)
+    mask[1, :3] = 0
+    vis = torch.randn(B, Lv, 256, device=dev).to(torch.bfloat16)
+    cmask = torch.ones(B, Lv, dtype=torch.bool, device=dev)
+    cmask[0, 30:] = False
+    cmask[2, ::3] = False
+    tt = torch.ones(B, P, dtype=torch.long, device=dev)
+    tt[0, :2] = 3
+    tt[2, 1:4] = 3                                            # sample 1 carries no image token
+    with torch.no_grad():
+        c0 = KVCache()
+        m(emb, attention_mask=mask, past_key_values=c0)
+        plain = _KernelStepper(m, B, mask, c0, new, torch.bfloat16)
+        m.condition_vis_x(vis, cmask, tt)
+        assert _KernelStepper.supported(m, B, torch.bfloat16, dev)
+        c1, c2 = KVCache(), KVCache()
+        m(emb, attention_mask=mask, past_key_values=c1)
+        m(emb, attention_mask=mask, past_key_values=c2)
+        ks = _KernelStepper(m, B, mask, c1, new, torch.bfloat16)
+        ts = _GraphStepper(m, B, mask, c2, new, torch.bfloat16)
+        assert sorted(ks.cond) == [0, 2]
+        g = torch.Generator(device="cpu").manual_seed(1)
+        beam = torch.arange(B, device=dev)
+        moved = 0.0
+        for k in range(new):
+            tok = torch.randint(3, 512, (B,), generator=g).to(dev)
+            lk = ks.step(tok, beam, k).float().clone()
+            lt = ts.step(tok, beam, k).float().clone()
+            scale = float(lt.abs().max())
+            assert_close(lk, lt, 0.03 * scale, 0.03, f"conditioned logits at step {k}")
+            if k == 0:
+                moved = float((lk - plain.step(tok, beam, 0).float()).abs().max()) / scale
+        assert moved > 0.05, "the image context must move the logits"
+        # generate() itself picks the kernel stepper for the conditioned decoder and re-projects the image tokens per call
+        kw = dict(attention_mask=mask, num_beams=1, min_new_tokens=3, max_new_tokens=5, eos_token_id=2, pad_token_id=0, do_sample=False)
+        out1 = m.generate(emb, **kw)
+        assert all(type(st) is _KernelStepper and sorted(st.cond) == [0, 2] for st in m._steppers.values())
+        m.condition_vis_x(-vis, cmask, tt)
+        out2 = m.generate(emb, **kw)                      # same shapes: the cached stepper / graph is reused with new K_img / V_img
+        m.condition_vis_x(vis, cmask, tt)
+        assert torch.equal(m.generate(emb, **kw), out1) and out1.shape == out2.shape
+    m.clear_vis_x()
+
+
 # ---- HF-pinned checks of the HIP decode kernels (tests/golden/decode_llama_hd64.npz: head_dim 64, bf16 weights) --------
 HD64 = dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
             num_key_value_heads=1, rms_norm_eps=1e-6, max_position_embeddings=128)
