@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = p.N, L = p.L;
-  float* sB = smem;                        // [N][CH]  quarter-major, odd quarter bank-swizzled (see scan_fwd_stream.h qpos)
+  float* sB = smem;                        // [N][CH]  quarter-major, odd quarter rotated by 16 words (see scan_fwd_stream.h qpos)
   float* sC = sB + N * CH;                 // [N][CH]
   // dB/dC shares of a group of FG states, one tile per WAVE (its 4 rows summed in registers first), double-buffered:
   // plain LDS stores, then a NWAVES-way tree sum one group behind.  (ds_add_f32 measured 7x the whole rest of the kernel,
@@ -127,13 +127,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   float* sAcc = sC + N * CH;               // [2 buffers][FG][NWAVES][2 (dB,dC)][CH]
   float* sO = sAcc;                        // [DT][CH] store transpose tile of unaligned rows: aliases sAcc (idle between the
                                            // last flush barrier of a chunk and the barrier that opens the next one)
-  float2* sAC = (float2*)(sAcc + 2 * FG * NWAVES * 2 * CH);   // [DT+1][N] {A*log2e, state entering the chunk}; row DT = 0
-  float* sG = (float*)(sAC + (DT + 1) * N);  // [DT+1][N] adjoint entering the chunk from the right; row DT = 0
-  float* sdA = sG + (DT + 1) * N;          // [DT][N] dA accumulated over the chunks
+  // The three per-(row, state) tables are padded to NP = N + 1 entries per row: at a stride of N (= 16 or 32 words) the same
+  // state of every row sat on one bank and the per-state b32 accesses of a wave's 4 rows (+ the zero row) conflicted 2-3-way.
+  const int NP = N + 1;
+  float2* sAC = (float2*)(sAcc + 2 * FG * NWAVES * 2 * CH);   // [DT+1][NP] {A*log2e, state entering the chunk}; row DT = 0
+  float* sG = (float*)(sAC + (DT + 1) * NP);  // [DT+1][NP] adjoint entering the chunk from the right; row DT = 0
+  float* sdA = sG + (DT + 1) * NP;         // [DT][NP] dA accumulated over the chunks
   // u, delta, z, dout of the chunk as loaded, parked here across the state loop.  They are only needed again for the
   // per-step outputs; in registers (32 VGPRs) they push the loop to the 256-VGPR limit, where the compiler re-computes the 8
   // v_exp_f32 of a_t in the second pass instead of keeping them (17 instead of 9 transcendentals per state).
-  io_t* sPark = (io_t*)(smem + (((sdA + DT * N) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
+  io_t* sPark = (io_t*)(smem + (((sdA + DT * NP) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane >> 4, j = lane & 15;
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
-    sAC[i] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
-    sG[i] = 0.0f;
-    if (rr < DT) sdA[i] = 0.0f;
+    sAC[rr * NP + n] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    sG[rr * NP + n] = 0.0f;
+    if (rr < DT) sdA[rr * NP + n] = 0.0f;
   }
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
         const float4 bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e);
         const float4 cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e);
-        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4) ^ (((e >> 2) & 1) * 32));   // odd quarter bank-swizzled: conflict-free staging writes
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4 + ((e >> 2) & 1) * 16) & 63);   // odd quarter rotated by 16 words: conflict-free staging writes (scan_fwd_stream.h qpos)
         *(float4*)(sB + pos) = bv;
         *(float4*)(sC + pos) = cv;
       }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
           bv = io::ld(Bp + (int64_t)n * p.B_ns + t);
           cv = io::ld(Cp + (int64_t)n * p.C_ns + t);
         }
-        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4) ^ (((e >> 2) & 1) * 32)) + (e & 3);
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4 + ((e >> 2) & 1) * 16) & 63) + (e & 3);
         sB[pos] = bv;
         sC[pos] = cv;
       }
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       const int dd = d0 + wave * RPW + rr;
       float h0 = 0.0f;
       if (c > 0 && dd < d_end) h0 = p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n];
-      sAC[(wave * RPW + rr) * N + n].y = h0;
+      sAC[(wave * RPW + rr) * NP + n].y = h0;
     }
     __syncthreads();
     if constexpr (PF) {
@@ -364,13 +367,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 #pragma unroll
     for (int i = 0; i < T; ++i) dsum += dl[i];
 
-    float2* ac = sAC + row * N;
-    const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;
-    float* gq = sG + row * N;
-    const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * N;
-    const float* cB = sB + j * 4;                   // even quarter (steps 8j..8j+3) at word 4j, odd quarter at 64 + (4j ^ 32)
+    float2* ac = sAC + row * NP;
+    const float2* ac_in = sAC + ((j == 0) ? row : DT) * NP;
+    float* gq = sG + row * NP;
+    const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * NP;
+    const float* cB = sB + j * 4;                   // even quarter (steps 8j..8j+3) at word 4j, odd quarter at 64 + ((4j + 16) & 63)
     const float* cC = sC + j * 4;
-    const int q1 = 64 + ((j * 4) ^ 32) - j * 4;     // word offset of the odd quarter relative to cB / cC
+    const int q1 = 64 + ((j * 4 + 16) & 63) - j * 4;     // word offset of the odd quarter relative to cB / cC
     // A wave first sums the dB / dC shares of its 4 rows in registers (v_permlane{32,16}_swap), so only ONE
     // share per wave goes to LDS; states are flushed in groups of FG, one group behind -- sAcc is two buffers of
     // [FG][NWAVES][2][CH] -- so the sums of group g run while group g+1 is computed and one barrier per FG states separates a
@@ -378,13 +381,21 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     // states cost 30 % of the kernel in LDS stores, flush reads and barriers; per-wave global atomics without LDS, 8x the
     // atomics, ran 4x slower.)
     constexpr int FK = FG * 2 * CH / NT;          // elements of a group per thread: 2 (8 waves) / 4 (4 waves)
-    float* wAcc = sAcc + wave * (2 * CH) + j * T + (r & 1) + (r >> 1) * 4;   // lane (r, j) holds step 8 j + {0, 1, 4, 5}[r] (and +2)
+    // lane (r, j) holds step e = 8 j + i, i = {0, 1, 4, 5}[r] (and i + 2).  Inside its 8-word block a step sits rotated by
+    // 2 (j >> 2): the 32 lanes of one ds_write_b32 group (two rows x 16 j) then hit 32 different banks -- at position e the four
+    // j that are 4 apart collided 4-way, 50 M of the kernel's 55 M conflict cycles -- and the flush's consecutive-e reads stay
+    // conflict-free (a 32-step run keeps j >> 2 fixed).
+    const int i0 = (r & 1) + (r >> 1) * 4, rot = 2 * (j >> 2);
+    float* wAcc = sAcc + wave * (2 * CH) + j * T;
+    const int wp0 = (i0 + rot) & 7, wp2 = (i0 + 2 + rot) & 7;
     auto flush_load = [&](int g, float (&part)[FK * NWAVES]) {
 #pragma unroll
       for (int k = 0; k < FK; ++k) {
         // element x = tid + NT k of the group: state slot x / (2 CH), dB|dC (x / CH) & 1, step x % CH
         const int x = tid + NT * k;
-        const float* qq = sAcc + (g & 1) * (FG * NWAVES * 2 * CH) + (x / (2 * CH)) * (NWAVES * 2 * CH) + (x % (2 * CH));
+        const int xe = x % (2 * CH);                                  // dB|dC * CH + step; the step's slot is rotated (see wAcc)
+        const float* qq = sAcc + (g & 1) * (FG * NWAVES * 2 * CH) + (x / (2 * CH)) * (NWAVES * 2 * CH) + (xe & ~7) +
+                          ((xe + 2 * ((xe % CH) >> 5)) & 7);
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) part[k * NWAVES + w] = qq[w * 2 * CH];
       }
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       }
       {
         dA_part = row_sum_to_lane15(dA_part);
-        if (j == LPR - 1) sdA[row * N + n] += dA_part;
+        if (j == LPR - 1) sdA[row * NP + n] += dA_part;
         if (!MXVL_ABL(p.ablate & 1)) {
           // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
           // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
@@ -487,8 +498,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
           for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
           lane16_swap_x4(sr);
           float* w = wAcc + (((n / FG) & 1) * FG + (n % FG)) * (NWAVES * 2 * CH);
-          w[0] = sr[0] + sr[1]; w[2] = sr[2] + sr[3];
-          w[CH] = sr[4] + sr[5]; w[CH + 2] = sr[6] + sr[7];
+          w[wp0] = sr[0] + sr[1]; w[wp2] = sr[2] + sr[3];
+          w[CH + wp0] = sr[4] + sr[5]; w[CH + wp2] = sr[6] + sr[7];
         }
         if (f_first && !MXVL_ABL(p.ablate & 16)) flush_add(n / FG - 1, fpart);
         if (((n % FG) == FG - 1 || n == N - 1) && !MXVL_ABL(p.ablate & 8)) __syncthreads();
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + wave * RPW + rr;
     // d a / d A = delta * a and A2 = A*log2e only rescales the exponent argument: sdA already holds dA
-    if (dd < d_end) unsafeAtomicAdd(p.dA + (int64_t)dd * N + n, sdA[(wave * RPW + rr) * N + n]);
+    if (dd < d_end) unsafeAtomicAdd(p.dA + (int64_t)dd * N + n, sdA[(wave * RPW + rr) * NP + n]);
   }
 }
 
@@ -603,7 +614,7 @@ extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxv
 template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * a.N + (size_t)DT * a.N) +
+  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1)) +
                      16 + (size_t)4 * NWAVES * 64 * 8 * sizeof(io_t);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
   auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL>;

@@ -386,7 +386,7 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
 template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
 static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name) {
   constexpr int CH = 128, DT = NWAVES * (64 / (CH / T));
-  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * a.N);
+  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * (a.N + 1));
   auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T>;
   const int dpg = a.dim / a.G;
   dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);

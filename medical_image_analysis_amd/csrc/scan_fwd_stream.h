@@ -8,7 +8,7 @@
 //   * the B/C tile of chunk c+1 is fetched by the whole workgroup during chunk c and written into the other half
 //     of a double-buffered LDS tile after the state loop: one barrier per chunk.  The tile is stored
 //     "quarter-major" ([T/4][LPR][4] per row) so the per-lane 16-byte reads of a DPP row are conflict-free, with the odd
-//     quarter bank-swizzled so the staging writes are too (see qpos);
+//     quarter rotated by 16 words so the staging writes are too (see qpos);
 //   * the prefix scan over the LPR lanes is fused-DPP (v_fmac/v_mul with row_shr).  For LPR = 8 two rows share a
 //     16-lane DPP row: the first lane of every row scans with P = 0 (after absorbing the incoming state), which
 //     cuts every contribution that would cross the row boundary -- no exec masking needed;
@@ -49,7 +49,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const int N = p.N, L = p.L;
   float* sBC = smem;                          // [2 buffers][B|C][N][CH]
   float* sO = sBC + 4 * N * CH;               // [DT][CH] out tile (unaligned rows / ragged tail)
-  float2* sAC = (float2*)(sO + DT * CH);      // [DT + 1][N] {A*log2(e), running state h}; row DT stays zero
+  float2* sAC = (float2*)(sO + DT * CH);      // [DT + 1][NP] {A*log2(e), running state h}; row DT stays zero
+  // rows are padded by one float2: with a stride of 2N = 32 words every row's state n sat on the same bank, and the per-state
+  // b32 accesses of the 4 rows of a wave (+ the zero row) were 2-3-way conflicts (half of SQ_LDS_BANK_CONFLICT)
+  const int NP = N + 1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane / LPR, j = lane % LPR;
@@ -77,18 +80,18 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
-    sAC[i] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    sAC[rr * NP + n] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
   }
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
 
   // element e = jj*T + i of a tile row lives at quarter-major position (i/4)*(LPR*4) + jj*4 + i%4.  For 16-lane rows the odd
-  // quarter is stored with bit 5 of the word offset flipped (SWZ): the 16 lanes of one ds_write_b128 pass of the staging
-  // (8 even + 8 odd quarters) then cover 64 different banks -- unswizzled, the two quarters sit 64 words apart and every
-  // staging write was a 2-way conflict (29 % of the LDS-active cycles in profiles/r01_scan_sq.txt).  The reads stay one
-  // contiguous 256-byte run per quarter, in a lane order that does not matter.
-  constexpr int SWZ = (LPR == 16) ? 32 : 0;
-  auto qpos = [](int e) { const int q = (e % T) >> 2; return q * (LPR * 4) + (((e / T) * 4) ^ ((q & 1) * SWZ)) + (e & 3); };
+  // quarter is stored ROTATED by 16 words (SWZ): ds_write_b128 is serviced in groups of 8 consecutive lanes against 32 banks
+  // (MI355X_MICROARCH.md, LDS table), and the 8 staging lanes of a group hold 4 even + 4 odd quarters -- unrotated, both sets sit
+  // on banks 0-15 (the quarters are 64 words apart): a 2-way conflict on every staging write (SQ_LDS_BANK_CONFLICT was 29 % of
+  // SQ_LDS_IDX_ACTIVE, profiles/r01_scan_sq.txt).  The reads stay one 256-byte run per quarter, rotated: still conflict-free.
+  constexpr int SWZ = (LPR == 16) ? 16 : 0;
+  auto qpos = [](int e) { const int q = (e % T) >> 2; return q * (LPR * 4) + ((((e / T) * 4) + (q & 1) * SWZ) & (LPR * 4 - 1)) + (e & 3); };
 
   // ---- B/C tile fetch (global -> registers) and commit (registers -> LDS buffer) ------------------
   float4 bq[VEC ? BCV : 1], cq[VEC ? BCV : 1];
@@ -240,16 +243,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int i = lane; i < RPW * N; i += 64) {
         const int rr = i / N, n = i - rr * N;
         const int dd = d0 + wave * RPW + rr;
-        if (dd < d_end) p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n] = sAC[(wave * RPW + rr) * N + n].y;
+        if (dd < d_end) p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
       }
     }
-    float2* ac = sAC + row * N;
-    const float2* ac_in = sAC + ((j == 0) ? row : DT) * N;  // only lane 0 sees the state entering the chunk
+    float2* ac = sAC + row * NP;
+    const float2* ac_in = sAC + ((j == 0) ? row : DT) * NP;  // only lane 0 sees the state entering the chunk
     const float* cB = sBC + (c & 1) * 2 * N * CH;
     const float* cC = cB + N * CH;
     int rq[TQ];                                               // this lane's word offset inside a tile row, per quarter
 #pragma unroll
-    for (int k = 0; k < TQ; ++k) rq[k] = k * (LPR * 4) + ((j * 4) ^ ((k & 1) * SWZ));
+    for (int k = 0; k < TQ; ++k) rq[k] = k * (LPR * 4) + ((j * 4 + (k & 1) * SWZ) & (LPR * 4 - 1));
 
 #pragma unroll 4
     for (int n = 0; n < (MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N); ++n) {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     for (int i = lane; i < RPW * N; i += 64) {
       const int rr = i / N, n = i - rr * N;
       const int dd = d0 + wave * RPW + rr;
-      if (dd < d_end) p.last_state[((int64_t)b * p.dim + dd) * N + n] = sAC[(wave * RPW + rr) * N + n].y;
+      if (dd < d_end) p.last_state[((int64_t)b * p.dim + dd) * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
     }
   }
 }

@@ -18,9 +18,10 @@ prof bwd_fetch --kernel-trace --pmc FETCH_SIZE -d $P/bwd_fetch -o r -- $BW
 prof bwd_write --kernel-trace --pmc WRITE_SIZE -d $P/bwd_write -o r -- $BW
 prof bwd_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $P/bwd_sq -o r -- $BW
 prof bwd_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $P/bwd_sq2 -o r -- $BW
+prof fwd_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $P/fwd_sq -o r -- python $R/bench.py --workload scan_fwd_target --steps 10 --warmup 2 --no-cpu-baseline
 prof pretrain_stats --kernel-trace --stats -d $P/pretrain_stats -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 cd $R
-for n in bwd_fetch bwd_write bwd_sq bwd_sq2 pretrain_stats; do
+for n in bwd_fetch bwd_write bwd_sq bwd_sq2 fwd_sq pretrain_stats; do
   python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -60 | cut -c1-170 > $O/prof_${TAG}_$n.txt
 done
 python tools/pmc_traffic.py scan_bwd_pretrain scan_bwd_kernel $O/prof_${TAG}_bwd_fetch.txt $O/prof_${TAG}_bwd_write.txt $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
