@@ -75,7 +75,10 @@ template <typename E> struct Pol16 {
   // (profiles/r02_attn_pmc.txt).
   template <int D> static __device__ __forceinline__ int unit_off(int row, int u) {
     constexpr int UPR = D / 8, SH = UPR >= 16 ? 0 : (UPR == 8 ? 1 : 2);
-    const int key = UPR == 8 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> SH) & (UPR - 1));
+    // D = 128 (UPR = 16, a row is a whole bank row): rows r .. r + 3 of a transposed read must land in four different 64-byte
+    // blocks -> row bits 1..0 go to key bits 3..2; the 16 rows of a b128 group still get 16 different keys.
+    const int key = UPR == 8 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))
+                  : UPR == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> SH) & (UPR - 1));
     return row * (D * 2) + ((u ^ key) << 4);
   }
   // A operand, row-major rows: lane (row, hi) takes elements [16 ks + 8 hi, +8) of its row
