@@ -311,3 +311,61 @@ def test_beam_step_kernel_equals_torch_restatement(cfg):
         assert torch.allclose(hip.fin_score[done], ref.fin_score[done], rtol=2e-6, atol=2e-5)
         assert torch.equal(hip.fin_seq[done], ref.fin_seq[done]), f"step {steps}: finished hypotheses"
     assert steps >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,Hkv,Lv,div,flags", [(64, 4, 2, 37, 1, 3), (128, 8, 8, 197, 3, 1), (64, 6, 2, 5, 2, 0), (128, 4, 1, 300, 1, 2)])
+def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags):
+    """mxvl_decode_cross_attn alone against a torch restatement of `all2media_cross_attn` for one token per row
+    (hybrid_decoder_layer.py:653-697) that rounds to bf16 where the reference's bf16 tensor ops round: grouped-query heads, beams
+    sharing a sample's image K / V (kv_rows_div), masked image tokens, a sample without image (row_on = 0), an all-masked
+    sample (context 0), tanh / raw gate and tanh / raw warm-up."""
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    dev = "cuda:0"
+    lib = _abi.load()
+    g = torch.Generator().manual_seed(D + Lv)
+    samples = 2
+    rows = samples * div
+    hidden = H * D
+    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).to(dev)
+    q, ts = bf(rows, hidden), bf(rows, hidden)
+    k, v = bf(samples, Hkv, Lv, D), bf(samples, Hkv, Lv, D)
+    km = (torch.rand(samples, Lv, generator=g) > 0.3)
+    km[:, 0] = True
+    if Lv == 5:
+        km[1] = False                                   # every image token of sample 1 masked: its context is defined as 0
+    row_on = torch.tensor([1, 0 if Lv == 37 else 1], dtype=torch.uint8)
+    gw, gb, warm = bf(hidden, sc=hidden ** -0.5), bf(1), bf(1)
+    out = torch.empty_like(ts)
+    kmd, ond = km.to(torch.uint8).to(dev), row_on.to(dev)
+    d = _abi.DecodeCrossAttnDesc()
+    d.rows, d.n_heads, d.n_kv_heads, d.head_dim, d.n_keys, d.kv_rows_div, d.gate_flags, d.scale = rows, H, Hkv, D, Lv, div, flags, D ** -0.5
+    d.q_rope, d.k, d.v, d.key_mask, d.row_on = q.data_ptr(), k.data_ptr(), v.data_ptr(), kmd.data_ptr(), ond.data_ptr()
+    d.text_state, d.gate_weight, d.gate_bias, d.warm_up_gate, d.out = ts.data_ptr(), gw.data_ptr(), gb.data_ptr(), warm.data_ptr(), out.data_ptr()
+    _abi.check(lib.mxvl_decode_cross_attn(ctypes.byref(d), _abi.stream_ptr(torch.device(dev))), "mxvl_decode_cross_attn")
+    torch.cuda.synchronize()
+    r = lambda t: t.to(torch.bfloat16).float()          # one bf16 rounding
+    f = lambda t: t.float().cpu()
+    gate = r((f(ts) * f(gw)).sum(-1, keepdim=True) + f(gb))
+    if flags & 1:
+        gate = r(torch.tanh(gate))
+    wu = f(warm)
+    if flags & 2:
+        wu = r(torch.tanh(wu))
+    gate = r(gate * wu)
+    ctx = torch.zeros(rows, H, D)
+    for m in range(rows):
+        s_ = m // div
+        for h in range(H):
+            hk = h // (H // Hkv)
+            sc = (f(k)[s_, hk] @ f(q)[m, h * D:(h + 1) * D]) * D ** -0.5
+            sc = sc.masked_fill(~km[s_], float("-inf"))
+            if bool(km[s_].any()) and int(row_on[s_]):
+                ctx[m, h] = torch.softmax(sc, -1) @ f(v)[s_, hk]
+    want = r(f(ts) + r(r(ctx.reshape(rows, hidden)) * gate))
+    err = (f(out) - want).abs()
+    tol = 2.0 ** -7 * want.abs().clamp(min=1.0)         # one bf16 ulp of the result: the kernel's fp32 softmax vs this one's
+    assert float((err > tol).float().mean()) < 2e-3 and float(err.max()) < 0.06, (float(err.max()), float((err > tol).float().mean()))
+    if Lv == 37:
+        assert torch.equal(out[div:], ts[div:]), "a sample without image keeps its self-attention output bit for bit"
