@@ -118,3 +118,36 @@ def test_r2gencsr_context_sample_plumbing(tmp_path):
     assert neg["image"].shape == pos["image"].shape == (3, 3, 16, 16) and len(neg["id"]) == 3
     assert all(t.startswith("no acute process") for t in neg["input_text"]) and all(t.startswith("note") for t in pos["input_text"])
     assert len(seen) == 2 and all(len(s) == 3 and all(shape[2] == 3 for shape in s) for s in seen)   # raw (H, W, 3) images went in
+
+
+@pytest.mark.gpu
+def test_r2gencsr_context_sample_on_the_device(tmp_path):
+    """context_sample (R2GenCSR.py:308-374) with the DEVICE image pipeline (mxvl_image_preprocess behind XrayImageProcessor), no
+    stand-in: the context batches arrive on the GPU in bf16 and equal the CPU pipeline the reference runs -- Pillow bicubic resize
+    + rescale + normalise (dataset/data_helper.py:17-26), rounded to bf16 like its `.to(torch.bfloat16)` -- bit for bit."""
+    Image = pytest.importorskip("PIL.Image")
+    pytest.importorskip("pandas")
+    import numpy as np
+    from medical_image_analysis_amd.r2gencsr import R2GenCSR
+    rows = []
+    for i in range(80):
+        os.makedirs(tmp_path / f"s{i}", exist_ok=True)
+        Image.fromarray(synthetic_xray(300 + 7 * (i % 5), 280 + 3 * (i % 7), i)).save(tmp_path / f"s{i}" / "a.png")
+        rows.append({"id": f"s{i}", "report": ("note: effusion ." if i % 2 else "no acute process ."), "image_path": [f"s{i}/a.png"]})
+    (tmp_path / "ann.json").write_text(json.dumps({"train": rows, "val": [], "test": []}))
+    args = SimpleNamespace(dataset="mimic_cxr", annotation=str(tmp_path / "ann.json"), base_dir=str(tmp_path), input_size=224,
+                           context_pair_seed=1, context_retrieval_mode=None)
+    model = SimpleNamespace(args=args, pick_context_studies=lambda n, c: R2GenCSR.pick_context_studies(SimpleNamespace(args=args), n, c))
+    neg, pos = R2GenCSR.context_sample(model, num=3)
+    from oracle import image_ref as ir
+    for batch, word in ((neg, "no acute process"), (pos, "note")):
+        img = batch["image"]
+        assert img.is_cuda and img.dtype == torch.bfloat16 and img.shape == (3, 3, 224, 224)
+        assert all(t.startswith(word) for t in batch["input_text"])
+        for k, sid in enumerate(batch["id"]):
+            rgb = np.asarray(Image.open(tmp_path / sid / "a.png").convert("RGB"))
+            # live Pillow resize (where Pillow is importable) and the numpy oracle of Pillow + transformers (pinned to their goldens)
+            pil = np.asarray(Image.fromarray(rgb).resize((224, 224), resample=Image.BICUBIC))
+            assert np.array_equal(pil, ir.resize_u8(rgb, 224, 224))
+            ref = torch.from_numpy(np.ascontiguousarray(ir.preprocess_ref(rgb, 224)))
+            assert torch.equal(img[k].cpu(), ref.to(torch.bfloat16)), f"study {sid}: device pipeline != Pillow + transformers arithmetic"
