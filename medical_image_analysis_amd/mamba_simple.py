@@ -19,6 +19,7 @@ What is different underneath (MI355X-first, not a translation):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -77,10 +78,13 @@ class _DirGather(torch.autograd.Function):
     zero-padded to Lp (csrc/dir_perm.hip).  Backward = the merge with the inverse permutations."""
 
     @staticmethod
-    def forward(ctx, x, xd, perm, inv, perm_d, inv_d, Lp):
+    def forward(ctx, x, xd, perm, inv, perm_d, inv_d, Lp, channel_major=False):
         B, D, L = x.shape
         K = perm.shape[0] + (perm_d.shape[0] if xd is not None else 0)
-        X = torch.empty((B, K, D, Lp), dtype=x.dtype, device=x.device)
+        if channel_major:    # stored (K, D, B, Lp): each direction is a (D, B*Lp) matrix (selective_scan_interface._MultiDirInnerFn)
+            X = torch.empty((K, D, B, Lp), dtype=x.dtype, device=x.device).permute(2, 0, 1, 3)
+        else:
+            X = torch.empty((B, K, D, Lp), dtype=x.dtype, device=x.device)
         _dir_perm(False, _rows_view(x), X[:, :perm.shape[0]], perm, L, Lp)
         if xd is not None:
             _dir_perm(False, _rows_view(xd.to(x.dtype)), X[:, perm.shape[0]:], perm_d, L, Lp)
@@ -92,7 +96,8 @@ class _DirGather(torch.autograd.Function):
     def backward(ctx, dX):
         inv, inv_d = ctx.saved_tensors
         L, Lp, K0, has_d, d_dtype = ctx.meta
-        dX = dX.contiguous()
+        if dX.stride(-1) != 1:
+            dX = dX.contiguous()     # any batch / direction / channel strides are fine: the kernel takes them
         B, K, D, _ = dX.shape
         dx = torch.empty((B, D, L), dtype=dX.dtype, device=dX.device)
         _dir_perm(True, dx, dX[:, :K0], inv, L, Lp)
@@ -101,7 +106,7 @@ class _DirGather(torch.autograd.Function):
             dxd = torch.empty((B, D, L), dtype=dX.dtype, device=dX.device)
             _dir_perm(True, dxd, dX[:, K0:], inv_d, L, Lp)
             dxd = dxd.to(d_dtype)
-        return dx, dxd, None, None, None, None, None
+        return dx, dxd, None, None, None, None, None, None
 
 
 class _DirMerge(torch.autograd.Function):
@@ -155,6 +160,48 @@ class _DirMergeGate(torch.autograd.Function):
         dz = torch.empty((B, D, L), dtype=z.dtype, device=dout.device)
         _dir_perm(False, _rows_view(dout.to(z.dtype)), dy, perm, L, Lp, gate=z, pre=pre, dgate=dz, scale=scale)
         return dy, dz, None, None, None, None
+
+
+class _MultiDirMixerFn(torch.autograd.Function):
+    """The whole bimamba-v3 mixer between in_proj and out_proj as ONE autograd node: xz (B, 2D, L) -> scan-order gather of x
+    (all K directions, zero-padded to Lp, direction-channel-major) -> conv1d+SiLU -> x_proj -> dt_proj -> selective scan
+    (selective_scan_interface.mdir_core_*) -> merge of the directions * silu(z) * scale -> (B, D, L)
+    (arm/Finetuning/mamba_simple.py:447-532).  The backward writes dz (the gate gradient of the merge's adjoint kernel) and dx
+    (the merge of dX) straight into the two halves of ONE channel-major d(xz) buffer -- the separate-node form copied both."""
+
+    @staticmethod
+    def forward(ctx, xz, perm, inv, Lp, scale, conv_w, conv_b, Wx, Wdt, A, Dv, dbias):
+        from .selective_scan_interface import mdir_core_forward
+        B, two_d, L = xz.shape
+        D, K = two_d // 2, perm.shape[0]
+        if xz.stride(-1) != 1:
+            xz = xz.contiguous()
+        x, z = xz[:, :D], xz[:, D:]
+        X = torch.empty((K, D, B, Lp), dtype=xz.dtype, device=xz.device).permute(2, 0, 1, 3)
+        _dir_perm(False, x, X, perm, L, Lp)
+        needs_grad = any(ctx.needs_input_grad)
+        y, saved, ctx.meta = mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad)
+        out = torch.empty((B, D, L), dtype=y.dtype, device=y.device)
+        pre = torch.empty((B, D, L), dtype=y.dtype, device=y.device) if needs_grad else None
+        _dir_perm(True, out, y, inv, L, Lp, gate=z, pre=pre, scale=scale)
+        ctx.save_for_backward(xz, perm, inv, pre, *saved)
+        ctx.dims = (Lp, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .selective_scan_interface import mdir_core_backward
+        xz, perm, inv, pre = ctx.saved_tensors[:4]
+        Lp, scale = ctx.dims
+        B, two_d, L = xz.shape
+        D, K = two_d // 2, perm.shape[0]
+        z = xz[:, D:]
+        dxz = torch.empty((two_d, B, L), dtype=xz.dtype, device=xz.device).permute(1, 0, 2)     # channel-major, proj_in's layout
+        dy = torch.empty((K, D, B, Lp), dtype=xz.dtype, device=xz.device).permute(2, 0, 1, 3)
+        _dir_perm(False, _rows_view(dout.to(xz.dtype)), dy, perm, L, Lp, gate=z, pre=pre, dgate=dxz[:, D:], scale=scale)
+        grads = mdir_core_backward(ctx.saved_tensors[4:], ctx.meta, dy)
+        _dir_perm(True, dxz[:, :D], grads[0], inv, L, Lp)
+        return (dxz, None, None, None, None) + tuple(grads[1:])
 
 
 class _PermuteLast(torch.autograd.Function):
@@ -270,6 +317,18 @@ class Mamba(nn.Module):
         Bz, _, L = xz.shape
         D, N, R = self.d_inner, self.d_state, self.dt_rank
         fwd, inv, fwd32, inv32 = self._perms(L, xz.device)
+        if (xd is None and xz.is_cuda and L <= 5120 and Bz <= 65535 and os.environ.get("MXVL_MIXER_NODE") != "0"
+                and xz.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+            # v3 on the GPU: gather -> conv -> x_proj -> dt_proj -> scan -> gated merge as ONE node, batch-of-K GEMMs
+            mods = [self._dir(s) for s in ["", "_b", "_c", "_c_b"]]
+            gated = _MultiDirMixerFn.apply(
+                xz, fwd32, inv32, (L + 7) // 8 * 8, 0.25, torch.cat([m[0].weight for m in mods], dim=0),
+                torch.cat([m[0].bias for m in mods], dim=0) if mods[0][0].bias is not None else None,
+                torch.stack([m[1].weight for m in mods]), torch.stack([m[2].weight for m in mods]),
+                -torch.exp(torch.cat([m[3].float() for m in mods], dim=0)), torch.cat([m[4].float() for m in mods], dim=0),
+                torch.cat([m[2].bias.float() for m in mods], dim=0))
+            return F.linear(gated.transpose(1, 2), self.out_proj.weight.to(gated.dtype),
+                            None if self.out_proj.bias is None else self.out_proj.bias.to(gated.dtype))
         x, z = _SplitHalves.apply(xz)       # the gradient of xz is written once, channel-major (proj_in's layout)
         sfxs = ["", "_b", "_c", "_c_b"]
         x_d = None

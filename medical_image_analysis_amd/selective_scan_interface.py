@@ -544,6 +544,87 @@ class _MambaInnerFn(torch.autograd.Function):
                 dD.to(D_dt) if dD is not None else None, dbias.to(bias_dt) if dbias is not None else None, dBb, dCb, None)
 
 
+def mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad):
+    """The K-direction mixer core (bimamba v3: conv1d+SiLU -> x_proj -> dt_proj -> selective scan of all K directions,
+    arm/Finetuning/mamba_simple.py:447-532) over direction-channel-major activations: X is logically (B, K, D, Lp) but STORED
+    (K, D, B, Lp), so every projection is a batch-of-K GEMM over the (D, B*Lp) matrix of its direction -- (K, R+2N, D) @
+    (K, D, B*Lp) -- instead of B*K tiny ones ((B, K, R+2N, D) @ (B, K, D, Lp): 256 GEMMs of 96 x 1024 x 200 ran at 3.7 TFLOP/s),
+    and B / C are strided rows of x_dbl (no copies).  The conv and the scan read the layout through their strides.
+    Returns y (B, K, D, Lp) in the same layout and the tensors mdir_core_backward needs."""
+    from .causal_conv1d import conv1d_fwd_raw, _w2
+    _abi.require_gpu(X, conv_w, Wx, Wdt, A)
+    B, K, D, Lp = X.shape
+    T = B * Lp
+    if X.stride() != (Lp, D * T, T, 1):
+        X = X.permute(1, 2, 0, 3).contiguous().permute(2, 0, 1, 3)
+    N, R = A.shape[1], Wdt.shape[2]
+    Xf = X.reshape(B, K * D, Lp)                                   # view: strides (Lp, B*Lp, 1)
+    w32 = _w2(conv_w).detach().float().contiguous()
+    b32 = conv_b.detach().float().contiguous() if conv_b is not None else None
+    Xc = conv1d_fwd_raw(Xf, w32, b32, 1)                           # same (channel-major) layout
+    io = Xc.dtype
+    wx, wdt = Wx.detach().to(io), Wdt.detach().to(io)
+    x_dbl = torch.bmm(wx, Xc.permute(1, 0, 2).reshape(K, D, T))    # (K, R+2N, T)
+    dt = torch.bmm(wdt, x_dbl[:, :R]).view(K * D, B, Lp).permute(1, 0, 2)          # (B, K*D, Lp)
+    Bm = x_dbl[:, R:R + N].view(K, N, B, Lp).permute(2, 0, 1, 3)                   # (B, K, N, Lp), strided rows of x_dbl
+    Cm = x_dbl[:, R + N:R + 2 * N].view(K, N, B, Lp).permute(2, 0, 1, 3)
+    _, u_, dt_, A_, B_, C_, D_, _, bias_ = _prep(Xc, dt, A.detach(), Bm, Cm, None if Dv is None else Dv.detach(), None,
+                                                 None if dbias is None else dbias.detach())
+    out, _, ckpt = scan_fwd_raw(u_, dt_, A_, B_, C_, D_, None, bias_, True, want_ckpt=needs_grad)
+    meta = (conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, Wx.dtype, Wdt.dtype, A.dtype,
+            None if Dv is None else Dv.dtype, None if dbias is None else dbias.dtype)
+    return out.view(B, K, D, Lp), (Xf, w32, b32, u_, x_dbl, dt_, wx, wdt, A_, B_, C_, D_, bias_, ckpt), meta
+
+
+def mdir_core_backward(saved, meta, dy):
+    """dy (B, K, D, Lp) (any batch / direction / channel strides) -> (dX in X's layout, d conv_w, d conv_b, dWx, dWdt, dA, dD,
+    d delta_bias): hand-ordered like _MambaInnerFn's backward (dB | dC in one fp32 buffer, du accumulated by the dgrad GEMM)."""
+    from .causal_conv1d import conv1d_bwd_raw
+    Xf, w32, b32, Xc, x_dbl, dt, wx, wdt, A, Bm, Cm, D_, bias, ckpt = saved
+    cw_shape, cw_dt, cb_dt, wx_dt, wdt_dt, A_dt, D_dt, bias_dt = meta
+    B, KD, Lp = Xf.shape
+    K, R = wdt.shape[0], wdt.shape[2]
+    D, N, T = KD // K, A.shape[1], B * Lp
+    io = Xc.dtype
+    du = torch.empty((KD, B, Lp), dtype=io, device=Xf.device).permute(1, 0, 2)
+    dBC = torch.zeros((K, 2 * N, B, Lp), dtype=torch.float32, device=Xf.device)   # dB | dC rows per direction, fp32 accumulators
+    dB, dC = dBC[:, :N].permute(2, 0, 1, 3), dBC[:, N:].permute(2, 0, 1, 3)
+    _, ddelta, dA, _, _, dD, _, dbias = scan_bwd_raw(Xc, dt, A, Bm, Cm, D_, None, bias, True, ckpt,
+                                                      dy.reshape(B, KD, Lp).to(io), du=du, dB=dB, dC=dC)
+    dd3 = ddelta.permute(1, 0, 2).reshape(K, D, T)                  # free view (ddelta follows dt's layout)
+    dx_dbl = torch.empty((K, R + 2 * N, T), dtype=io, device=Xf.device)
+    dx_dbl[:, :R].copy_(torch.bmm(wdt.transpose(1, 2), dd3))
+    dx_dbl[:, R:].copy_(dBC.view(K, 2 * N, T))                      # the cast selective_scan.cpp:347 makes
+    dwdt = _bmm_f32(dd3, x_dbl[:, :R].transpose(1, 2))             # (K, D, R)
+    Xc3 = Xc.permute(1, 0, 2).reshape(K, D, T)
+    dwx = _bmm_f32(dx_dbl, Xc3.transpose(1, 2))                    # (K, R+2N, D)
+    du.permute(1, 0, 2).reshape(K, D, T).baddbmm_(wx.transpose(1, 2), dx_dbl)      # du += Wx^T d(x_dbl), in the GEMM
+    dXf, dcw, dcb = conv1d_bwd_raw(Xf, w32, b32, 1, du)
+    return (dXf.view(B, K, D, Lp), dcw.reshape(cw_shape).to(cw_dt), dcb.to(cb_dt) if dcb is not None else None,
+            dwx.to(wx_dt), dwdt.to(wdt_dt), dA.to(A_dt), dD.to(D_dt) if dD is not None else None,
+            dbias.to(bias_dt) if dbias is not None else None)
+
+
+class _MultiDirInnerFn(torch.autograd.Function):
+    """mdir_core_forward / mdir_core_backward as an autograd node of its own (X in, y out); the v3 mixer uses the wider node
+    mamba_simple._MultiDirMixerFn, which adds the scan-order gather and the gated merge around the same core."""
+
+    @staticmethod
+    def forward(ctx, X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias):
+        y, saved, ctx.meta = mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, any(ctx.needs_input_grad))
+        ctx.save_for_backward(*saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return mdir_core_backward(ctx.saved_tensors, ctx.meta, dy)
+
+
+def multi_direction_inner(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias):
+    """X (B, K, D, Lp) stored (K, D, B, Lp) -> y in the same layout; see _MultiDirInnerFn."""
+    return _MultiDirInnerFn.apply(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias)
+
+
 # The single-node mixer (above) is the default on the GPU; MXVL_MIXER_NODE=0 keeps the composition of separate autograd nodes
 # (same kernels), which the tests hold against it.
 def _use_mixer_node(xz):

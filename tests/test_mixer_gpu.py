@@ -288,3 +288,38 @@ def test_single_node_mixer_equals_composed_nodes(dtype, L, proj_bias, monkeypatc
         scale = max(1.0, float(g0[k].abs().max()))
         tol = 2e-5 if dtype == torch.float32 else 2e-2
         assert_close(g1[k], g0[k], tol * scale, tol, "grad " + k)
+
+
+@pytest.mark.parametrize("dtype,S", [(torch.float32, 5), (torch.bfloat16, 14)])
+def test_v3_mixer_single_node_equals_composed_nodes(dtype, S, monkeypatch):
+    """bimamba v3 (4 scan directions): the direction-channel-major single node (_MultiDirInnerFn: batch-of-4 GEMMs over the
+    (D, B*Lp) matrix of each direction, B / C as strided rows of x_dbl, hand-ordered backward) against the composition of
+    separate autograd nodes over the same kernels (MXVL_MIXER_NODE=0): same forward bits, gradients equal up to GEMM
+    summation order (fp32) / bf16 rounding of intermediate gradients."""
+    from medical_image_analysis_amd.mamba_simple import Mamba
+    torch.manual_seed(3)
+    L = S * S + 1
+    m = Mamba(d_model=64, d_state=16, expand=2, bimamba_type="v3").to(DEV)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    x0 = torch.randn(3, L, 64, device=DEV)
+    dout = torch.randn(3, L, 64, device=DEV)
+
+    def run(node):
+        monkeypatch.setenv("MXVL_MIXER_NODE", "1" if node else "0")
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
+            y = m(x)
+        y.backward(dout.to(y.dtype))
+        return y.detach().float(), x.grad.clone(), {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}
+
+    y1, gx1, g1 = run(True)
+    y0, gx0, g0 = run(False)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert_close(y1, y0, tol * max(1.0, float(y0.abs().max())), tol, "out")
+    assert set(g1) == set(g0) and len(g0) >= 20
+    assert_close(gx1, gx0, tol * max(1.0, float(gx0.abs().max())), tol, "dx")
+    for k in g0:
+        assert_close(g1[k], g0[k], tol * max(1.0, float(g0[k].abs().max())), tol, "grad " + k)
