@@ -116,6 +116,45 @@ __global__ __launch_bounds__(256) void conv1d_fwd_vec_kernel(const ConvArgs p) {
 // 3 of dy, 2 vector stores of dx; the overlapping halves of neighbouring threads' loads are L1 hits.  dweight / dbias: wave
 // shuffle + one LDS hop + ONE fp32 atomic per (d, k) per workgroup.  No LDS staging, one barrier.  (The LDS-staged kernel
 // below needs 3 barriers per 1024 steps and stores dx two bytes at a time: 292 us at B16 D1024 L4080 bf16 = 2.75 TB/s.)
+// per-thread body of the vector backward: 8 steps t0 .. t0+7 of one row from registers; adds into dw_acc / db_acc
+template <typename io_t, int WT>
+__device__ __forceinline__ void conv_bwd_vec_body(const io_t* xr, const io_t* gr, io_t* dxr, int t0, int L, const float (&w)[WT],
+                                                  float bias, int silu_on, float (&dw_acc)[WT], float& db_acc) {
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float xv[16], g[12];   // x[t0-4 .. t0+12), dy[t0 .. t0+12)
+  const float4 x0 = t0 > 0 ? ld4<io_t>(xr + t0 - 4) : z4, x1 = ld4<io_t>(xr + t0);
+  const float4 x2 = t0 + 4 < L ? ld4<io_t>(xr + t0 + 4) : z4, x3 = t0 + 8 < L ? ld4<io_t>(xr + t0 + 8) : z4;
+  const float4 g0 = ld4<io_t>(gr + t0), g1 = t0 + 4 < L ? ld4<io_t>(gr + t0 + 4) : z4, g2 = t0 + 8 < L ? ld4<io_t>(gr + t0 + 8) : z4;
+  xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+  xv[8] = x2.x; xv[9] = x2.y; xv[10] = x2.z; xv[11] = x2.w; xv[12] = x3.x; xv[13] = x3.y; xv[14] = x3.z; xv[15] = x3.w;
+  g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  g[8] = g2.x; g[9] = g2.y; g[10] = g2.z; g[11] = g2.w;
+  // d(pre-activation) of steps t0 .. t0 + 7 + (WT - 1); pre[t] = bias + sum_k w[k] x[t - (WT-1) + k], x[t0 + i] = xv[4 + i]
+  if (silu_on) {
+#pragma unroll
+    for (int i = 0; i < 8 + WT - 1; ++i) {
+      float pre = bias;
+#pragma unroll
+      for (int k = 0; k < WT; ++k) pre = fmaf(w[k], xv[4 + i - (WT - 1) + k], pre);
+      const float sgm = sigmoid(pre);
+      g[i] *= sgm * fmaf(pre, 1.0f - sgm, 1.0f);
+    }
+  }
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int m = 0; m < WT; ++m) acc = fmaf(w[WT - 1 - m], g[i + m], acc);   // dx[s] = sum_m w[W-1-m] dpre[s+m]; dpre beyond L is 0
+    o[i] = acc;
+    db_acc += g[i];
+#pragma unroll
+    for (int k = 0; k < WT; ++k) dw_acc[k] = fmaf(g[i], xv[4 + i - (WT - 1) + k], dw_acc[k]);
+  }
+  st4<io_t>(dxr + t0, make_float4(o[0], o[1], o[2], o[3]));
+  if (t0 + 4 < L) st4<io_t>(dxr + t0 + 4, make_float4(o[4], o[5], o[6], o[7]));
+}
+
 template <typename io_t, int WT>
 __global__ __launch_bounds__(128) void conv1d_bwd_vec_kernel(const ConvArgs p) {
   static_assert(WT >= 1 && WT <= 5, "halo of one 4-vector on each side");
@@ -133,41 +172,7 @@ __global__ __launch_bounds__(128) void conv1d_bwd_vec_kernel(const ConvArgs p) {
   float dw_acc[WT], db_acc = 0.0f;
 #pragma unroll
   for (int k = 0; k < WT; ++k) dw_acc[k] = 0.0f;
-  if (t0 < L) {
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float xv[16], g[12];   // x[t0-4 .. t0+12), dy[t0 .. t0+12)
-    const float4 x0 = t0 > 0 ? ld4<io_t>(xr + t0 - 4) : z4, x1 = ld4<io_t>(xr + t0);
-    const float4 x2 = t0 + 4 < L ? ld4<io_t>(xr + t0 + 4) : z4, x3 = t0 + 8 < L ? ld4<io_t>(xr + t0 + 8) : z4;
-    const float4 g0 = ld4<io_t>(gr + t0), g1 = t0 + 4 < L ? ld4<io_t>(gr + t0 + 4) : z4, g2 = t0 + 8 < L ? ld4<io_t>(gr + t0 + 8) : z4;
-    xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
-    xv[8] = x2.x; xv[9] = x2.y; xv[10] = x2.z; xv[11] = x2.w; xv[12] = x3.x; xv[13] = x3.y; xv[14] = x3.z; xv[15] = x3.w;
-    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-    g[8] = g2.x; g[9] = g2.y; g[10] = g2.z; g[11] = g2.w;
-    // d(pre-activation) of steps t0 .. t0 + 7 + (WT - 1); pre[t] = bias + sum_k w[k] x[t - (WT-1) + k], x[t0 + i] = xv[4 + i]
-    if (p.silu) {
-#pragma unroll
-      for (int i = 0; i < 8 + WT - 1; ++i) {
-        float pre = bias;
-#pragma unroll
-        for (int k = 0; k < WT; ++k) pre = fmaf(w[k], xv[4 + i - (WT - 1) + k], pre);
-        const float sgm = sigmoid(pre);
-        g[i] *= sgm * fmaf(pre, 1.0f - sgm, 1.0f);
-      }
-    }
-    float o[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int m = 0; m < WT; ++m) acc = fmaf(w[WT - 1 - m], g[i + m], acc);   // dx[s] = sum_m w[W-1-m] dpre[s+m]; dpre beyond L is 0
-      o[i] = acc;
-      db_acc += g[i];
-#pragma unroll
-      for (int k = 0; k < WT; ++k) dw_acc[k] = fmaf(g[i], xv[4 + i - (WT - 1) + k], dw_acc[k]);
-    }
-    st4<io_t>(dxr + t0, make_float4(o[0], o[1], o[2], o[3]));
-    if (t0 + 4 < L) st4<io_t>(dxr + t0 + 4, make_float4(o[4], o[5], o[6], o[7]));
-  }
+  if (t0 < L) conv_bwd_vec_body<io_t, WT>(xr, gr, dxr, t0, L, w, bias, p.silu, dw_acc, db_acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k <= WT; ++k) {
@@ -180,6 +185,46 @@ __global__ __launch_bounds__(128) void conv1d_bwd_vec_kernel(const ConvArgs p) {
   if (threadIdx.x <= WT) {
     const int k = threadIdx.x;
     const float v = red[0][k] + red[1][k];
+    if (k < WT) unsafeAtomicAdd(p.dw + (int64_t)d * WT + k, v);
+    else if (p.dbias) unsafeAtomicAdd(p.dbias + d, v);
+  }
+}
+
+// The same register-only body for SHORT aligned rows (L <= 512: the 197 -> 200-step rows of the 224x224 encoders): a workgroup
+// owns one channel and as many batch rows as its 256 threads cover at 8 steps per thread (10 rows at L = 200), one reduction +
+// atomic set per workgroup.  The LDS-staged short-row kernel below moves two bytes per load: 213 us at B64 D4096 L200 bf16
+// (1.5 TB/s).
+template <typename io_t, int WT>
+__global__ __launch_bounds__(256) void conv1d_bwd_vec_rows_kernel(const ConvArgs p, int TPR, int RW) {
+  const int L = p.L, d = blockIdx.y;
+  const int s_ = threadIdx.x / TPR, c = threadIdx.x - s_ * TPR;
+  const int b = blockIdx.x * RW + s_, t0 = c * 8;
+  __shared__ float red[4][WT + 1];
+  float w[WT];
+#pragma unroll
+  for (int k = 0; k < WT; ++k) w[k] = p.w[(int64_t)d * WT + k];
+  const float bias = p.bias ? p.bias[d] : 0.0f;
+  float dw_acc[WT], db_acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < WT; ++k) dw_acc[k] = 0.0f;
+  if (s_ < RW && b < p.batch && t0 < L) {
+    const io_t* xr = (const io_t*)p.x + (int64_t)b * p.x_bs + (int64_t)d * p.x_ds;
+    const io_t* gr = (const io_t*)p.dy + (int64_t)b * p.dy_bs + (int64_t)d * p.dy_ds;
+    io_t* dxr = (io_t*)p.dx + (int64_t)b * p.dx_bs + (int64_t)d * p.dx_ds;
+    conv_bwd_vec_body<io_t, WT>(xr, gr, dxr, t0, L, w, bias, p.silu, dw_acc, db_acc);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k <= WT; ++k) {
+    float v = (k < WT) ? dw_acc[k] : db_acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x <= WT) {
+    const int k = threadIdx.x;
+    const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     if (k < WT) unsafeAtomicAdd(p.dw + (int64_t)d * WT + k, v);
     else if (p.dbias) unsafeAtomicAdd(p.dbias + d, v);
   }
@@ -481,9 +526,14 @@ int mxvl_conv1d_bwd(const mxvl_conv1d_bwd_desc* d, void* hip_stream) {
   const dim3 sgrid(S ? (a.batch + S - 1) / S : 1, a.dim);
   // register-only vector kernel: aligned x / dy / dx rows of a multiple of 4 steps, d_conv 4, long rows
   const bool bvec = a.vec && a.W == 4 && a.L % 4 == 0 && a.L > 512 && rows_aligned(d->dx, d->dx_bs, d->dx_ds, d->fwd.io_dtype);
+  // short aligned rows: the register-only body, several batch rows per workgroup
+  const bool svec = a.vec && a.W == 4 && a.L % 4 == 0 && a.L <= 512 && a.dim <= 65535 && rows_aligned(d->dx, d->dx_bs, d->dx_ds, d->fwd.io_dtype);
+  const int TPR = (a.L + 7) / 8, RW = svec ? 256 / TPR : 0;          // L <= 512 -> TPR <= 64, RW >= 4
+  const dim3 vgrid(RW > 0 ? (a.batch + RW - 1) / RW : 1, a.dim);
 #define MXVL_CONV_BWD(T) \
   do { \
-    if (S >= 2) hipLaunchKernelGGL((conv1d_bwd_short_kernel<T, 4>), sgrid, dim3(256), 0, s, a, S); \
+    if (svec && RW >= 2) hipLaunchKernelGGL((conv1d_bwd_vec_rows_kernel<T, 4>), vgrid, dim3(256), 0, s, a, TPR, RW); \
+    else if (S >= 2) hipLaunchKernelGGL((conv1d_bwd_short_kernel<T, 4>), sgrid, dim3(256), 0, s, a, S); \
     else if (bvec) hipLaunchKernelGGL((conv1d_bwd_vec_kernel<T, 4>), grid, dim3(128), 0, s, a); \
     else if (a.W == 4) hipLaunchKernelGGL((conv1d_bwd_kernel<T, 4>), grid, dim3(256), 0, s, a); \
     else hipLaunchKernelGGL((conv1d_bwd_kernel<T, 0>), grid, dim3(256), 0, s, a); \

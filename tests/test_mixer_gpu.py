@@ -30,7 +30,10 @@ def test_conv1d_fwd_bwd_golden(name):
                                    (2, 64, 1024, 4, torch.bfloat16), (1, 8, 2, 4, torch.float32),
                                    # aligned rows -> the 8-steps-per-thread vector forward and vector tile loads
                                    (2, 48, 4080, 4, torch.float32), (2, 48, 4080, 4, torch.bfloat16), (1, 16, 2052, 4, torch.float16),
-                                   (2, 16, 12, 4, torch.float32), (1, 8, 1028, 4, torch.bfloat16)])
+                                   (2, 16, 12, 4, torch.float32), (1, 8, 1028, 4, torch.bfloat16),
+                                   # short aligned rows -> the register-only backward with several batch rows per workgroup
+                                   (23, 48, 200, 4, torch.bfloat16), (3, 40, 200, 4, torch.float32), (9, 8, 512, 4, torch.float16),
+                                   (5, 24, 8, 4, torch.float32), (11, 16, 204, 4, torch.bfloat16)])
 def test_conv1d_vs_oracle(shape):
     from oracle import oracle as orc
     from medical_image_analysis_amd.causal_conv1d import causal_conv1d_fn
