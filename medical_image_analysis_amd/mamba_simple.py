@@ -78,13 +78,10 @@ class _DirGather(torch.autograd.Function):
     zero-padded to Lp (csrc/dir_perm.hip).  Backward = the merge with the inverse permutations."""
 
     @staticmethod
-    def forward(ctx, x, xd, perm, inv, perm_d, inv_d, Lp, channel_major=False):
+    def forward(ctx, x, xd, perm, inv, perm_d, inv_d, Lp):
         B, D, L = x.shape
         K = perm.shape[0] + (perm_d.shape[0] if xd is not None else 0)
-        if channel_major:    # stored (K, D, B, Lp): each direction is a (D, B*Lp) matrix (selective_scan_interface._MultiDirInnerFn)
-            X = torch.empty((K, D, B, Lp), dtype=x.dtype, device=x.device).permute(2, 0, 1, 3)
-        else:
-            X = torch.empty((B, K, D, Lp), dtype=x.dtype, device=x.device)
+        X = torch.empty((B, K, D, Lp), dtype=x.dtype, device=x.device)
         _dir_perm(False, _rows_view(x), X[:, :perm.shape[0]], perm, L, Lp)
         if xd is not None:
             _dir_perm(False, _rows_view(xd.to(x.dtype)), X[:, perm.shape[0]:], perm_d, L, Lp)
@@ -106,7 +103,7 @@ class _DirGather(torch.autograd.Function):
             dxd = torch.empty((B, D, L), dtype=dX.dtype, device=dX.device)
             _dir_perm(True, dxd, dX[:, K0:], inv_d, L, Lp)
             dxd = dxd.to(d_dtype)
-        return dx, dxd, None, None, None, None, None, None
+        return dx, dxd, None, None, None, None, None
 
 
 class _DirMerge(torch.autograd.Function):

@@ -605,26 +605,6 @@ def mdir_core_backward(saved, meta, dy):
             dbias.to(bias_dt) if dbias is not None else None)
 
 
-class _MultiDirInnerFn(torch.autograd.Function):
-    """mdir_core_forward / mdir_core_backward as an autograd node of its own (X in, y out); the v3 mixer uses the wider node
-    mamba_simple._MultiDirMixerFn, which adds the scan-order gather and the gated merge around the same core."""
-
-    @staticmethod
-    def forward(ctx, X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias):
-        y, saved, ctx.meta = mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, any(ctx.needs_input_grad))
-        ctx.save_for_backward(*saved)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        return mdir_core_backward(ctx.saved_tensors, ctx.meta, dy)
-
-
-def multi_direction_inner(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias):
-    """X (B, K, D, Lp) stored (K, D, B, Lp) -> y in the same layout; see _MultiDirInnerFn."""
-    return _MultiDirInnerFn.apply(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias)
-
-
 # The single-node mixer (above) is the default on the GPU; MXVL_MIXER_NODE=0 keeps the composition of separate autograd nodes
 # (same kernels), which the tests hold against it.
 def _use_mixer_node(xz):

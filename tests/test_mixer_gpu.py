@@ -295,7 +295,7 @@ def test_single_node_mixer_equals_composed_nodes(dtype, L, proj_bias, monkeypatc
 
 @pytest.mark.parametrize("dtype,S", [(torch.float32, 5), (torch.bfloat16, 14)])
 def test_v3_mixer_single_node_equals_composed_nodes(dtype, S, monkeypatch):
-    """bimamba v3 (4 scan directions): the direction-channel-major single node (_MultiDirInnerFn: batch-of-4 GEMMs over the
+    """bimamba v3 (4 scan directions): the direction-channel-major single node (_MultiDirMixerFn: batch-of-4 GEMMs over the
     (D, B*Lp) matrix of each direction, B / C as strided rows of x_dbl, hand-ordered backward) against the composition of
     separate autograd nodes over the same kernels (MXVL_MIXER_NODE=0): same forward bits, gradients equal up to GEMM
     summation order (fp32) / bf16 rounding of intermediate gradients."""
