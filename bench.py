@@ -365,7 +365,8 @@ def run_pretrain(args, rank, world, dev, dist):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kind,
                      "kernel_ms": tot_ms / calls, "launches_timed": calls,
                      "algorithmic_bytes_per_launch": tot_bytes // calls,
-                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}},
+                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()},
+                     "limited_by": "VALU issue rate of the fp32 recurrence, not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
     }
     attach_traffic(out["roofline"], "scan_bwd_pretrain" if (kind == "scan_bwd" and args.workload == DEFAULT_WORKLOAD and B == 16)
                    else args.workload)
@@ -646,7 +647,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": ("scan_bwd_kernel + scan_bwd_reduce_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
                                     if backward else "scan_fwd_stream_kernel"),
-                         "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms},
+                         "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms,
+                         "limited_by": "VALU issue rate of the fp32 recurrence, not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
         }
         attach_traffic(out["roofline"], args.workload)
         if world == 1 and not args.no_cpu_baseline and not backward:
