@@ -109,71 +109,103 @@ __global__ __launch_bounds__(256) void dir_merge_kernel(const PermArgs p) {
 // and its K indices -- is issued before the first use, so one round trip covers them all.
 constexpr int kMaxDirs = 6;
 
+// A workgroup takes RPB consecutive channels of one batch element: the K indices of a step are loaded once per thread and
+// reused for all of them (at one row per workgroup the index loads were twice the bytes of the row itself), and the RPB
+// row loads of a thread are in flight together.
+constexpr int kRowsPerBlock = 8;
+
 template <typename io_t>
 __global__ __launch_bounds__(256) void dir_gather_short_kernel(const PermArgs p) {
-  __shared__ float srow[256];
+  constexpr int RPB = kRowsPerBlock;
+  __shared__ float srow[RPB][256];
   using io = Io<io_t>;
-  const int d = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int d0 = blockIdx.x * RPB, b = blockIdx.y, t = threadIdx.x;
   const bool live = t < p.L;
-  const io_t* x = (const io_t*)p.src + (long long)b * p.x_bs + (long long)d * p.x_ds;
   // unconditional loads from clamped (always valid) addresses: no control flow between them, so all are in flight together
   const int tc = live ? t : 0;
   int ixv[kMaxDirs];
 #pragma unroll
   for (int k = 0; k < kMaxDirs; ++k) ixv[k] = p.idx[(k < p.K ? k : 0) * p.L + tc];
-  float v = io::ld(x + tc);
-  if (p.gate) {   // backward of the gated merge: x is d(out)
-    const float zv = io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc);
-    const float pre = io::ld((const io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds + tc);
-    const float g = v * p.scale, sg = sigmoid(zv);
-    v = g * (zv * sg);
-    if (live) io::st((io_t*)p.dgate + (long long)b * p.dg_bs + (long long)d * p.dg_ds + t, g * pre * (sg * fmaf(zv, 1.0f - sg, 1.0f)));
+  float v[RPB], zv[RPB], pre[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    const int d = min(d0 + r, p.D - 1);
+    v[r] = io::ld((const io_t*)p.src + (long long)b * p.x_bs + (long long)d * p.x_ds + tc);
+    if (p.gate) {
+      zv[r] = io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc);
+      pre[r] = io::ld((const io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds + tc);
+    }
   }
-  srow[t] = v;
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    float x = v[r];
+    if (p.gate) {   // backward of the gated merge: x is d(out)
+      const float g = x * p.scale, sg = sigmoid(zv[r]);
+      x = g * (zv[r] * sg);
+      if (live && d0 + r < p.D)
+        io::st((io_t*)p.dgate + (long long)b * p.dg_bs + (long long)(d0 + r) * p.dg_ds + t, g * pre[r] * (sg * fmaf(zv[r], 1.0f - sg, 1.0f)));
+    }
+    srow[r][t] = x;
+  }
   __syncthreads();
   if (t >= p.Lp) return;
 #pragma unroll
-  for (int k = 0; k < kMaxDirs; ++k) {
-    if (k < p.K) {
-      io_t* X = (io_t*)p.dst + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)d * p.X_ds;
-      io::st(X + t, live ? srow[ixv[k]] : 0.0f);
+  for (int r = 0; r < RPB; ++r) {
+    if (d0 + r >= p.D) break;
+#pragma unroll
+    for (int k = 0; k < kMaxDirs; ++k) {
+      if (k < p.K) {
+        io_t* X = (io_t*)p.dst + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)(d0 + r) * p.X_ds;
+        io::st(X + t, live ? srow[r][ixv[k]] : 0.0f);
+      }
     }
   }
 }
 
+// merge: RPB / 2 channels per workgroup (K x rows x 256 floats of LDS)
 template <typename io_t>
 __global__ __launch_bounds__(256) void dir_merge_short_kernel(const PermArgs p) {
-  __shared__ float srow[kMaxDirs * 256];
+  constexpr int RPB = kRowsPerBlock / 2;
+  __shared__ float srow[RPB][kMaxDirs][256];
   using io = Io<io_t>;
-  const int d = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int d0 = blockIdx.x * RPB, b = blockIdx.y, t = threadIdx.x;
   const bool live = t < p.L;
   // unconditional loads from clamped (always valid) addresses: no control flow between them, so all are in flight together
   const int tc = live ? t : 0;
-  float yv[kMaxDirs];
   int ixv[kMaxDirs];
 #pragma unroll
-  for (int k = 0; k < kMaxDirs; ++k) {
-    const int kc = k < p.K ? k : 0;
-    const io_t* y = (const io_t*)p.src + (long long)b * p.X_bs + (long long)kc * p.X_ks + (long long)d * p.X_ds;
-    yv[k] = io::ld(y + tc);
-    ixv[k] = p.idx[kc * p.L + tc];
-  }
-  float zv = 0.0f;
-  if (p.gate) zv = io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc);
+  for (int k = 0; k < kMaxDirs; ++k) ixv[k] = p.idx[(k < p.K ? k : 0) * p.L + tc];
+  float yv[RPB][kMaxDirs], zv[RPB];
 #pragma unroll
-  for (int k = 0; k < kMaxDirs; ++k) srow[k * 256 + t] = yv[k];
+  for (int r = 0; r < RPB; ++r) {
+    const int d = min(d0 + r, p.D - 1);
+#pragma unroll
+    for (int k = 0; k < kMaxDirs; ++k) {
+      const int kc = k < p.K ? k : 0;
+      yv[r][k] = io::ld((const io_t*)p.src + (long long)b * p.X_bs + (long long)kc * p.X_ks + (long long)d * p.X_ds + tc);
+    }
+    zv[r] = p.gate ? io::ld((const io_t*)p.gate + (long long)b * p.g_bs + (long long)d * p.g_ds + tc) : 0.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < RPB; ++r)
+#pragma unroll
+    for (int k = 0; k < kMaxDirs; ++k) srow[r][k][t] = yv[r][k];
   __syncthreads();
   if (!live) return;
-  float acc = 0.0f;
 #pragma unroll
-  for (int k = 0; k < kMaxDirs; ++k)
-    if (k < p.K) acc += srow[k * 256 + ixv[k]];          // k ascending, like the generic kernel
-  io_t* out = (io_t*)p.dst + (long long)b * p.x_bs + (long long)d * p.x_ds;
-  if (p.gate) {
-    if (p.pre) io::st((io_t*)p.pre + (long long)b * p.p_bs + (long long)d * p.p_ds + t, acc);
-    io::st(out + t, acc * silu(zv) * p.scale);
-  } else {
-    io::st(out + t, acc);
+  for (int r = 0; r < RPB; ++r) {
+    if (d0 + r >= p.D) break;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxDirs; ++k)
+      if (k < p.K) acc += srow[r][k][ixv[k]];          // k ascending, like the generic kernel
+    io_t* out = (io_t*)p.dst + (long long)b * p.x_bs + (long long)(d0 + r) * p.x_ds;
+    if (p.gate) {
+      if (p.pre) io::st((io_t*)p.pre + (long long)b * p.p_bs + (long long)(d0 + r) * p.p_ds + t, acc);
+      io::st(out + t, acc * silu(zv[r]) * p.scale);
+    } else {
+      io::st(out + t, acc);
+    }
   }
 }
 
@@ -194,10 +226,11 @@ static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   const size_t lds = sizeof(float) * (size_t)a.L;
   hipStream_t s = (hipStream_t)stream;
   const bool short_rows = a.Lp <= 256 && a.K <= kMaxDirs;
+  const dim3 ggrid((a.D + kRowsPerBlock - 1) / kRowsPerBlock, a.B), mgrid((a.D + kRowsPerBlock / 2 - 1) / (kRowsPerBlock / 2), a.B);
 #define MXVL_PERM(T)                                                                                   \
   do {                                                                                                  \
-    if (short_rows && merge) hipLaunchKernelGGL(dir_merge_short_kernel<T>, grid, dim3(256), 0, s, a);   \
-    else if (short_rows) hipLaunchKernelGGL(dir_gather_short_kernel<T>, grid, dim3(256), 0, s, a);      \
+    if (short_rows && merge) hipLaunchKernelGGL(dir_merge_short_kernel<T>, mgrid, dim3(256), 0, s, a);   \
+    else if (short_rows) hipLaunchKernelGGL(dir_gather_short_kernel<T>, ggrid, dim3(256), 0, s, a);      \
     else if (merge) hipLaunchKernelGGL(dir_merge_kernel<T>, grid, dim3(256), lds, s, a);                \
     else hipLaunchKernelGGL(dir_gather_kernel<T>, grid, dim3(256), lds, s, a);                          \
   } while (0)
