@@ -741,6 +741,96 @@ def gen_decode_hd64():
          attention_mask=att.numpy().copy(), logits_prompt=np_(logits_prompt), greedy=gr.sequences.numpy().copy(),
          greedy_step_logits=np_(step_logits), beam3=b3.numpy().copy(), **out)
 
+DECODE_KEYED = {
+    # the instantiations bench.py's decode workload times (cfg#4, Llama-2-7B: head_dim 128, GQA off there, K = 4096 / 11008):
+    # head_dim 128 with grouped KV heads, intermediate not a power of two, a vocabulary wide enough for the beam kernel's
+    # multi-block path -- and the head_dim 256 instantiation the stepper also accepts.  Weights are NOT stored:
+    # keyed_fill_llama_(module, weight_seed) regenerates them (bf16-exact) on both sides.
+    "decode_llama_hd128": dict(vocab_size=2048, hidden_size=512, intermediate_size=1408, num_hidden_layers=2,
+                               num_attention_heads=4, num_key_value_heads=2),
+    "decode_llama_hd256": dict(vocab_size=1024, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                               num_attention_heads=2, num_key_value_heads=1),
+}
+
+
+def gen_decode_keyed(name):
+    """HF LlamaForCausalLM at the head dims the HIP decode kernels instantiate besides 64 (decode_attn_kernel<128>, <256>;
+    csrc/decode.hip), weights by keyed_fill_llama_ (bf16-exact, not stored).  Same content and same robustness search as
+    gen_decode_hd64: per-step raw greedy logits for the teacher-forced kernel check, greedy + beam-3 streams that are
+    identical under HF-bf16, this package's bf16 CPU path and injected logit noise (noise and margin scale with the logits)."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import LlamaConfig, LlamaForCausalLM, LogitsProcessor, LogitsProcessorList
+    from keyed_fill import keyed_fill_llama_
+    shape = DECODE_KEYED[name]
+    hid = shape["hidden_size"]
+
+    class Noise(LogitsProcessor):
+        def __init__(self, seed, amp):
+            self.g, self.amp = torch.Generator().manual_seed(seed), amp
+
+        def __call__(self, input_ids, scores):
+            return scores + self.amp * torch.randn(scores.shape, generator=self.g)
+
+    cfg = LlamaConfig(max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                      attention_bias=False, tie_word_embeddings=False, **shape)
+    kw_g = dict(num_beams=1, min_new_tokens=4, max_new_tokens=12)
+    kw_b = dict(num_beams=3, min_new_tokens=6, max_new_tokens=12)
+    weight_seed = 1
+    m = keyed_fill_llama_(LlamaForCausalLM(cfg).eval(), weight_seed)
+    mb = LlamaForCausalLM(cfg).eval()
+    mb.load_state_dict(m.state_dict())
+    mb = mb.to(torch.bfloat16)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    rd = ReportDecoder(rms_norm_eps=1e-6, max_position_embeddings=128, **shape)
+    keyed_fill_llama_(rd, weight_seed)
+    for (k1, v1), (k2, v2) in zip(sorted(m.state_dict().items()), sorted((k, v) for k, v in rd.state_dict().items() if not k.endswith("_proj.bias"))):
+        assert k1 == k2 and torch.equal(v1, v2), (k1, k2)         # the test side regenerates exactly HF's weights
+    rd = rd.to(torch.bfloat16).eval()
+    eq = lambda x, y: x.shape == y.shape and torch.equal(x, y)
+    for seed in range(20000):
+        g = torch.Generator().manual_seed(100 + seed)
+        emb = (0.5 * torch.randn(2, 9, hid, generator=g)).to(torch.bfloat16).float()
+        att = torch.ones(2, 9, dtype=torch.long)
+        att[1, :3] = 0
+        common = dict(inputs_embeds=emb, attention_mask=att, do_sample=False, repetition_penalty=2.0, length_penalty=2.0,
+                      pad_token_id=0, eos_token_id=2)
+        with torch.no_grad():
+            gr = m.generate(output_logits=True, return_dict_in_generate=True, **kw_g, **common)
+            step_logits = torch.stack(gr.logits, dim=1)
+            scale = float(step_logits.abs().max())
+            top2 = step_logits.topk(2, dim=-1).values
+            margin = float((top2[..., 0] - top2[..., 1]).min())
+            if margin <= 0.012 * scale:                # bf16 moves a logit by ~0.4 % of the scale; the checks below decide
+                continue
+            b3 = m.generate(**kw_b, **common)
+            cb = dict(common, inputs_embeds=emb.to(torch.bfloat16))
+            same = eq(gr.sequences, mb.generate(**kw_g, **cb)) and eq(b3, mb.generate(**kw_b, **cb))
+            if same:
+                kw = dict(attention_mask=att, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+                same = eq(rd.generate(emb.to(torch.bfloat16), **kw_g, **kw), gr.sequences) and \
+                    eq(rd.generate(emb.to(torch.bfloat16), **kw_b, **kw), b3)
+            for t in range(4):
+                if not same:
+                    break
+                lp = lambda: LogitsProcessorList([Noise(1000 * seed + t, 0.0024 * scale)])
+                same = eq(m.generate(logits_processor=lp(), **kw_g, **common), gr.sequences) and \
+                    eq(m.generate(logits_processor=lp(), **kw_b, **common), b3)
+        print(f"{name} prompt seed {seed}: robust={same} min greedy top-2 margin {margin:.3f} (scale {scale:.1f})")
+        if same:
+            break
+    else:
+        raise RuntimeError("no robust seed found")
+    with torch.no_grad():
+        logits_prompt = m(inputs_embeds=emb, attention_mask=att).logits
+    print({"greedy": gr.sequences.tolist(), "beam3": b3.tolist()})
+    save(name, seed=np.array(seed), weight_seed=np.array(weight_seed), margin=np.array(margin), inputs_embeds=np_(emb),
+         attention_mask=att.numpy().copy(), logits_prompt=np_(logits_prompt[:, -1]), greedy=gr.sequences.numpy().copy(),
+         greedy_step_logits=np_(step_logits), beam3=b3.numpy().copy(),
+         weight_checksum=np_(sum(v.double().abs().sum() for v in m.state_dict().values()).float()),
+         **{"cfg_" + k: np.array(v) for k, v in shape.items()})
+
 
 def gen_vmamba(scan_ref):
     """VMamba / SS2D (R2GenCSR/VMamba/classification/models/vmamba.py) on CPU.  The vendored CUDA extension
@@ -884,6 +974,9 @@ def main():
         gen_decode()
     if want("decode_hd64"):
         gen_decode_hd64()
+    for nm in DECODE_KEYED:
+        if want(nm):
+            gen_decode_keyed(nm)
     if want("image_preprocess"):
         gen_image_preprocess()
     if want("report_metrics"):

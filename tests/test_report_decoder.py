@@ -256,6 +256,138 @@ def test_hip_decode_generate_tokens_match_hf():
         assert torch.equal(out.cpu(), g[name]), f"{name}: {out.cpu().tolist()} vs HF {g[name].tolist()}"
 
 
+# ---- the instantiations bench.py's decode workload runs (cfg#4: head_dim 128; gemv K = 4096 / 11008) and head_dim 256 -----
+# goldens decode_llama_hd128 / hd256: HF LlamaForCausalLM, weights regenerated by keyed_fill_llama_ (bf16-exact, not stored)
+KEYED = ["decode_llama_hd128", "decode_llama_hd256"]
+
+
+def _model_keyed(g, dev, dtype):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from keyed_fill import keyed_fill_llama_
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    shape = {k[4:]: int(v) for k, v in g.items() if k.startswith("cfg_")}
+    m = ReportDecoder(rms_norm_eps=1e-6, max_position_embeddings=128, **shape)
+    keyed_fill_llama_(m, int(g["weight_seed"]))
+    chk = sum(v.double().abs().sum() for k, v in m.state_dict().items() if not k.endswith("_proj.bias")).float()
+    assert abs(float(chk) - float(g["weight_checksum"])) <= 1e-6 * float(chk), "keyed weights differ from the generator's"
+    return m.to(dev).to(dtype).eval()
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+@pytest.mark.parametrize("name", KEYED)
+def test_keyed_fp32_path_matches_hf(dev, name):
+    """fp32 torch path at head_dim 128 / 256 (GQA): last-prompt-position logits, greedy and beam-3 streams equal HF's."""
+    g = load_golden(name)
+    m = _model_keyed(g, dev, torch.float32)
+    emb, att = g["inputs_embeds"].to(dev), g["attention_mask"].to(dev)
+    with torch.no_grad():
+        logits = m(emb, attention_mask=att)[:, -1]
+    scale = float(g["logits_prompt"].abs().max())
+    assert_close(logits, g["logits_prompt"], 3e-5 * scale, 1e-4, "prompt logits")
+    for key, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
+        out = m.generate(emb, attention_mask=att, use_graph=False, **kw, **HD64_GEN)
+        assert torch.equal(out.cpu(), g[key]), f"{key}: {out.cpu().tolist()} vs HF {g[key].tolist()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", KEYED)
+def test_hip_decode_kernels_match_hf_logits_teacher_forced_hd128_hd256(name):
+    """decode_attn_kernel<128> / <256> (the Llama-2-7B instantiation bench.py times, and the widest one) + gemv at
+    K = 512 / 1408 against HF's per-step logits, teacher-forced with HF's greedy tokens -- same check as the head_dim-64 one."""
+    from medical_image_analysis_amd.report_decoder import KVCache, _KernelStepper
+    dev = "cuda:0"
+    g = load_golden(name)
+    m = _model_keyed(g, dev, torch.bfloat16)
+    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    want, toks = g["greedy_step_logits"], g["greedy"].to(dev)
+    B, steps, V = want.shape
+    D = m.config.hidden_size // m.config.num_attention_heads
+    assert D == (128 if name.endswith("128") else 256)
+    assert _KernelStepper.supported(m, B, torch.bfloat16, dev), f"head_dim {D} / bf16 must take the HIP kernels"
+    scale = float(want.abs().max())
+    tol = 0.02 * scale
+    with torch.no_grad():
+        cache = KVCache()
+        pre = m(emb, attention_mask=att, past_key_values=cache)[:, -1].float()
+        assert_close(pre, want[:, 0], tol, 0.02, "prefill logits (torch bf16 path)")
+        ks = _KernelStepper(m, B, att, cache, steps, torch.bfloat16)
+        ident = torch.arange(B, device=dev)
+        worst = 0.0
+        for k in range(steps - 1):
+            got = ks.step(toks[:, k], ident, k).float().cpu()
+            ref = want[:, k + 1]
+            worst = max(worst, float((got - ref).abs().max()))
+            assert_close(got, ref, tol, 0.02, f"HIP logits after token {k} vs HF (head_dim {D})")
+            top2 = ref.topk(2, dim=-1)
+            clear = (top2.values[:, 0] - top2.values[:, 1]) > 2 * tol
+            assert torch.equal(got.argmax(-1)[clear], top2.indices[:, 0][clear]), f"arg-max after token {k}"
+    assert 0.0 < worst < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", KEYED)
+def test_hip_decode_generate_tokens_match_hf_hd128_hd256(name):
+    """generate() through _KernelStepper (asserted) at head_dim 128 / 256: HF-token-exact greedy and beam-3 streams."""
+    dev = "cuda:0"
+    g = load_golden(name)
+    m = _model_keyed(g, dev, torch.bfloat16)
+    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    for key, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
+        out = m.generate(emb, attention_mask=att, use_graph=True, **kw, **HD64_GEN)
+        st = [v for k, v in m._steppers.items() if k[0] == emb.shape[0] * kw["num_beams"]][-1]
+        assert type(st).__name__ == "_KernelStepper", "generate() must have taken the HIP kernels"
+        assert torch.equal(out.cpu(), g[key]), f"{key}: {out.cpu().tolist()} vs HF {g[key].tolist()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,N,mode", [(4096, 4096, "plain"), (4096, 12288, "norm_bias"), (4096, 11008, "norm_swiglu"),
+                                      (11008, 4096, "residual"), (4096, 32000, "norm_f32"), (11008, 32000, "plain"),
+                                      (1408, 512, "residual"), (512, 2048, "norm_f32")])
+@pytest.mark.parametrize("rows", [3, 1, 8])
+def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
+    """mxvl_decode_gemv called directly at the Llama-2-7B matrix shapes bench.py's decode line times (K 4096 / 11008,
+    N 4096 / 11008 / 12288 / 32000, rows = beams 3) with every prologue / epilogue the stepper uses: RMSNorm prologue,
+    bias, residual, SwiGLU pair, fp32 logits.  Reference: fp32 torch on the SAME bf16 inputs, with torch's bf16 rounding
+    points (normalised activations are rounded to bf16 before the product, as the module path does)."""
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    lib = _abi.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(K * 7 + N + rows)
+    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(torch.bfloat16).to(dev)
+    x, W = bf(rows, K), bf(N, K, sc=K ** -0.5)
+    norm = (1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev) if "norm" in mode else None
+    W2 = bf(N, K, sc=K ** -0.5) if "swiglu" in mode else None
+    bias = bf(N, sc=0.5) if "bias" in mode else None
+    res = bf(rows, N) if "residual" in mode else None
+    f32 = "f32" in mode
+    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    d = _abi.GemvDesc()
+    d.rows, d.K, d.N = rows, K, N
+    d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(f32), 1e-6
+    d.x, d.norm_weight, d.W = x.data_ptr(), _abi.ptr(norm), W.data_ptr()
+    d.W2, d.bias, d.residual, d.y = _abi.ptr(W2), _abi.ptr(bias), _abi.ptr(res), y.data_ptr()
+    _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv")
+    torch.cuda.synchronize()
+    xf = x.float()
+    if norm is not None:      # Qwen2RMSNorm / LlamaRMSNorm: fp32 statistics, cast to bf16, times the bf16 gain (hybrid_decoder_layer.py:185-199)
+        xf = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+        xf = (norm * xf).float()
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    ref = xf @ W.float().t()
+    if W2 is not None:        # the modules round gate and up to bf16, then silu, then the product (Qwen2MLP, :326-337)
+        ref = r16(torch.nn.functional.silu(r16(ref))) * r16(xf @ W2.float().t())
+    if bias is not None:
+        ref = ref + bias.float()
+    if res is not None:       # the linear output is a bf16 tensor before the residual add
+        ref = r16(ref) + res.float()
+    scale = float(ref.abs().max())
+    # fp32 logits: accumulation-order noise of a K-term dot product; bf16 outputs: one ulp where a rounding boundary flips
+    tol = (3e-5 if f32 else 1e-3) * scale
+    assert_close(y.float(), ref, tol, 1e-5 if f32 else 2.0 ** -7, f"gemv K={K} N={N} rows={rows} {mode}")
+
+
 @pytest.mark.gpu
 def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning():
     """A captured decode graph holds weight addresses and the unconditioned layer structure: after the parameters move
