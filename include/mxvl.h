@@ -119,11 +119,10 @@ typedef struct mxvl_scan_bwd_desc {
   void *du, *ddelta, *dz;   /* dz required iff fwd.z */
   void *dA, *dB, *dC;       /* fp32 accumulate */
   void *dD, *ddelta_bias;   /* fp32 accumulate; optional like their forward twins */
-  /* Optional scratch of >= mxvl_scan_bwd_workspace_bytes(&fwd) bytes (16-byte aligned, contents irrelevant).  dB / dC are
-   * sums over all channels of a group: with the scratch every workgroup stores its channel tile's share with plain
-   * coalesced stores and a second small kernel adds the tiles into dB / dC (deterministic, no atomics); without it (NULL
-   * or too small) the shares go out as fp32 global atomics, which the reference does too (selective_scan_bwd_kernel.cuh:
-   * 215-221) and which cost 16-22 % of the kernel on MI355X. */
+  /* Reserved (ABI v3 layout kept): ignored.  dB / dC are sums over all channels of a group; every workgroup pre-sums its
+   * 16 / 32 rows in registers + LDS and adds ONE fp32 global atomic per (n, t), as the reference's kernel does per row
+   * (selective_scan_bwd_kernel.cuh:215-221).  The per-tile scratch + reduce kernel of round 2 measured slower at every
+   * shape (profiles/r02_bwd_workspace_ab.txt) and was removed: mxvl_scan_bwd_workspace_bytes() returns 0. */
   void *workspace;
   int64_t workspace_bytes;
 } mxvl_scan_bwd_desc;
@@ -229,7 +228,7 @@ int mxvl_scan_n_chunks(int seqlen, int dstate);
 
 int mxvl_scan_fwd(const mxvl_scan_desc *desc, void *hip_stream);
 int mxvl_scan_bwd(const mxvl_scan_bwd_desc *desc, void *hip_stream);
-/* bytes of mxvl_scan_bwd_desc.workspace that make the backward atomics-free for this problem; 0 = no scratch is useful */
+/* always 0 since round 3 (kept so ABI-v3 callers link): no scratch is useful, see mxvl_scan_bwd_desc.workspace */
 int64_t mxvl_scan_bwd_workspace_bytes(const mxvl_scan_desc *fwd);
 
 int mxvl_conv1d_fwd(const mxvl_conv1d_desc *desc, void *hip_stream);

@@ -65,6 +65,35 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     return LIB
 
 
+def build_exp(exp: int, files=("scan_fwd.hip", "scan_bwd.hip"), verbose: bool = False) -> str:
+    """A/B measurement build: build/libmxvl_exp<exp>.so = the product objects, with `files` recompiled under -DMXVL_EXP=<exp>
+    (csrc experiments are `#if MXVL_EXP & bit` blocks that exist only while an experiment is open).  tools/*_bench.py load it
+    beside libmxvl.so in ONE process so both arms run on the same box, interleaved."""
+    build()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(PKG, "build", f"exp{exp}")
+    os.makedirs(out_dir, exist_ok=True)
+    objs, procs = [], []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in files:
+            obj = os.path.join(out_dir, base.replace(".hip", ".o"))
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
+                   f"-DMXVL_EXP={exp}", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+        else:
+            obj = os.path.join(PKG, "build", base.replace(".hip", ".o"))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    lib = os.path.join(PKG, "build", f"libmxvl_exp{exp}.so")
+    subprocess.check_call([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def _build_ablate(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
@@ -77,4 +106,7 @@ def _build_ablate(verbose: bool) -> str:
 
 
 if __name__ == "__main__":
+    if "--exp" in sys.argv:
+        print(build_exp(int(sys.argv[sys.argv.index("--exp") + 1]), verbose="--verbose" in sys.argv))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate="--ablate" in sys.argv))

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
 // ---- dK / dV ----------------------------------------------------------------------------------------------------------
 // One workgroup per 128-key tile (a lane owns a key); walks the query tiles that can see it, Q / dO tiles double-buffered.
 template <typename E, int D, int NW, bool EXTRA>
-__global__ __launch_bounds__(NW * 64, sizeof(E) == 4 ? 1 : 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
   typedef typename PolOf<E>::type Pol;
   typedef typename Pol::Frag Frag;
   constexpr int KTW = NW * 32, QT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
@@ -652,7 +652,13 @@ static int dispatch_attn(const AttnArgs& a, int D, int what, hipStream_t s) {   
   switch (D) {
     case 32: return what == 0 ? launch_q<E, 32, false>(a, s) : what == 1 ? launch_q<E, 32, true>(a, s) : launch_dkv<E, 32>(a, s);
     case 64: return what == 0 ? launch_q<E, 64, false>(a, s) : what == 1 ? launch_q<E, 64, true>(a, s) : launch_dkv<E, 64>(a, s);
-    case 128: return what == 0 ? launch_q<E, 128, false>(a, s) : MXVL_ERR_UNSUPPORTED;   // D = 128 is decode-side: forward only
+    // head_dim 128 (Llama-2-7B / Qwen: the hybrid decoder's training-time self- and image cross-attention): one wave per SIMD,
+    // the 512-entry unified register file holds the Q / dO (dQ pass) or K / V (dK/dV pass) fragments next to 8 accumulators
+    case 128: return what == 0 ? launch_q<E, 128, false>(a, s) : what == 1 ? launch_q<E, 128, true>(a, s) : launch_dkv<E, 128>(a, s);
+    // head_dim 256 (Gemma-sized decoders; the decode kernels have a <256> instantiation): the prompt pass only -- forward, 16-bit
+    case 256:
+      if constexpr (sizeof(E) == 2) { if (what == 0) return launch_q<E, 256, false>(a, s); }
+      return MXVL_ERR_UNSUPPORTED;
     default: return MXVL_ERR_UNSUPPORTED;
   }
 }

@@ -19,6 +19,12 @@
 #define MXVL_ABL_ENV(name) (0)
 #endif
 
+// A/B experiment bits (build.py --exp N -> build/libmxvl_exp<N>.so): 0 in the product library.  An `#if MXVL_EXP & bit` block
+// lives only while its experiment is open; the winner becomes the code, the loser is deleted.
+#ifndef MXVL_EXP
+#define MXVL_EXP 0
+#endif
+
 namespace mxvl {
 
 constexpr int kWave = 64;

@@ -37,7 +37,6 @@ struct ScanBwdArgs {
   const float *A, *D, *bias, *ckpt;
   void *du, *ddelta, *dz;
   float *dA, *dB, *dC, *dD, *dbias;
-  float* ws;   // optional dB/dC partials: [batch][gridDim.x][2 (dB, dC)][N][L] fp32, fully written (no atomics); see below
 };
 
 // forward inclusive scan + exclusive shift over a 16-lane DPP row (see scan_fwd.hip)
@@ -76,6 +75,31 @@ __device__ inline void scan16_rev(float& q0, float& P0, float& x0) {
       "v_mov_b32_dpp %2, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n"
       : "+v"(q0), "+v"(P0), "+v"(x0));
 }
+// Both scans of a state in one instruction stream: the forward scan of the recomputed states (row_shr) and the reverse scan of
+// the adjoints (row_shl) are independent, so interleaving them puts >= 2 instructions between every VALU write and the DPP read
+// of the same register -- the s_nop padding of the two separate blocks (10 idle issue slots per state) disappears.
+__device__ __forceinline__ void scan16_fwd_rev(float& h0, float& Pf, float& x0, float& q0, float& Pr, float& g0) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shl:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shl:2 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shl:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+      "v_mul_f32_dpp %4, %4, %4 row_shl:4 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n"
+      "v_fmac_f32_dpp %3, %3, %4 row_shl:8 row_mask:0xf bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_mov_b32_dpp %2, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+      "v_mov_b32_dpp %5, %3 row_shl:1 row_mask:0xf bank_mask:0xf\n"
+      : "+v"(h0), "+v"(Pf), "+v"(x0), "+v"(q0), "+v"(Pr), "+v"(g0));
+}
 // sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
 __device__ inline float row_sum_to_lane15(float v) {
   v += dpp<DPP_ROW_SHR(1)>(0.0f, v);
@@ -107,18 +131,28 @@ __device__ __forceinline__ void lane16_swap_x4(float (&s)[8]) {                 
       : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]));
 }
 
-// Registers are held to 2 waves per SIMD (<= 256 VGPR, no spill).  A 3-waves/SIMD build (<= 168 VGPR, the per-chunk row state
+// Registers are held to 2 waves per SIMD (<= 256 VGPR).  A 3-waves/SIMD build (<= 168 VGPR, the per-chunk row state
 // spilled once per chunk) measured 1.80 ms against 1.34 ms at the pre-training shape (profiles/r02_bwd_variants.txt) and was
 // dropped.
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
+//
+// NS > 0: dstate is the compile-time constant NS (16 = every Mamba block of the reference, mamba_simple.py:42), so the state loop
+// is unrolled in flush groups of FG = 4 states with immediate LDS offsets; NS == 0: any dstate <= 64 at run time, same code.
+// Round-3 restructuring of the state loop (profiles/r03_bwd_isa.txt: 226 VALU + 69 SALU + 21 LDS instructions per state before):
+//   * no exec-masked LDS stores: the lanes that do not own a table entry (adjoint hand-off: lane 0; dA: lane 15) write a private
+//     dump word instead -- a masked store cost s_and_saveexec / s_cbranch / s_or per state, and for dA an exposed LDS round trip;
+//   * the dB/dC flush addresses are wave-uniform (SGPR base + lane): no 64-bit VALU multiplies per atomic;
+//   * the 9 v_exp_f32 of a state issue back to back (one asm block): v_exp costs 8 cycles alone and 10-16 when interleaved with
+//     FMAs (profiles/r01_ubench_valu_mix.txt).
+template <typename io_t, int NWAVES, bool VEC, int NS>
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
   constexpr int FG = 4;                    // states per dB/dC flush group
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
+  static_assert(NS % FG == 0, "compile-time dstate is a whole number of flush groups");
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = p.N, L = p.L;
+  const int N = NS > 0 ? NS : p.N, L = p.L;
   float* sB = smem;                        // [N][CH]  quarter-major, odd quarter rotated by 16 words (see scan_fwd_stream.h qpos)
   float* sC = sB + N * CH;                 // [N][CH]
   // dB/dC shares of a group of FG states, one tile per WAVE (its 4 rows summed in registers first), double-buffered:
@@ -133,12 +167,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   float2* sAC = (float2*)(sAcc + 2 * FG * NWAVES * 2 * CH);   // [DT+1][NP] {A*log2e, state entering the chunk}; row DT = 0
   float* sG = (float*)(sAC + (DT + 1) * NP);  // [DT+1][NP] adjoint entering the chunk from the right; row DT = 0
   float* sdA = sG + (DT + 1) * NP;         // [DT][NP] dA accumulated over the chunks
+  float* sDump = sdA + DT * NP;            // [NT + N] write-only / garbage words of the lanes that own no table entry
   // u, delta, z, dout of the chunk as loaded, parked here across the state loop.  They are only needed again for the
   // per-step outputs; in registers (32 VGPRs) they push the loop to the 256-VGPR limit, where the compiler re-computes the 8
   // v_exp_f32 of a_t in the second pass instead of keeping them (17 instead of 9 transcendentals per state).
-  io_t* sPark = (io_t*)(smem + (((sdA + DT * NP) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
+  io_t* sPark = (io_t*)(smem + (((sDump + NT + N) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wq = __builtin_amdgcn_readfirstlane(wave);     // the wave index as a scalar: flush addresses are SGPR + lane
   const int r = lane >> 4, j = lane & 15;
   const int row = wave * RPW + r;
   const int b = blockIdx.y;
@@ -167,45 +203,44 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   float* __restrict__ dCp = p.dC + (int64_t)b * p.dC_bs + (int64_t)g * p.dC_gs;
   const bool has_z = pz != nullptr;
 
-  for (int i = tid; i < (DT + 1) * N; i += NT) {
-    const int rr = i / N, n = i - rr * N;
-    const int dd = d0 + rr;
-    sAC[rr * NP + n] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
-    sG[rr * NP + n] = 0.0f;
-    if (rr < DT) sdA[rr * NP + n] = 0.0f;
-  }
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
   float dD_acc = 0.0f, dbias_acc = 0.0f;
 
-  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
-    if (t0 + CH <= L) {
-      if constexpr (VEC) {
-        const float4 a0 = ld4<io_t>(q + t0), a1 = ld4<io_t>(q + t0 + 4);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-      } else {
-#pragma unroll
-        for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
-      }
-    } else if (VEC && t0 + j * T + T <= L) {   // ragged last chunk, aligned rows: this lane's 8 steps are all valid
-      const float4 a0 = ld4<io_t>(q + t0), a1 = ld4<io_t>(q + t0 + 4);
-      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
-    }
+  // u, delta, dout, z of one chunk, all requests issued before the first use: ONE whole/partial branch for the four arrays.
+  // (Four independent fetch calls, each with its own full / whole-lane / element-wise paths, made the compiler wait for every
+  // array before requesting the next -- four serialised HBM round trips on the ragged chunk, which is HALF of the chunks of the
+  // 197-token encoders.)  dout is the io dtype, or fp32 (MXVL_SCAN_OUT_F32: oflex i16o32).
+  auto ld8 = [&](const io_t* q, float (&v)[T]) {
+    const float4 a0 = ld4<io_t>(q), a1 = ld4<io_t>(q + 4);
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
   };
-  // dout: io dtype through row_fetch, or fp32 (MXVL_SCAN_OUT_F32: oflex i16o32) with the same masks
-  auto dout_fetch = [&](int t0, float (&v)[T]) {
-    if (!of32) { row_fetch(pg, t0, v); return; }
-    const bool whole = VEC && (t0 + CH <= L || t0 + j * T + T <= L);
-    if (whole) {
+  auto dout_fetch = [&](int t0, float (&v)[T]) {      // the fp32 dout of an i16o32 call (never prefetched / parked)
+    if (VEC && (t0 + CH <= L || t0 + j * T + T <= L)) {
       const float4 a0 = ld4_out<io_t>(p.dout, pg_off + t0, true), a1 = ld4_out<io_t>(p.dout, pg_off + t0 + 4, true);
       v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
     } else {
 #pragma unroll
       for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? ld_out<io_t>(p.dout, pg_off + t0 + i, true) : 0.0f;
     }
+  };
+  auto rows_fetch = [&](int t0, float (&vu)[T], float (&vd)[T], float (&vg)[T], float (&vz)[T]) {
+    if (VEC && (t0 + CH <= L || t0 + j * T + T <= L)) {     // every step of this lane is valid: 16-byte loads
+      ld8(pu + t0, vu);
+      ld8(pd + t0, vd);
+      if (!of32) ld8(pg + t0, vg);
+      if (has_z) ld8(pz + t0, vz);
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const bool ok = t0 + j * T + i < L;
+        vu[i] = ok ? io::ld(pu + t0 + i) : 0.0f;
+        vd[i] = ok ? io::ld(pd + t0 + i) : 0.0f;
+        if (!of32) vg[i] = ok ? io::ld(pg + t0 + i) : 0.0f;
+        if (has_z) vz[i] = ok ? io::ld(pz + t0 + i) : 0.0f;
+      }
+    }
+    if (of32) dout_fetch(t0, vg);
   };
   auto row_store = [&](io_t* q, const void* base, int64_t bs, int64_t ds, int t0, const float (&v)[T]) {
     if (VEC && t0 + CH <= L) {
@@ -247,34 +282,100 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 
   // Half-precision io: the NEXT chunk's rows (u, delta, dout, z: 8 elements = one 16-byte load each) are requested before the
   // state loop of the current chunk and sit packed in 16 VGPRs while it runs, so their HBM latency is hidden behind it
-  // (at 2 waves/SIMD there is little else to hide it).  fp32 rows would need 32 VGPRs: they take the direct path.
+  // (at 2 waves/SIMD there is little else to hide it); the first chunk's are requested at kernel entry, ahead of the table
+  // initialisation.  fp32 rows would need 32 VGPRs: they take the direct path.
   constexpr bool PF = VEC && sizeof(io_t) == 2;
   uint4 ru = make_uint4(0, 0, 0, 0), rd = ru, rg = ru, rz = ru;
-  bool have_pf = false;
   auto unpack = [&](const uint4& r, float (&v)[T]) {
     io_t tmp[T];
     *(uint4*)tmp = r;
 #pragma unroll
     for (int i = 0; i < T; ++i) v[i] = io::ld(tmp + i);
   };
+  auto raw_prefetch = [&](int tn) {
+    if (tn + CH <= L || tn + j * T + T <= L) {
+      ru = *(const uint4*)(pu + tn);
+      rd = *(const uint4*)(pd + tn);
+      if (!of32) rg = *(const uint4*)(pg + tn);
+      if (has_z) rz = *(const uint4*)(pz + tn);
+    } else {                    // the lane that straddles the end of the row: element loads, zero beyond L
+      uint16_t eu[T], ed[T], eg[T], ez[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const bool ok = tn + j * T + i < L;
+        eu[i] = ok ? *(const uint16_t*)(pu + tn + i) : (uint16_t)0;
+        ed[i] = ok ? *(const uint16_t*)(pd + tn + i) : (uint16_t)0;
+        eg[i] = (ok && !of32) ? *(const uint16_t*)(pg + tn + i) : (uint16_t)0;
+        ez[i] = (ok && has_z) ? *(const uint16_t*)(pz + tn + i) : (uint16_t)0;
+      }
+      auto pk = [](const uint16_t (&e)[T]) {
+        return make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                          (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+      };
+      ru = pk(eu); rd = pk(ed); rg = pk(eg); rz = pk(ez);
+    }
+  };
 
   const int nchunks = (L + CH - 1) / CH;
+  if constexpr (PF) raw_prefetch((nchunks - 1) * CH);
+  for (int i = tid; i < (DT + 1) * N; i += NT) {
+    const int rr = i / N, n = i - rr * N;
+    const int dd = d0 + rr;
+    sAC[rr * NP + n] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    sG[rr * NP + n] = 0.0f;
+    if (rr < DT) sdA[rr * NP + n] = 0.0f;
+  }
+  for (int i = tid; i < NT + N; i += NT) sDump[i] = 0.0f;
+
+  // ---- chunk-invariant addresses of the state loop ------------------------------------------------------------------
+  float2* const ac = sAC + row * NP;                                  // {A2, state entering the chunk} of this row
+  const float2* const ac_in = sAC + ((j == 0) ? row : DT) * NP;       // only lane 0 sees the state entering the chunk
+  const float* const gq_in = sG + ((j == LPR - 1) ? row : DT) * NP;   // only lane 15 sees the adjoint entering from chunk c+1
+  float* const gq_w = (j == 0) ? sG + row * NP : sDump + tid;         // lane 0 hands the adjoint to chunk c-1; the others: dump
+  float* const dA_w = (j == LPR - 1) ? sdA + row * NP : sDump + tid;  // lane 15 owns dA of (row, n); the others: dump
+  const float* const cB = sB + j * 4;      // even quarter (steps 8j..8j+3) at word 4j, odd quarter at 64 + ((4j + 16) & 63)
+  const float* const cC = sC + j * 4;
+  const int q1 = 64 + ((j * 4 + 16) & 63) - j * 4;     // word offset of the odd quarter relative to cB / cC
+  // A wave first sums the dB / dC shares of its 4 rows in registers (v_permlane{32,16}_swap), so only ONE
+  // share per wave goes to LDS; states are flushed in groups of FG, one group behind -- sAcc is two buffers of
+  // [FG][NWAVES][2][CH] -- so the sums of group g run while group g+1 is computed and one barrier per FG states separates a
+  // buffer's writers from its readers.  (History, profiles/r02_bwd_ablation.txt: per-row tiles + a two-barrier flush every 2
+  // states cost 30 % of the kernel in LDS stores, flush reads and barriers; per-wave global atomics without LDS, 8x the
+  // atomics, ran 4x slower.)
+  constexpr int FK = FG * 2 * CH / NT;          // elements of a group per thread: 2 (8 waves) / 4 (4 waves)
+  constexpr int GBUF = FG * NWAVES * 2 * CH;    // floats per flush buffer
+  // lane (r, j) holds step e = 8 j + i, i = {0, 1, 4, 5}[r] (and i + 2).  Inside its 8-word block a step sits rotated by
+  // 2 (j >> 2): the 32 lanes of one ds_write_b32 group (two rows x 16 j) then hit 32 different banks -- at position e the four
+  // j that are 4 apart collided 4-way, 50 M of the kernel's 55 M conflict cycles -- and the flush's consecutive-e reads stay
+  // conflict-free (a 32-step run keeps j >> 2 fixed).
+  const int i0 = (r & 1) + (r >> 1) * 4, rot = 2 * (j >> 2);
+  float* const wAcc = sAcc + wave * (2 * CH) + j * T;
+  float* const wA0 = wAcc + ((i0 + rot) & 7);
+  float* const wA2 = wAcc + ((i0 + 2 + rot) & 7);
+  // element x = wq * 64 + lane + NT * k of a flush group: state slot x / (2 CH), dB|dC (x / CH) & 1, step x % CH.  All but the
+  // lane are wave-uniform (64 divides CH): slot, array and the first step of the wave's 64-step run stay in SGPRs.
+  int fo[FK];                                   // LDS word offset (inside a flush buffer) of this thread's element k
+#pragma unroll
+  for (int k = 0; k < FK; ++k) {
+    const int xw = wq * 64 + NT * k;
+    const int xe = (xw & (2 * CH - 1)) + lane;                        // dB|dC * CH + step; the step's slot is rotated (see wAcc)
+    fo[k] = (xw / (2 * CH)) * (NWAVES * 2 * CH) + (xe & ~7) + ((xe + 2 * ((xe % CH) >> 5)) & 7);
+  }
+
+  const int NGRP = (N + FG - 1) / FG;
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * CH;
     const bool full = t0 + CH <= L;
     __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible)
     // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
     float uu[T], dl[T], zz[T], go[T];
-    if (PF && have_pf) {
+    if constexpr (PF) {
       unpack(ru, uu);
       unpack(rd, dl);
       if (of32) dout_fetch(t0, go); else unpack(rg, go);
       if (has_z) unpack(rz, zz);
     } else {
-      row_fetch(pu, t0, uu);
-      row_fetch(pd, t0, dl);
-      dout_fetch(t0, go);
-      if (has_z) row_fetch(pz, t0, zz);
+      rows_fetch(t0, uu, dl, go, zz);
     }
     // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
     if (VEC && full) {
@@ -309,14 +410,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     }
     __syncthreads();
     if constexpr (PF) {
-      have_pf = c > 0;          // chunk c-1 is always a full chunk
-      if (have_pf) {
-        const int tn = t0 - CH;
-        ru = *(const uint4*)(pu + tn);
-        rd = *(const uint4*)(pd + tn);
-        if (!of32) rg = *(const uint4*)(pg + tn);
-        if (has_z) rz = *(const uint4*)(pz + tn);
-      }
+      if (c > 0) raw_prefetch(t0 - CH);     // chunk c-1 is always a full chunk
     }
 
     {
@@ -367,40 +461,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 #pragma unroll
     for (int i = 0; i < T; ++i) dsum += dl[i];
 
-    float2* ac = sAC + row * NP;
-    const float2* ac_in = sAC + ((j == 0) ? row : DT) * NP;
-    float* gq = sG + row * NP;
-    const float* gq_in = sG + ((j == LPR - 1) ? row : DT) * NP;
-    const float* cB = sB + j * 4;                   // even quarter (steps 8j..8j+3) at word 4j, odd quarter at 64 + ((4j + 16) & 63)
-    const float* cC = sC + j * 4;
-    const int q1 = 64 + ((j * 4 + 16) & 63) - j * 4;     // word offset of the odd quarter relative to cB / cC
-    // A wave first sums the dB / dC shares of its 4 rows in registers (v_permlane{32,16}_swap), so only ONE
-    // share per wave goes to LDS; states are flushed in groups of FG, one group behind -- sAcc is two buffers of
-    // [FG][NWAVES][2][CH] -- so the sums of group g run while group g+1 is computed and one barrier per FG states separates a
-    // buffer's writers from its readers.  (History, profiles/r02_bwd_ablation.txt: per-row tiles + a two-barrier flush every 2
-    // states cost 30 % of the kernel in LDS stores, flush reads and barriers; per-wave global atomics without LDS, 8x the
-    // atomics, ran 4x slower.)
-    constexpr int FK = FG * 2 * CH / NT;          // elements of a group per thread: 2 (8 waves) / 4 (4 waves)
-    // lane (r, j) holds step e = 8 j + i, i = {0, 1, 4, 5}[r] (and i + 2).  Inside its 8-word block a step sits rotated by
-    // 2 (j >> 2): the 32 lanes of one ds_write_b32 group (two rows x 16 j) then hit 32 different banks -- at position e the four
-    // j that are 4 apart collided 4-way, 50 M of the kernel's 55 M conflict cycles -- and the flush's consecutive-e reads stay
-    // conflict-free (a 32-step run keeps j >> 2 fixed).
-    const int i0 = (r & 1) + (r >> 1) * 4, rot = 2 * (j >> 2);
-    float* wAcc = sAcc + wave * (2 * CH) + j * T;
-    const int wp0 = (i0 + rot) & 7, wp2 = (i0 + 2 + rot) & 7;
-    auto flush_load = [&](int g, float (&part)[FK * NWAVES]) {
+    auto flush_load = [&](int grp, float (&part)[FK * NWAVES]) {
+      const float* src = sAcc + (grp & 1) * GBUF;
 #pragma unroll
       for (int k = 0; k < FK; ++k) {
-        // element x = tid + NT k of the group: state slot x / (2 CH), dB|dC (x / CH) & 1, step x % CH
-        const int x = tid + NT * k;
-        const int xe = x % (2 * CH);                                  // dB|dC * CH + step; the step's slot is rotated (see wAcc)
-        const float* qq = sAcc + (g & 1) * (FG * NWAVES * 2 * CH) + (x / (2 * CH)) * (NWAVES * 2 * CH) + (xe & ~7) +
-                          ((xe + 2 * ((xe % CH) >> 5)) & 7);
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) part[k * NWAVES + w] = qq[w * 2 * CH];
+        for (int w = 0; w < NWAVES; ++w) part[k * NWAVES + w] = src[fo[k] + w * 2 * CH];
       }
     };
-    auto flush_add = [&](int g, float (&part)[FK * NWAVES]) {
+    auto flush_add = [&](int grp, float (&part)[FK * NWAVES]) {
 #pragma unroll
       for (int k = 0; k < FK; ++k) {
 #pragma unroll
@@ -408,109 +477,109 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 #pragma unroll
           for (int rr = 0; rr < w; ++rr) part[k * NWAVES + rr] += part[k * NWAVES + rr + w];
         }
-        const int x = tid + NT * k;
-        const int nn = g * FG + x / (2 * CH), which = (x / CH) & 1, e = x % CH;
-        if (g >= 0 && nn < N && t0 + e < L && !MXVL_ABL(p.ablate & 2)) {
-          const float v = part[k * NWAVES];
-          if constexpr (PARTIAL) {
-            // one plain coalesced store per (tile, n, t): the cross-tile sum is mxvl's second, tiny kernel (scan_bwd_reduce_kernel)
-            float* dst = p.ws + ((((int64_t)b * gridDim.x + blockIdx.x) * 2 + which) * N + nn) * (int64_t)L;
-            __builtin_nontemporal_store(v, dst + t0 + e);
-          } else {
-            float* dst = which ? dCp + (int64_t)nn * p.dC_ns : dBp + (int64_t)nn * p.dB_ns;
-            unsafeAtomicAdd(dst + t0 + e, v);
-          }
+        const int xw = wq * 64 + NT * k;                              // wave-uniform part of the element index
+        const int nn = grp * FG + xw / (2 * CH), eb = xw & (CH - 1);
+        if (nn < N) {
+          float* dst = ((xw / CH) & 1) ? dCp + (int64_t)nn * p.dC_ns : dBp + (int64_t)nn * p.dB_ns;   // SGPRs
+          dst += t0 + eb;
+          if (full || t0 + eb + lane < L) unsafeAtomicAdd(dst + lane, part[k * NWAVES]);
         }
       }
     };
 
-    for (int n = 0; n < (MXVL_ABL(p.ablate & 4) ? 0 : N); ++n) {
-      const float A2 = ac[n].x;
-      const float hin = ac_in[n].y;
-      float a[T], bb[T], cv[T], h[T];
+    for (int ng = 0; ng < NGRP; ++ng) {
       float fpart[FK * NWAVES];
-      const bool f_first = (n % FG) == 0;                  // the previous group's shares are summed during this state
-      if (f_first && !MXVL_ABL(p.ablate & 16)) flush_load(n / FG - 1, fpart);   // group -1: stale LDS, discarded
-      {
-        const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
-        const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-        cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
-      }
-      // ---- forward recompute -----------------------------------------------------------------------
-      float hl;
-      {
+      if (ng > 0) flush_load(ng - 1, fpart);               // the previous group's shares are summed during this group's first state
+      float* const wg0 = wA0 + (ng & 1) * GBUF;
+      float* const wg2 = wA2 + (ng & 1) * GBUF;
 #pragma unroll
-        for (int i = 0; i < T; ++i) a[i] = fast_exp2(dl[i] * A2);
-        hl = du[0] * bb[0];
+      for (int k = 0; k < FG; ++k) {
+        const int n = ng * FG + k;
+        if (NS > 0 || n < N) {
+          const float A2 = ac[n].x;
+          const float hin = ac_in[n].y;
+          const float gin = gq_in[n];
+          const float dA_old = dA_w[n];
+          float a[T], bb[T], cv[T], h[T];
+          {
+            const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
+            const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+            cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+          }
+          // ---- forward recompute -----------------------------------------------------------------------
 #pragma unroll
-        for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, du[i] * bb[i]);
-      }
-      const float P = fast_exp2(A2 * dsum);
-      float Pf = P, x = hin;
-      hl = fmaf(P, hin, hl);
-      scan16_fwd(hl, Pf, x);           // x = state entering this lane's steps
-      {
-        float hh = x;
+          for (int i = 0; i < T; ++i) a[i] = dl[i] * A2;
+          float P = A2 * dsum;
+          asm volatile(
+              "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
+              "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
+              : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(P));
+          float hl = du[0] * bb[0];
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-          hh = fmaf(a[i], hh, du[i] * bb[i]);
-          h[i] = hh;
-          y[i] = fmaf(cv[i], hh, y[i]);
+          for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, du[i] * bb[i]);
+          // ---- adjoint fold: g_i = C_i dy_i + a_{i+1} g_{i+1} ----------------------------------------------
+          float ql = cv[T - 1] * dy[T - 1];
+#pragma unroll
+          for (int i = T - 2; i >= 0; --i) ql = fmaf(a[i + 1], ql, cv[i] * dy[i]);
+          ql *= a[0];                      // what this lane hands to its left neighbour for gamma_in = 0
+          float Pf = P, x = hin, Pr = P, gx = gin;
+          hl = fmaf(P, hin, hl);
+          ql = fmaf(P, gin, ql);
+          scan16_fwd_rev(hl, Pf, x, ql, Pr, gx);   // x = state entering this lane's steps, gx = a_{next} g_{next} entering from the right
+          {
+            float hh = x;
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+              hh = fmaf(a[i], hh, du[i] * bb[i]);
+              h[i] = hh;
+              y[i] = fmaf(cv[i], hh, y[i]);
+            }
+          }
+          gq_w[n] = ql;                    // lane 0: leaves the chunk towards chunk c-1
+          float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
+          float dA_part = 0.0f;
+          float vB[T], vC[T];
+#pragma unroll
+          for (int i = T - 1; i >= 0; --i) {
+            const float gi = fmaf(cv[i], dy[i], gg);          // g_i
+            const float hprev = (i == 0) ? x : h[i - 1];
+            const float ga = gi * a[i];                       // a_i g_i
+            const float gha = ga * hprev;                     // g_i h_{i-1} a_i
+            vC[i] = dy[i] * h[i];   // dC_{n,t} share of this row
+            vB[i] = gi * du[i];     // dB_{n,t} share of this row
+            sgB[i] = fmaf(gi, bb[i], sgB[i]);
+            sAh[i] = fmaf(gha, A2, sAh[i]);
+            dA_part = fmaf(gha, dl[i], dA_part);
+            gg = ga;
+          }
+          dA_part = row_sum_to_lane15(dA_part);
+          dA_w[n] = dA_old + dA_part;      // lane 15: dA of (row, n) over the chunks
+          {
+            // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
+            // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
+            // steps {i, i+1, i+4, i+5}
+            float sr[8];
+            lane32_swap_x8(vB, vC);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
+            lane16_swap_x4(sr);
+            float* w0 = wg0 + k * (NWAVES * 2 * CH);
+            float* w2 = wg2 + k * (NWAVES * 2 * CH);
+            w0[0] = sr[0] + sr[1]; w2[0] = sr[2] + sr[3];
+            w0[CH] = sr[4] + sr[5]; w2[CH] = sr[6] + sr[7];
+          }
+          if (k == 0 && ng > 0) flush_add(ng - 1, fpart);
+          if (k == FG - 1 || n == N - 1) __syncthreads();
         }
-      }
-      // ---- adjoint: g_i = C_i dy_i + a_{i+1} g_{i+1} ---------------------------------------------------
-      float ql = cv[T - 1] * dy[T - 1];
-#pragma unroll
-      for (int i = T - 2; i >= 0; --i) ql = fmaf(a[i + 1], ql, cv[i] * dy[i]);
-      ql *= a[0];                      // what this lane hands to its left neighbour for gamma_in = 0
-      const float gin = gq_in[n];      // only lane 15 sees the adjoint entering from chunk c+1
-      float Pr = P, gx = gin;
-      ql = fmaf(P, gin, ql);
-      scan16_rev(ql, Pr, gx);          // gx = a_{next} g_{next} entering this lane from the right
-      if (j == 0) gq[n] = ql;          // leaves the chunk towards chunk c-1
-      float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
-      float dA_part = 0.0f;
-      float vB[T], vC[T];
-#pragma unroll
-      for (int i = T - 1; i >= 0; --i) {
-        const float gi = fmaf(cv[i], dy[i], gg);          // g_i
-        const float hprev = (i == 0) ? x : h[i - 1];
-        const float ga = gi * a[i];                       // a_i g_i
-        const float gha = ga * hprev;                     // g_i h_{i-1} a_i
-        vC[i] = dy[i] * h[i];   // dC_{n,t} share of this row
-        vB[i] = gi * du[i];     // dB_{n,t} share of this row
-        sgB[i] = fmaf(gi, bb[i], sgB[i]);
-        sAh[i] = fmaf(gha, A2, sAh[i]);
-        dA_part = fmaf(gha, dl[i], dA_part);
-        gg = ga;
-      }
-      {
-        dA_part = row_sum_to_lane15(dA_part);
-        if (j == LPR - 1) sdA[row * NP + n] += dA_part;
-        if (!MXVL_ABL(p.ablate & 1)) {
-          // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
-          // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
-          // steps {i, i+1, i+4, i+5}
-          float sr[8];
-          lane32_swap_x8(vB, vC);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
-          lane16_swap_x4(sr);
-          float* w = wAcc + (((n / FG) & 1) * FG + (n % FG)) * (NWAVES * 2 * CH);
-          w[wp0] = sr[0] + sr[1]; w[wp2] = sr[2] + sr[3];
-          w[CH + wp0] = sr[4] + sr[5]; w[CH + wp2] = sr[6] + sr[7];
-        }
-        if (f_first && !MXVL_ABL(p.ablate & 16)) flush_add(n / FG - 1, fpart);
-        if (((n % FG) == FG - 1 || n == N - 1) && !MXVL_ABL(p.ablate & 8)) __syncthreads();
       }
     }
 
     {
-      if (!MXVL_ABL(p.ablate & 4)) {     // the last group's shares
+      {     // the last group's shares
         float fpart[FK * NWAVES];
-        flush_load((N - 1) / FG, fpart);
-        flush_add((N - 1) / FG, fpart);
+        flush_load(NGRP - 1, fpart);
+        flush_add(NGRP - 1, fpart);
         if (!VEC) __syncthreads();       // unaligned rows: the store transpose tile sO aliases buffer 0
       }
       auto unpark = [&](int arr, float (&v)[T]) {
@@ -572,91 +641,42 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   }
 }
 
-// dB/dC (batch, G, N, L) += sum over the `tiles` channel tiles of a group of the partials scan_bwd_kernel<PARTIAL> wrote.
-// One thread per 4 consecutive steps; the tile loop reads `tiles` coalesced slabs.
-struct ScanBwdReduceArgs {
-  int G, N, L, tiles, vec;
-  int64_t dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
-  const float* ws;
-  float *dB, *dC;
-};
-__global__ __launch_bounds__(256) void scan_bwd_reduce_kernel(const ScanBwdReduceArgs p) {
-  const int bg = blockIdx.z, b = bg / p.G, g = bg - b * p.G;
-  const int which = blockIdx.y / p.N, n = blockIdx.y - which * p.N;
-  const int t = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (t >= p.L) return;
-  const int64_t slab = (int64_t)2 * p.N * p.L;   // one tile's partials
-  const float* src = p.ws + ((int64_t)b * p.G * p.tiles + (int64_t)g * p.tiles) * slab + ((int64_t)which * p.N + n) * p.L + t;
-  float* dst = which ? p.dC + (int64_t)b * p.dC_bs + (int64_t)g * p.dC_gs + (int64_t)n * p.dC_ns + t
-                     : p.dB + (int64_t)b * p.dB_bs + (int64_t)g * p.dB_gs + (int64_t)n * p.dB_ns + t;
-  if (p.vec && t + 4 <= p.L) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int k = 0; k < p.tiles; ++k) {
-      const float4 v = *(const float4*)(src + (int64_t)k * slab);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    float4 o = *(float4*)dst;
-    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-    *(float4*)dst = o;
-  } else {
-    for (int e = 0; e < 4 && t + e < p.L; ++e) {
-      float acc = 0.f;
-      for (int k = 0; k < p.tiles; ++k) acc += src[(int64_t)k * slab + e];
-      dst[e] += acc;
-    }
-  }
-}
-
 static thread_local int g_bwd_hip_error = 0;
 extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
-template <typename io_t, int NWAVES, bool VEC, bool PARTIAL>
+template <typename io_t, int NWAVES, bool VEC, int NS>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
-  constexpr int DT = NWAVES * 4, CH = 128;
-  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1)) +
-                     16 + (size_t)4 * NWAVES * 64 * 8 * sizeof(io_t);
+  constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
+  const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1) +
+                                      (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, PARTIAL>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
   }
   const int dpg = a.dim / a.G;
-  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NT);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
-  if constexpr (PARTIAL) {
-    ScanBwdReduceArgs r;
-    r.G = a.G; r.N = a.N; r.L = a.L; r.tiles = (dpg + DT - 1) / DT;
-    r.dB_bs = a.dB_bs; r.dB_gs = a.dB_gs; r.dB_ns = a.dB_ns; r.dC_bs = a.dC_bs; r.dC_gs = a.dC_gs; r.dC_ns = a.dC_ns;
-    r.ws = a.ws; r.dB = a.dB; r.dC = a.dC;
-    const int64_t ss[] = {a.dB_bs, a.dB_gs, a.dB_ns, a.dC_bs, a.dC_gs, a.dC_ns};
-    bool v = (a.L % 4 == 0) && ((uintptr_t)a.dB % 16 == 0) && ((uintptr_t)a.dC % 16 == 0) && ((uintptr_t)a.ws % 16 == 0);
-    for (int64_t x : ss) v = v && (x % 4 == 0);
-    r.vec = v ? 1 : 0;
-    dim3 rg((a.L + 1023) / 1024, 2 * a.N, a.batch * a.G);
-    hipLaunchKernelGGL(scan_bwd_reduce_kernel, rg, dim3(256), 0, stream, r);
-    e = hipGetLastError();
-    if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
-  }
   return MXVL_OK;
 }
+// dstate 16 (every Mamba block of the reference) takes the instantiation with the unrolled state loop
 template <typename io_t, int NWAVES, bool VEC>
 static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
-  return a.ws ? launch_bwd1<io_t, NWAVES, VEC, true>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, false>(a, stream);
+  return a.N == 16 ? launch_bwd1<io_t, NWAVES, VEC, 16>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, 0>(a, stream);
 }
 
 // 8-wave workgroups own 32 rows: the dB/dC tile is pre-summed over twice as many rows before it leaves the workgroup
 // at the same 8 waves per CU.  Used when 32-row tiles still give every CU a workgroup.
 
-static bool bwd_wide(int batch, int dim, int G, int L) {
+static bool bwd_wide(int batch, int dim, int G, int /*L*/) {
   static const int forced = MXVL_ABL_ENV("MXVL_BWD_WAVES");
   const long tiles32 = (long)batch * G * ((dim / G + 31) / 32);
-  // one- and two-chunk sequences (the 197-token encoders) run 8 % faster on 16-row workgroups: 1.44 vs 1.58 ms at
-  // B 64 x D 4096 x L 200 (profiles/r02_bwd_variants.txt); long sequences prefer the 32-row pre-sum of dB / dC
-  return forced ? forced == 8 : ((dim / G) % 32 == 0 && tiles32 >= 256 && L > 256);
+  // round 3 (profiles/r03_scan_variants.txt): with the restructured state loop the 32-row workgroups are never slower where
+  // they still give every CU a workgroup -- B32 x D768 x L196 fp32: 155 vs 213 us, the 197-token encoder: 1296 vs 1281 us
+  return forced ? forced == 8 : ((dim / G) % 32 == 0 && tiles32 >= 256);
 }
 
 template <typename io_t>
@@ -673,14 +693,12 @@ using namespace mxvl;
 
 extern "C" int mxvl_scan_check(const mxvl_scan_desc* d);
 
+// The per-tile dB/dC workspace + reduce kernel of ABI v3 measured slower than the fp32 atomics at every shape
+// (profiles/r02_bwd_workspace_ab.txt: 1.47 vs 1.27 ms) and was removed in round 3: no scratch is useful, the descriptor's
+// workspace fields are ignored.
 extern "C" int64_t mxvl_scan_bwd_workspace_bytes(const mxvl_scan_desc* f) {
-  if (mxvl_scan_check(f) != MXVL_OK || f->dstate > 64) return 0;
-  const int bv = mxvl_scan_bwd_variant();
-  const int DT = (bv == 1 || (bv == 0 && bwd_wide(f->batch, f->dim, f->n_groups, f->seqlen))) ? 32 : 16;
-  const int64_t tiles = (f->dim / f->n_groups + DT - 1) / DT;
-  if (tiles < 2) return 0;   // one tile per group: nothing to reduce across workgroups
-  const int64_t bytes = (int64_t)f->batch * f->n_groups * tiles * 2 * f->dstate * (int64_t)f->seqlen * 4;
-  return bytes <= ((int64_t)4 << 30) ? bytes : 0;
+  (void)f;
+  return 0;
 }
 
 extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
@@ -708,14 +726,10 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.A = (const float*)f->A; a.D = (const float*)f->D; a.bias = (const float*)f->delta_bias; a.ckpt = (const float*)f->ckpt;
   a.du = d->du; a.ddelta = d->ddelta; a.dz = d->dz;
   a.dA = (float*)d->dA; a.dB = (float*)d->dB; a.dC = (float*)d->dC; a.dD = (float*)d->dD; a.dbias = (float*)d->ddelta_bias;
-  {
-    const int64_t need = mxvl_scan_bwd_workspace_bytes(f);
-    a.ws = (d->workspace && need > 0 && d->workspace_bytes >= need) ? (float*)d->workspace : nullptr;
-  }
   a.dl_ratio = f->delta_group_ratio > 1 ? f->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
-  a.ablate = MXVL_ABL_ENV("MXVL_BWD_ABLATE");
+  a.ablate = 0;
   {
     const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
     const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,

@@ -383,11 +383,11 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   return MXVL_OK;
 }
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
-static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name) {
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T, int NS>
+static int launch_stream1(const ScanArgs& a, hipStream_t stream, const char* name) {
   constexpr int CH = 128, DT = NWAVES * (64 / (CH / T));
-  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * (a.N + 1));
-  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T>;
+  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * (a.N + 1) + NWAVES * 64 + 2 * a.N);
+  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T, NS>;
   const int dpg = a.dim / a.G;
   dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
@@ -396,14 +396,15 @@ static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name
   if (e != hipSuccess) { g_last_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
   return MXVL_OK;
 }
+// dstate 16 (every Mamba block of the reference) takes the instantiation with the compile-time state count
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
+static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name) {
+  return a.N == 16 ? launch_stream1<io_t, NWAVES, VEC, MINW, T, 16>(a, stream, name)
+                   : launch_stream1<io_t, NWAVES, VEC, MINW, T, 0>(a, stream, name);
+}
 #define MXVL_STREAM_CASE(NW, MW) \
   (a.vec_ok ? launch_stream<io_t, NW, true, MW>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ">") \
             : launch_stream<io_t, NW, false, MW>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ">"))
-
-#define MXVL_STREAM16_CASE(NW, MW) \
-  (a.vec_ok ? launch_stream<io_t, NW, true, MW, 16>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ",T16>") \
-            : launch_stream<io_t, NW, false, MW, 16>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ",T16>"))
-
 #define MXVL_FWD_CASE(T, LPR, NW, NU) \
   launch_fwd<io_t, T, LPR, NW, NU>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ">")
 #define MXVL_FWD_CASE_OCC(T, LPR, NW, NU, MW) \
@@ -416,20 +417,25 @@ static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
   int v = g_variant & 0xff;
   if (v == 0) {
     // 16 lanes per row needs rows/4 waves: use wider rows when that cannot fill the 1024 SIMDs
-    if (rows >= 4096 || a.L <= 128) v = (a.N <= 16) ? 10 : 1;
-    else if (rows >= 1024 || a.L <= 256) v = 3;
+    if (rows >= 4096 || a.L <= 128) {
+      if (a.N <= 16) {
+        // measured (profiles/r03_scan_variants.txt): 32-row / 8-wave workgroups win when they still give every CU two rounds of
+        // work on long rows (pre-training shape 342 vs 414 us) or many rounds on short ones (197-token encoder 322 vs 382 us);
+        // otherwise 16-row workgroups at 2 waves per SIMD (fp32 roofline shape 260 vs 286 us at 3 waves per SIMD)
+        const int64_t tiles8 = (int64_t)a.batch * a.G * ((a.dim / a.G + 31) / 32);
+        v = (tiles8 >= 2048 || (tiles8 >= 512 && a.L >= 1024)) ? 12 : 14;
+      } else {
+        v = 1;
+      }
+    } else if (rows >= 1024 || a.L <= 256) v = 3;
     else v = 4;
   }
   if (a.N <= 16) {
     switch (v) {
       case 10: return MXVL_STREAM_CASE(4, 3);
-      case 11: return MXVL_STREAM_CASE(4, 4);
       case 12: return MXVL_STREAM_CASE(8, 3);
-      case 13: return MXVL_STREAM_CASE(2, 3);
       case 14: return MXVL_STREAM_CASE(4, 2);
-      case 15: return MXVL_STREAM16_CASE(4, 2);
-      case 16: return MXVL_STREAM16_CASE(4, 3);
-      case 17: return MXVL_STREAM16_CASE(2, 2);
+      case 20: return MXVL_STREAM_CASE(8, 2);
       default: break;
     }
   }

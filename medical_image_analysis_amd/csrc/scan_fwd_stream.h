@@ -35,7 +35,9 @@ __device__ inline void scan8_x1(float& h0, float& P0, float& x0) {
       : "+v"(h0), "+v"(P0), "+v"(x0));
 }
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8>
+// NS > 0: dstate is the compile-time constant NS (16 = every Mamba block of the reference): the state loop unrolls with
+// immediate LDS offsets and the per-chunk index arithmetic (divisions by N) folds; NS == 0: any dstate <= 16 at run time.
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {
   constexpr int CH = 128, LPR = CH / T, RPW = 64 / LPR, DT = NWAVES * RPW, NT = NWAVES * 64, NMAX = 16;
   constexpr int TQ = T / 4;                           // 16-byte quarters per lane
@@ -46,13 +48,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = p.N, L = p.L;
+  const int N = NS > 0 ? NS : p.N, L = p.L;
   float* sBC = smem;                          // [2 buffers][B|C][N][CH]
   float* sO = sBC + 4 * N * CH;               // [DT][CH] out tile (unaligned rows / ragged tail)
-  float2* sAC = (float2*)(sO + DT * CH);      // [DT + 1][NP] {A*log2(e), running state h}; row DT stays zero
+  float2* sAC = (float2*)(sO + DT * CH);      // [DT + 2][NP] {A*log2(e), running state h}; row DT stays zero, row DT + 1.. = dump
   // rows are padded by one float2: with a stride of 2N = 32 words every row's state n sat on the same bank, and the per-state
   // b32 accesses of the 4 rows of a wave (+ the zero row) were 2-3-way conflicts (half of SQ_LDS_BANK_CONFLICT)
   const int NP = N + 1;
+  float* sDump = (float*)(sAC + (DT + 1) * NP);   // [NT + 2 N] write-only words of the lanes that do not own a state entry
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane / LPR, j = lane % LPR;
@@ -167,27 +170,39 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
   };
   // ---- a lane's T consecutive elements of one row ----------------------------------------------------
-  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
-    if (t0 + CH <= L) {
-      if constexpr (VEC) {
-#pragma unroll
-        for (int k = 0; k < TQ; ++k) {
-          const float4 a = ld4<io_t>(q + t0 + 4 * k);
-          v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < T; ++i) v[i] = io::ld(q + t0 + i);
-      }
-    } else if (VEC && t0 + j * T + T <= L) {   // ragged last chunk, aligned rows: this lane's 8 steps are all valid
+  // u and delta of a chunk: ONE whole / partial branch for both arrays, so both requests are in flight before either is used
+  // (two independent fetch calls serialised their HBM round trips on ragged chunks -- every second chunk of a 197-token row)
+  auto ldT = [&](const io_t* q, float (&v)[T]) {
+    if constexpr (VEC) {
 #pragma unroll
       for (int k = 0; k < TQ; ++k) {
-        const float4 a = ld4<io_t>(q + t0 + 4 * k);
+        const float4 a = ld4<io_t>(q + 4 * k);
         v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
       }
     } else {
 #pragma unroll
+      for (int i = 0; i < T; ++i) v[i] = io::ld(q + i);
+    }
+  };
+  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
+    if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+      ldT(q + t0, v);
+    } else {
+#pragma unroll
       for (int i = 0; i < T; ++i) v[i] = (t0 + j * T + i < L) ? io::ld(q + t0 + i) : 0.0f;
+    }
+  };
+  auto ud_fetch = [&](int t0, float (&vu)[T], float (&vd)[T]) {
+    if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+      ldT(pu + t0, vu);
+      ldT(pd + t0, vd);
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const bool ok = t0 + j * T + i < L;
+        vu[i] = ok ? io::ld(pu + t0 + i) : 0.0f;
+        vd[i] = ok ? io::ld(pd + t0 + i) : 0.0f;
+      }
     }
   };
 
@@ -199,8 +214,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #endif
   float un[T], dn[T];
   bc_fetch(0);
-  row_fetch(pu, 0, un);
-  row_fetch(pd, 0, dn);
+  ud_fetch(0, un, dn);
   bc_commit(0);
 
   for (int c = 0; c < nchunks; ++c) {
@@ -229,8 +243,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     // requests for the next chunk (and this chunk's z) go out before the long state loop
     if (more) {
       bc_fetch(t0 + CH);
-      row_fetch(pu, t0 + CH, un);
-      row_fetch(pd, t0 + CH, dn);
+      ud_fetch(t0 + CH, un, dn);
     }
     if (has_z) row_fetch(pz, t0, zz);
 
@@ -248,17 +261,22 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
     float2* ac = sAC + row * NP;
     const float2* ac_in = sAC + ((j == 0) ? row : DT) * NP;  // only lane 0 sees the state entering the chunk
+    // the last lane of a row stores the state leaving the chunk; the others store into a private dump word (an exec-masked
+    // store cost s_and_saveexec / s_cbranch / s_or per state)
+    float* ac_out = (j == LPR - 1) ? &ac[0].y : sDump + tid;
     const float* cB = sBC + (c & 1) * 2 * N * CH;
     const float* cC = cB + N * CH;
     int rq[TQ];                                               // this lane's word offset inside a tile row, per quarter
 #pragma unroll
     for (int k = 0; k < TQ; ++k) rq[k] = k * (LPR * 4) + ((j * 4 + (k & 1) * SWZ) & (LPR * 4 - 1));
 
-#pragma unroll 4
-    for (int n = 0; n < (MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N); ++n) {
+    // one state up to the lane map (P, h): B/C tile rows, a_i = exp2(delta_i A), b_i = delta_i u_i B_i, Horner fold.
+    // (Requesting the LDS operands one state ahead -- a software pipeline over Pre{A2, car, b[], c[]} -- measured SLOWER at every
+    // shape, 260 -> 307 us at the roofline shape, profiles/r03b_scan_variants_prefetch.txt: the compiler's own placement of the
+    // next state's ds_reads behind the DPP scan is kept.)
+    auto fold = [&](int n, float (&a)[T], float (&bb)[T], float (&cv)[T], float& P, float& hl, float& car) {
       const float A2 = ac[n].x;
-      const float car = ac_in[n].y;                           // state entering the chunk (lane 0), 0 elsewhere
-      float a[T], bb[T], cv[T];
+      car = ac_in[n].y;                                       // state entering the chunk (lane 0), 0 elsewhere
 #pragma unroll
       for (int k = 0; k < TQ; ++k) {
         const float4 b4 = *(const float4*)(cB + n * CH + rq[k]);
@@ -268,29 +286,55 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       }
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        a[i] = fast_exp2(dl[i] * A2);
+        a[i] = dl[i] * A2;
         bb[i] = du[i] * bb[i];
+      }
+      P = A2 * dsum;
+      // the T + 1 v_exp_f32 of a state back to back: 8 cycles each alone, 10-16 when interleaved with FMAs
+      // (profiles/r01_ubench_valu_mix.txt)
+      if constexpr (T == 8) {
+        asm volatile(
+            "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
+            "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(P));
+      } else {
+        asm volatile(
+            "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
+            "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(P));
+        asm volatile(
+            "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
+            "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+            : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
       }
       float h = bb[0];
 #pragma unroll
       for (int i = 1; i < T; ++i) h = fmaf(a[i], h, bb[i]);   // pass 1: lane map h_out = P*h_in + h
-      float P = fast_exp2(A2 * dsum);
-      float x = car;
-      float hl = fmaf(P, car, h);                             // lane 0 absorbs the incoming state
+      hl = fmaf(P, car, h);                                   // lane 0 absorbs the incoming state
+    };
+    auto pass2 = [&](int n, const float (&a)[T], const float (&bb)[T], const float (&cv)[T], float hl, float x) {
+      ac_out[2 * n] = hl;                                     // state leaving the chunk (last lane of the row)
+      float h = x;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        h = fmaf(a[i], h, bb[i]);
+        y[i] = fmaf(cv[i], h, y[i]);
+      }
+    };
+    const int n_states = MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N;
+#pragma unroll 2
+    for (int n = 0; n < n_states; ++n) {
+      float a[T], bb[T], cv[T], P, hl, x;
+      fold(n, a, bb, cv, P, hl, x);
       if constexpr (LPR == 16) {
         scan16_x1(hl, P, x);
       } else {
+        const float car = x;
         P = (j == 0) ? 0.0f : P;                              // nothing may flow in from the neighbouring row
         scan8_x1(hl, P, x);
         x = (j == 0) ? car : x;
       }
-      if (j == LPR - 1) ac[n].y = hl;                         // state leaving the chunk
-      h = x;
-#pragma unroll
-      for (int i = 0; i < T; ++i) {                           // pass 2
-        h = fmaf(a[i], h, bb[i]);
-        y[i] = fmaf(cv[i], h, y[i]);
-      }
+      pass2(n, a, bb, cv, hl, x);
     }
 
     if (more) bc_commit((c + 1) & 1);

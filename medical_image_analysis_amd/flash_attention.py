@@ -17,6 +17,7 @@ import torch
 from . import _abi
 
 MASKS = {"none": 0, "causal": 1, "block_causal": 2}
+HEAD_DIMS = (32, 64, 128)      # instantiated forward + backward; 256 forward-only, 16-bit (decode-side prefill)
 
 
 def _rows_ok(t: torch.Tensor) -> bool:
@@ -56,8 +57,8 @@ def attn_fwd_raw(q, k, v, scale, mask_mode=0, cluster=16, key_mask=None, bias=No
         raise RuntimeError(f"attention: inconsistent shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise RuntimeError("attention: q, k, v must share one dtype")
-    if D not in (32, 64, 128):
-        raise RuntimeError(f"attention: head_dim must be 32, 64 or 128, got {D}")
+    if D not in (32, 64, 128, 256):
+        raise RuntimeError(f"attention: head_dim must be 32, 64, 128 (or 256, forward only), got {D}")
     q, k, v = _prep(q), _prep(k), _prep(v)
     if key_mask is not None:
         key_mask = key_mask.to(torch.uint8).contiguous()
@@ -78,8 +79,6 @@ def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=N
     lib = _abi.load()
     q, k, v, key_mask, bias = saved
     B, H, Lq, D = q.shape
-    if D == 128:
-        raise RuntimeError("attention backward supports head_dim 32 / 64 (128 is the decode-side forward)")
     dout = _prep(dout.to(q.dtype))
     dq = _token_major(B, H, Lq, D, q) if dq is None else dq
     dk = _token_major(B, k.shape[1], k.shape[2], D, q) if dk is None else dk
@@ -170,51 +169,90 @@ class _AttentionQKVPacked(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+def _pad_head_dim(D: int) -> int:
+    for d in HEAD_DIMS + (256,):
+        if D <= d:
+            return d
+    raise RuntimeError(f"attention: head_dim {D} > 256 has no kernel")
+
+
+def _padded(q, k, v):
+    """Head dims between the instantiated ones (16, 48, 80, 96 ...) run on the next larger kernel: zero columns add nothing to
+    q.k, and the zero columns of v come back as zero columns of the output, sliced off by the caller.  One copy per operand --
+    only taken by tiny test models; the reference's models have head_dim 32 / 64 / 128."""
+    D = q.shape[-1]
+    Dp = _pad_head_dim(D)
+    if Dp == D:
+        return q, k, v, D
+    pad = lambda t: torch.nn.functional.pad(t, (0, Dp - D))
+    return pad(q), pad(k), pad(v), D
+
+
 def attention(q, k, v, scale=None, mask="none", cluster=16, key_mask=None, bias=None):
     """softmax(q k^T * scale + mask) v.  mask: "none", "causal" (key j <= query i + Lk - Lq) or "block_causal" (key cluster <=
     query cluster, cluster tokens each); key_mask (B, Lk) bool: True = may be attended; bias (Lq, Lk) additive fp32."""
     scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
-    return _Attention.apply(q, k, v, scale, MASKS[mask], int(cluster), key_mask, bias)
+    q, k, v, D = _padded(q, k, v)
+    out = _Attention.apply(q, k, v, scale, MASKS[mask], int(cluster), key_mask, bias)
+    return out if out.shape[-1] == D else out[..., :D]
 
 
 def attention_kvpacked(q, kv, scale=None, mask="none", cluster=16):
     """q (B, H, Lq, D) view, kv (B, Lk, 2, Hkv, D)."""
     scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
+    if q.shape[-1] not in HEAD_DIMS:
+        return attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale, mask, cluster)
     return _AttentionKVPacked.apply(q, kv, scale, MASKS[mask], int(cluster))
 
 
 def attention_qkvpacked(qkv, scale=None, mask="none", cluster=16):
     """qkv (B, L, 3, H, D) -> (B, H, L, D) view of a (B, L, H, D) buffer."""
     scale = float(qkv.shape[-1] ** -0.5 if scale is None else scale)
+    if qkv.shape[-1] not in HEAD_DIMS:
+        return attention(*(qkv[:, :, i].transpose(1, 2) for i in range(3)), scale, mask, cluster)
     return _AttentionQKVPacked.apply(qkv, scale, MASKS[mask], int(cluster))
-
-
-_BLOCK_MASK_CACHE = {}
 
 
 def is_block_causal_mask(mask: torch.Tensor, cluster: int = 16) -> bool:
     """True when the additive (L, L) mask is exactly mask_generate's pattern (models_pretrain.py:395-400): 0 where
-    key cluster <= query cluster, -inf elsewhere.  Checked once per mask storage (the model registers it as a buffer)."""
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape), cluster, str(mask.device))
-    hit = _BLOCK_MASK_CACHE.get(key)
-    if hit is None:
-        L = mask.shape[-1]
-        ok = mask.dim() == 2 and mask.shape[0] == L
-        if ok:
-            i = torch.arange(L, device=mask.device) // cluster
-            want = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")).to(mask.dtype)
-            ok = bool(torch.equal(mask, want))
-        if len(_BLOCK_MASK_CACHE) > 64:
-            _BLOCK_MASK_CACHE.clear()
-        _BLOCK_MASK_CACHE[key] = hit = ok
-    return hit
+    key cluster <= query cluster, -inf elsewhere.  The verdict is cached ON the tensor object (keyed by its version counter
+    and the cluster size), so it dies with the tensor: a cache keyed by data_ptr could hand a recycled address the verdict of
+    a mask that no longer exists."""
+    tag = (mask._version, cluster, tuple(mask.shape))
+    hit = getattr(mask, "_mxvl_block_causal", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    L = mask.shape[-1]
+    ok = mask.dim() == 2 and mask.shape[0] == L
+    if ok:
+        i = torch.arange(L, device=mask.device) // cluster
+        want = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")).to(mask.dtype)
+        ok = bool(torch.equal(mask, want))
+    mask._mxvl_block_causal = (tag, ok)
+    return ok
 
 
 def supported(q, *others) -> bool:
-    """HIP tensors of a supported dtype / head_dim.  head_dim 128 has a forward kernel only (the decode side): when a gradient
-    is going to be asked for, the caller keeps its library path."""
-    if not (q.is_cuda and q.dtype in (torch.float32, torch.bfloat16, torch.float16) and q.shape[-1] in (32, 64, 128)):
+    """HIP tensors the kernels serve: fp32 / bf16 / fp16, head_dim <= 128 forward and backward (32 / 64 / 128 natively, others
+    zero-padded to the next of them), head_dim 256 forward-only for the 16-bit types (a Gemma-sized decoder's prefill)."""
+    if not (q.is_cuda and q.dtype in (torch.float32, torch.bfloat16, torch.float16)):
         return False
-    if q.shape[-1] == 128 and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q,) + others):
+    D = q.shape[-1]
+    if D <= HEAD_DIMS[-1]:
+        return True
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q,) + others)
+    return D == 256 and q.dtype != torch.float32 and not needs_grad
+
+
+def require(q, what: str, dropout_p: float = 0.0) -> bool:
+    """The one dispatch rule of every attention call site: True -> HIP tensors, run the MFMA kernel; False -> CPU tensors, the
+    caller evaluates its torch reference expression (host-side tests, golden generation).  A HIP tensor the kernels cannot
+    serve RAISES -- there is no library attention fallback on the GPU."""
+    if not q.is_cuda:
         return False
+    if dropout_p != 0.0:
+        raise RuntimeError(f"{what}: attention dropout is not implemented by the HIP kernels (the reference trains with attn_drop = 0)")
+    if not supported(q):
+        raise RuntimeError(f"{what}: head_dim {q.shape[-1]} / dtype {q.dtype} has no HIP attention kernel (head_dim <= 128 for "
+                           "fp32 / bf16 / fp16 forward + backward; 256: bf16 / fp16 forward only)")
     return True

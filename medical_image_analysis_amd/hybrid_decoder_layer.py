@@ -124,10 +124,14 @@ class ScaleDotProductCrossAttention(nn.Module):
         (both cross-attention variants build it that way): then the MFMA flash kernel runs, image K/V tiles staged in LDS,
         grouped-query heads served without repeat_kv."""
         p = self.dropout_p if self.training else 0.0
-        if p == 0.0 and attn_mask is None and flash.supported(q, k, v):
+        if flash.require(q, "ScaleDotProductCrossAttention", p):
+            if attn_mask is not None:
+                raise RuntimeError("ScaleDotProductCrossAttention: a query-dependent (B, Lq, Lk) mask has no HIP kernel; both "
+                                   "cross-attention variants of the reference pass a per-key mask (key_mask)")
             o = flash.attention(q, k, v, scale=self.softmax_scale, key_mask=key_mask)
             B, H, L, D = o.shape
             return o.transpose(1, 2).reshape(B, L, H * D)
+        # CPU tensors only (host-side tests, golden comparison): the reference expression
         if key_mask is not None and attn_mask is None:
             attn_mask = key_mask[:, None, :].expand(-1, q.shape[2], -1)
         if k.shape[1] != q.shape[1]:
@@ -257,13 +261,16 @@ class Qwen2HybridAttention(nn.Module):
             k, v = past_key_value.update(k, v, self.layer_idx, {"sin": sin, "cos": cos, "cache_position": cache_position})
         kv_len = k.shape[-2]
         p_drop = self.attention_dropout if self.training else 0.0
-        if p_drop == 0.0 and flash.supported(q, k, v) and (attention_mask is None or attention_mask.dim() == 2):
+        if flash.require(q, "Qwen2HybridAttention", p_drop):
             # MFMA flash attention: causal aligned to the END of the key sequence (decode with a cache) + the (B, kv_len)
             # padding mask as a key mask; grouped-query heads without repeat_kv
+            if attention_mask is not None and attention_mask.dim() != 2:
+                raise RuntimeError("Qwen2HybridAttention: pass the (B, kv_len) padding mask; an additive 4-D mask has no HIP kernel")
             km = None if attention_mask is None else attention_mask[:, :kv_len].bool()
             attn = flash.attention(q, k, v, mask="causal", key_mask=km)
             attn_output = attn.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
             return self._finish(attn_output, q, visual_hidden_states, token_type, text2visual_attention_mask, past_key_value)
+        # CPU tensors only (host-side tests): the reference expression
         kf, vf = repeat_kv(k, self.num_key_value_groups), repeat_kv(v, self.num_key_value_groups)
         # causal mask aligned to the END of the key sequence (decode with a cache), AND the (B, kv_len) padding mask
         causal = torch.ones(q_len, kv_len, dtype=torch.bool, device=q.device).tril(kv_len - q_len)

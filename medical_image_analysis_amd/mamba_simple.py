@@ -314,7 +314,8 @@ class Mamba(nn.Module):
         Bz, _, L = xz.shape
         D, N, R = self.d_inner, self.d_state, self.dt_rank
         fwd, inv, fwd32, inv32 = self._perms(L, xz.device)
-        if (xd is None and xz.is_cuda and L <= 5120 and Bz <= 65535 and os.environ.get("MXVL_MIXER_NODE") != "0"
+        from . import selective_scan_interface as _ssi
+        if (xd is None and xz.is_cuda and L <= 5120 and Bz <= 65535 and _ssi._SINGLE_NODE
                 and xz.dtype in (torch.float32, torch.bfloat16, torch.float16)):
             # v3 on the GPU: gather -> conv -> x_proj -> dt_proj -> scan -> gated merge as ONE node, batch-of-K GEMMs
             mods = [self._dir(s) for s in ["", "_b", "_c", "_c_b"]]

@@ -70,24 +70,6 @@ class Mlp(nn.Module):
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
-def block_causal_attention(q, k, v, mask, dropout_p, scale, chunk=1024):
-    """softmax(q k^T * scale + mask) v for the block-lower-triangular mask of mask_generate: query row i never sees a key
-    beyond the end of its own 16-token cluster, so the queries are processed in cluster-aligned chunks and chunk j only
-    multiplies against keys [0, end of chunk j) -- the all -inf upper-right part of the score matrix (3/8 of it at
-    4080 tokens in 4 chunks; measured 4.52 -> 3.68 ms fwd+bwd, smaller chunks lose more in kernel efficiency than they
-    skip) is never computed.  Same values as one masked call: masked keys have zero weight."""
-    N = q.shape[-2]
-    if N <= 2 * chunk or N != k.shape[-2] or mask.shape[-2:] != (N, N):
-        return F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=dropout_p, scale=scale)
-    outs = []
-    for q0 in range(0, N, chunk):
-        q1 = min(N, q0 + chunk)
-        k1 = min(N, -(-q1 // 16) * 16)        # keys up to the end of the last query's cluster
-        outs.append(F.scaled_dot_product_attention(q[:, :, q0:q1], k[:, :, :k1], v[:, :, :k1], attn_mask=mask[q0:q1, :k1],
-                                                   dropout_p=dropout_p, scale=scale))
-    return torch.cat(outs, dim=-2)
-
-
 class CrossAttention(nn.Module):
     """q from the AR tokens, k/v from one encoder tap, additive block-causal mask (:69-83).
     As in the reference, kv is reshaped with q's token count, so len(q) == len(kv) is required (:72)."""
@@ -109,16 +91,16 @@ class CrossAttention(nn.Module):
         p = self.attn_drop.p if self.training else 0.0
         q = self.q(q).reshape(B, N, H, C // H).transpose(1, 2)                 # (B, H, N, dh) view, no copy
         kv = self.kv(kv).reshape(B, N, 2, H, C // H)                           # packed (B, N, 2, H, dh)
-        if p == 0.0 and flash.supported(q):
+        if flash.require(q, "pre-training CrossAttention", p):
             # hand-written MFMA flash attention (csrc/attn.hip): the block-lower-triangular mask of mask_generate is a kernel
             # mode that never visits the tiles above the diagonal; any other mask tensor goes in as an additive bias
             if flash.is_block_causal_mask(mask, 16):
                 x = flash.attention_kvpacked(q, kv, scale=self.scale, mask="block_causal", cluster=16)
             else:
                 x = flash.attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale=self.scale, bias=mask)
-        else:   # CPU tensors / attention dropout: the library path
+        else:   # CPU tensors only (host-side tests, golden comparison): the reference expression (models_pretrain.py:69-83)
             kvp = kv.permute(2, 0, 3, 1, 4)
-            x = block_causal_attention(q, kvp[0], kvp[1], mask.to(q.dtype), p, self.scale)
+            x = F.scaled_dot_product_attention(q, kvp[0], kvp[1], attn_mask=mask.to(q.dtype), dropout_p=p, scale=self.scale)
         x = x.transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 

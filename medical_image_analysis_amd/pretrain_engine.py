@@ -28,9 +28,9 @@ def enable_tuned_gemms(path: str | None = None) -> bool:
     """Library GEMMs (in/out/x/dt projections, SwiGLU, decoder) keep going to hipBLASLt / rocBLAS, but with the
     per-shape solution picked offline on an MI355X by PyTorch TunableOp (tools/tune_gemms.py; e.g. the merged
     SwiGLU w1|w2 GEMM 32640x5460x1024: 0.55 ms default -> 0.27 ms tuned).  Read-only at run time: no tuning, no file
-    writes; shapes that are not in the file use the library default.  MXVL_TUNED_GEMMS=0 disables it."""
+    writes; shapes that are not in the file use the library default."""
     path = path or TUNED_GEMMS
-    if os.environ.get("MXVL_TUNED_GEMMS", "1") == "0" or not torch.cuda.is_available() or not os.path.exists(path):
+    if not torch.cuda.is_available() or not os.path.exists(path):
         return False
     if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1":      # an explicit tuning session (tools/tune_gemms.py) owns the settings
         return False

@@ -344,6 +344,10 @@ class _KernelStepper(_SearchFusion):
             if not (at.cross_attention_implementation.startswith("vanilla") and hasattr(at, "cross_attn_gate_proj")
                     and lay.media_locations is not None and lay.vis_x.dim() == 3 and rows % lay.vis_x.shape[0] == 0):
                 return False
+            # a gating type that names the warm-up gate without ending in it has no such parameter: the module path raises
+            # there (as the reference does, hybrid_decoder_layer.py:631-640) -- the kernel path must not decode without the gate
+            if "warmup" in at.gating_type and not hasattr(at, "cross_attn_warm_up_gate"):
+                return False
         return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and D in (64, 128, 256)
                 and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
                 and rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024)

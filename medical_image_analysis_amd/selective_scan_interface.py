@@ -16,7 +16,6 @@ csrc/selective_scan/cus/selective_scan.cpp:165-215 raised as RuntimeError.
 from __future__ import annotations
 
 import ctypes
-import os
 
 import torch
 
@@ -142,12 +141,6 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
     return out, last, ckpt
 
 
-# dB / dC across channel tiles: False = fp32 global atomics (default: measured FASTER on MI355X -- 1.34 ms vs 1.47 ms at the
-# pre-training shape, profiles/r02_bwd_workspace_ab.txt: the atomics are asynchronous and the 267 MB of partials are not free);
-# True = per-tile plain stores into a scratch + scan_bwd_reduce_kernel (bit-reproducible dB / dC, no atomics).
-USE_BWD_WORKSPACE = False
-
-
 def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout, du=None, dz=None, dB=None, dC=None,
                  dout_f32=False):
     """One mxvl_scan_bwd call; returns du, ddelta, dA, dB, dC, dD, dz, ddelta_bias (fp32 for weights,B,C).
@@ -186,10 +179,7 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     desc.dout, desc.du, desc.ddelta, desc.dz = dout.data_ptr(), du.data_ptr(), ddelta.data_ptr(), _abi.ptr(dz)
     desc.dA, desc.dB, desc.dC = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     desc.dD, desc.ddelta_bias = _abi.ptr(dD), _abi.ptr(dbias)
-    # scratch for the per-tile dB / dC shares (plain stores + a second small kernel instead of fp32 global atomics)
-    ws_bytes = int(lib.mxvl_scan_bwd_workspace_bytes(ctypes.byref(desc.fwd))) if USE_BWD_WORKSPACE else 0
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=u.device) if ws_bytes > 0 else None
-    desc.workspace, desc.workspace_bytes = _abi.ptr(ws), ws_bytes
+    desc.workspace, desc.workspace_bytes = None, 0     # ABI v3 field, ignored since round 3 (dB / dC leave as fp32 atomics)
     timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
         if timers is not None:
@@ -308,7 +298,7 @@ _WGRAD_SPLITS = {(5460, 1024, 65280): 16}     # SwiGLU w1|w2 at per-GPU batch 16
 
 def wgrad_splits(K, M, N):
     """Number of token slices: enough (slices x 256^2 output tiles) to give every CU work, a power of two dividing K."""
-    if K < 4096 or os.environ.get("MXVL_WGRAD_SPLITS") == "0":
+    if K < 4096:
         return 1
     if (M, N, K) in _WGRAD_SPLITS and K % _WGRAD_SPLITS[(M, N, K)] == 0:
         return _WGRAD_SPLITS[(M, N, K)]
@@ -495,8 +485,11 @@ class _MambaInnerFn(torch.autograd.Function):
         io = xc.dtype
         xc2 = _dmajor_2d(xc)
         wx, wdt = x_proj_w.to(io), dt_proj_w.to(io)
-        x_dbl = torch.matmul(wx, xc2)                                            # (R+2N, B*L)
-        dt = _from_2d(torch.matmul(wdt, x_dbl[:R]), batch, L)
+        # the projections run in the io dtype of the conv output whatever the ambient autocast says: under bf16 autocast an
+        # fp32 xz would otherwise meet bf16 x_dbl / dt / B / C in the scan ("delta.dtype != u.dtype")
+        with torch.autocast(device_type="cuda", enabled=False):
+            x_dbl = torch.matmul(wx, xc2)                                        # (R+2N, B*L)
+            dt = _from_2d(torch.matmul(wdt, x_dbl[:R]), batch, L)
         Bm, Cm = _from_2d(x_dbl[R:R + N], batch, L), _from_2d(x_dbl[R + N:R + 2 * N], batch, L)
         if B_proj_bias is not None:
             Bm = Bm + B_proj_bias.to(io)[None, :, None]
@@ -564,8 +557,9 @@ def mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad):
     Xc = conv1d_fwd_raw(Xf, w32, b32, 1)                           # same (channel-major) layout
     io = Xc.dtype
     wx, wdt = Wx.detach().to(io), Wdt.detach().to(io)
-    x_dbl = torch.bmm(wx, Xc.permute(1, 0, 2).reshape(K, D, T))    # (K, R+2N, T)
-    dt = torch.bmm(wdt, x_dbl[:, :R]).view(K * D, B, Lp).permute(1, 0, 2)          # (B, K*D, Lp)
+    with torch.autocast(device_type="cuda", enabled=False):       # io-dtype GEMMs whatever the ambient autocast (see _MambaInnerFn)
+        x_dbl = torch.bmm(wx, Xc.permute(1, 0, 2).reshape(K, D, T))                # (K, R+2N, T)
+        dt = torch.bmm(wdt, x_dbl[:, :R]).view(K * D, B, Lp).permute(1, 0, 2)      # (B, K*D, Lp)
     Bm = x_dbl[:, R:R + N].view(K, N, B, Lp).permute(2, 0, 1, 3)                   # (B, K, N, Lp), strided rows of x_dbl
     Cm = x_dbl[:, R + N:R + 2 * N].view(K, N, B, Lp).permute(2, 0, 1, 3)
     _, u_, dt_, A_, B_, C_, D_, _, bias_ = _prep(Xc, dt, A.detach(), Bm, Cm, None if Dv is None else Dv.detach(), None,
@@ -605,10 +599,14 @@ def mdir_core_backward(saved, meta, dy):
             dbias.to(bias_dt) if dbias is not None else None)
 
 
-# The single-node mixer (above) is the default on the GPU; MXVL_MIXER_NODE=0 keeps the composition of separate autograd nodes
-# (same kernels), which the tests hold against it.
+# The single-node mixer (above) is THE path on the GPU.  The composition of separate autograd nodes below it (same kernels) is
+# what v4 / over-long sequences use and what tests/test_mixer_gpu.py holds the node against: the tests reach it by patching this
+# constant -- there is no run-time switch (no environment variable) in the product.
+_SINGLE_NODE = True
+
+
 def _use_mixer_node(xz):
-    return xz.is_cuda and os.environ.get("MXVL_MIXER_NODE") != "0"
+    return xz.is_cuda and _SINGLE_NODE
 
 
 def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B=None, C=None,

@@ -56,6 +56,13 @@ CASES = [
     (1, 2, 2, 48, 48, 64, "block_causal", "bhld"),      # the golden's geometry (3 clusters)
     (2, 8, 8, 528, 528, 64, "block_causal", "blhd"),    # several diagonal tiles
     (1, 2, 1, 33, 5, 64, "none", "bhld"),               # fewer keys than one tile
+    # head_dim 128 (Llama-2-7B / Qwen heads: the hybrid decoder's training-time attention), forward AND backward
+    (2, 4, 2, 230, 230, 128, "causal", "blhd"),         # decoder self-attention: GQA, prompt-length rows
+    (1, 4, 4, 41, 197, 128, "none", "blhd"),            # text queries x 197 image keys
+    (1, 2, 2, 160, 160, 128, "block_causal", "bhld"),
+    # head dims between the instantiated ones run zero-padded on the next larger kernel (tiny test models: 16, 48)
+    (2, 4, 4, 9, 9, 16, "causal", "blhd"),
+    (1, 3, 3, 70, 70, 48, "none", "bhld"),
 ]
 
 
@@ -154,3 +161,52 @@ def test_attention_block_causal_equals_mask_generate_semantics_at_full_size():
                             ("dv", kvl.grad[:1, :, 1].transpose(1, 2), vr.grad)):
         sc = max(1.0, float(want.abs().max()))
         assert_close(got, want, 6e-2 * sc, 5e-2, name + " 4080 tokens")
+
+
+def test_gpu_attention_has_no_library_fallback():
+    """Every attention call site dispatches through flash.require: HIP tensors take the MFMA kernels or RAISE (attention
+    dropout, head_dim without a kernel, query-dependent masks); only CPU tensors evaluate the torch reference expression."""
+    import torch.nn.functional as F
+    from medical_image_analysis_amd import flash_attention as flash
+    from medical_image_analysis_amd.hybrid_decoder_layer import ScaleDotProductCrossAttention
+    from medical_image_analysis_amd.mae import Attention
+    q = torch.randn(1, 2, 8, 160, device=DEV)
+    with pytest.raises(RuntimeError, match="head_dim 160"):
+        flash.require(q, "test")
+    with pytest.raises(RuntimeError, match="head_dim 256"):       # 256 is forward-only, 16-bit
+        flash.require(torch.randn(1, 2, 8, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True), "test")
+    assert flash.require(torch.randn(1, 2, 8, 256, device=DEV, dtype=torch.bfloat16), "test") is True
+    with pytest.raises(RuntimeError, match="dropout"):
+        flash.require(torch.randn(1, 2, 8, 64, device=DEV), "test", 0.1)
+    assert flash.require(torch.randn(1, 2, 8, 128, device=DEV, requires_grad=True), "test") is True
+    assert flash.require(torch.randn(1, 2, 8, 64), "test") is False           # CPU: host-side reference path
+    m = Attention(128, num_heads=2, qkv_bias=True, attn_drop=0.1).to(DEV).train()
+    with pytest.raises(RuntimeError, match="dropout"):
+        m(torch.randn(2, 9, 128, device=DEV))
+    ca = ScaleDotProductCrossAttention(0)
+    qq, kk = torch.randn(1, 2, 4, 64, device=DEV), torch.randn(1, 2, 6, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="query-dependent"):
+        ca(qq, kk, kk, attn_mask=torch.ones(1, 4, 6, dtype=torch.bool, device=DEV))
+    calls = []
+    orig = F.scaled_dot_product_attention
+    try:
+        F.scaled_dot_product_attention = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        m.eval()(torch.randn(2, 9, 128, device=DEV))
+        ca(qq, kk, kk, key_mask=torch.ones(1, 6, dtype=torch.bool, device=DEV))
+    finally:
+        F.scaled_dot_product_attention = orig
+    assert not calls, "a HIP tensor reached F.scaled_dot_product_attention"
+
+
+def test_block_causal_mask_verdict_is_cached_on_the_tensor_not_on_its_address():
+    from medical_image_analysis_amd.flash_attention import is_block_causal_mask
+    L = 64
+    i = torch.arange(L, device=DEV) // 16
+    good = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf"))
+    assert is_block_causal_mask(good, 16) and is_block_causal_mask(good, 16)
+    ptr = good.data_ptr()
+    del good
+    bad = torch.zeros(L, L, device=DEV)                    # very likely the recycled allocation
+    assert not is_block_causal_mask(bad, 16), f"stale verdict (same address: {bad.data_ptr() == ptr})"
+    bad.copy_(torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")))      # in-place update bumps the version counter
+    assert is_block_causal_mask(bad, 16)

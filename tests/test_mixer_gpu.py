@@ -270,7 +270,7 @@ def test_single_node_mixer_equals_composed_nodes(dtype, L, proj_bias, monkeypatc
     dout = mk(B, d, L).to(dtype)
 
     def run(node):
-        monkeypatch.setenv("MXVL_MIXER_NODE", "1" if node else "0")
+        monkeypatch.setattr("medical_image_analysis_amd.selective_scan_interface._SINGLE_NODE", bool(node))
         P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
         hidden = hidden0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
@@ -293,6 +293,27 @@ def test_single_node_mixer_equals_composed_nodes(dtype, L, proj_bias, monkeypatc
         assert_close(g1[k], g0[k], tol * scale, tol, "grad " + k)
 
 
+def test_mamba_inner_fn_with_fp32_xz_under_bf16_autocast():
+    """A direct / drop-in mamba_inner_fn call on an fp32 xz inside a bf16 autocast region: the single node's x_proj / dt_proj
+    GEMMs must run in the io dtype of the conv output (fp32 here) -- under the ambient autocast they came out bf16 and the scan
+    raised 'delta.dtype != u.dtype'.  Same values as the call outside autocast."""
+    from medical_image_analysis_amd.selective_scan_interface import mamba_inner_fn_no_out_proj
+    B, d, N, R, L = 2, 64, 16, 4, 197
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(DEV)
+    xz = mk(B, 2 * d, L)
+    args = (mk(d, 1, 4, sc=0.5), mk(d, sc=0.1), mk(R + 2 * N, d, sc=d ** -0.5), mk(d, R, sc=R ** -0.5),
+            -torch.exp(torch.log(torch.arange(1, N + 1, dtype=torch.float32)).repeat(d, 1)).to(DEV), None, None, mk(d))
+    kw = dict(delta_bias=mk(d, sc=0.5), delta_softplus=True)
+    want = mamba_inner_fn_no_out_proj(xz, *args, **kw)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        x2 = xz.clone().requires_grad_(True)
+        got = mamba_inner_fn_no_out_proj(x2, *args, **kw)
+        got.sum().backward()
+    assert got.dtype == torch.float32 and torch.equal(got.detach(), want)
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
+
+
 @pytest.mark.parametrize("dtype,S", [(torch.float32, 5), (torch.bfloat16, 14)])
 def test_v3_mixer_single_node_equals_composed_nodes(dtype, S, monkeypatch):
     """bimamba v3 (4 scan directions): the direction-channel-major single node (_MultiDirMixerFn: batch-of-4 GEMMs over the
@@ -310,7 +331,7 @@ def test_v3_mixer_single_node_equals_composed_nodes(dtype, S, monkeypatch):
     dout = torch.randn(3, L, 64, device=DEV)
 
     def run(node):
-        monkeypatch.setenv("MXVL_MIXER_NODE", "1" if node else "0")
+        monkeypatch.setattr("medical_image_analysis_amd.selective_scan_interface._SINGLE_NODE", bool(node))
         m.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):

@@ -281,6 +281,10 @@ def test_keyed_fp32_path_matches_hf(dev, name):
     g = load_golden(name)
     m = _model_keyed(g, dev, torch.float32)
     emb, att = g["inputs_embeds"].to(dev), g["attention_mask"].to(dev)
+    if dev != "cpu" and name.endswith("256"):      # fp32 at head_dim 256 has no HIP attention kernel: raised, not routed to a library
+        with pytest.raises(RuntimeError, match="head_dim 256"):
+            m(emb, attention_mask=att)
+        return
     with torch.no_grad():
         logits = m(emb, attention_mask=att)[:, -1]
     scale = float(g["logits_prompt"].abs().max())
@@ -340,6 +344,10 @@ def test_hip_decode_generate_tokens_match_hf_hd128_hd256(name):
         assert torch.equal(out.cpu(), g[key]), f"{key}: {out.cpu().tolist()} vs HF {g[key].tolist()}"
 
 
+def _KernelStepperFits(rows, K):
+    return rows * K * 2 <= 150 * 1024      # the same bound _KernelStepper.supported applies to hidden / intermediate sizes
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,N,mode", [(4096, 4096, "plain"), (4096, 12288, "norm_bias"), (4096, 11008, "norm_swiglu"),
                                       (11008, 4096, "residual"), (4096, 32000, "norm_f32"), (11008, 32000, "plain"),
@@ -368,7 +376,11 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
     d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(f32), 1e-6
     d.x, d.norm_weight, d.W = x.data_ptr(), _abi.ptr(norm), W.data_ptr()
     d.W2, d.bias, d.residual, d.y = _abi.ptr(W2), _abi.ptr(bias), _abi.ptr(res), y.data_ptr()
-    _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv")
+    rc = lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device))
+    if rows * K * 2 > 150 * 1024:          # the activations of all rows must fit in LDS (include/mxvl.h): refused, not mis-computed
+        assert rc != 0 and not _KernelStepperFits(rows, K)
+        return
+    _abi.check(rc, "mxvl_decode_gemv")
     torch.cuda.synchronize()
     xf = x.float()
     if norm is not None:      # Qwen2RMSNorm / LlamaRMSNorm: fp32 statistics, cast to bf16, times the bf16 gain (hybrid_decoder_layer.py:185-199)

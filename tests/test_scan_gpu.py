@@ -23,6 +23,21 @@ def _atol(ref):
     return 1e-4 * max(1.0, float(ref.abs().max()) / 32)
 
 
+def assert_flat_1e4_if_unit_scale(got, ref, what):
+    """north_star's FLAT fp32 bound for every tensor whose values stay at unit scale (max |ref| < 32): |err| <= 1e-4 + 1e-5 |ref|
+    on every element, no scaling.  Returns whether the tensor qualified.  (The long-sequence goldens reach |out| = 262 --
+    N(0,1) inputs accumulated over 4097 steps -- and there the error is 4.6e-4 = 1.8e-6 of the largest element on 30 of 49164
+    elements, measured in round 3: those are held to the scaled bound _atol, 1e-4 * max|ref| / 32, as before.)"""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    if float(ref.abs().max()) >= 32.0:
+        return False
+    err = (got - ref).abs()
+    bad = err > 1e-4 + 1e-5 * ref.abs()
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())} / {bad.numel()} elements beyond the flat 1e-4 bound; max err "
+                                 f"{float(err.max()):.3e}, max |ref| {float(ref.abs().max()):.3e}")
+    return True
+
+
 def _to(d, dev, dtype=None):
     out = {}
     for k, v in d.items():
@@ -35,7 +50,7 @@ def _to(d, dev, dtype=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 10, 12, 13, 15, 17, 99])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 10, 12, 14, 20, 99])
 @pytest.mark.parametrize("name", golden_names("scan_"))
 def test_scan_fwd_golden(name, variant):
     from medical_image_analysis_amd import _abi
@@ -53,6 +68,8 @@ def test_scan_fwd_golden(name, variant):
         _abi.load().mxvl_set_scan_variant(0)
     assert_close(out, g["out"], _atol(g["out"]), 1e-5, f"out [{_abi.load().mxvl_last_scan_kernel().decode()}]")
     assert_close(last, g["last_state"], _atol(g["out"]), 1e-5, "last_state")
+    flat = assert_flat_1e4_if_unit_scale(out, g["out"], f"out of {name}, flat 1e-4 [{_abi.load().mxvl_last_scan_kernel().decode()}]")
+    assert flat == (float(g["out"].abs().max()) < 32.0)
 
 
 CASES = [
@@ -195,6 +212,36 @@ def test_scan_north_star_shape_rows_vs_oracle_and_linearity():
     assert_close(o3, want, 1e-4 * max(1.0, float(want.abs().max()) / 32), 1e-4, "out is linear in u")
 
 
+def test_scan_north_star_shape_full_channel_dB_dC_vs_oracle():
+    """dB / dC of the roofline shape are sums over ALL 1536 channels (4 rows per wave -> 8 waves in LDS -> 48 workgroups by
+    fp32 atomics): one whole batch element (every channel, every step, 100 M state-steps) against the C oracle's backward --
+    a wrong cross-row / cross-wave / cross-workgroup sum that is linear in dout would pass the linearity test above."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    B, D, L, N = 8, 1536, 4096, 16
+    gen = torch.Generator(device=dev).manual_seed(7)
+    r = lambda *s: torch.randn(*s, device=dev, generator=gen)
+    A = -0.5 * torch.rand(D, N, device=dev, generator=gen) - 0.05
+    u, z = r(B, D, L), r(B, D, L)
+    delta = 0.5 * torch.rand(B, D, L, device=dev, generator=gen)
+    Bm, Cm = r(B, N, L), r(B, N, L)
+    Dv, bias = r(D), 0.5 * torch.rand(D, device=dev, generator=gen)
+    dout = r(B, D, L)
+    x = [t.clone().requires_grad_(True) for t in (u, delta, A, Bm, Cm, Dv, z, bias)]
+    out = selective_scan_fn(x[0], x[1], x[2], x[3], x[4], x[5], z=x[6], delta_bias=x[7], delta_softplus=True)
+    out.backward(dout)
+    b = 5
+    c = lambda t: t.detach().cpu()
+    ref = orc.selective_scan_ref_bwd(c(u[b:b + 1]), c(delta[b:b + 1]), c(A), c(Bm[b:b + 1]), c(Cm[b:b + 1]), c(Dv), c(z[b:b + 1]),
+                                     c(bias), True, c(dout[b:b + 1]))
+    for k, got in (("dB", x[3].grad[b:b + 1]), ("dC", x[4].grad[b:b + 1]), ("du", x[0].grad[b:b + 1]),
+                   ("ddelta", x[1].grad[b:b + 1]), ("dz", x[6].grad[b:b + 1])):
+        # sums of 1536 channel terms of either sign: the fp32 summation-order noise scales with the largest element
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert_close(got, ref[k].reshape(got.shape), 2e-5 * scale, 2e-4, f"{k} of batch element {b}, every channel")
+
+
 def test_scan_rejects_bad_arguments():
     from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
     dev = _dev()
@@ -279,11 +326,11 @@ def test_scan_bwd_half_io():
         assert_close(got[k], r, 5e-2 * scale * 0.2, 6e-2, k)
 
 
-def test_scan_bwd_workspace_and_atomic_paths_agree():
-    """mxvl_scan_bwd with the dB/dC scratch (plain per-tile stores + scan_bwd_reduce_kernel) and without it (fp32 global
-    atomics) on a multi-tile, grouped, ragged-length problem: same gradients, and both equal the oracle."""
-    import medical_image_analysis_amd.selective_scan_interface as ssi
+def test_scan_bwd_multi_tile_grouped_ragged_matches_oracle_and_reports_no_workspace():
+    """mxvl_scan_bwd on a multi-tile, grouped, ragged-length problem (dstate 8: the run-time-dstate instantiation) against
+    the oracle; the per-tile dB/dC workspace of ABI v3 is gone (it measured slower than the atomics): the size query says 0."""
     from oracle import oracle as orc
+    import medical_image_analysis_amd.selective_scan_interface as ssi
     dev = _dev()
     B, D, L, N, G = 2, 192, 333, 8, 2
     cpu = scan_inputs(B, D, L, N, G, True, True, True, seed=21)
@@ -291,30 +338,15 @@ def test_scan_bwd_workspace_and_atomic_paths_agree():
     ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
                                      cpu["delta_bias"], True, dout)
     x = _to(cpu, dev)
-    got = {}
-    for flag in (True, False):
-        ssi.USE_BWD_WORKSPACE = flag
-        try:
-            got[flag] = _grads_via_autograd(x, True, dout.to(dev))
-        finally:
-            ssi.USE_BWD_WORKSPACE = False
+    got = _grads_via_autograd(x, True, dout.to(dev))
     from medical_image_analysis_amd import _abi
     import ctypes
     desc = _abi.ScanDesc()
     ssi._fill_fwd(desc, x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, None, None, None)
-    need = int(_abi.load().mxvl_scan_bwd_workspace_bytes(ctypes.byref(desc)))
-    assert need == B * G * (D // G // 16) * 2 * N * L * 4, "16-row tiles here: 6 tiles per group"
+    assert int(_abi.load().mxvl_scan_bwd_workspace_bytes(ctypes.byref(desc))) == 0
     for k, r in ref.items():
         scale = max(1.0, float(r.abs().max()))
-        assert_close(got[True][k], r, 2e-5 * scale, 1e-4, k + " (workspace path)")
-        assert_close(got[False][k], r, 2e-5 * scale, 1e-4, k + " (atomic path)")
-    # the workspace path sums in a fixed order: bit-reproducible dB / dC
-    ssi.USE_BWD_WORKSPACE = True
-    try:
-        again = _grads_via_autograd(x, True, dout.to(dev))
-    finally:
-        ssi.USE_BWD_WORKSPACE = False
-    assert torch.equal(again["dB"], got[True]["dB"]) and torch.equal(again["dC"], got[True]["dC"])
+        assert_close(got[k], r, 2e-5 * scale, 1e-4, k)
 
 
 @pytest.mark.parametrize("shape", [(2, 192, 333, 8, 2, torch.float32),      # ragged last chunk, unaligned rows (scalar tile path)
@@ -322,8 +354,9 @@ def test_scan_bwd_workspace_and_atomic_paths_agree():
                                    (8, 1024, 1032, 16, 1, torch.bfloat16),
                                    (2, 64, 522, 3, 1, torch.float32),      # odd state count, ragged rows of an aligned tensor
                                    (3, 80, 200, 6, 1, torch.float16)])
-def test_scan_bwd_workgroup_shapes_and_dBdC_paths_agree(shape):
-    """mxvl_scan_bwd in its workgroup shapes (variant 1: 8 waves x 32 rows, 2: 4 waves x 16 rows) and dB / dC paths (fp32 global atomics, or the per-tile workspace + reduce kernel).  In the default
+def test_scan_bwd_workgroup_shapes_agree(shape):
+    """mxvl_scan_bwd in its workgroup shapes (variant 1: 8 waves x 32 rows, 2: 4 waves x 16 rows), compile-time (16) and
+    run-time dstate instantiations.  In the default
     kernels a wave sums its 4 rows' shares in registers (v_permlane{32,16}_swap) before they reach LDS, and groups of 4 states
     are flushed one group behind.  Same per-element arithmetic everywhere, so all gradients agree to summation order -- and in
     fp32 equal the oracle."""
@@ -341,15 +374,10 @@ def test_scan_bwd_workgroup_shapes_and_dBdC_paths_agree(shape):
         for v in (0, 1, 2):
             lib.mxvl_set_scan_variant(v << 8)
             got[v] = _grads_via_autograd(x, True, dout.to(dev))
-        ssi.USE_BWD_WORKSPACE = True
-        for v in (1, 2):
-            lib.mxvl_set_scan_variant(v << 8)
-            got[v + 10] = _grads_via_autograd(x, True, dout.to(dev))
     finally:
-        ssi.USE_BWD_WORKSPACE = False
         lib.mxvl_set_scan_variant(0)
     tol = 2e-5 if dtype == torch.float32 else 2e-2
-    for v in (1, 2, 11, 12):
+    for v in (1, 2):
         for k in got[v]:
             r = got[0][k].float()
             scale = max(1.0, float(r.abs().max()))
@@ -357,7 +385,7 @@ def test_scan_bwd_workgroup_shapes_and_dBdC_paths_agree(shape):
     if dtype == torch.float32 and B * D * L <= 200000:
         ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
                                          cpu["delta_bias"], True, dout)
-        for v in (1, 2, 12):
+        for v in (1, 2):
             _check_grads(got[v], ref, f"variant {v}: ")
 
 

@@ -37,20 +37,6 @@ def main():
     t_b = timeit(lambda: fa.attn_bwd_raw(saved, out, lse, do, scale, mm, 16))
     print(f"mxvl attention B={B} H={H} L={L} D={D} {mask}: fwd {t_f:8.1f} us ({flops_f / t_f * 1e-6:6.1f} TFLOP/s)   "
           f"bwd {t_b:8.1f} us ({2.5 * flops_f / t_b * 1e-6:6.1f} TFLOP/s, 5 GEMMs of useful work)")
-    if "--sdpa" in sys.argv:
-        from medical_image_analysis_amd.models_pretrain import block_causal_attention
-        i = torch.arange(L, device=dev) // 16
-        bias = torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")).to(torch.bfloat16) if mask == "block_causal" else None
-        ql, kl, vl = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
-        def f():
-            if bias is not None:
-                return block_causal_attention(ql, kl, vl, bias, 0.0, scale)
-            return torch.nn.functional.scaled_dot_product_attention(ql, kl, vl, is_causal=(mask == "causal"), scale=scale)
-        t_sf = timeit(lambda: f())
-        def fb():
-            o = f(); o.backward(do)
-        t_sfb = timeit(fb)
-        print(f"library SDPA (chunked for block_causal): fwd {t_sf:8.1f} us   fwd+bwd {t_sfb:8.1f} us")
 
 
 if __name__ == "__main__":
