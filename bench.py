@@ -641,7 +641,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtname],
             "data": "synthetic (reference test distribution, seed = rank), inputs resident in HBM",
             "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "seq_len": L, "d_inner": D,
-                       "d_state": N, "parallelism": f"dp{world} (independent batch shards, no collective)",
+                       "d_state": N, "parallelism": f"dp{world} (independent batch shards, no collective)" + (
+                           " -- DEV CHECK: all ranks on cuda:0, gloo barriers, not a scaling number" if one_gpu and world > 1 else ""),
                        "kernel": _abi.load().mxvl_last_scan_kernel().decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

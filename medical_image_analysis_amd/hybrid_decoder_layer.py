@@ -340,6 +340,14 @@ class Qwen2HybridDecoderLayer(nn.Module):
         if self.vis_x is not None:
             visual_tokens = self.input_layernorm(self.vis_x)   # image tokens share the layer's input norm (:1428)
             cross_attn_mask, token_type = self.cross_attn_mask, self.media_locations
+            rep, rem = divmod(hidden_states.shape[0], visual_tokens.shape[0])
+            if rep > 1 and rem == 0:
+                # beam search: HF expands every per-sample model input with repeat_interleave(num_beams) (generation/utils.py,
+                # _expand_inputs_for_generation) -- the conditioning the reference stores on the layer (:1366-1373) is such an
+                # input, but lives outside generate()'s kwargs, so it is expanded here: the beams of a sample share its image
+                visual_tokens = visual_tokens.repeat_interleave(rep, dim=0)
+                cross_attn_mask = None if cross_attn_mask is None else cross_attn_mask.repeat_interleave(rep, dim=0)
+                token_type = None if token_type is None else token_type.repeat_interleave(rep, dim=0)
         else:
             visual_tokens = cross_attn_mask = None
             token_type = torch.ones(1, 1, dtype=torch.bool, device=hidden_states.device)

@@ -1,4 +1,4 @@
-"""-m gpu: the REAL stage-1 model under DDP with 2 ranks (both on cuda:0, gloo collectives -- the box has one GPU), through
+"""-m gpu: the REAL stage-1 model under DDP with 2 and 4 ranks (all on cuda:0, gloo collectives -- the box has one GPU), through
 PretrainEngine exactly as bench.py drives it (custom autograd Functions over the HIP kernels + gradient_as_bucket_view +
 fused AdamW + the in-step loss all-reduce), against the single-process step on the concatenated batch.
 Reference: CXPMRG_Bench_MambaXray_VL/pretrain/main_pretrain.py:167-169 (DDP), engine_pretrain.py:37-62 (step)."""
@@ -50,9 +50,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_real_model_ddp_two_ranks_equals_single_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_real_model_ddp_ranks_equal_single_process(world):
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -62,10 +63,11 @@ def test_real_model_ddp_two_ranks_equals_single_process():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, sd0, g0), (_, l1, sd1, g1) = results
-    assert l0 == l1, "the in-step all_reduce_mean(loss) must agree on every rank"
-    for k in sd0:
-        assert (sd0[k] == sd1[k]).all(), f"replicas diverged at {k}"
+    (_, l0, sd0, g0), (_, l1, sd1, g1) = results[0], results[-1]
+    for (_, lr_, sdr, _g) in results[1:]:
+        assert l0 == lr_, "the in-step all_reduce_mean(loss) must agree on every rank"
+        for k in sd0:
+            assert (sd0[k] == sdr[k]).all(), f"replicas diverged at {k}"
 
     from medical_image_analysis_amd.models_pretrain import VisionMamba
     from medical_image_analysis_amd.pretrain_engine import PretrainEngine
@@ -91,4 +93,28 @@ def test_real_model_ddp_two_ranks_equals_single_process():
                 worst = max(worst, err / scale)
                 assert err <= 2e-4 * scale + 1e-7, f"grad {k}: max |diff| {err} (scale {scale})"
                 assert (g0[k] == g1[k]).all(), f"ranks hold different averaged gradients at {k}"
-            print(f"DDP(2 ranks) vs single process: worst relative gradient difference {worst:.2e}")
+            print(f"DDP({world} ranks) vs single process: worst relative gradient difference {worst:.2e}")
+
+
+def test_bench_self_launch_eight_ranks_dev_mode():
+    """`python bench.py --gpus 8` launches its own 8 ranks the way the driver does (torch.distributed.run, 127.0.0.1) and rank 0
+    prints ONE JSON line with n_gpus 8, the MAX-over-ranks wall and whole-job throughput.  The box has one GPU, so the ranks share
+    cuda:0 over gloo (MXVL_BENCH_ONE_GPU=1, a bench-only dev switch): the label must say so -- this checks the rank plumbing,
+    the barriers and the reduction, not a scaling number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MXVL_BENCH_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "scan_fwd_cfg2", "--steps", "5",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"rank 0 prints exactly one JSON line, got {len(lines)}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert "gloo" in out["config"]["parallelism"] and "dp8" in out["config"]["parallelism"]
+    # whole-job throughput: 8 ranks x 32 sequences x 5 steps over the MAX-reduced wall
+    assert abs(out["value"] - 8 * 32 * 5 / (out["ms_per_step"] * 5e-3)) <= 1e-6 * out["value"]

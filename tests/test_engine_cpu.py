@@ -1,6 +1,8 @@
-"""CPU (gloo, world_size 2): the data-parallel step of pretrain_engine.py -- gradients are averaged over ranks,
+"""CPU (gloo, world_size 2 and 8): the data-parallel step of pretrain_engine.py -- gradients are averaged over ranks,
 replicas stay bit-identical, and the result equals one process fed the concatenated batch.  The Mamba model
-itself needs a GPU, so a small stand-in module with the same `model(imgs) -> per-token loss` contract is used."""
+itself needs a GPU, so a small stand-in module with the same `model(imgs) -> per-token loss` contract is used.
+World size 8 = one rank per GPU of the MI355X node the driver scales to (main_pretrain.py:109,125-131,167-169); the bucket cap
+is set below the model size so the gradient all-reduce runs as SEVERAL buckets (bucket boundaries, gradient_as_bucket_view)."""
 import os
 import socket
 
@@ -40,7 +42,7 @@ def _worker(rank, world, port, out):
                       MASTER_PORT=str(port))
     from medical_image_analysis_amd.pretrain_engine import PretrainEngine, init_distributed
     init_distributed("gloo")
-    eng = PretrainEngine(TinyLossModel(), lr=1e-2, amp_dtype=None, device=None)
+    eng = PretrainEngine(TinyLossModel(), lr=1e-2, amp_dtype=None, device=None, bucket_cap_mb=0.0005)   # ~131 floats per bucket
     g = torch.Generator().manual_seed(100 + rank)          # per-rank shard, as seed + rank in main_pretrain.py:109
     losses = []
     for _ in range(3):
@@ -53,8 +55,9 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_ddp_step_matches_single_process_on_the_concatenated_batch():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 8])
+def test_ddp_step_matches_single_process_on_the_concatenated_batch(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -64,11 +67,12 @@ def test_ddp_step_matches_single_process_on_the_concatenated_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, l0, sd0), (_, l1, sd1) = results
-    assert l0 == l1, "all_reduce_mean(loss) must agree on every rank"
-    for k in sd0:
-        assert (sd0[k] == sd1[k]).all(), f"replicas diverged at {k}"
-    # single process, global batch = concat of the two shards: mean loss over 8 samples == mean of rank means
+    (_, l0, sd0) = results[0]
+    for (_, l1, sd1) in results[1:]:
+        assert l0 == l1, "all_reduce_mean(loss) must agree on every rank"
+        for k in sd0:
+            assert (sd0[k] == sd1[k]).all(), f"replicas diverged at {k}"
+    # single process, global batch = concat of the shards: mean loss over 4 * world samples == mean of rank means
     from medical_image_analysis_amd.pretrain_engine import PretrainEngine
     eng = PretrainEngine(TinyLossModel(), lr=1e-2, amp_dtype=None, device=None)
     gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]

