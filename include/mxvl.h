@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 3
+#define MXVL_ABI_VERSION 4
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -307,6 +307,23 @@ typedef struct mxvl_add_ln_bwd_desc {
 int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc *desc, void *hip_stream);
 int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc *desc, void *hip_stream);
 int mxvl_add_layernorm_partials(int rows);
+/*
+ * mxvl_gemm_swiglu_fwd (ABI v4): the SwiGLU input projection of the block MLP as ONE MFMA GEMM with the gate in its epilogue --
+ *   ab = x [w1; w2]^T + [b1 | b2],   h = silu(ab[:, :H]) * ab[:, H:]
+ * replaces `self.w1(x)`, `self.w2(x)`, `self.act(x1) * x2` (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:59-83;
+ * pretrain/models_pretrain.py twin).  x (M, K), weight (2H, K) = nn.Linear layout of the merged [w1; w2], bias (2H) fp32 or the
+ * io dtype or NULL; h (M, H) always; ab (M, 2H) only when the caller needs the pre-activations (training: the backward reads
+ * them), NULL otherwise.  bf16 / fp16, fp32 accumulation; h is gated from the fp32 accumulators, ab is their io-dtype rounding.
+ * K % 64 == 0; x / weight rows 16-byte aligned (strides % 8 == 0); any M, any H (ragged tiles are masked).
+ */
+typedef struct mxvl_gemm_swiglu_desc {
+  int32_t M, K, H;
+  int32_t io_dtype, bias_dtype;
+  int64_t x_rs, w_rs, ab_rs, h_rs;       /* row strides in elements */
+  const void *x, *weight, *bias;
+  void *ab, *h;
+} mxvl_gemm_swiglu_desc;
+int mxvl_gemm_swiglu_fwd(const mxvl_gemm_swiglu_desc *desc, void *hip_stream);
 /* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */
 int mxvl_swiglu_fwd(const void *ab, void *y, int rows, int hidden, int io_dtype, void *hip_stream);

@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -35,7 +35,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
 ]
@@ -146,6 +146,14 @@ class AddLnDesc(ctypes.Structure):
     ]
 
 
+class GemmSwigluDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int32), ("K", c_int32), ("H", c_int32), ("io_dtype", c_int32), ("bias_dtype", c_int32),
+        ("x_rs", c_int64), ("w_rs", c_int64), ("ab_rs", c_int64), ("h_rs", c_int64),
+        ("x", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("ab", c_void_p), ("h", c_void_p),
+    ]
+
+
 class AddLnBwdDesc(ctypes.Structure):
     _fields_ = [
         ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
@@ -205,7 +213,7 @@ def load() -> ctypes.CDLL:
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
     lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
     for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn",
-                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd"):
+                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_conv1d_update.restype = c_int

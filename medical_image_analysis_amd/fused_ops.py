@@ -138,6 +138,33 @@ class _SwiGLU(torch.autograd.Function):
         return dab.view(ctx.shape)
 
 
+def gemm_swiglu_supported(x2: torch.Tensor, w: torch.Tensor) -> bool:
+    """shapes / layouts mxvl_gemm_swiglu_fwd takes: 16-bit io, whole 64-wide K steps, 16-byte aligned rows"""
+    return (x2.is_cuda and x2.dtype in (torch.bfloat16, torch.float16) and w.dtype == x2.dtype and x2.shape[1] % 64 == 0
+            and x2.stride(1) == 1 and w.stride(1) == 1 and x2.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def gemm_swiglu_fwd_raw(x2, w, bias=None, want_ab=True):
+    """One mxvl_gemm_swiglu_fwd call: x2 (M, K), w (2H, K) = [w1; w2], bias (2H) fp32 / io dtype -> (h (M, H), ab (M, 2H) | None)."""
+    lib = _abi.load()
+    M, K = x2.shape
+    H = w.shape[0] // 2
+    h = torch.empty((M, H), dtype=x2.dtype, device=x2.device)
+    ab = torch.empty((M, 2 * H), dtype=x2.dtype, device=x2.device) if want_ab else None
+    if bias is not None and bias.dtype not in (torch.float32, x2.dtype):
+        bias = bias.float()
+    d = _abi.GemmSwigluDesc()
+    d.M, d.K, d.H = M, K, H
+    d.io_dtype = _abi.dtype_code(x2.dtype)
+    d.bias_dtype = _abi.dtype_code(bias.dtype) if bias is not None else 0
+    d.x_rs, d.w_rs, d.ab_rs, d.h_rs = x2.stride(0), w.stride(0), 2 * H, H
+    d.x, d.weight, d.bias, d.ab, d.h = x2.data_ptr(), w.data_ptr(), _abi.ptr(bias), _abi.ptr(ab), h.data_ptr()
+    with torch.cuda.device(x2.device):
+        _abi.check(lib.mxvl_gemm_swiglu_fwd(ctypes.byref(d), _abi.stream_ptr(x2.device)), "mxvl_gemm_swiglu_fwd")
+    return h, ab
+
+
 class _LinearSwiGLU(torch.autograd.Function):
     """silu(w1 x) * (w2 x) with [w1; w2] as ONE GEMM (models_mamba.py:59-83) as a single autograd node, so the backward can
     hand the GEMM its bias gradient for free: `mxvl_swiglu_bwd_colsum` leaves the column sums of d[a|b] while it writes them
@@ -151,13 +178,21 @@ class _LinearSwiGLU(torch.autograd.Function):
         cd = _compute_dtype(x)
         x2 = x.reshape(-1, x.shape[-1]).to(cd)
         w = weight.to(cd)
-        ab = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
-        H = ab.shape[1] // 2
-        y = torch.empty((ab.shape[0], H), dtype=ab.dtype, device=ab.device)
-        with torch.cuda.device(ab.device):
-            _abi.check(lib.mxvl_swiglu_fwd(ab.data_ptr(), y.data_ptr(), ab.shape[0], H, _abi.dtype_code(ab.dtype),
-                                           _abi.stream_ptr(ab.device)), "mxvl_swiglu_fwd")
-        ctx.save_for_backward(x2, w, ab)
+        needs_grad = any(ctx.needs_input_grad)
+        H = w.shape[0] // 2
+        # ONE MFMA kernel: GEMM + bias + gate (csrc/gemm_swiglu.hip).  Measured per ARM layer (profiles/r03_gemm_swiglu_bench.txt):
+        # without the pre-activations (no gradient) it beats library GEMM + gate kernel at every shape (0.73 vs 0.85 ms at 65 280
+        # tokens); with them (training) it wins or ties up to K = 1024 and loses at the ARM-huge width, which keeps the library.
+        if gemm_swiglu_supported(x2, w) and (not needs_grad or x2.shape[1] <= 1024):
+            y, ab = gemm_swiglu_fwd_raw(x2, w, bias, want_ab=needs_grad)
+        else:
+            ab = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
+            y = torch.empty((ab.shape[0], H), dtype=ab.dtype, device=ab.device)
+            with torch.cuda.device(ab.device):
+                _abi.check(lib.mxvl_swiglu_fwd(ab.data_ptr(), y.data_ptr(), ab.shape[0], H, _abi.dtype_code(ab.dtype),
+                                               _abi.stream_ptr(ab.device)), "mxvl_swiglu_fwd")
+        if needs_grad:
+            ctx.save_for_backward(x2, w, ab)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y.view(*x.shape[:-1], H)
 

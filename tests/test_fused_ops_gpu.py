@@ -89,7 +89,7 @@ def test_swiglu_forward_backward(H, dtype):
         assert float((d > 0).float().mean()) < 2e-2 and float((d / yt.abs().clamp_min(1e-6)).max()) <= 2.0 ** -6
 
 
-@pytest.mark.parametrize("rows,K,H", [(2 * 197, 64, 170), (9000, 96, 2730), (33, 32, 7)])
+@pytest.mark.parametrize("rows,K,H", [(2 * 197, 64, 170), (9000, 96, 2730), (33, 32, 7), (1000, 1024, 2730), (300, 1536, 520)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_swiglu_equals_unfused_pipeline(rows, K, H, dtype):
     """One autograd node for `silu(w1 x) * w2 x` (models_mamba.py:59-83) whose backward takes the GEMM's bias gradient from the
@@ -114,3 +114,43 @@ def test_linear_swiglu_equals_unfused_pipeline(rows, K, H, dtype):
         err = float((got.double() - want.detach()).abs().max())
         assert err <= tol * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
     assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32
+
+
+@pytest.mark.parametrize("M,K,H,dtype,bias", [
+    (4 * 4080, 1024, 2730, torch.bfloat16, "f32"),      # ARM-large layer (4 images): ragged last column tile (2730 = 21 x 128 + 42)
+    (2 * 197 + 5, 768, 2048, torch.bfloat16, "io"),     # ARM-base encoder rows: ragged token tile, bias in the io dtype
+    (777, 64, 50, torch.float16, None),                 # one K step, one partial tile, fp16, no bias
+    (2048 + 77, 192, 8 * 128 + 3, torch.bfloat16, "f32"),   # last gate column tile of 3 columns: the element-wise store tail
+    (70000, 128, 136, torch.bfloat16, "f32"),           # more token tiles than workgroups: every persistent workgroup loops
+])
+def test_gemm_swiglu_kernel_vs_fp32_torch(M, K, H, dtype, bias):
+    """mxvl_gemm_swiglu_fwd (csrc/gemm_swiglu.hip: the SwiGLU projection of models_mamba.py:59-83 as ONE MFMA GEMM whose epilogue
+    applies bias and gate) against fp32 torch on the same 16-bit inputs: h is gated from the fp32 accumulators (tolerance = one
+    rounding of the output), ab is their rounding; h is bit-identical whether or not ab is requested; ragged token / column tiles
+    and the persistent tile loop are covered by the shapes; a weight-row perturbation catches operand transpositions."""
+    from medical_image_analysis_amd import fused_ops
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, K, generator=g).to(DEV, dtype)
+    w = (torch.randn(2 * H, K, generator=g) * K ** -0.5).to(DEV, dtype)
+    b = None if bias is None else (0.5 * torch.randn(2 * H, generator=g)).to(DEV, torch.float32 if bias == "f32" else dtype)
+    assert fused_ops.gemm_swiglu_supported(x, w)
+    h, ab = fused_ops.gemm_swiglu_fwd_raw(x, w, b, want_ab=True)
+    h2, none = fused_ops.gemm_swiglu_fwd_raw(x, w, b, want_ab=False)
+    assert none is None and torch.equal(h, h2)
+    ref_ab = x.float() @ w.float().t()
+    if b is not None:
+        ref_ab = ref_ab + b.float()
+    ref_h = F.silu(ref_ab[:, :H]) * ref_ab[:, H:]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # fp32 accumulation over K terms + one output rounding (relative eps of the element), absolute floor from the largest element
+    for name, got, want in (("ab", ab, ref_ab), ("h", h, ref_h)):
+        err = (got.float() - want).abs()
+        bound = eps * want.abs() + 2e-3 * eps * float(want.abs().max()) + 1e-6
+        bad = err > bound
+        assert not bool(bad.any()), f"{name}: {int(bad.sum())} / {bad.numel()} beyond one rounding; worst {float((err / bound).max()):.2f} x"
+    # transposition check with an asymmetric weight: column n of ab only depends on row n of w
+    w2 = w.clone()
+    w2[3] += 1.0
+    ab2 = fused_ops.gemm_swiglu_fwd_raw(x[:256], w2, b, want_ab=True)[1]
+    changed = (ab2.float() - ab[:256].float()).abs().amax(0) > 0
+    assert bool(changed[3]) and int(changed.sum()) == 1
