@@ -308,6 +308,24 @@ int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc *desc, void *hip_stream);
 int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc *desc, void *hip_stream);
 int mxvl_add_layernorm_partials(int rows);
 /*
+ * ViT-MAE index / loss glue (ABI v4), HD_Xray_Pretrain_MAE/pretrain/models/mae.py:
+ * mxvl_row_gather:  out[n, r, :] = (idx[n, r] >= 0 ? src[n, idx[n, r], :] : fill[:]) + add[r, :]   (fill / add fp32, optional:
+ *   NULL fill = zero row, NULL add = nothing added).  One kernel for `torch.gather(x, 1, ids_keep...)` of random_masking[_yiliao]
+ *   (:157-253), for its backward, for forward_decoder's cat(mask tokens) -> gather(ids_restore) -> cat(cls) -> + decoder_pos_embed
+ *   (:280-305: idx = 1 + ids_restore or -1, row 0 = cls) and for that one's backward.  src (N, rows_src, D) / out (N, rows_out, D)
+ *   with contiguous rows and the given batch strides (elements); src_dtype == out_dtype without add is a bit copy, otherwise the
+ *   value passes through fp32 (torch's type promotion / autograd's cast back).  idx int32 (N, rows_out).
+ * mxvl_patch_loss:  loss[n, l] = mean_j (pred[n, l, j] - target[n, l, j])^2, target = patchify(img) (:129-141), normalised per patch
+ *   with the unbiased variance and eps 1e-6 when norm_pix (:307-323); img (N, C, HW, HW) fp32 contiguous, pred (N, L, patch^2 C)
+ *   contiguous io dtype.  Forward: loss != NULL (dpred NULL).  Backward: dpred != NULL, dloss (N, L) fp32 given:
+ *   dpred = dloss * 2 (pred - target) / (patch^2 C).
+ */
+int mxvl_row_gather(const void *src, const int32_t *idx, const float *fill, const float *add, void *out, int batch, int rows_src,
+                    int rows_out, int dim, int64_t src_bs, int64_t out_bs, int src_dtype, int out_dtype, void *hip_stream);
+int mxvl_patch_loss(const void *img, const void *pred, const void *dloss, void *loss, void *dpred, int batch, int channels, int hw,
+                    int patch, int norm_pix, int io_dtype, void *hip_stream);
+
+/*
  * mxvl_gemm_swiglu_fwd (ABI v4): the SwiGLU input projection of the block MLP as ONE MFMA GEMM with the gate in its epilogue --
  *   ab = x [w1; w2]^T + [b1 | b2],   h = silu(ab[:, :H]) * ab[:, H:]
  * replaces `self.w1(x)`, `self.w2(x)`, `self.act(x1) * x2` (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:59-83;

@@ -1,0 +1,192 @@
+// mae_ops.hip -- the index / loss glue of ViT-MAE pre-training as HIP kernels (gfx950).
+//
+// Replaces the eager torch sequences of HD_Xray_Pretrain_MAE/pretrain/models/mae.py:
+//   :157-182, :184-253   random_masking / random_masking_yiliao: `torch.gather(x, 1, ids_keep[..., None].repeat(1, 1, D))`
+//   :280-305             forward_decoder: cat(x[:, 1:], mask_tokens) -> gather(ids_restore) -> cat(cls, .) -> + decoder_pos_embed
+//   :129-141, :307-323   patchify + per-patch normalisation (mean, unbiased var, eps 1e-6) + mean squared error per patch
+// and their backward passes (autograd's gather-backward is a zero fill + scatter_add; the loss chain is ~10 element-wise
+// kernels over the (N, L, p*p) target).  Two kernels:
+//
+//   row_gather_kernel    out[n, r, :] = (idx[n, r] >= 0 ? src[n, idx[n, r], :] : fill[:]) (+ add[r, :])
+//                        One kernel covers the four uses -- encoder masking (idx = ids_keep), its backward (idx = position of
+//                        token l among the kept ones, or -1 -> zero row), the decoder un-shuffle (idx = 1 + ids_restore or -1 ->
+//                        mask token, row 0 = cls, add = decoder_pos_embed) and its backward (idx = 1 + ids_keep).  The host
+//                        builds the small (N, rows) int32 index tensors; every output element is ONE copy (+ ONE add, the same
+//                        fp32 add torch performs): bit-exact with the reference expressions.  16-byte accesses, a wave per row.
+//   patch_loss_kernel    loss[n, l] = mean_j (pred[n, l, j] - tgt[n, l, j])^2 with tgt = patchify(img) (normalised per patch when
+//                        norm_pix_loss): one workgroup per patch reads its p x p pixels from the image once (fp32 two-pass
+//                        statistics), never materialising the (N, L, p*p) target; the backward recomputes the target the same
+//                        way and writes d pred = dloss * 2 (pred - tgt) / (p*p).
+// HBM-bound: algorithmic bytes = read + write of every row once (gather), image + pred (+ dpred) once (loss).
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+struct RowGatherArgs {
+  int N, rows_out, rows_src, D;
+  int64_t src_bs, out_bs;                // batch strides in elements (rows are contiguous, D elements each)
+  const void* src;
+  const float *fill, *add;               // fp32: fill (D) or null -> zeros; add (rows_out, D) or null
+  const int* idx;                        // (N, rows_out)
+  void* out;
+};
+
+// one wave per output row, 4 elements per lane per trip.  S = source dtype, O = output dtype: S == O without `add` is a bit copy;
+// otherwise fp32 in between (what torch's type promotion of `cat(bf16, fp32 mask_token) + fp32 pos_embed` computes, and the cast
+// autograd applies to a gradient that flows back into a 16-bit tensor).
+template <typename S, typename O>
+__global__ __launch_bounds__(256) void row_gather_kernel(const RowGatherArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= (int64_t)p.N * p.rows_out) return;
+  const int n = (int)(row / p.rows_out), r = (int)(row - (int64_t)n * p.rows_out);
+  const int s = p.idx[row];
+  const S* srow = s >= 0 ? (const S*)p.src + (int64_t)n * p.src_bs + (int64_t)s * p.D : nullptr;
+  O* orow = (O*)p.out + (int64_t)n * p.out_bs + (int64_t)r * p.D;
+  const float* arow = p.add ? p.add + (int64_t)r * p.D : nullptr;
+  const bool vec = (p.D % 4 == 0) && (!srow || (uintptr_t)srow % (4 * sizeof(S)) == 0) && ((uintptr_t)orow % (4 * sizeof(O)) == 0) &&
+                   (!arow || (uintptr_t)arow % 16 == 0) && (!p.fill || (uintptr_t)p.fill % 16 == 0);
+  if (vec) {
+    for (int c = lane * 4; c < p.D; c += 256) {
+      if constexpr (__is_same(S, O)) {
+        if (srow && !arow) {                       // pure row copy: bits, not values
+          if constexpr (sizeof(S) == 4) *(uint4*)(orow + c) = *(const uint4*)(srow + c);
+          else *(uint2*)(orow + c) = *(const uint2*)(srow + c);
+          continue;
+        }
+      }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (srow) v = ld4<S>(srow + c);
+      else if (p.fill) v = *(const float4*)(p.fill + c);
+      if (arow) {
+        const float4 a = *(const float4*)(arow + c);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      st4<O>(orow + c, v);
+    }
+  } else {
+    for (int c = lane; c < p.D; c += 64) {
+      if constexpr (__is_same(S, O)) {
+        if (srow && !arow) { orow[c] = srow[c]; continue; }
+      }
+      float v = srow ? Io<S>::ld(srow + c) : (p.fill ? p.fill[c] : 0.0f);
+      if (arow) v += arow[c];
+      Io<O>::st(orow + c, v);
+    }
+  }
+}
+
+struct PatchLossArgs {
+  int N, C, HW, p, gw, norm;             // image (N, C, HW, HW) fp32, patch p, gw = HW / p patches per row
+  const float* img;
+  const void* pred;                      // (N, L, p*p*C) io dtype
+  const float* dloss;                    // backward: (N, L)
+  float* loss;                           // forward: (N, L)
+  void* dpred;                           // backward: (N, L, p*p*C) io dtype
+};
+
+__device__ inline float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup (256 threads) per patch.  Element j of the patch vector = (py * p + px) * C + c ('nchpwq->nhwpqc', mae.py:139)
+template <typename E, bool BWD>
+__global__ __launch_bounds__(256) void patch_loss_kernel(const PatchLossArgs p) {
+  __shared__ float red[4];
+  const int l = blockIdx.x, n = blockIdx.y;
+  const int gy = l / p.gw, gx = l - gy * p.gw;
+  const int P = p.p * p.p * p.C;
+  const float* img = p.img + (int64_t)n * p.C * p.HW * p.HW;
+  auto pixel = [&](int j) {
+    const int c = j % p.C, q = j / p.C, py = q / p.p, px = q - py * p.p;
+    return img[((int64_t)c * p.HW + gy * p.p + py) * p.HW + gx * p.p + px];
+  };
+  float mean = 0.f, rstd = 1.f;
+  if (p.norm) {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < P; j += 256) s += pixel(j);
+    mean = block_sum256(s, red) / (float)P;
+    float q = 0.f;
+    for (int j = threadIdx.x; j < P; j += 256) { const float d = pixel(j) - mean; q += d * d; }
+    const float var = block_sum256(q, red) / (float)(P - 1);           // torch.var: unbiased
+    rstd = 1.0f / sqrtf(var + 1.0e-6f);
+  }
+  const E* pr = (const E*)p.pred + ((int64_t)n * gridDim.x + l) * P;
+  if constexpr (!BWD) {
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < P; j += 256) {
+      const float d = Io<E>::ld(pr + j) - (pixel(j) - mean) * rstd;
+      acc += d * d;
+    }
+    acc = block_sum256(acc, red);
+    if (threadIdx.x == 0) p.loss[(int64_t)n * gridDim.x + l] = acc / (float)P;
+  } else {
+    const float g = p.dloss[(int64_t)n * gridDim.x + l] * 2.0f / (float)P;
+    E* dp = (E*)p.dpred + ((int64_t)n * gridDim.x + l) * P;
+    for (int j = threadIdx.x; j < P; j += 256) Io<E>::st(dp + j, g * (Io<E>::ld(pr + j) - (pixel(j) - mean) * rstd));
+  }
+}
+
+static int mae_check() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" int mxvl_row_gather(const void* src, const int32_t* idx, const float* fill, const float* add, void* out, int N, int rows_src,
+                               int rows_out, int D, int64_t src_bs, int64_t out_bs, int src_dtype, int out_dtype, void* hip_stream) {
+  if (!src || !idx || !out) return MXVL_ERR_NULL;
+  if (N <= 0 || rows_out <= 0 || rows_src <= 0 || D <= 0) return MXVL_ERR_SHAPE;
+  auto ok = [](int d) { return d == MXVL_F32 || d == MXVL_BF16 || d == MXVL_F16; };
+  if (!ok(src_dtype) || !ok(out_dtype)) return MXVL_ERR_DTYPE;
+  if (src_dtype != out_dtype && src_dtype != MXVL_F32 && out_dtype != MXVL_F32) return MXVL_ERR_DTYPE;   // 16-bit <-> 16-bit of another kind: no use
+  RowGatherArgs a;
+  a.N = N; a.rows_out = rows_out; a.rows_src = rows_src; a.D = D;
+  a.src_bs = src_bs; a.out_bs = out_bs; a.src = src; a.fill = fill; a.add = add; a.idx = idx; a.out = out;
+  const int64_t rows = (int64_t)N * rows_out;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t s = (hipStream_t)hip_stream;
+#define MXVL_RG(S, O) hipLaunchKernelGGL((row_gather_kernel<S, O>), grid, dim3(256), 0, s, a)
+  if (src_dtype == MXVL_F32 && out_dtype == MXVL_F32) MXVL_RG(float, float);
+  else if (src_dtype == MXVL_BF16 && out_dtype == MXVL_BF16) MXVL_RG(bf16_t, bf16_t);
+  else if (src_dtype == MXVL_F16 && out_dtype == MXVL_F16) MXVL_RG(f16_t, f16_t);
+  else if (src_dtype == MXVL_BF16) MXVL_RG(bf16_t, float);
+  else if (src_dtype == MXVL_F16) MXVL_RG(f16_t, float);
+  else if (out_dtype == MXVL_BF16) MXVL_RG(float, bf16_t);
+  else MXVL_RG(float, f16_t);
+#undef MXVL_RG
+  return mae_check();
+}
+
+extern "C" int mxvl_patch_loss(const void* img, const void* pred, const void* dloss, void* loss, void* dpred, int N, int C, int HW,
+                               int patch, int norm_pix, int io_dtype, void* hip_stream) {
+  if (!img || !pred || (!loss && !dpred) || (dpred && !dloss)) return MXVL_ERR_NULL;
+  if (N <= 0 || C <= 0 || HW <= 0 || patch <= 0 || HW % patch != 0) return MXVL_ERR_SHAPE;
+  if (io_dtype != MXVL_F32 && io_dtype != MXVL_BF16 && io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  if (norm_pix && patch * patch * C < 2) return MXVL_ERR_SHAPE;
+  PatchLossArgs a;
+  a.N = N; a.C = C; a.HW = HW; a.p = patch; a.gw = HW / patch; a.norm = norm_pix ? 1 : 0;
+  a.img = (const float*)img; a.pred = pred; a.dloss = (const float*)dloss; a.loss = (float*)loss; a.dpred = dpred;
+  dim3 grid(a.gw * a.gw, N);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const bool bwd = dpred != nullptr;
+#define MXVL_PL(E) \
+  do { if (bwd) hipLaunchKernelGGL((patch_loss_kernel<E, true>), grid, dim3(256), 0, s, a); \
+       else hipLaunchKernelGGL((patch_loss_kernel<E, false>), grid, dim3(256), 0, s, a); } while (0)
+  switch (io_dtype) {
+    case MXVL_F32: MXVL_PL(float); break;
+    case MXVL_BF16: MXVL_PL(bf16_t); break;
+    default: MXVL_PL(f16_t); break;
+  }
+#undef MXVL_PL
+  return mae_check();
+}

@@ -273,7 +273,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     // one state up to the lane map (P, h): B/C tile rows, a_i = exp2(delta_i A), b_i = delta_i u_i B_i, Horner fold.
     // (Requesting the LDS operands one state ahead -- a software pipeline over Pre{A2, car, b[], c[]} -- measured SLOWER at every
     // shape, 260 -> 307 us at the roofline shape, profiles/r03b_scan_variants_prefetch.txt: the compiler's own placement of the
-    // next state's ds_reads behind the DPP scan is kept.)
+    // next state's ds_reads behind the DPP scan is kept.  Likewise rejected: filling the 7 wait-state slots of the DPP scan with the
+    // next state's 8 `delta_i * A2` products (one asm block, bit-identical results) -- 288 -> 295 us here, 363 -> 482 us on the
+    // 8-wave instantiation, profiles/r03_fwd_dpp_fill_ab.txt: the longer opaque block costs the compiler more than the nops.)
     auto fold = [&](int n, float (&a)[T], float (&bb)[T], float (&cv)[T], float& P, float& hl, float& car) {
       const float A2 = ac[n].x;
       car = ac_in[n].y;                                       // state entering the chunk (lane 0), 0 elsewhere

@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import flash_attention as flash
+from . import mae_ops
 from . import fused_ops
 from .models_mamba import DropPath, run_blocks, to_2tuple, trunc_normal_
 from .models_pretrain import get_2d_sincos_pos_embed as _sincos_no_cls
@@ -211,10 +212,17 @@ class MaskedAutoencoderViT(nn.Module):
         ids_shuffle = torch.argsort(noise, dim=1)
         ids_restore = torch.argsort(ids_shuffle, dim=1)
         ids_keep = ids_shuffle[:, :len_keep]
-        x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).expand(-1, -1, D))
+        x_masked = self._take(x, ids_keep, ids_restore)
         mask = torch.ones([N, L], device=x.device)
         mask[:, :len_keep] = 0
         return x_masked, torch.gather(mask, 1, ids_restore), ids_restore
+
+    @staticmethod
+    def _take(x, ids_keep, ids_restore):
+        """x[n, ids_keep[n, k], :]: one HIP row-gather (and one for its gradient) on the GPU; the reference expression on CPU."""
+        if x.is_cuda:
+            return mae_ops.take_rows(x, ids_keep, ids_restore)
+        return torch.gather(x, 1, ids_keep.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
 
     @staticmethod
     def region_indices(L, device):
@@ -241,7 +249,7 @@ class MaskedAutoencoderViT(nn.Module):
         ids_keep = torch.cat((sh_out[:, :keep_out], sh_in[:, :keep_in]), dim=1)
         ids_shuffle = torch.cat((ids_keep, sh_out[:, keep_out:], sh_in[:, keep_in:]), dim=1)
         ids_restore = torch.argsort(ids_shuffle, dim=1)
-        x_masked = torch.gather(x, 1, ids_keep.unsqueeze(-1).expand(-1, -1, D))
+        x_masked = self._take(x, ids_keep, ids_restore)
         mask = torch.ones([N, L], device=x.device)
         mask[:, :keep_out + keep_in] = 0
         return x_masked, torch.gather(mask, 1, ids_restore), ids_restore
@@ -262,16 +270,21 @@ class MaskedAutoencoderViT(nn.Module):
 
     def forward_decoder(self, x, ids_restore):
         x = self.decoder_embed(x)
-        mask_tokens = self.mask_token.expand(x.shape[0], ids_restore.shape[1] + 1 - x.shape[1], -1)
-        x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
-        x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).expand(-1, -1, x.shape[2]))
-        x = torch.cat([x[:, :1, :], x_], dim=1) + self.decoder_pos_embed
+        if x.is_cuda:      # mask tokens, un-shuffle, cls and the position embedding in ONE row-gather kernel
+            x = mae_ops.unshuffle_with_mask_tokens(x, ids_restore, self.mask_token, self.decoder_pos_embed)
+        else:
+            mask_tokens = self.mask_token.expand(x.shape[0], ids_restore.shape[1] + 1 - x.shape[1], -1)
+            x_ = torch.cat([x[:, 1:, :], mask_tokens], dim=1)
+            x_ = torch.gather(x_, 1, ids_restore.unsqueeze(-1).expand(-1, -1, x.shape[2]))
+            x = torch.cat([x[:, :1, :], x_], dim=1) + self.decoder_pos_embed
         x = run_blocks(self.decoder_blocks, x.contiguous())
         x = self.decoder_norm(x)
         tezheng = x
         return self.decoder_pred(x)[:, 1:, :], tezheng
 
     def forward_loss(self, imgs, pred, mask):
+        if pred.is_cuda:   # patchify + normalisation + per-patch MSE without materialising the (N, L, p*p) target
+            return mae_ops.patch_loss(imgs, pred, self.patch_embed.patch_size[0], self.norm_pix_loss)
         target = self.patchify(imgs)
         if self.norm_pix_loss:
             mean = target.mean(dim=-1, keepdim=True)

@@ -85,9 +85,14 @@ def ab(rounds, libs, what):
         dB = torch.zeros(Bm.shape, dtype=torch.float32, device=dev)
         dC = torch.zeros_like(dB)
         res = {l: [] for l in libs}
+        ref_out = None
         for r in range(rounds + 1):
             for l in libs:
                 use_lib(l)
+                if what == "fwd" and r == 0:       # every arm must produce the product library's bits
+                    o = scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, want_ckpt=(dt != torch.float32))[0]
+                    ref_out = o.clone() if ref_out is None else ref_out
+                    print(f"      {os.path.basename(l)}: max |out - product out| = {float((o.float() - ref_out.float()).abs().max()):.3e}")
                 if what == "bwd":
                     f = lambda: scan_bwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, ckpt, dout, dB=dB, dC=dC)
                 else:
