@@ -135,7 +135,9 @@ def make_scan_inputs(B, D, L, N, dtype, device, seed):
 def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
     """Time the C oracle (selective_scan_ref restatement, fp32, OpenMP over (b,d) rows) on the host."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    # physical cores of one socket, the same count the training-step baseline uses (all 256 hardware threads of the pool's
+    # 2-socket hosts oversubscribe the OpenMP team and made the number box-dependent)
+    cores = min(host_physical_cores(), 64)
     orc.set_threads(cores)
     # bounded sample: shrink the batch until one call is ~<= 2 s, then repeat within the budget
     Bs = B
@@ -165,7 +167,7 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
     except OSError:
         pass
     return {
-        "value": 1.0 / per_image, "unit": "images/sec", "cores": int(orc.max_threads()), "kind": "port",
+        "value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model,
         "sample": f"oracle/mxvl_oracle.c orc_scan_fwd (restatement of selective_scan_ref), {reps} x batch {Bs} "
                   f"of the same (D={D}, L={L}, N={N}) fp32 scan, OpenMP over rows, {elapsed:.1f} s of CPU work",
         "cpu": cpu_model,
@@ -338,7 +340,7 @@ def run_pretrain(args, rank, world, dev, dist):
         # decoder of configs[3], measured by the same process right after the training steps (replicas on every rank)
         del eng, model, batches
         torch.cuda.empty_cache()
-        secondary = measure_decode("decode_llama7b_128", 2, 1, rank, world, dev, dist)
+        secondary = measure_decode("decode_llama7b_128", 5, 1, rank, world, dev, dist)
     if rank != 0:
         return
     stats = {}
@@ -366,7 +368,7 @@ def run_pretrain(args, rank, world, dev, dist):
                      "kernel_ms": tot_ms / calls, "launches_timed": calls,
                      "algorithmic_bytes_per_launch": tot_bytes // calls,
                      "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()},
-                     "limited_by": "VALU issue rate of the fp32 recurrence, not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
+                     "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
     }
     attach_traffic(out["roofline"], "scan_bwd_pretrain" if (kind == "scan_bwd" and args.workload == DEFAULT_WORKLOAD and B == 16)
                    else args.workload)
@@ -380,8 +382,8 @@ def run_pretrain(args, rank, world, dev, dist):
 
 def run_mae(args, rank, world, dev, dist):
     """ViT-MAE pre-training step (HD_Xray_Pretrain_MAE/pretrain/main.py:319-323: loss = sum(loss*mask)/sum(mask)).  The
-    transformer blocks are library GEMM + SDPA; this path's own code is the GEMM patch embedding, the vectorised
-    chest-region masking and the gather/scatter index ops -- the roofline object therefore reports the model-level MFMA
+    transformer blocks are library GEMMs + the MFMA flash-attention kernels (csrc/attn.hip); masking gather, mask-token
+    un-shuffle and the per-patch loss are HIP kernels (csrc/mae_ops.hip) -- the roofline object reports the model-level MFMA
     rate (analytic flops of the visible tokens / step time against the 2.5 PFLOP/s dense bf16 peak)."""
     import torch.nn as nn
     from medical_image_analysis_amd.mae import mae_vit_large_patch16
@@ -444,7 +446,7 @@ def run_mae(args, rank, world, dev, dist):
                    "final_loss": float(loss)},
         "roofline": {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": flops / step_s / 1e12 / 2500.0, "traffic": None,
-                     "kernel": "whole step (library GEMM + SDPA; analytic flops of the visible tokens)"}}))
+                     "kernel": "whole step (library GEMMs + mxvl flash attention + mxvl MAE index / loss kernels; analytic flops of the visible tokens)"}}))
 
 
 def run_vmamba(args, rank, world, dev, dist):
@@ -649,7 +651,7 @@ def main():
                          "kernel": ("scan_bwd_kernel + scan_bwd_reduce_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
                                     if backward else "scan_fwd_stream_kernel"),
                          "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms,
-                         "limited_by": "VALU issue rate of the fp32 recurrence, not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
+                         "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
         }
         attach_traffic(out["roofline"], args.workload)
         if world == 1 and not args.no_cpu_baseline and not backward:
