@@ -85,6 +85,9 @@ class PatchEmbed(nn.Module):
         return self.norm(x)
 
 
+_HIDDEN_TILE = 64     # the SwiGLU hidden axis is zero-padded to whole tiles of this many columns on the GPU path (see SwiGLU.forward)
+
+
 class SwiGLU(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.SiLU, drop=0.0,
                  norm_layer=nn.LayerNorm, subln=False):
@@ -98,13 +101,37 @@ class SwiGLU(nn.Module):
         self.w3 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
+    def _zeros(self, *shape):
+        """cached zero block that pads the hidden axis (never a parameter, never in the state dict)"""
+        w = self.w1.weight
+        key = (w.device, w.dtype)
+        if getattr(self, "_zpad_key", None) != key:
+            self._zpad_key, self._zpad = key, {}
+        if shape not in self._zpad:
+            self._zpad[shape] = torch.zeros(shape, device=w.device, dtype=w.dtype)
+        return self._zpad[shape]
+
     def forward(self, x):
         if x.is_cuda and isinstance(self.act, nn.SiLU) and isinstance(self.ffn_ln, nn.Identity):
-            # [w1 x | w2 x] from ONE GEMM, then the gate as one HIP kernel (csrc/fused_norm_act.hip)
-            w = torch.cat([self.w1.weight, self.w2.weight], dim=0)
-            b = torch.cat([self.w1.bias, self.w2.bias], dim=0)
+            # [w1 x | w2 x] from ONE GEMM with the gate in its epilogue (csrc/gemm_swiglu.hip) or as one HIP kernel behind the
+            # library GEMM (csrc/fused_norm_act.hip).  The reference's hidden size dim*8//3 is 2730 for ARM-large (3413 for huge):
+            # rows that are only 4-byte aligned in bf16.  The three GEMMs and the gate kernels run on a hidden axis zero-padded to
+            # whole 64-column tiles instead (2752): silu(0) * 0 = 0 and the padded rows / columns of the weights are zero, so every
+            # value and gradient is unchanged, while the six library GEMMs of the layer take 3.21 instead of 3.46 ms at 65 280
+            # tokens (profiles/r03_pad_gemm_bench.txt) and every row becomes 16-byte aligned.  Parameters keep the reference shapes.
+            H, K = self.w1.weight.shape
+            pad = -H % _HIDDEN_TILE
+            if pad:
+                zw, zb = self._zeros(pad, K), self._zeros(pad)
+                w = torch.cat([self.w1.weight, zw, self.w2.weight, zw], dim=0)
+                b = torch.cat([self.w1.bias, zb, self.w2.bias, zb], dim=0)
+                w3 = torch.cat([self.w3.weight, self._zeros(self.w3.weight.shape[0], pad)], dim=1)
+            else:
+                w = torch.cat([self.w1.weight, self.w2.weight], dim=0)
+                b = torch.cat([self.w1.bias, self.w2.bias], dim=0)
+                w3 = self.w3.weight
             h = fused_ops.linear_swiglu(x, w, b)
-            return self.drop(linear_splitk(h, self.w3.weight, self.w3.bias))
+            return self.drop(linear_splitk(h, w3, self.w3.bias))
         return self.drop(self.w3(self.ffn_ln(self.act(self.w1(x)) * self.w2(x))))
 
 

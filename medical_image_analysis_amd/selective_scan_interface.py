@@ -293,7 +293,7 @@ def _bmm_f32(a, b):
 
 
 # measured exceptions to the rule below (tools/wgrad_bench.py on an MI355X, profiles/r02_wgrad_bench.txt): (M, N, K) -> slices
-_WGRAD_SPLITS = {(5460, 1024, 65280): 16}     # SwiGLU w1|w2 at per-GPU batch 16: 995 us at 4 slices, 816 us at 16
+_WGRAD_SPLITS = {(5460, 1024, 65280): 16, (5504, 1024, 65280): 16}     # SwiGLU w1|w2 at per-GPU batch 16: 995 us at 4 slices, 816 us at 16
 
 
 def wgrad_splits(K, M, N):

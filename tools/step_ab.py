@@ -15,10 +15,15 @@ model = VisionMamba(img_size=1024, patch_size=16, stride=16, embed_dim=1024, dep
 eng = PretrainEngine(model, device=dev)
 x = torch.randn(16, 3, 1024, 1024, device=dev)
 orig = fused_ops.gemm_swiglu_supported
-arms = {"fused GEMM+gate": lambda: setattr(fused_ops, "gemm_swiglu_supported", orig),
-        "library GEMM + gate kernel": lambda: setattr(fused_ops, "gemm_swiglu_supported", lambda *a: False)}
+from medical_image_analysis_amd import models_mamba
+if what == "swiglu_pad":
+    arms = {"hidden 2730 padded to 2752": lambda: setattr(models_mamba, "_HIDDEN_TILE", 64),
+            "hidden 2730 as is": lambda: setattr(models_mamba, "_HIDDEN_TILE", 1)}
+else:
+  arms = {"fused GEMM+gate": lambda: setattr(fused_ops, "gemm_swiglu_supported", orig),
+          "library GEMM + gate kernel": lambda: setattr(fused_ops, "gemm_swiglu_supported", lambda *a: False)}
 res = {k: [] for k in arms}
-for r in range(4):
+for r in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     for k, setup in arms.items():
         setup()
         eng.step(x); torch.cuda.synchronize()
