@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 5
+#define MXVL_ABI_VERSION 4
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -220,49 +220,6 @@ typedef struct mxvl_decode_cross_attn_desc {
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);
 int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
 int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc *desc, void *hip_stream);
-
-/*
- * mxvl_decode_stack (ABI v5): the WHOLE decoder stack of one generation step -- n_layers x (the five launches above, six for a
- * layer conditioned on image tokens) + final RMSNorm + lm_head -- as ONE persistent launch, one workgroup per CU; the first
- * weight rows of the next phase are in flight while the activations change hands through flagged 8-byte slots in `workspace`
- * (csrc/decode_stack.hip).  Same arithmetic and roundings as the per-launch entries; what it replaces is the same per-token HF
- * forward (MambaXrayVL_DownStream.py:292-301 -> LlamaForCausalLM; hybrid_decoder_layer.py:185-199, 266-337, 392-457, 653-697).
- * The layer table lives in DEVICE memory (n_layers entries).  `workspace`: mxvl_decode_stack_workspace_bytes(...) bytes of
- * device memory, ZEROED once by the caller, then owned by the entry across calls.  `sync` = 2 device uint32, zeroed once by the
- * caller: [0] a launch counter the entry advances, [1] an error word the kernel only ever sets: != 0 after a launch means a
- * poll timed out (the launch was not co-resident) and the logits of that and later steps are invalid.
- * MXVL_ERR_UNSUPPORTED: head_dim not in {64,128,256}, hidden > 8192, rows * max(hidden, intermediate) * 2 > 150 KiB, or a
- * projection wider than 64 columns per CU-wave slot (4 x 16 x #CU) -- use the per-launch entries there.
- */
-typedef struct mxvl_decode_layer {
-  const void *input_norm_weight;                /* (hidden) bf16 */
-  const void *qkv_weight, *qkv_bias;            /* ((n_heads + 2 n_kv_heads) * head_dim, hidden) bf16; bias optional */
-  const void *o_weight;                         /* (hidden, n_heads * head_dim) bf16 */
-  const void *post_norm_weight;                 /* (hidden) bf16 */
-  const void *gate_weight, *up_weight;          /* (intermediate, hidden) bf16 */
-  const void *down_weight;                      /* (hidden, intermediate) bf16 */
-  void *k_cache, *v_cache;                      /* as mxvl_decode_attn_desc */
-  const void *img_k, *img_v;                    /* conditioned hybrid layer (else NULL): as mxvl_decode_cross_attn_desc.k / .v */
-  const void *img_key_mask, *img_row_on;        /* optional, as .key_mask / .row_on */
-  const void *img_gate_weight, *img_gate_bias, *img_warm_up_gate;
-  float input_norm_eps, post_norm_eps;
-  int32_t img_n_keys, img_kv_rows_div, img_gate_flags, reserved;
-} mxvl_decode_layer;
-
-typedef struct mxvl_decode_stack_desc {
-  int32_t rows, hidden, intermediate, n_heads, n_kv_heads, head_dim, max_len, vocab, n_layers;
-  float scale, final_norm_eps;
-  const mxvl_decode_layer *layers;              /* DEVICE pointer, n_layers entries */
-  const void *x;                                /* (rows, hidden) bf16 token embeddings */
-  void *workspace;                              /* mxvl_decode_stack_workspace_bytes() bytes, zeroed once */
-  const void *cos, *sin, *slot_table, *pos, *mask;   /* as mxvl_decode_attn_desc */
-  const void *final_norm_weight;                /* (hidden) bf16 */
-  const void *lm_head_weight;                   /* (vocab, hidden) bf16 */
-  void *logits;                                 /* (rows, vocab) fp32 */
-  void *sync;                                   /* 2 x uint32, device, zeroed once */
-} mxvl_decode_stack_desc;
-int64_t mxvl_decode_stack_workspace_bytes(int rows, int hidden, int intermediate, int n_heads, int n_kv_heads, int head_dim);
-int mxvl_decode_stack(const mxvl_decode_stack_desc *desc, void *hip_stream);
 
 int mxvl_abi_version(void);
 /* time steps covered by one checkpoint chunk for a sequence of `seqlen` steps and `dstate` states */

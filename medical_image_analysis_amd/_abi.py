@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 5
+ABI_VERSION = 4
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -32,7 +32,7 @@ SYMBOLS = [
     "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
-    "mxvl_decode_cross_attn", "mxvl_decode_stack", "mxvl_decode_stack_workspace_bytes",
+    "mxvl_decode_cross_attn",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss",
@@ -137,29 +137,6 @@ class DecodeCrossAttnDesc(ctypes.Structure):
     ]
 
 
-class DecodeLayer(ctypes.Structure):
-    _fields_ = [
-        ("input_norm_weight", c_void_p), ("qkv_weight", c_void_p), ("qkv_bias", c_void_p), ("o_weight", c_void_p),
-        ("post_norm_weight", c_void_p), ("gate_weight", c_void_p), ("up_weight", c_void_p), ("down_weight", c_void_p),
-        ("k_cache", c_void_p), ("v_cache", c_void_p),
-        ("img_k", c_void_p), ("img_v", c_void_p), ("img_key_mask", c_void_p), ("img_row_on", c_void_p),
-        ("img_gate_weight", c_void_p), ("img_gate_bias", c_void_p), ("img_warm_up_gate", c_void_p),
-        ("input_norm_eps", ctypes.c_float), ("post_norm_eps", ctypes.c_float),
-        ("img_n_keys", c_int32), ("img_kv_rows_div", c_int32), ("img_gate_flags", c_int32), ("reserved", c_int32),
-    ]
-
-
-class DecodeStackDesc(ctypes.Structure):
-    _fields_ = [
-        ("rows", c_int32), ("hidden", c_int32), ("intermediate", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32),
-        ("head_dim", c_int32), ("max_len", c_int32), ("vocab", c_int32), ("n_layers", c_int32),
-        ("scale", ctypes.c_float), ("final_norm_eps", ctypes.c_float),
-        ("layers", c_void_p), ("x", c_void_p), ("workspace", c_void_p),
-        ("cos", c_void_p), ("sin", c_void_p), ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p),
-        ("final_norm_weight", c_void_p), ("lm_head_weight", c_void_p), ("logits", c_void_p), ("sync", c_void_p),
-    ]
-
-
 class AddLnDesc(ctypes.Structure):
     _fields_ = [
         ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
@@ -248,10 +225,6 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_beam_step.restype = c_int
     lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
-    lib.mxvl_decode_stack.restype = c_int
-    lib.mxvl_decode_stack.argtypes = [c_void_p, c_void_p]
-    lib.mxvl_decode_stack_workspace_bytes.restype = c_int64
-    lib.mxvl_decode_stack_workspace_bytes.argtypes = [c_int] * 6
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

@@ -101,9 +101,6 @@ class _SearchFusion:
         self.pos.copy_((state.cur + (self.P - 1)).view(1))
         state.advance(self._body())
 
-    def check_sync(self):
-        """steppers with device-side failure words report them here, once per generation"""
-
     def step_search(self, state):
         if self.sgraph is None or self.sstate is not state:
             self._search_body(state)            # eager once: the warm-up capture needs; advances exactly one token
@@ -313,9 +310,6 @@ class _BeamState:
         self.cur.add_(1)
 
 
-_STACKED = True      # the whole stack as one persistent launch (dev tools flip it to time the per-launch step)
-
-
 class _KernelStepper(_SearchFusion):
     """One decode step on the hand-written HIP kernels (csrc/decode.hip): per layer a fused RMSNorm+QKV GEMV, the
     RoPE/cache-append/attention kernel, o_proj GEMV (+residual), fused RMSNorm + gate/up GEMV + SwiGLU, down GEMV
@@ -396,14 +390,6 @@ class _KernelStepper(_SearchFusion):
         self.pos = torch.zeros(1, dtype=torch.long, device=dev)
         self.step_no = torch.zeros(1, dtype=torch.long, device=dev)
         self.graph = None
-        self.table = None                                         # device copy of the layer table of mxvl_decode_stack
-        self.sync = torch.zeros(2, dtype=torch.int32, device=dev)           # launch counter, error word
-        self.stack_ws = torch.zeros(self.lib.mxvl_decode_stack_workspace_bytes(rows, self.hidden, self.inter, self.H, self.Hkv, self.D),
-                                    dtype=torch.uint8, device=dev)          # flagged activation slots, owned by the kernel
-        # one persistent launch for the whole stack where its limits hold (include/mxvl.h), else one launch per projection
-        cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        widest = max((self.H + 2 * self.Hkv) * self.D, self.inter, self.hidden)
-        self.stacked = _STACKED and self.hidden <= 8192 and widest <= 4 * 16 * cus
         self.reset(prompt_mask, dyn_cache)
 
     def reset(self, prompt_mask, dyn_cache):
@@ -417,9 +403,6 @@ class _KernelStepper(_SearchFusion):
         self.n_real.copy_(self.mask[:, :self.P].sum(-1, keepdim=True))
         self.slot.copy_(self.own.expand(-1, self.max_len))
         self._project_image_tokens()
-        if self.stacked:
-            self.sync[1:].zero_()            # the error word; the launch counter keeps counting
-            self._layer_table()
 
     @torch.no_grad()
     def _project_image_tokens(self):
@@ -440,7 +423,7 @@ class _KernelStepper(_SearchFusion):
                          km=None if km is None else torch.empty(km.shape, dtype=torch.uint8, device=self.x.device),
                          on=torch.empty(on.shape, dtype=torch.uint8, device=self.x.device))
                 self.cond[i] = c
-                self.graph = self.table = None          # new buffers: a captured graph / layer table no longer describes this step
+                self.graph = None                       # new buffers: a captured graph no longer describes this step
             c["k"].copy_(k)
             c["v"].copy_(v)
             if km is not None:
@@ -452,7 +435,7 @@ class _KernelStepper(_SearchFusion):
             c["div"] = self.rows // k.shape[0]
         for i in [i for i in self.cond if i not in self._cond_layers(self.model)]:
             del self.cond[i]
-            self.graph = self.table = None
+            self.graph = None
 
     def _cross_attn(self, i, sp):
         c = self.cond[i]
@@ -473,50 +456,6 @@ class _KernelStepper(_SearchFusion):
         d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), y.data_ptr()
         self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
 
-    def _layer_table(self):
-        """mxvl_decode_layer[n_layers] in device memory for mxvl_decode_stack (weights, caches, image K / V of conditioned layers)."""
-        m, ab = self.model, self._abi
-        tab = (ab.DecodeLayer * len(m.model.layers))()
-        for i, layer in enumerate(m.model.layers):
-            at, e = layer.self_attn, tab[i]
-            e.input_norm_weight, e.input_norm_eps = layer.input_layernorm.weight.data_ptr(), layer.input_layernorm.variance_epsilon
-            e.qkv_weight, e.qkv_bias, e.o_weight = at.qkv_weight.data_ptr(), ab.ptr(at.qkv_bias), at.o_proj.weight.data_ptr()
-            e.post_norm_weight = layer.post_attention_layernorm.weight.data_ptr()
-            e.post_norm_eps = layer.post_attention_layernorm.variance_epsilon
-            e.gate_weight, e.up_weight = layer.mlp.gate_proj.weight.data_ptr(), layer.mlp.up_proj.weight.data_ptr()
-            e.down_weight = layer.mlp.down_proj.weight.data_ptr()
-            e.k_cache, e.v_cache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
-            c = self.cond.get(i)
-            if c is not None:
-                e.img_k, e.img_v, e.img_key_mask, e.img_row_on = c["k"].data_ptr(), c["v"].data_ptr(), ab.ptr(c["km"]), c["on"].data_ptr()
-                e.img_gate_weight, e.img_gate_bias = c["gate_w"].data_ptr(), c["gate_b"].data_ptr()
-                e.img_warm_up_gate = ab.ptr(c["warm"])
-                e.img_n_keys, e.img_kv_rows_div, e.img_gate_flags = c["k"].shape[2], c["div"], c["flags"]
-        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
-        if self.table is None:
-            self.table = raw.to(self.x.device)
-        else:
-            self.table.copy_(raw)        # same device buffer: a captured graph keeps pointing at it
-
-    def _stack(self):
-        """The whole decoder stack + lm_head as ONE persistent launch (csrc/decode_stack.hip)."""
-        m, cfg = self.model, self.model.config
-        d = self._abi.DecodeStackDesc()
-        d.rows, d.hidden, d.intermediate, d.n_heads, d.n_kv_heads = self.rows, self.hidden, self.inter, self.H, self.Hkv
-        d.head_dim, d.max_len, d.vocab, d.n_layers = self.D, self.max_len, self.V, cfg.num_hidden_layers
-        d.scale, d.final_norm_eps = self.D ** -0.5, m.model.norm.variance_epsilon
-        d.layers = self.table.data_ptr()
-        d.x, d.workspace = self.x.data_ptr(), self.stack_ws.data_ptr()
-        d.cos, d.sin, d.slot_table, d.pos, d.mask = (t.data_ptr() for t in (self.cos, self.sin, self.slot, self.pos, self.mask))
-        d.final_norm_weight, d.lm_head_weight = m.model.norm.weight.data_ptr(), m.lm_head.weight.data_ptr()
-        d.logits, d.sync = self.logits.data_ptr(), self.sync.data_ptr()
-        self._abi.check(self.lib.mxvl_decode_stack(self._ct.byref(d), self._abi.stream_ptr(self.x.device)), "mxvl_decode_stack")
-
-    def check_sync(self):
-        """A poll of the persistent launch timed out (the launch was not co-resident): the logits are garbage."""
-        if self.stacked and int(self.sync[1]) != 0:
-            raise RuntimeError("mxvl_decode_stack: a poll timed out -- the GPU was shared with another launch")
-
     def _body(self):
         m = self.model
         self.slot.copy_(self.slot.index_select(0, self.beam))
@@ -526,9 +465,6 @@ class _KernelStepper(_SearchFusion):
         cos, sin = m.model.rotary_emb(self.cos, self.n_real + self.step_no)   # fp32 (rows, 1, D)
         self.cos.copy_(cos[:, 0])
         self.sin.copy_(sin[:, 0])
-        if self.stacked:
-            self._stack()
-            return self.logits
         a = self._abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
         a.scale = self.D ** -0.5
@@ -676,8 +612,6 @@ class ReportDecoder(nn.Module):
             if has_eos:
                 alive = alive & ~torch.isin(tok, eos_t)
             if seq.shape[1] >= max_new or not bool(alive.any()):
-                if stepper is not None:
-                    stepper.check_sync()
                 return seq
             if stepper is not None:
                 logits = stepper.step(tok, torch.arange(B, device=dev), seq.shape[1] - 1)
@@ -757,8 +691,6 @@ class ReportDecoder(nn.Module):
             emb = self.model.embed_tokens(state.tok)[:, None, :]
             logits = self.forward(emb.to(inputs_embeds.dtype), attention_mask=attn, past_key_values=cache)[:, -1]
             state.advance(logits)
-        if stepper is not None:
-            stepper.check_sync()
         fin_seq = state.fin_seq
         out = fin_seq[:, 0].clone()
         # trim to the longest returned hypothesis (HF trims by the recorded beam indices)
