@@ -224,32 +224,36 @@ def create_block(d_model, ssm_cfg=None, norm_epsilon=1e-5, drop_path=0.0, rms_no
 
 
 def _init_weights(module, n_layer, initializer_range=0.02, rescale_prenorm_residual=True, n_residuals_per_layer=1):
-    """Mamba / GPT-2 style init (models_mamba.py:168-198)."""
-    if isinstance(module, nn.Linear):
-        if module.bias is not None and not getattr(module.bias, "_no_reinit", False):
-            nn.init.zeros_(module.bias)
-    elif isinstance(module, nn.Embedding):
-        nn.init.normal_(module.weight, std=initializer_range)
-    if rescale_prenorm_residual:
-        for name, p in module.named_parameters():
-            if name in ["out_proj.weight", "fc2.weight"]:
-                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
-                with torch.no_grad():
-                    p /= math.sqrt(n_residuals_per_layer * n_layer)
+    """What `ARM.apply` runs on every sub-module (reference models_mamba.py:168-198, the Mamba / GPT-2 scheme): Linear biases
+    to zero unless tagged `_no_reinit` (dt_proj), embeddings N(0, range), and the two projections that write into the residual
+    stream re-drawn kaiming-uniform and shrunk by sqrt(residual branches so far)."""
+    bias = getattr(module, "bias", None)
+    if isinstance(module, nn.Linear) and bias is not None and not getattr(bias, "_no_reinit", False):
+        bias.data.zero_()
+    if isinstance(module, nn.Embedding):
+        module.weight.data.normal_(std=initializer_range)
+    if not rescale_prenorm_residual:
+        return
+    shrink = math.sqrt(n_residuals_per_layer * n_layer)
+    for name, p in module.named_parameters():
+        if name in ("out_proj.weight", "fc2.weight"):
+            nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            p.data.div_(shrink)
+
+
+_NORMS = (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)
 
 
 def segm_init_weights(m):
-    if isinstance(m, nn.Linear):
-        trunc_normal_(m.weight, std=0.02)
-        if m.bias is not None:
-            nn.init.constant_(m.bias, 0)
-    elif isinstance(m, nn.Conv2d):
-        lecun_normal_(m.weight)
-        if m.bias is not None:
-            nn.init.zeros_(m.bias)
-    elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm2d)):
-        nn.init.zeros_(m.bias)
-        nn.init.ones_(m.weight)
+    """Patch-embedding / head init (reference models_mamba.py:201-217): truncated normal for Linear, LeCun normal for the patch
+    convolution, zero biases, unit norms."""
+    draw = (lambda w: trunc_normal_(w, std=0.02)) if isinstance(m, nn.Linear) else lecun_normal_ if isinstance(m, nn.Conv2d) else None
+    if draw is not None:
+        draw(m.weight)
+    elif isinstance(m, _NORMS):
+        m.weight.data.fill_(1.0)
+    if (draw is not None or isinstance(m, _NORMS)) and m.bias is not None:
+        m.bias.data.zero_()
 
 
 class ARM(nn.Module):
