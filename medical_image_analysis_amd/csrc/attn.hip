@@ -241,8 +241,11 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   float* sMaskAll = (float*)(smem + 4 * TB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.H / p.Hkv);
-  const int qt = p.mask_mode ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;   // long rows first
+  // grid = (heads x batch, query tiles): the dispatcher walks x fastest, so with a causal mask ALL workgroups of the longest
+  // query tile start first and the shortest fill the tail (longest-processing-time order over the whole launch; ordering only
+  // inside a head left the chip half empty at the end: 675 -> 470 us for the 64-query forward, profiles/r03_attn_fwd64.txt)
+  const int b = (int)blockIdx.x / p.H, h = (int)blockIdx.x % p.H, hk = h / (p.H / p.Hkv);
+  const int qt = p.mask_mode ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int q0 = qt * QT, qrow = q0 + wave * 32 + j;
   const bool qv = qrow < p.Lq;
   const int64_t qr = qv ? qrow : 0;
@@ -449,6 +452,218 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   }
 }
 
+// ---- forward, head_dim 64, 16-bit, no key mask / bias: 64 queries per wave ----------------------------------------------------
+// attn_q_kernel gives a wave 32 queries, so every wave reads the whole 64-key K and V tile from LDS (16 KB) for 16 MFMAs: 8 waves
+// keep the CU's LDS port busy 1760 cycles per round against 1024 MFMA cycles -- the LDS port, not the matrix core, was the first
+// wall (13-14 % of the MFMA peak).  Here a wave owns TWO 32-query blocks: every K fragment (ds_read_b128) and every
+// V^T fragment (ds_read_b64_tr_b16) feeds two MFMAs, 32 MFMAs per 16 KB of LDS reads.
+//   * workgroup = 4 waves = 256 queries, 64-key tiles, THREE LDS stages of [K | V] (48 KB, two workgroups per CU)
+//   * K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4 from inline asm, as in gemm_swiglu.hip): no staging registers, no
+//     ds_write pass; the XOR swizzle of unit_off<64> is applied on the DMA's SOURCE address (the DMA writes LDS linearly).
+//     Tile t + 2 is requested right after the barrier of tile t; the only waits are one counted vmcnt + one barrier per tile.
+//     Key rows past Lk are fetched from row Lk - 1 (finite values under a zero probability), never left as stale LDS bits.
+//   * softmax: the scale rides in the exponent's FMA (exp2(s * c - m)), the row maximum is taken on the raw scores
+//   * a wave skips the arithmetic of a diagonal tile none of its 64 queries can see (it still keeps the barriers)
+template <typename E>
+__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
+  typedef Pol16<E> Pol;
+  typedef uint4 Frag;
+  constexpr int D = 64, NW = 4, QT = NW * 64, KT = kKT, NKD = 4, NKR = 2, NDT = 2, TB = KT * D * 2, NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // grid = (heads x batch, query tiles): the dispatcher walks x fastest, so ALL workgroups of the longest query tile start
+  // first and the shortest ones fill the tail (longest-processing-time order over the whole launch, not per head)
+  const int b = (int)blockIdx.x / p.H, h = (int)blockIdx.x % p.H, hk = h / (p.H / p.Hkv);
+  const int qt = p.mask_mode ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int q0 = qt * QT, wq0 = q0 + wave * 64;
+  const float c = p.scale * kLog2e;
+
+  int qrow[2], klim[2];
+  bool qv[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qrow[qb] = wq0 + 32 * qb + j;
+    qv[qb] = qrow[qb] < p.Lq;
+    klim[qb] = key_limit(p, qrow[qb]);
+  }
+  const int qlast = (q0 + QT < p.Lq ? q0 + QT : p.Lq) - 1;
+  const int kend = key_limit(p, qlast);            // limits grow with the row index in every mask mode
+  const int kfull = key_limit(p, q0);              // keys below this are visible to every row of the workgroup
+  const int wlast = (wq0 + 64 < p.Lq ? wq0 + 64 : p.Lq) - 1;
+  const int wkend = wq0 < p.Lq ? key_limit(p, wlast) : 0;     // keys at or beyond this are invisible to the whole wave
+  const int ntiles = (kend + KT - 1) / KT;
+
+  // ---- LDS-DMA: this wave moves rows 16 wave .. 16 wave + 15 of the K tile and of the V tile (2 x 1 KB each) ----------------
+  const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+  // address = (tile base, wave-uniform, in SGPRs) + (per-lane 32-bit byte offset, the same for every full tile)
+  int drow[2], dunit[2];
+  unsigned offK[2], offV[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    drow[i] = 16 * wave + 8 * i + (lane >> 3);
+    const int key = (((drow[i] >> 1) & 1) << 2) | ((drow[i] >> 2) & 3);     // Pol16::unit_off<64>
+    dunit[i] = ((lane & 7) ^ key) * 8;                                      // element offset of the 16-byte unit this lane fetches
+    offK[i] = (unsigned)(((int64_t)drow[i] * p.k_ts + dunit[i]) * 2);
+    offV[i] = (unsigned)(((int64_t)drow[i] * p.v_ts + dunit[i]) * 2);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
+  auto issue = [&](int kt) {
+    const int k0 = kt * KT;
+    const E* gk = kb + (int64_t)k0 * p.k_ts;
+    const E* gv = vb + (int64_t)k0 * p.v_ts;
+    unsigned o[4] = {offK[0], offK[1], offV[0], offV[1]};
+    if (k0 + KT > p.Lk) {                            // wave-uniform: the ragged last tile re-reads row Lk - 1 for the missing rows
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = k0 + drow[i] < p.Lk ? drow[i] : p.Lk - 1 - k0;
+        o[i] = (unsigned)(((int64_t)r * p.k_ts + dunit[i]) * 2);
+        o[2 + i] = (unsigned)(((int64_t)r * p.v_ts + dunit[i]) * 2);
+      }
+    }
+    const unsigned dst = lds0 + (unsigned)((kt % NST) * 2 * TB + wave * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[gk]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[gk]\n\t"
+        "s_add_u32 m0, m0, 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[gv]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o3], %[gv]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [dst] "s"(dst), [gk] "s"(gk), [gv] "s"(gv), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3])
+        : "memory", "scc");
+  };
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+
+  Frag qf[2][NKD];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const E* qp = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + (int64_t)(qv[qb] ? qrow[qb] : 0) * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) qf[qb][ks] = qv[qb] ? Pol::ldg(qp, ks, hi) : Pol::zero();
+  }
+  f32x16 acc[2][NDT];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
+  float m[2] = {kNegInf, kNegInf}, l[2] = {0.f, 0.f};
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KT;
+    // tile kt has landed (this wave's share: at most tile kt + 1's four transfers may still be in flight), then everybody's has,
+    // and everybody is done reading the stage tile kt + 2 will overwrite
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) issue(kt + 2);
+    if (k0 >= wkend) continue;                       // wave-uniform: nothing in this tile is visible to these 64 queries
+    const char* sK = smem + (kt % NST) * 2 * TB;
+    const char* sV = sK + TB;
+
+    f32x16 s[2][2];                                  // [key half][query block]
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      Frag ka[NKD];
+#pragma unroll
+      for (int ks = 0; ks < NKD; ++ks) ka[ks] = Pol::template a_row<D>(sK, 32 * h2 + j, ks, hi);
+#pragma unroll
+      for (int ks = 0; ks < NKD; ++ks)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)   // first step: C = the inline constant 0, not 16 zeroed registers per accumulator
+          s[h2][qb] = Pol::mma(ka[ks], qf[qb][ks], ks == 0 ? zero16 : s[h2][qb]);
+    }
+    const bool masked = k0 + KT > kfull;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (masked) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + 32 * h2 + crow(r, hi);
+            s[h2][qb][r] = key < klim[qb] ? s[h2][qb][r] : kNegInf;
+          }
+      }
+      float mx = kNegInf;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[h2][qb][r]);
+      mx = pair_max(mx) * c;                         // c > 0: the maximum commutes with the scale
+      const float mn = fmaxf(m[qb], mx);
+      const float mu = (mn == kNegInf) ? 0.f : mn;
+      const float alpha = fast_exp2(m[qb] - mu);
+      float rs = 0.f;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(fmaf(s[h2][qb][r], c, -mu));
+          s[h2][qb][r] = pv;
+          rs += pv;
+        }
+      rs = pair_sum(rs);
+      l[qb] = fmaf(l[qb], alpha, rs);
+      m[qb] = mn;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[qb][dt][r] *= alpha;
+      }
+    }
+    // O^T += V^T P^T; the V^T operands of a key half are requested together, one half ahead of their MFMAs (holding all 32
+    // registers of them across the softmax pushed the loop into scratch spills, and a spill reload waits on vmcnt = on the DMA)
+    Frag ta[2][NKR][NDT];
+#pragma unroll
+    for (int ks = 0; ks < NKR; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) ta[0][ks][dt] = Pol::template a_tr<D>(sV, 0, ks, hi, 32 * dt, lane);
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      if (h2 == 0) {
+#pragma unroll
+        for (int ks = 0; ks < NKR; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt) ta[1][ks][dt] = Pol::template a_tr<D>(sV, 32, ks, hi, 32 * dt, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKR; ++ks) {
+        Frag pb[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) pb[qb] = Pol::b_from_acc(s[h2][qb], ks);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) acc[qb][dt] = Pol::mma(ta[h2][ks][dt], pb[qb], acc[qb][dt]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (!qv[qb]) continue;
+    const int64_t qr = qrow[qb];
+    const float inv = l[qb] > 0.f ? fast_rcp(l[qb]) : 0.f;
+    E* op = (E*)p.out + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + qr * p.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        Pol::st4(op + 32 * dt + 8 * g + 4 * hi, acc[qb][dt][4 * g] * inv, acc[qb][dt][4 * g + 1] * inv, acc[qb][dt][4 * g + 2] * inv,
+                 acc[qb][dt][4 * g + 3] * inv);
+    if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qr] = l[qb] > 0.f ? m[qb] + fast_log2(l[qb]) : __builtin_inff();
+  }
+}
+
 // ---- dK / dV ----------------------------------------------------------------------------------------------------------
 // One workgroup per 128-key tile (a lane owns a key); walks the query tiles that can see it, Q / dO tiles double-buffered.
 template <typename E, int D, int NW, bool EXTRA>
@@ -461,8 +676,9 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   float* sRow = (float*)(smem + 4 * TB);      // [buf][3][QT]: lse, delta, key limit (int bits)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, hk = blockIdx.y, grp = p.H / p.Hkv;
-  const int kk0 = blockIdx.x * KTW, krow = kk0 + wave * 32 + j;
+  // grid = (kv heads x batch, key tiles): key tile 0 is seen by every query tile of a causal mask -- longest first, globally
+  const int b = (int)blockIdx.x / p.Hkv, hk = (int)blockIdx.x % p.Hkv, grp = p.H / p.Hkv;
+  const int kk0 = blockIdx.y * KTW, krow = kk0 + wave * 32 + j;
   const bool kv = krow < p.Lk;
   const int64_t kr = kv ? krow : 0;
   const float c = p.scale * kLog2e;
@@ -619,12 +835,25 @@ static int launch_q1(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_q_kernel<E, D, NW, DQ, EXTRA>;
   int rc = raise_lds(kern, lds);
   if (rc != MXVL_OK) return rc;
-  dim3 grid((a.Lq + NW * 32 - 1) / (NW * 32), a.H, a.batch);
+  dim3 grid(a.H * a.batch, (a.Lq + NW * 32 - 1) / (NW * 32), 1);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+  return attn_launch_check();
+}
+template <typename E>
+static int launch_fwd64(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = 3 * 2 * (size_t)(kKT * 64 * 2);
+  dim3 grid(a.H * a.batch, (a.Lq + 255) / 256, 1);
+  hipLaunchKernelGGL(attn_fwd64_kernel<E>, grid, dim3(256), lds, s, a);
   return attn_launch_check();
 }
 template <typename E, int D, bool DQ>
 static int launch_q(const AttnArgs& a, hipStream_t s) {
+  if constexpr (D == 64 && !DQ && sizeof(E) == 2) {
+    // 16-byte aligned rows (the DMA moves 16-byte units) and no key mask / bias: the 64-queries-per-wave forward
+    const bool aligned = a.k_ts % 8 == 0 && a.v_ts % 8 == 0 && a.k_hs % 8 == 0 && a.v_hs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0 &&
+                         ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0;
+    if (!a.kmask && !a.bias && aligned && a.Lk > 0) return launch_fwd64<E>(a, s);
+  }
   return (a.kmask || a.bias) ? launch_q1<E, D, DQ, true>(a, s) : launch_q1<E, D, DQ, false>(a, s);
 }
 
@@ -642,7 +871,7 @@ static int launch_dkv1(const AttnArgs& a, hipStream_t s) {
   auto kern = attn_bwd_dkv_kernel<E, D, NW, EXTRA>;
   int rc = raise_lds(kern, lds);
   if (rc != MXVL_OK) return rc;
-  dim3 grid((a.Lk + NW * 32 - 1) / (NW * 32), a.Hkv, a.batch);
+  dim3 grid(a.Hkv * a.batch, (a.Lk + NW * 32 - 1) / (NW * 32), 1);
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
   return attn_launch_check();
 }
