@@ -299,6 +299,92 @@ __global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const io_t* __re
   }
 }
 
+// The same backward for 16-bit rows that are 16-byte aligned (H % 8 == 0: every ARM width once the hidden axis is padded to whole
+// 64-column tiles, models_mamba.SwiGLU): a lane owns 8 consecutive columns -- one 16-byte load per operand and row, two rows in
+// flight, 16 column sums in registers.  Column tiles are equal-width multiples of 8 (<= 512), as above.
+template <typename io_t>
+__global__ __launch_bounds__(256) void swiglu_bwd_colsum_vec_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy,
+                                                                     io_t* __restrict__ out, float* __restrict__ partial, int rows,
+                                                                     int H, int R) {
+  const int lane = threadIdx.x & 63;
+  const int tiles = (H + 511) / 512;
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long)tiles * R) return;
+  const int tile = (int)(w % tiles), rg = (int)(w / tiles);
+  const int tw = (((H + tiles - 1) / tiles) + 7) & ~7;
+  const int c = tile * tw + lane * 8;
+  const bool on = lane * 8 < tw && c < H;          // H % 8 == 0: a lane's 8 columns are all inside or all outside
+  float sa[8], sb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sa[k] = sb[k] = 0.0f;
+  auto unpack = [](const uint4 v, float (&f)[8]) {
+    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (sizeof(io_t) == 2 && __is_same(io_t, bf16_t)) {
+        f[2 * k] = __builtin_bit_cast(float, wd[k] << 16);
+        f[2 * k + 1] = __builtin_bit_cast(float, wd[k] & 0xffff0000u);
+      } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 hv = __builtin_bit_cast(h2, wd[k]);
+        f[2 * k] = (float)hv.x;
+        f[2 * k + 1] = (float)hv.y;
+      }
+    }
+  };
+  auto pack = [](const float (&f)[8]) {
+    uint32_t wd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (__is_same(io_t, bf16_t)) wd[k] = cvt_pk_bf16(f[2 * k], f[2 * k + 1]);
+      else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        wd[k] = __builtin_bit_cast(uint32_t, h2{(_Float16)f[2 * k], (_Float16)f[2 * k + 1]});
+      }
+    }
+    return make_uint4(wd[0], wd[1], wd[2], wd[3]);
+  };
+  if (on) {
+    for (int r0 = rg; r0 < rows; r0 += 2 * R) {
+      uint4 av[2], bv[2], gv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * R;
+        av[u] = bv[u] = gv[u] = make_uint4(0, 0, 0, 0);
+        if (r < rows) {
+          const io_t* a = ab + (size_t)r * 2 * H + c;
+          av[u] = *(const uint4*)a;
+          bv[u] = *(const uint4*)(a + H);
+          gv[u] = *(const uint4*)(dy + (size_t)r * H + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * R;
+        if (r >= rows) continue;
+        float a[8], b[8], g[8], da[8], db[8];
+        unpack(av[u], a); unpack(bv[u], b); unpack(gv[u], g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float sg = sigmoid(a[k]);
+          da[k] = rnd_io<io_t>(g[k] * b[k] * (sg * (1.0f + a[k] * (1.0f - sg))));
+          db[k] = rnd_io<io_t>(g[k] * (a[k] * sg));
+          sa[k] += da[k];
+          sb[k] += db[k];
+        }
+        io_t* d = out + (size_t)r * 2 * H + c;
+        *(uint4*)d = pack(da);
+        *(uint4*)(d + H) = pack(db);
+      }
+    }
+    float* pr = partial + (size_t)rg * 2 * H + c;
+    *(float4*)pr = make_float4(sa[0], sa[1], sa[2], sa[3]);
+    *(float4*)(pr + 4) = make_float4(sa[4], sa[5], sa[6], sa[7]);
+    *(float4*)(pr + H) = make_float4(sb[0], sb[1], sb[2], sb[3]);
+    *(float4*)(pr + H + 4) = make_float4(sb[4], sb[5], sb[6], sb[7]);
+  }
+}
+
 template <typename io_t, bool BWD>
 __global__ __launch_bounds__(256) void swiglu_scalar_kernel(const io_t* __restrict__ ab, const io_t* __restrict__ dy,
                                                              io_t* __restrict__ out, int rows, int H) {
@@ -424,6 +510,13 @@ int mxvl_swiglu_bwd_colsum(const void* ab, const void* dy, void* dab, void* part
   const int tiles = (hidden + 511) / 512;
   const int grid = (int)(((long)tiles * n_partials + 3) / 4);
   hipStream_t s = (hipStream_t)hip_stream;
+  const bool vec = hidden % 8 == 0 && io_dtype != MXVL_F32 && ((uintptr_t)ab % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                   ((uintptr_t)dab % 16) == 0 && ((uintptr_t)partial % 16) == 0;
+  if (vec) {
+    if (io_dtype == MXVL_BF16) hipLaunchKernelGGL(swiglu_bwd_colsum_vec_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (const bf16_t*)dy, (bf16_t*)dab, (float*)partial, rows, hidden, n_partials);
+    else hipLaunchKernelGGL(swiglu_bwd_colsum_vec_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)ab, (const f16_t*)dy, (f16_t*)dab, (float*)partial, rows, hidden, n_partials);
+    return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+  }
   switch (io_dtype) {
     case MXVL_F32: hipLaunchKernelGGL(swiglu_bwd_colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)ab, (const float*)dy, (float*)dab, (float*)partial, rows, hidden, n_partials); break;
     case MXVL_BF16: hipLaunchKernelGGL(swiglu_bwd_colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)ab, (const bf16_t*)dy, (bf16_t*)dab, (float*)partial, rows, hidden, n_partials); break;

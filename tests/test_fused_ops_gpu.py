@@ -89,7 +89,8 @@ def test_swiglu_forward_backward(H, dtype):
         assert float((d > 0).float().mean()) < 2e-2 and float((d / yt.abs().clamp_min(1e-6)).max()) <= 2.0 ** -6
 
 
-@pytest.mark.parametrize("rows,K,H", [(2 * 197, 64, 170), (9000, 96, 2730), (33, 32, 7), (1000, 1024, 2730), (300, 1536, 520)])
+@pytest.mark.parametrize("rows,K,H", [(2 * 197, 64, 170), (9000, 96, 2730), (33, 32, 7), (1000, 1024, 2730), (300, 1536, 520),
+                                      (9000, 64, 2752), (130, 64, 8), (2 * 4080 + 3, 128, 3456)])   # H % 8 == 0: the 16-byte backward
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_linear_swiglu_equals_unfused_pipeline(rows, K, H, dtype):
     """One autograd node for `silu(w1 x) * w2 x` (models_mamba.py:59-83) whose backward takes the GEMM's bias gradient from the
