@@ -498,15 +498,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
   const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
   const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
   // address = (tile base, wave-uniform, in SGPRs) + (per-lane 32-bit byte offset, the same for every full tile)
-  int drow[2], dunit[2];
+  auto dma_row = [&](int i) { return 16 * wave + 8 * i + (lane >> 3); };
+  auto dma_unit = [&](int row) {                      // element offset of the 16-byte unit this lane fetches (Pol16::unit_off<64>)
+    const int key = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return ((lane & 7) ^ key) * 8;
+  };
   unsigned offK[2], offV[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    drow[i] = 16 * wave + 8 * i + (lane >> 3);
-    const int key = (((drow[i] >> 1) & 1) << 2) | ((drow[i] >> 2) & 3);     // Pol16::unit_off<64>
-    dunit[i] = ((lane & 7) ^ key) * 8;                                      // element offset of the 16-byte unit this lane fetches
-    offK[i] = (unsigned)(((int64_t)drow[i] * p.k_ts + dunit[i]) * 2);
-    offV[i] = (unsigned)(((int64_t)drow[i] * p.v_ts + dunit[i]) * 2);
+    const int row = dma_row(i), unit = dma_unit(row);
+    offK[i] = (unsigned)(((int64_t)row * p.k_ts + unit) * 2);
+    offV[i] = (unsigned)(((int64_t)row * p.v_ts + unit) * 2);
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
   auto issue = [&](int kt) {
@@ -516,10 +518,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
     unsigned o[4] = {offK[0], offK[1], offV[0], offV[1]};
     if (k0 + KT > p.Lk) {                            // wave-uniform: the ragged last tile re-reads row Lk - 1 for the missing rows
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = k0 + drow[i] < p.Lk ? drow[i] : p.Lk - 1 - k0;
-        o[i] = (unsigned)(((int64_t)r * p.k_ts + dunit[i]) * 2);
-        o[2 + i] = (unsigned)(((int64_t)r * p.v_ts + dunit[i]) * 2);
+      for (int i = 0; i < 2; ++i) {      // (recomputed here: the row / unit of a lane are not worth two registers each in the loop)
+        const int row = dma_row(i), unit = dma_unit(row);
+        const int r = k0 + row < p.Lk ? row : p.Lk - 1 - k0;
+        o[i] = (unsigned)(((int64_t)r * p.k_ts + unit) * 2);
+        o[2 + i] = (unsigned)(((int64_t)r * p.v_ts + unit) * 2);
       }
     }
     const unsigned dst = lds0 + (unsigned)((kt % NST) * 2 * TB + wave * 2048);
@@ -661,6 +664,191 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
         Pol::st4(op + 32 * dt + 8 * g + 4 * hi, acc[qb][dt][4 * g] * inv, acc[qb][dt][4 * g + 1] * inv, acc[qb][dt][4 * g + 2] * inv,
                  acc[qb][dt][4 * g + 3] * inv);
     if (p.lse && hi == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qr] = l[qb] > 0.f ? m[qb] + fast_log2(l[qb]) : __builtin_inff();
+  }
+}
+
+// ---- dQ pass, head_dim 64, 16-bit, no key mask / bias: the same 64-queries-per-wave / LDS-DMA structure as attn_fwd64_kernel.
+// Per 64-key tile and wave 48 MFMAs (S^T, dP^T, dQ^T for two query blocks) against 24 KB of LDS reads (K rows, V rows, K^T);
+// attn_q_kernel<DQ> needs 40 KB for 24.  Also writes delta = rowsum(dO * O) for the dK/dV kernel.
+template <typename E>
+__global__ __launch_bounds__(256, 2) void attn_dq64_kernel(const AttnArgs p) {
+  typedef Pol16<E> Pol;
+  typedef uint4 Frag;
+  constexpr int D = 64, NW = 4, QT = NW * 64, KT = kKT, NKD = 4, NKR = 2, NDT = 2, TB = KT * D * 2, NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // grid = (heads x batch, query tiles): the dispatcher walks x fastest, so ALL workgroups of the longest query tile start
+  // first and the shortest ones fill the tail (longest-processing-time order over the whole launch, not per head)
+  const int b = (int)blockIdx.x / p.H, h = (int)blockIdx.x % p.H, hk = h / (p.H / p.Hkv);
+  const int qt = p.mask_mode ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int q0 = qt * QT, wq0 = q0 + wave * 64;
+  const float c = p.scale * kLog2e;
+
+  int qrow[2], klim[2];
+  bool qv[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    qrow[qb] = wq0 + 32 * qb + j;
+    qv[qb] = qrow[qb] < p.Lq;
+    klim[qb] = key_limit(p, qrow[qb]);
+  }
+  const int qlast = (q0 + QT < p.Lq ? q0 + QT : p.Lq) - 1;
+  const int kend = key_limit(p, qlast);            // limits grow with the row index in every mask mode
+  const int kfull = key_limit(p, q0);              // keys below this are visible to every row of the workgroup
+  const int wlast = (wq0 + 64 < p.Lq ? wq0 + 64 : p.Lq) - 1;
+  const int wkend = wq0 < p.Lq ? key_limit(p, wlast) : 0;     // keys at or beyond this are invisible to the whole wave
+  const int ntiles = (kend + KT - 1) / KT;
+
+  // ---- LDS-DMA: this wave moves rows 16 wave .. 16 wave + 15 of the K tile and of the V tile (2 x 1 KB each) ----------------
+  const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
+  // address = (tile base, wave-uniform, in SGPRs) + (per-lane 32-bit byte offset, the same for every full tile)
+  auto dma_row = [&](int i) { return 16 * wave + 8 * i + (lane >> 3); };
+  auto dma_unit = [&](int row) {                      // element offset of the 16-byte unit this lane fetches (Pol16::unit_off<64>)
+    const int key = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return ((lane & 7) ^ key) * 8;
+  };
+  unsigned offK[2], offV[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = dma_row(i), unit = dma_unit(row);
+    offK[i] = (unsigned)(((int64_t)row * p.k_ts + unit) * 2);
+    offV[i] = (unsigned)(((int64_t)row * p.v_ts + unit) * 2);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
+  auto issue = [&](int kt) {
+    const int k0 = kt * KT;
+    const E* gk = kb + (int64_t)k0 * p.k_ts;
+    const E* gv = vb + (int64_t)k0 * p.v_ts;
+    unsigned o[4] = {offK[0], offK[1], offV[0], offV[1]};
+    if (k0 + KT > p.Lk) {                            // wave-uniform: the ragged last tile re-reads row Lk - 1 for the missing rows
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {      // (recomputed here: the row / unit of a lane are not worth two registers each in the loop)
+        const int row = dma_row(i), unit = dma_unit(row);
+        const int r = k0 + row < p.Lk ? row : p.Lk - 1 - k0;
+        o[i] = (unsigned)(((int64_t)r * p.k_ts + unit) * 2);
+        o[2 + i] = (unsigned)(((int64_t)r * p.v_ts + unit) * 2);
+      }
+    }
+    const unsigned dst = lds0 + (unsigned)((kt % NST) * 2 * TB + wave * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[gk]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[gk]\n\t"
+        "s_add_u32 m0, m0, 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[gv]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o3], %[gv]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [dst] "s"(dst), [gk] "s"(gk), [gv] "s"(gv), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3])
+        : "memory", "scc");
+  };
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+
+  Frag qf[2][NKD], dof[2][NKD];
+  float lse[2], delta[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int64_t qr = qv[qb] ? qrow[qb] : 0;
+    const E* qp = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + qr * p.q_ts;
+    const E* dop = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)h * p.do_hs + qr * p.do_ts;
+    const E* op = (const E*)p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + qr * p.o_ts;
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) {
+      qf[qb][ks] = qv[qb] ? Pol::ldg(qp, ks, hi) : Pol::zero();
+      dof[qb][ks] = qv[qb] ? Pol::ldg(dop, ks, hi) : Pol::zero();
+      const Frag of = qv[qb] ? Pol::ldg(op, ks, hi) : Pol::zero();
+      dl += Pol::dot(dof[qb][ks], of);
+    }
+    delta[qb] = pair_sum(dl);                     // rowsum(dO * O): lanes l and l ^ 32 hold the two halves of a row
+    const int64_t ro = ((int64_t)b * p.H + h) * p.Lq + qr;
+    lse[qb] = qv[qb] ? p.lse[ro] : __builtin_inff();
+    if (qv[qb] && hi == 0) p.delta[ro] = delta[qb];
+  }
+  f32x16 acc[2][NDT];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * KT;
+    // tile kt has landed (this wave's share: at most tile kt + 1's four transfers may still be in flight), then everybody's has,
+    // and everybody is done reading the stage tile kt + 2 will overwrite
+    if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < ntiles) issue(kt + 2);
+    if (k0 >= wkend) continue;                       // wave-uniform: nothing in this tile is visible to these 64 queries
+    const char* sK = smem + (kt % NST) * 2 * TB;
+    const char* sV = sK + TB;
+    const bool masked = k0 + KT > kfull;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      // P^T = exp2(K Q^T c - lse), dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T -- one 32-key half at a time
+      f32x16 sc[2], dp[2];
+      {
+        Frag ka[NKD];
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) ka[ks] = Pol::template a_row<D>(sK, 32 * h2 + j, ks, hi);
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) sc[qb] = Pol::mma(ka[ks], qf[qb][ks], ks == 0 ? zero16 : sc[qb]);
+      }
+      {
+        Frag va[NKD];
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks) va[ks] = Pol::template a_row<D>(sV, 32 * h2 + j, ks, hi);
+#pragma unroll
+        for (int ks = 0; ks < NKD; ++ks)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) dp[qb] = Pol::mma(va[ks], dof[qb][ks], ks == 0 ? zero16 : dp[qb]);
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = fast_exp2(fmaf(sc[qb][r], c, -lse[qb]));      // rows without keys: lse = +inf -> 0
+          if (masked) pv = (k0 + 32 * h2 + crow(r, hi)) < klim[qb] ? pv : 0.f;
+          sc[qb][r] = pv * (dp[qb][r] - delta[qb]);
+        }
+      Frag kt_a[NKR][NDT];
+#pragma unroll
+      for (int ks = 0; ks < NKR; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) kt_a[ks][dt] = Pol::template a_tr<D>(sK, 32 * h2, ks, hi, 32 * dt, lane);
+#pragma unroll
+      for (int ks = 0; ks < NKR; ++ks) {
+        Frag db[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) db[qb] = Pol::b_from_acc(sc[qb], ks);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) acc[qb][dt] = Pol::mma(kt_a[ks][dt], db[qb], acc[qb][dt]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (!qv[qb]) continue;
+    E* dqp = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)h * p.dq_hs + (int64_t)qrow[qb] * p.dq_ts;
+    const float sc2 = p.scale;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        Pol::st4(dqp + 32 * dt + 8 * g + 4 * hi, acc[qb][dt][4 * g] * sc2, acc[qb][dt][4 * g + 1] * sc2, acc[qb][dt][4 * g + 2] * sc2,
+                 acc[qb][dt][4 * g + 3] * sc2);
   }
 }
 
@@ -839,20 +1027,21 @@ static int launch_q1(const AttnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
   return attn_launch_check();
 }
-template <typename E>
+template <typename E, bool DQ>
 static int launch_fwd64(const AttnArgs& a, hipStream_t s) {
   const size_t lds = 3 * 2 * (size_t)(kKT * 64 * 2);
   dim3 grid(a.H * a.batch, (a.Lq + 255) / 256, 1);
-  hipLaunchKernelGGL(attn_fwd64_kernel<E>, grid, dim3(256), lds, s, a);
+  if constexpr (DQ) hipLaunchKernelGGL(attn_dq64_kernel<E>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(attn_fwd64_kernel<E>, grid, dim3(256), lds, s, a);
   return attn_launch_check();
 }
 template <typename E, int D, bool DQ>
 static int launch_q(const AttnArgs& a, hipStream_t s) {
-  if constexpr (D == 64 && !DQ && sizeof(E) == 2) {
-    // 16-byte aligned rows (the DMA moves 16-byte units) and no key mask / bias: the 64-queries-per-wave forward
+  if constexpr (D == 64 && sizeof(E) == 2) {
+    // 16-byte aligned rows (the DMA moves 16-byte units) and no key mask / bias: the 64-queries-per-wave kernels
     const bool aligned = a.k_ts % 8 == 0 && a.v_ts % 8 == 0 && a.k_hs % 8 == 0 && a.v_hs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0 &&
                          ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0;
-    if (!a.kmask && !a.bias && aligned && a.Lk > 0) return launch_fwd64<E>(a, s);
+    if (!a.kmask && !a.bias && aligned && a.Lk > 0) return launch_fwd64<E, DQ>(a, s);
   }
   return (a.kmask || a.bias) ? launch_q1<E, D, DQ, true>(a, s) : launch_q1<E, D, DQ, false>(a, s);
 }
