@@ -56,6 +56,10 @@ CASES = [
     (1, 2, 2, 48, 48, 64, "block_causal", "bhld"),      # the golden's geometry (3 clusters)
     (2, 8, 8, 528, 528, 64, "block_causal", "blhd"),    # several diagonal tiles
     (1, 2, 1, 33, 5, 64, "none", "bhld"),               # fewer keys than one tile
+    # several 256-query workgroup tiles, > 3 key tiles (the LDS-DMA ring of the 64-queries-per-wave kernels wraps), ragged ends
+    (1, 2, 2, 700, 700, 64, "none", "blhd"),
+    (2, 4, 2, 515, 900, 64, "causal", "blhd"),          # GQA, Lk > Lq, diagonal crosses workgroup tiles
+    (1, 3, 3, 1040, 1040, 64, "block_causal", "bhld"),
     # head_dim 128 (Llama-2-7B / Qwen heads: the hybrid decoder's training-time attention), forward AND backward
     (2, 4, 2, 230, 230, 128, "causal", "blhd"),         # decoder self-attention: GQA, prompt-length rows
     (1, 4, 4, 41, 197, 128, "none", "blhd"),            # text queries x 197 image keys
@@ -210,3 +214,25 @@ def test_block_causal_mask_verdict_is_cached_on_the_tensor_not_on_its_address():
     assert not is_block_causal_mask(bad, 16), f"stale verdict (same address: {bad.data_ptr() == ptr})"
     bad.copy_(torch.where(i[None, :] <= i[:, None], 0.0, float("-inf")))      # in-place update bumps the version counter
     assert is_block_causal_mask(bad, 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_kv_packed_strided_views_head_dim_64(dtype):
+    """k / v as the strided halves of ONE (B, L, 2, H, D) projection output (models_pretrain's CrossAttention `kv` Linear): the
+    LDS-DMA kernels address rows through the token stride 2*H*D, not H*D."""
+    from medical_image_analysis_amd.flash_attention import attention
+    B, H, L, D = 2, 4, 333, 64
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, L, H, D, generator=g).to(DEV, dtype).transpose(1, 2).requires_grad_(True)
+    kv = torch.randn(B, L, 2, H, D, generator=g).to(DEV, dtype).requires_grad_(True)
+    k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+    out = attention(q, k, v, scale=D ** -0.5, mask="block_causal", cluster=16)
+    dout = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV, dtype)
+    out.backward(dout)
+    qr = q.detach().double().requires_grad_(True)
+    kvr = kv.detach().double().requires_grad_(True)
+    ref = ref_attention(qr, kvr[:, :, 0].transpose(1, 2), kvr[:, :, 1].transpose(1, 2), D ** -0.5, "block_causal", 16)
+    ref.backward(dout.double())
+    assert_close(out, ref, 2e-2, 2e-2, "out kv-packed")
+    assert_close(q.grad, qr.grad, 6e-2 * max(1.0, float(qr.grad.abs().max())), 5e-2, "dq kv-packed")
+    assert_close(kv.grad, kvr.grad, 6e-2 * max(1.0, float(kvr.grad.abs().max())), 5e-2, "dkv kv-packed")
