@@ -222,7 +222,7 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
         "config": {"workload": f"{workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step = 161 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step = 129 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)",
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}
 
 
