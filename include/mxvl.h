@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 4
+#define MXVL_ABI_VERSION 5
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -61,6 +61,13 @@ typedef enum mxvl_dtype { MXVL_F32 = 0, MXVL_BF16 = 1, MXVL_F16 = 2 } mxvl_dtype
  * The vendored VMamba extension's "oflex" i16o32 mode (cusoflex/selective_scan_oflex.cpp:150,207): half-precision inputs,
  * the fp32 accumulator stored unrounded. */
 #define MXVL_SCAN_OUT_F32 2u
+/* ABI v5: fold the batch into the sequence.  A workgroup walks several batch elements of its channels as ONE sequence (the state
+ * is cut at every row start), so short rows (197-token encoders: 2 chunks of 128 steps, the second 44 % full) stop paying for
+ * their padding and for a prologue per (batch element, channel tile).  Same results up to fp32 summation order.  Ask with
+ * mxvl_scan_fold_ok(batch, seqlen, dstate) first; needs seqlen % 8 == 0, dstate 16, rows that qualify for 16-byte access, no
+ * last_state; else MXVL_ERR_UNSUPPORTED.  ckpt of a folded call is (dim, mxvl_scan_fold_slots(...), dstate) fp32, indexed by
+ * (channel, part, chunk of the part's folded sequence): the backward must be called with the same flag and buffer. */
+#define MXVL_SCAN_FOLD_BATCH 4u
 
 /*
  * Forward selective scan.
@@ -222,6 +229,8 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
 int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc *desc, void *hip_stream);
 
 int mxvl_abi_version(void);
+int mxvl_scan_fold_ok(int batch, int seqlen, int dstate);   /* 1: MXVL_SCAN_FOLD_BATCH is supported and pays at this shape */
+int mxvl_scan_fold_slots(int batch, int seqlen, int dim, int n_groups);   /* folded calls: ckpt is (dim, slots, dstate) fp32 */
 /* time steps covered by one checkpoint chunk for a sequence of `seqlen` steps and `dstate` states */
 int mxvl_scan_chunk_len(int seqlen, int dstate);
 int mxvl_scan_n_chunks(int seqlen, int dstate);

@@ -15,11 +15,12 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
 SCAN_OUT_F32 = 2          # out / dout fp32 whatever io_dtype is (the oflex i16o32 mode)
+SCAN_FOLD_BATCH = 4       # the batch folded into the sequence (short rows; ask mxvl_scan_fold_ok)
 
 STATUS = {
     0: "MXVL_OK", -1: "MXVL_ERR_NULL", -2: "MXVL_ERR_DTYPE", -3: "MXVL_ERR_SHAPE", -4: "MXVL_ERR_DSTATE",
@@ -28,7 +29,7 @@ STATUS = {
 
 # every symbol include/mxvl.h declares (tests/test_abi.py checks the .so exports all of them)
 SYMBOLS = [
-    "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fwd", "mxvl_scan_bwd",
+    "mxvl_abi_version", "mxvl_scan_chunk_len", "mxvl_scan_n_chunks", "mxvl_scan_fold_ok", "mxvl_scan_fold_slots", "mxvl_scan_fwd", "mxvl_scan_bwd",
     "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
@@ -259,6 +260,10 @@ def load() -> ctypes.CDLL:
     lib.mxvl_patch_loss.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int
     lib.mxvl_scan_n_chunks.restype = c_int
+    lib.mxvl_scan_fold_ok.restype = c_int
+    lib.mxvl_scan_fold_ok.argtypes = [c_int, c_int, c_int]
+    lib.mxvl_scan_fold_slots.restype = c_int
+    lib.mxvl_scan_fold_slots.argtypes = [c_int, c_int, c_int, c_int]
     lib.mxvl_set_scan_variant.argtypes = [c_int]
     _lib = lib
     return lib

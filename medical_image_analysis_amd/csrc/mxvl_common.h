@@ -147,4 +147,21 @@ __device__ inline int delta_row(int d, int ratio, uint32_t magic) { return ratio
 // magic = floor(2^32 / ratio) + 1: umulhi(d, magic) == d / ratio for every d with d * ratio < 2^32 (checked by the callers: d < dim)
 inline uint32_t delta_magic(int ratio) { return ratio <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint64_t)ratio + 1ull); }
 
+// ---- batch folded into the sequence (MXVL_SCAN_FOLD_BATCH; scan_fwd_stream.h / scan_bwd.hip, FOLD) -------------------------------
+// tv / seqlen by one multiply-high: exact while tv * seqlen < 2^32 (mxvl_scan_fold_ok checks batch * seqlen^2)
+inline uint32_t scan_fold_magic(int seqlen) { return (uint32_t)((1ull << 32) / (uint64_t)seqlen + 1); }
+// element offset of (segment sb, step sl) for an array with batch stride bs: ONE v_mad_u64_u32 -- the launchers only fold when every
+// batch stride fits 32 bits (a 64 x 32-bit multiply per array and chunk was a tenth of the folded forward)
+__device__ inline int64_t seg_off(int sb, int64_t bs, int sl) { return (int64_t)((uint64_t)(uint32_t)sb * (uint32_t)bs + (uint32_t)sl); }
+// batch elements per workgroup sequence, the SAME function for the forward (which lays the checkpoints out by it) and the
+// backward: enough parts to give the forward >= 768 workgroups of 16 rows, but sequences of >= 1024 steps where the batch allows
+inline int scan_fold_bpp(int batch, int seqlen, int dim, int n_groups) {
+  const int tiles16 = n_groups * ((dim / n_groups + 15) / 16);
+  int parts = (768 + tiles16 - 1) / tiles16;
+  parts = parts < 1 ? 1 : (parts > batch ? batch : parts);
+  int bpp = (batch + parts - 1) / parts;
+  while (bpp * seqlen < 1024 && bpp < batch) ++bpp;
+  return bpp;
+}
+
 }  // namespace mxvl

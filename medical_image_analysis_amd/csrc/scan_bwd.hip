@@ -28,7 +28,8 @@ constexpr int kCkptLenB = 128;
 struct ScanBwdArgs {
   int batch, dim, L, N, G, n_ckpt;
   int softplus, vec_ok, ablate, dl_ratio, out_f32;
-  uint32_t dl_magic;
+  uint32_t dl_magic, fold_magic;   // fold_magic != 0: batch folded into the sequence (FOLD below)
+  int fold_bpp, fold_cpp;
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, do_bs, do_ds;
   int64_t du_bs, du_ds, dd_bs, dd_ds, dz_bs, dz_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
@@ -143,7 +144,12 @@ __device__ __forceinline__ void lane16_swap_x4(float (&s)[8]) {                 
 //   * the dB/dC flush addresses are wave-uniform (SGPR base + lane): no 64-bit VALU multiplies per atomic;
 //   * the 9 v_exp_f32 of a state issue back to back (one asm block): v_exp costs 8 cycles alone and 10-16 when interleaved with
 //     FMAs (profiles/r01_ubench_valu_mix.txt).
-template <typename io_t, int NWAVES, bool VEC, int NS>
+//
+// FOLD (MXVL_SCAN_FOLD_BATCH, see scan_fwd_stream.h): the workgroup walks batch elements [b0, b0 + nb) of its channels as ONE
+// sequence of nb * SL steps, last chunk first.  The first step of every segment has a_t = 0 (and the lane product P = 0): no
+// state enters a segment in the recomputation, no adjoint leaves it towards the previous one, and dA / ddelta see h_{-1} = 0.
+// Addresses of a lane's 8 steps, of a staging quarter and of a flush lane's step come from one multiply-high each.
+template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
   constexpr int FG = 4;                    // states per dB/dC flush group
@@ -152,7 +158,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = NS > 0 ? NS : p.N, L = p.L;
+  const int N = NS > 0 ? NS : p.N, SL = p.L;
+  const int b0 = FOLD ? (int)blockIdx.y * p.fold_bpp : 0;
+  const int L = FOLD ? (p.batch - b0 < p.fold_bpp ? p.batch - b0 : p.fold_bpp) * SL : SL;   // steps this workgroup walks
   float* sB = smem;                        // [N][CH]  quarter-major, odd quarter rotated by 16 words (see scan_fwd_stream.h qpos)
   float* sC = sB + N * CH;                 // [N][CH]
   // dB/dC shares of a group of FG states, one tile per WAVE (its 4 rows summed in registers first), double-buffered:
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   const int wq = __builtin_amdgcn_readfirstlane(wave);     // the wave index as a scalar: flush addresses are SGPR + lane
   const int r = lane >> 4, j = lane & 15;
   const int row = wave * RPW + r;
-  const int b = blockIdx.y;
+  const int b = FOLD ? b0 : blockIdx.y;            // FOLD: first batch element of the part (base pointers start there)
   const int dpg = p.dim / p.G;
   const int tiles = (dpg + DT - 1) / DT;
   const int g = blockIdx.x / tiles;
@@ -202,6 +210,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   float* __restrict__ dBp = p.dB + (int64_t)b * p.dB_bs + (int64_t)g * p.dB_gs;
   float* __restrict__ dCp = p.dC + (int64_t)b * p.dC_bs + (int64_t)g * p.dC_gs;
   const bool has_z = pz != nullptr;
+  auto seg_of = [&](int tv) { return (int)__umulhi((unsigned)tv, p.fold_magic); };
+  auto fold_off = [&](int tv, int64_t bs) {        // element offset of virtual step tv: (segment tv / SL) * bs + tv % SL
+    const int sb = seg_of(tv);
+    return seg_off(sb, bs, tv - sb * SL);
+  };
 
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
@@ -225,7 +238,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     }
   };
   auto rows_fetch = [&](int t0, float (&vu)[T], float (&vd)[T], float (&vg)[T], float (&vz)[T]) {
-    if (VEC && (t0 + CH <= L || t0 + j * T + T <= L)) {     // every step of this lane is valid: 16-byte loads
+    if constexpr (FOLD) {
+      const int tv = t0 + j * T;
+      if (tv < L) {
+        const int sb = seg_of(tv), sl = tv - sb * SL;       // (the row pointers already carry + j * T)
+        ld8(pu - j * T + seg_off(sb, p.u_bs, sl), vu);
+        ld8(pd - j * T + seg_off(sb, p.dl_bs, sl), vd);
+        if (!of32) ld8(pg - j * T + seg_off(sb, p.do_bs, sl), vg);
+        if (has_z) ld8(pz - j * T + seg_off(sb, p.z_bs, sl), vz);
+      } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) { vu[i] = 0.0f; vd[i] = 0.0f; vg[i] = 0.0f; vz[i] = 0.0f; }
+      }
+    } else if (VEC && (t0 + CH <= L || t0 + j * T + T <= L)) {     // every step of this lane is valid: 16-byte loads
       ld8(pu + t0, vu);
       ld8(pd + t0, vd);
       if (!of32) ld8(pg + t0, vg);
@@ -243,7 +268,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     if (of32) dout_fetch(t0, vg);
   };
   auto row_store = [&](io_t* q, const void* base, int64_t bs, int64_t ds, int t0, const float (&v)[T]) {
-    if (VEC && t0 + CH <= L) {
+    if constexpr (FOLD) {
+      const int tv = t0 + j * T;
+      if (row_ok && tv < L) {
+        io_t* w = q + fold_off(tv, bs) - j * T;
+        st4<io_t>(w, make_float4(v[0], v[1], v[2], v[3]));
+        st4<io_t>(w + 4, make_float4(v[4], v[5], v[6], v[7]));
+      }
+    } else if (VEC && t0 + CH <= L) {
       if (row_ok) {
         st4<io_t>(q + t0, make_float4(v[0], v[1], v[2], v[3]));
         st4<io_t>(q + t0 + 4, make_float4(v[4], v[5], v[6], v[7]));
@@ -293,7 +325,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     for (int i = 0; i < T; ++i) v[i] = io::ld(tmp + i);
   };
   auto raw_prefetch = [&](int tn) {
-    if (tn + CH <= L || tn + j * T + T <= L) {
+    if constexpr (FOLD) {
+      const int tv = tn + j * T;
+      if (tv < L) {
+        const int sb = seg_of(tv), sl = tv - sb * SL;
+        ru = *(const uint4*)(pu - j * T + seg_off(sb, p.u_bs, sl));
+        rd = *(const uint4*)(pd - j * T + seg_off(sb, p.dl_bs, sl));
+        rg = *(const uint4*)(pg - j * T + seg_off(sb, p.do_bs, sl));
+        if (has_z) rz = *(const uint4*)(pz - j * T + seg_off(sb, p.z_bs, sl));
+      } else {
+        ru = make_uint4(0, 0, 0, 0); rd = ru; rg = ru; rz = ru;
+      }
+    } else if (tn + CH <= L || tn + j * T + T <= L) {
       ru = *(const uint4*)(pu + tn);
       rd = *(const uint4*)(pd + tn);
       if (!of32) rg = *(const uint4*)(pg + tn);
@@ -378,11 +421,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       rows_fetch(t0, uu, dl, go, zz);
     }
     // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
-    if (VEC && full) {
+    if (FOLD || (VEC && full)) {
       for (int i = tid; i < N * (CH / 4); i += NT) {   // 16-byte loads, 4 consecutive steps per thread
         const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
-        const float4 bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e);
-        const float4 cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cv = bv;
+        if constexpr (FOLD) {
+          if (t0 + e < L) {       // a quarter lies inside one segment (SL % 4 == 0)
+            bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + fold_off(t0 + e, p.B_bs));
+            cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + fold_off(t0 + e, p.C_bs));
+          }
+        } else {
+          bv = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e);
+          cv = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e);
+        }
         const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4 + ((e >> 2) & 1) * 16) & 63);   // odd quarter rotated by 16 words: conflict-free staging writes (scan_fwd_stream.h qpos)
         *(float4*)(sB + pos) = bv;
         *(float4*)(sC + pos) = cv;
@@ -405,7 +456,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       const int rr = i / N, n = i - rr * N;
       const int dd = d0 + wave * RPW + rr;
       float h0 = 0.0f;
-      if (c > 0 && dd < d_end) h0 = p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n];
+      if (c > 0 && dd < d_end) {
+        const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
+        h0 = p.ckpt[slot * N + n];
+      }
       sAC[(wave * RPW + rr) * NP + n].y = h0;
     }
     __syncthreads();
@@ -460,6 +514,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     float dsum = 0.0f;
 #pragma unroll
     for (int i = 0; i < T; ++i) dsum += dl[i];
+    // FOLD: a lane whose first step opens a segment: a_0 = P = 0 (exp2(-inf)); flush lanes know the (segment, step) of their element
+    float rbias = 0.0f;
+    int64_t f_off = 0;
+    bool f_ok = true;
+    if constexpr (FOLD) {
+      const int tv = t0 + j * T;
+      rbias = (tv - seg_of(tv) * SL == 0) ? -__builtin_inff() : 0.0f;
+      const int tf = t0 + ((wq * 64) & (CH - 1)) + lane;       // the step of this thread's flush elements (the same for every k)
+      f_ok = tf < L;
+      const int sb = seg_of(tf);
+      f_off = (int64_t)sb * p.dB_bs + (tf - sb * SL);          // dB and dC share their strides (checked by the launcher)
+    }
 
     auto flush_load = [&](int grp, float (&part)[FK * NWAVES]) {
       const float* src = sAcc + (grp & 1) * GBUF;
@@ -481,8 +547,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         const int nn = grp * FG + xw / (2 * CH), eb = xw & (CH - 1);
         if (nn < N) {
           float* dst = ((xw / CH) & 1) ? dCp + (int64_t)nn * p.dC_ns : dBp + (int64_t)nn * p.dB_ns;   // SGPRs
-          dst += t0 + eb;
-          if (full || t0 + eb + lane < L) unsafeAtomicAdd(dst + lane, part[k * NWAVES]);
+          if constexpr (FOLD) {
+            if (f_ok) unsafeAtomicAdd(dst + f_off, part[k * NWAVES]);
+          } else {
+            dst += t0 + eb;
+            if (full || t0 + eb + lane < L) unsafeAtomicAdd(dst + lane, part[k * NWAVES]);
+          }
         }
       }
     };
@@ -511,6 +581,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 #pragma unroll
           for (int i = 0; i < T; ++i) a[i] = dl[i] * A2;
           float P = A2 * dsum;
+          if constexpr (FOLD) {
+            a[0] += rbias;
+            P += rbias;
+          }
           asm volatile(
               "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
               "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
@@ -644,19 +718,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 static thread_local int g_bwd_hip_error = 0;
 extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
-template <typename io_t, int NWAVES, bool VEC, int NS>
+template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1) +
                                       (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t);
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS, FOLD>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
   }
   const int dpg = a.dim / a.G;
-  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NT);
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), FOLD ? (a.batch + a.fold_bpp - 1) / a.fold_bpp : a.batch), block(NT);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
@@ -681,6 +755,15 @@ static bool bwd_wide(int batch, int dim, int G, int /*L*/) {
 
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  if (a.fold_magic) {   // batch folded into the sequence (MXVL_SCAN_FOLD_BATCH): aligned rows, dstate 16, io-dtype dout
+    if (!a.vec_ok || a.N != 16 || a.out_f32 || a.dB_bs != a.dC_bs) return MXVL_ERR_UNSUPPORTED;
+    for (int64_t bs : {a.u_bs, a.dl_bs, a.z_bs, a.do_bs, a.du_bs, a.dd_bs, a.dz_bs, a.B_bs, a.C_bs, a.dB_bs})
+      if (bs >= (1ll << 32)) return MXVL_ERR_UNSUPPORTED;    // seg_off: 32-bit batch strides
+    const long parts = (a.batch + a.fold_bpp - 1) / a.fold_bpp;
+    const long tiles32 = parts * a.G * ((a.dim / a.G + 31) / 32);
+    if ((a.dim / a.G) % 32 == 0 && tiles32 >= 256) return launch_bwd1<io_t, 8, true, 16, true>(a, stream);
+    return launch_bwd1<io_t, 4, true, 16, true>(a, stream);
+  }
   const int variant = mxvl_scan_bwd_variant();   // tests / A-B measurements: 0 automatic
   const bool wide = variant == 1 ? true : variant == 2 ? false : bwd_wide(a.batch, a.dim, a.G, a.L);
   if (wide) return a.vec_ok ? launch_bwd<io_t, 8, true>(a, stream) : launch_bwd<io_t, 8, false>(a, stream);
@@ -730,6 +813,14 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
   a.dl_magic = delta_magic(a.dl_ratio);
   if (f->dstate > 64) return MXVL_ERR_UNSUPPORTED;
   a.ablate = 0;
+  a.fold_magic = 0; a.fold_bpp = 0; a.fold_cpp = 0;
+  if (f->flags & MXVL_SCAN_FOLD_BATCH) {       // the forward laid the checkpoints out by virtual chunk: the same geometry here
+    if (!mxvl_scan_fold_ok(f->batch, f->seqlen, f->dstate)) return MXVL_ERR_UNSUPPORTED;
+    a.fold_magic = scan_fold_magic(f->seqlen);
+    a.fold_bpp = scan_fold_bpp(f->batch, f->seqlen, f->dim, f->n_groups);
+    a.fold_cpp = (a.fold_bpp * f->seqlen + kCkptLenB - 1) / kCkptLenB;
+    if (a.fold_cpp > 1 && !f->ckpt) return MXVL_ERR_CHECKPOINT;
+  }
   {
     const int64_t esz = f->io_dtype == MXVL_F32 ? 4 : 2;
     const int64_t strides[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,

@@ -31,7 +31,8 @@ constexpr int kCkptLen = 128;  // checkpoint spacing in time steps (mxvl_scan_ch
 struct ScanArgs {
   int batch, dim, L, N, G, n_ckpt;
   int softplus, vec_ok, ablate, dl_ratio, out_f32;
-  uint32_t dl_magic;
+  uint32_t dl_magic, fold_magic;   // fold_magic != 0: the batch is folded into the sequence (scan_fwd_stream.h, FOLD)
+  int fold_bpp, fold_cpp;          // batch elements / checkpoint slots per workgroup sequence
   int64_t u_bs, u_ds, dl_bs, dl_ds, z_bs, z_ds, o_bs, o_ds;
   int64_t B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, A_ds, A_ns;
   const void *u, *delta, *B, *C, *z;
@@ -383,13 +384,13 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   return MXVL_OK;
 }
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T, int NS>
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T, int NS, bool FOLD = false>
 static int launch_stream1(const ScanArgs& a, hipStream_t stream, const char* name) {
   constexpr int CH = 128, DT = NWAVES * (64 / (CH / T));
   const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * (a.N + 1) + NWAVES * 64 + 2 * a.N);
-  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T, NS>;
+  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T, NS, FOLD>;
   const int dpg = a.dim / a.G;
-  dim3 grid(a.G * ((dpg + DT - 1) / DT), a.batch), block(NWAVES * 64);
+  dim3 grid(a.G * ((dpg + DT - 1) / DT), FOLD ? (a.batch + a.fold_bpp - 1) / a.fold_bpp : a.batch), block(NWAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
   hipError_t e = hipGetLastError();
   g_last_kernel = name;
@@ -412,6 +413,15 @@ static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name
 
 template <typename io_t>
 static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
+  if (a.fold_magic) {   // batch folded into the sequence: aligned rows, dstate 16 (the caller asked with MXVL_SCAN_FOLD_BATCH)
+    if (!a.vec_ok || a.N != 16) return MXVL_ERR_UNSUPPORTED;
+    for (int64_t bs : {a.u_bs, a.dl_bs, a.z_bs, a.o_bs, a.B_bs, a.C_bs})
+      if (bs >= (1ll << 32)) return MXVL_ERR_UNSUPPORTED;    // seg_off: 32-bit batch strides
+    // the same workgroup-shape rule as the plain launch, with (parts of the batch) in the place of (batch elements)
+    const int64_t tiles8 = (int64_t)((a.batch + a.fold_bpp - 1) / a.fold_bpp) * a.G * ((a.dim / a.G + 31) / 32);
+    if (tiles8 >= 512) return launch_stream1<io_t, 8, true, 3, 8, 16, true>(a, stream, "scan_fwd_stream<W8,vec,occ3,fold>");
+    return launch_stream1<io_t, 4, true, 2, 8, 16, true>(a, stream, "scan_fwd_stream<W4,vec,occ2,fold>");
+  }
   const bool even = (a.N % 2) == 0;
   const int64_t rows = (int64_t)a.batch * a.dim;
   int v = g_variant & 0xff;
@@ -463,6 +473,19 @@ extern "C" {
 int mxvl_abi_version(void) { return MXVL_ABI_VERSION; }
 int mxvl_scan_chunk_len(int, int) { return kCkptLen; }
 int mxvl_scan_n_chunks(int seqlen, int) { return (seqlen + kCkptLen - 1) / kCkptLen; }
+// 1: rows this short leave enough of their last 128-step chunk empty that MXVL_SCAN_FOLD_BATCH pays (and the kernels can do it)
+int mxvl_scan_fold_ok(int batch, int seqlen, int dstate) {
+  if (batch < 2 || seqlen < 8 || seqlen % 8 != 0 || dstate != 16) return 0;
+  if ((uint64_t)batch * (uint64_t)seqlen * (uint64_t)seqlen >= (1ull << 32)) return 0;   // multiply-high division by seqlen stays exact
+  const int padded = (seqlen + kCkptLen - 1) / kCkptLen * kCkptLen;
+  return (padded - seqlen) * 8 >= padded;          // >= 12.5 % of the computed steps are padding
+}
+// checkpoint slots per channel of a folded call: ckpt = (dim, slots, dstate) fp32
+int mxvl_scan_fold_slots(int batch, int seqlen, int dim, int n_groups) {
+  if (batch <= 0 || seqlen <= 0 || dim <= 0 || n_groups <= 0 || dim % n_groups) return 0;
+  const int bpp = scan_fold_bpp(batch, seqlen, dim, n_groups);
+  return ((batch + bpp - 1) / bpp) * ((bpp * seqlen + kCkptLen - 1) / kCkptLen);
+}
 int mxvl_last_hip_error(void) { return g_last_hip_error; }
 void mxvl_set_scan_variant(int v) { g_variant = MXVL_ABL(true) ? v : (v & 0xffff); }
 int mxvl_scan_bwd_variant(void) { return (g_variant >> 8) & 0xff; }
@@ -504,6 +527,13 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.dl_ratio = d->delta_group_ratio > 1 ? d->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
   a.ablate = MXVL_ABL(true) ? (g_variant >> 16) & 0xff : 0;
+  a.fold_magic = 0; a.fold_bpp = 0; a.fold_cpp = 0;
+  if (d->flags & MXVL_SCAN_FOLD_BATCH) {
+    if (!mxvl_scan_fold_ok(d->batch, d->seqlen, d->dstate) || d->last_state) return MXVL_ERR_UNSUPPORTED;
+    a.fold_magic = scan_fold_magic(d->seqlen);
+    a.fold_bpp = scan_fold_bpp(d->batch, d->seqlen, d->dim, d->n_groups);
+    a.fold_cpp = (a.fold_bpp * d->seqlen + kCkptLen - 1) / kCkptLen;
+  }
   // 4-element vector access is legal when every row of every io tensor starts on a 4-element boundary
   {
     const int64_t esz = d->io_dtype == MXVL_F32 ? 4 : 2;

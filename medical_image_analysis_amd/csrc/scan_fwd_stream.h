@@ -37,7 +37,16 @@ __device__ inline void scan8_x1(float& h0, float& P0, float& x0) {
 
 // NS > 0: dstate is the compile-time constant NS (16 = every Mamba block of the reference): the state loop unrolls with
 // immediate LDS offsets and the per-chunk index arithmetic (divisions by N) folds; NS == 0: any dstate <= 16 at run time.
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0>
+//
+// FOLD: the batch is folded into the sequence.  Rows of L <= a few hundred steps leave the second 128-step chunk mostly empty
+// (197-token encoders, padded to 200: 56 of 256 computed steps are padding; 144-token rows: 112 of 256), and a workgroup per
+// (batch element, channel tile) is all prologue.  With FOLD a workgroup owns a channel tile and walks the VIRTUAL sequence
+// tv = b * L + l of all batch elements: chunks are always full (but the last one), the per-chunk tables and A are set up once.
+// A recurrence must not run across a segment boundary: the first step of every segment gets a_t = 0 (exp2(-inf)) -- in the
+// lane product P as well -- which is exactly "state 0 enters the segment" (h = 0 * h_in + b).  L % 8 == 0, so a lane's 8 steps
+// and a staging quarter never straddle two segments; (b, l) of a step come from one multiply-high (fold_magic = 2^32 / L + 1).
+// Checkpoints are indexed by virtual chunk in the same buffer (batch * chunks(L) >= chunks(batch * L) entries per channel).
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {
   constexpr int CH = 128, LPR = CH / T, RPW = 64 / LPR, DT = NWAVES * RPW, NT = NWAVES * 64, NMAX = 16;
   constexpr int TQ = T / 4;                           // 16-byte quarters per lane
@@ -48,7 +57,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   using io = Io<io_t>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = NS > 0 ? NS : p.N, L = p.L;
+  // SL: segment (row) length; FOLD: this workgroup walks batch elements [b0, b0 + nb) as ONE sequence of L = nb * SL steps
+  const int N = NS > 0 ? NS : p.N, SL = p.L;
+  const int b0 = FOLD ? (int)blockIdx.y * p.fold_bpp : 0;
+  const int L = FOLD ? (p.batch - b0 < p.fold_bpp ? p.batch - b0 : p.fold_bpp) * SL : SL;
   float* sBC = smem;                          // [2 buffers][B|C][N][CH]
   float* sO = sBC + 4 * N * CH;               // [DT][CH] out tile (unaligned rows / ragged tail)
   float2* sAC = (float2*)(sO + DT * CH);      // [DT + 2][NP] {A*log2(e), running state h}; row DT stays zero, row DT + 1.. = dump
@@ -60,7 +72,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane / LPR, j = lane % LPR;
   const int row = wave * RPW + r;
-  const int b = blockIdx.y;
+  const int b = FOLD ? b0 : blockIdx.y;           // FOLD: the first batch element of the part; the arrays' base pointers start there
   const int dpg = p.dim / p.G;
   const int tiles = (dpg + DT - 1) / DT;
   const int g = blockIdx.x / tiles;
@@ -79,6 +91,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const io_t* __restrict__ Bp = (const io_t*)p.B + (int64_t)b * p.B_bs + (int64_t)g * p.B_gs;
   const io_t* __restrict__ Cp = (const io_t*)p.C + (int64_t)b * p.C_bs + (int64_t)g * p.C_gs;
   const bool has_z = pz != nullptr;
+  // FOLD: virtual step tv -> element offset of (batch tv / SL, step tv % SL) for an array with batch stride bs
+  auto seg_of = [&](int tv) { return (int)__umulhi((unsigned)tv, p.fold_magic); };
+  auto fold_off = [&](int tv, int64_t bs) {
+    const int sb = seg_of(tv);
+    return seg_off(sb, bs, tv - sb * SL);
+  };
 
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
@@ -104,13 +122,24 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     if constexpr (VEC) {
       constexpr int CQ = CH / 4, RSTEP = NT / CQ;
       const int e4 = (tid % CQ) * 4;
+      int64_t fB = 0, fC = 0;          // FOLD: this thread's quarter lies in ONE segment: its (segment, step) offset, once per chunk
+      if constexpr (FOLD) {
+        const int sb = seg_of(t0 + e4), sl = t0 + e4 - sb * SL;
+        fB = seg_off(sb, p.B_bs, sl);
+        fC = seg_off(sb, p.C_bs, sl);
+      }
 #pragma unroll
       for (int k = 0; k < BCV; ++k) {
         const int n = tid / CQ + k * RSTEP;
         bq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         cq[k] = bq[k];
         if (n < N) {
-          if (full) {
+          if constexpr (FOLD) {
+            if (t0 + e4 < L) {      // a quarter lies inside one segment (SL % 4 == 0)
+              bq[k] = ld4<io_t>(Bp + (int64_t)n * p.B_ns + fB);
+              cq[k] = ld4<io_t>(Cp + (int64_t)n * p.C_ns + fC);
+            }
+          } else if (full) {
             bq[k] = ld4<io_t>(Bp + (int64_t)n * p.B_ns + t0 + e4);
             cq[k] = ld4<io_t>(Cp + (int64_t)n * p.C_ns + t0 + e4);
           } else {
@@ -184,8 +213,15 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int i = 0; i < T; ++i) v[i] = io::ld(q + i);
     }
   };
-  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T]) {
-    if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+  auto row_fetch = [&](const io_t* q, int t0, float (&v)[T], int64_t bs) {
+    if constexpr (FOLD) {
+      if (t0 + j * T < L) {
+        ldT(q - j * T + bs, v);          // FOLD: `bs` carries the lane's (segment, step) element offset of this chunk
+      } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) v[i] = 0.0f;
+      }
+    } else if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
       ldT(q + t0, v);
     } else {
 #pragma unroll
@@ -193,7 +229,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
   };
   auto ud_fetch = [&](int t0, float (&vu)[T], float (&vd)[T]) {
-    if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+    if constexpr (FOLD) {
+      if (t0 + j * T < L) {
+        const int tv = t0 + j * T, sb = seg_of(tv), sl = tv - sb * SL;
+        ldT(pu - j * T + seg_off(sb, p.u_bs, sl), vu);
+        ldT(pd - j * T + seg_off(sb, p.dl_bs, sl), vd);
+      } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) { vu[i] = 0.0f; vd[i] = 0.0f; }
+      }
+    } else if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
       ldT(pu + t0, vu);
       ldT(pd + t0, vd);
     } else {
@@ -245,7 +290,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       bc_fetch(t0 + CH);
       ud_fetch(t0 + CH, un, dn);
     }
-    if (has_z) row_fetch(pz, t0, zz);
+    // FOLD: (segment, step) of this lane's 8 steps in chunk c, once for z, the reset test and the output store
+    int csb = 0, csl = 0;
+    if constexpr (FOLD) {
+      csb = seg_of(t0 + j * T);
+      csl = t0 + j * T - csb * SL;
+    }
+    if (has_z) row_fetch(pz, t0, zz, FOLD ? seg_off(csb, p.z_bs, csl) : 0);
 
     float dsum = 0.0f;
 #pragma unroll
@@ -256,9 +307,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int i = lane; i < RPW * N; i += 64) {
         const int rr = i / N, n = i - rr * N;
         const int dd = d0 + wave * RPW + rr;
-        if (dd < d_end) p.ckpt[(((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
+        if (dd < d_end) {
+          // FOLD: (channel, part, virtual chunk); a part owns fold_cpp = chunks(fold_bpp * SL) slots
+          const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
+          p.ckpt[slot * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
+        }
       }
     }
+    // FOLD: a lane whose first step opens a segment adds -inf to the exponent of a_0 and of the lane product: a_0 = P = 0
+    float rbias = 0.0f;
+    if constexpr (FOLD) rbias = (csl == 0) ? -__builtin_inff() : 0.0f;
     float2* ac = sAC + row * NP;
     const float2* ac_in = sAC + ((j == 0) ? row : DT) * NP;  // only lane 0 sees the state entering the chunk
     // the last lane of a row stores the state leaving the chunk; the others store into a private dump word (an exec-masked
@@ -292,6 +350,10 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
         bb[i] = du[i] * bb[i];
       }
       P = A2 * dsum;
+      if constexpr (FOLD) {
+        a[0] += rbias;
+        P += rbias;
+      }
       // the T + 1 v_exp_f32 of a state back to back: 8 cycles each alone, 10-16 when interleaved with FMAs
       // (profiles/r01_ubench_valu_mix.txt)
       if constexpr (T == 8) {
@@ -345,7 +407,14 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int i = 0; i < T; ++i) y[i] *= silu(zz[i]);
     }
     if (MXVL_ABL(p.ablate & 8)) continue;
-    if (VEC && full) {
+    if constexpr (FOLD) {
+      if (row_ok && t0 + j * T < L) {
+        const int64_t o = po - j * T + seg_off(csb, p.o_bs, csl);
+#pragma unroll
+        for (int k = 0; k < TQ; ++k)
+          st4_out<io_t>(p.out, o + 4 * k, make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]), of32);
+      }
+    } else if (VEC && full) {
       if (row_ok) {
 #pragma unroll
         for (int k = 0; k < TQ; ++k)

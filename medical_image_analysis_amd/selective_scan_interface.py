@@ -88,11 +88,12 @@ def _prep(u, delta, A, B, C, D, z, delta_bias):
     return dev, u, delta, A, B, C, D, z, delta_bias
 
 
-def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last_state, ckpt, out_f32=False):
+def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last_state, ckpt, out_f32=False, fold=False):
     batch, dim, L = u.shape
     desc.batch, desc.dim, desc.seqlen, desc.dstate, desc.n_groups = batch, dim, L, A.shape[1], B.shape[1]
     desc.io_dtype = _abi.dtype_code(u.dtype)
-    desc.flags = (_abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0) | (_abi.SCAN_OUT_F32 if out_f32 else 0)
+    desc.flags = ((_abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0) | (_abi.SCAN_OUT_F32 if out_f32 else 0)
+                  | (_abi.SCAN_FOLD_BATCH if fold else 0))
     desc.delta_group_ratio = dim // delta.shape[1]
     desc.u_bs, desc.u_ds = u.stride(0), u.stride(1)
     desc.delta_bs, desc.delta_ds = delta.stride(0), delta.stride(1)
@@ -108,6 +109,35 @@ def _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, la
     desc.out, desc.last_state, desc.ckpt = _abi.ptr(out), _abi.ptr(last_state), _abi.ptr(ckpt)
 
 
+def _ckpt_chunks(ckpt, batch, dim):
+    """checkpoints per (batch element, channel) -- for the algorithmic byte count; a folded call's tensor is (dim, slots, N)"""
+    if ckpt is None:
+        return 0
+    return ckpt.shape[2] if ckpt.dim() == 4 else max(1, ckpt.shape[1] // batch)
+
+
+FOLD_SHORT_ROWS = True     # dev tools flip it to time the per-batch-element launch geometry
+
+
+def _rows_16b(*tensors):
+    """every row of every tensor starts on a 16-byte boundary (what the folded kernels' vector accesses need)"""
+    for t in tensors:
+        if t is None:
+            continue
+        q = 16 // t.element_size()
+        if t.data_ptr() % 16 or any(st % q for st in t.stride()[:-1]):
+            return False
+    return True
+
+
+def _fold_short_rows(lib, u, delta, A, B, C, z, want_last_state, out_f32):
+    """MXVL_SCAN_FOLD_BATCH for rows whose last 128-step chunk is mostly padding (197-token encoders, 144-token pre-training):
+    the kernels walk several batch elements of a channel as one sequence (include/mxvl.h)."""
+    batch, dim, L = u.shape
+    return bool(FOLD_SHORT_ROWS and not want_last_state and not out_f32 and delta.shape[1] == dim
+                and lib.mxvl_scan_fold_ok(batch, L, A.shape[1]) and _rows_16b(u, delta, B, C, z))
+
+
 def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
                  want_last_state=False, want_ckpt=False, out_f32=False):
     """One mxvl_scan_fwd call on already-validated tensors; returns (out, last_state|None, ckpt|None).
@@ -120,12 +150,16 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
     out = torch.empty_like(u, dtype=torch.float32) if out_f32 else torch.empty_like(u)
     last = torch.empty((batch, dim, N), dtype=torch.float32, device=u.device) if want_last_state else None
     ckpt = None
+    fold = _fold_short_rows(lib, u, delta, A, B, C, z, want_last_state, out_f32) and _rows_16b(out)
     if want_ckpt:
-        n_chunks = lib.mxvl_scan_n_chunks(L, N)
-        if n_chunks > 1:
-            ckpt = torch.empty((batch, dim, n_chunks, N), dtype=torch.float32, device=u.device)
+        if fold:     # a 3-D checkpoint tensor IS the mark of a folded call: scan_bwd_raw reads the geometry off it
+            ckpt = torch.empty((dim, lib.mxvl_scan_fold_slots(batch, L, dim, B.shape[1]), N), dtype=torch.float32, device=u.device)
+        else:
+            n_chunks = lib.mxvl_scan_n_chunks(L, N)
+            if n_chunks > 1:
+                ckpt = torch.empty((batch, dim, n_chunks, N), dtype=torch.float32, device=u.device)
     desc = _abi.ScanDesc()
-    _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt, out_f32)
+    _fill_fwd(desc, u, delta, A, B, C, D, z, delta_bias, delta_softplus, out, last, ckpt, out_f32, fold)
     timers = KERNEL_TIMERS
     with torch.cuda.device(u.device):
         if timers is not None:
@@ -136,7 +170,7 @@ def scan_fwd_raw(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softp
             e1.record()
             timers.append(("scan_fwd", e0, e1, scan_algorithmic_bytes(
                 batch, dim, L, N, B.shape[1], u.element_size(), z is not None, False,
-                ckpt.shape[2] if ckpt is not None else 0)))
+                _ckpt_chunks(ckpt, batch, dim))))
     _abi.check(rc, "mxvl_scan_fwd")
     return out, last, ckpt
 
@@ -167,8 +201,13 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
         dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
     dD = torch.zeros_like(D) if D is not None else None
     dbias = torch.zeros(dim, dtype=torch.float32, device=u.device) if delta_bias is not None else None
+    fold = ckpt is not None and ckpt.dim() == 3          # the forward folded the batch into the sequence (scan_fwd_raw)
+    if fold and not _rows_16b(dout):
+        dout = dout.contiguous()
+    if fold and not _rows_16b(du, ddelta, dz):
+        raise RuntimeError("selective_scan backward of a folded forward needs 16-byte aligned rows for du / ddelta / dz")
     desc = _abi.ScanBwdDesc()
-    _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt, dout_f32)
+    _fill_fwd(desc.fwd, u, delta, A, B, C, D, z, delta_bias, delta_softplus, None, None, ckpt, dout_f32, fold)
     desc.dout_bs, desc.dout_ds = dout.stride(0), dout.stride(1)
     desc.du_bs, desc.du_ds = du.stride(0), du.stride(1)
     desc.ddelta_bs, desc.ddelta_ds = ddelta.stride(0), ddelta.stride(1)
@@ -190,7 +229,7 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
             e1.record()
             timers.append(("scan_bwd", e0, e1, scan_algorithmic_bytes(
                 batch, dim, L, A.shape[1], B.shape[1], u.element_size(), z is not None, True,
-                ckpt.shape[2] if ckpt is not None else 0)))
+                _ckpt_chunks(ckpt, batch, dim))))
     _abi.check(rc, "mxvl_scan_bwd")
     if ratio > 1:
         ddelta = ddelta.view(batch, dim // ratio, ratio, L).sum(2, dtype=torch.float32).to(delta.dtype)

@@ -509,3 +509,74 @@ def test_oflex_fp32_out_is_the_unrounded_accumulator(B, D, L, N, G, dtype):
     for k, t in (("dA", a[2]), ("dD", a[5]), ("ddelta_bias", a[6])):                # fp32 accumulators
         r = rg[k]
         assert_close(t.grad, r, 2e-5 * max(1.0, float(r.abs().max())), 1e-4, k)
+
+
+FOLD_CASES = [
+    # B, D,  L,   G, z,    D,    bias   (dstate 16; L % 8 == 0 and a mostly empty last chunk: mxvl_scan_fold_ok)
+    (5, 48, 200, 1, True, True, True),       # the 197-token encoder rows (padded to 200): segments straddle chunks everywhere
+    (64, 64, 144, 4, True, True, True),      # 144-token pre-training rows, grouped B / C, several parts of the batch
+    (3, 32, 104, 1, False, True, False),     # one chunk per row: the folded walk needs checkpoints the plain one does not
+    (7, 40, 8, 1, True, False, True),        # rows of ONE lane: 16 segments per chunk, channel tile ragged (40 of 48 rows)
+]
+
+
+@pytest.mark.parametrize("case", FOLD_CASES)
+def test_scan_batch_folded_into_the_sequence_matches_oracle_and_the_plain_launch(case):
+    """MXVL_SCAN_FOLD_BATCH (include/mxvl.h): a workgroup walks several batch elements of its channels as ONE sequence with the
+    state cut at every row start.  Forward and all gradients (fp32) against the C oracle, and against the per-batch-element launch
+    geometry of the same library -- the folded call must have been taken (3-D checkpoint tensor)."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    B, D, L, G, hz, hD, hb = case
+    cpu = scan_inputs(B, D, L, 16, G, hz, hD, hb, seed=31)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(32))
+    ref_out = orc.selective_scan_ref(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"], cpu["delta_bias"], True)
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], True, dout)
+    dev = _dev()
+    x = _to(cpu, dev)
+    Bm = x["B"] if G > 1 else x["B"].unsqueeze(1)
+    Cm = x["C"] if G > 1 else x["C"].unsqueeze(1)
+    out, _, ckpt = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], x["z"], x["delta_bias"], True, want_ckpt=True)
+    assert ckpt is not None and ckpt.dim() == 3, "the folded launch was not taken"
+    ref_o = ref_out[0] if isinstance(ref_out, tuple) else ref_out
+    assert_close(out, ref_o, _atol(ref_o), 1e-4, "folded out")
+    got = _grads_via_autograd(x, True, dout.to(dev))
+    _check_grads(got, ref, "folded ")
+    old = ssi.FOLD_SHORT_ROWS
+    try:
+        ssi.FOLD_SHORT_ROWS = False
+        out_p, _, ckpt_p = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], x["z"], x["delta_bias"], True, want_ckpt=True)
+        assert ckpt_p is None or ckpt_p.dim() == 4
+        plain = _grads_via_autograd(x, True, dout.to(dev))
+    finally:
+        ssi.FOLD_SHORT_ROWS = old
+    assert_close(out, out_p, 2e-5 * max(1.0, float(out_p.abs().max())), 1e-5, "folded vs plain out")
+    for k, r in plain.items():
+        assert_close(got[k], r, 5e-5 * max(1.0, float(r.abs().max())), 1e-4, f"folded vs plain {k}")
+
+
+def test_scan_batch_folding_half_io_and_fallbacks():
+    """bf16 rows fold too (16-byte loads of 8 steps never straddle a segment); rows that do not qualify keep the plain launch:
+    L % 8 != 0, a full last chunk, a requested last_state."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    dev = _dev()
+    cpu = scan_inputs(6, 64, 200, 16, 1, True, True, True, seed=41, dtype=torch.bfloat16)
+    dout = torch.randn(6, 64, 200, generator=torch.Generator().manual_seed(42)).to(torch.bfloat16)
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], True, dout)
+    x = _to(cpu, dev)
+    _, _, ckpt = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"].unsqueeze(1), x["C"].unsqueeze(1), x["D"], x["z"],
+                                  x["delta_bias"], True, want_ckpt=True)
+    assert ckpt.dim() == 3
+    got = _grads_via_autograd(x, True, dout.to(dev))
+    for k, r in ref.items():
+        scale = max(1.0, float(r.abs().max()))
+        assert_close(got[k], r, 5e-2 * scale * 0.2, 6e-2, "bf16 folded " + k)
+    for (B, L, last) in ((4, 197, False), (4, 256, False), (4, 200, True)):
+        c = _to(scan_inputs(B, 32, L, 16, 1, True, True, True, seed=43), dev)
+        _, ls, ck = ssi.scan_fwd_raw(c["u"], c["delta"], c["A"], c["B"].unsqueeze(1), c["C"].unsqueeze(1), c["D"], c["z"],
+                                     c["delta_bias"], True, want_last_state=last, want_ckpt=True)
+        assert ck is None or ck.dim() == 4, (B, L, last)
+        assert (ls is not None) == last
