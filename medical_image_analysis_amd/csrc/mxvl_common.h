@@ -154,14 +154,25 @@ inline uint32_t scan_fold_magic(int seqlen) { return (uint32_t)((1ull << 32) / (
 // batch stride fits 32 bits (a 64 x 32-bit multiply per array and chunk was a tenth of the folded forward)
 __device__ inline int64_t seg_off(int sb, int64_t bs, int sl) { return (int64_t)((uint64_t)(uint32_t)sb * (uint32_t)bs + (uint32_t)sl); }
 // batch elements per workgroup sequence, the SAME function for the forward (which lays the checkpoints out by it) and the
-// backward: enough parts to give the forward >= 768 workgroups of 16 rows, but sequences of >= 1024 steps where the batch allows
+// backward.  The backward runs ONE 32-row workgroup per CU, so the number of parts is chosen to make (32-row tiles x parts) fill
+// whole rounds of the 256 CUs (128 tiles x 3 parts = 1.5 rounds cost the 197-token encoder a quarter of the kernel), with at
+// least 512 sixteen-row workgroups for the forward where possible, sequences of >= 1024 steps; ties go to fewer parts.
 inline int scan_fold_bpp(int batch, int seqlen, int dim, int n_groups) {
-  const int tiles16 = n_groups * ((dim / n_groups + 15) / 16);
-  int parts = (768 + tiles16 - 1) / tiles16;
-  parts = parts < 1 ? 1 : (parts > batch ? batch : parts);
-  int bpp = (batch + parts - 1) / parts;
-  while (bpp * seqlen < 1024 && bpp < batch) ++bpp;
-  return bpp;
+  const int dpg = dim / n_groups;
+  const long tiles32 = (long)n_groups * ((dpg + 31) / 32), tiles16 = (long)n_groups * ((dpg + 15) / 16);
+  int best_parts = 1;
+  double best = -1.0;
+  for (int parts = 1; parts <= batch && parts <= 32; ++parts) {
+    const int bpp = (batch + parts - 1) / parts;
+    const int real_parts = (batch + bpp - 1) / bpp;
+    if (real_parts != parts) continue;
+    const long wgs = tiles32 * parts, rounds = (wgs + 255) / 256;
+    double score = (double)wgs / (double)(rounds * 256);          // fill of the backward's rounds
+    if (tiles16 * parts < 512) score *= 0.5 + 0.5 * (double)(tiles16 * parts) / 512.0;   // the forward wants >= 2 workgroups per CU
+    if ((long)bpp * seqlen < 1024 && parts > 1) continue;         // a sequence shorter than 8 chunks folds little padding away
+    if (score > best + 1e-9) { best = score; best_parts = parts; }
+  }
+  return (batch + best_parts - 1) / best_parts;
 }
 
 }  // namespace mxvl
