@@ -239,17 +239,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   };
   auto rows_fetch = [&](int t0, float (&vu)[T], float (&vd)[T], float (&vg)[T], float (&vz)[T]) {
     if constexpr (FOLD) {
-      const int tv = t0 + j * T;
-      if (tv < L) {
-        const int sb = seg_of(tv), sl = tv - sb * SL;       // (the row pointers already carry + j * T)
-        ld8(pu - j * T + seg_off(sb, p.u_bs, sl), vu);
-        ld8(pd - j * T + seg_off(sb, p.dl_bs, sl), vd);
-        if (!of32) ld8(pg - j * T + seg_off(sb, p.do_bs, sl), vg);
-        if (has_z) ld8(pz - j * T + seg_off(sb, p.z_bs, sl), vz);
-      } else {
-#pragma unroll
-        for (int i = 0; i < T; ++i) { vu[i] = 0.0f; vd[i] = 0.0f; vg[i] = 0.0f; vz[i] = 0.0f; }
-      }
+      // lanes past the end read step 0 (finite values; delta, d softplus and dout are zeroed for them below): unconditional loads
+      const int tv = t0 + j * T < L ? t0 + j * T : 0;
+      const int sb = seg_of(tv), sl = tv - sb * SL;       // (the row pointers already carry + j * T)
+      ld8(pu - j * T + seg_off(sb, p.u_bs, sl), vu);
+      ld8(pd - j * T + seg_off(sb, p.dl_bs, sl), vd);
+      if (!of32) ld8(pg - j * T + seg_off(sb, p.do_bs, sl), vg);
+      if (has_z) ld8(pz - j * T + seg_off(sb, p.z_bs, sl), vz);
     } else if (VEC && (t0 + CH <= L || t0 + j * T + T <= L)) {     // every step of this lane is valid: 16-byte loads
       ld8(pu + t0, vu);
       ld8(pd + t0, vd);
@@ -325,17 +321,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     for (int i = 0; i < T; ++i) v[i] = io::ld(tmp + i);
   };
   auto raw_prefetch = [&](int tn) {
-    if constexpr (FOLD) {
-      const int tv = tn + j * T;
-      if (tv < L) {
-        const int sb = seg_of(tv), sl = tv - sb * SL;
-        ru = *(const uint4*)(pu - j * T + seg_off(sb, p.u_bs, sl));
-        rd = *(const uint4*)(pd - j * T + seg_off(sb, p.dl_bs, sl));
-        rg = *(const uint4*)(pg - j * T + seg_off(sb, p.do_bs, sl));
-        if (has_z) rz = *(const uint4*)(pz - j * T + seg_off(sb, p.z_bs, sl));
-      } else {
-        ru = make_uint4(0, 0, 0, 0); rd = ru; rg = ru; rz = ru;
-      }
+    if constexpr (FOLD) {     // unconditional (a per-lane `if` makes the compiler wait for the loads at once); lanes past the end: step 0
+      const int tv = tn + j * T < L ? tn + j * T : 0;
+      const int sb = seg_of(tv), sl = tv - sb * SL;
+      ru = *(const uint4*)(pu - j * T + seg_off(sb, p.u_bs, sl));
+      rd = *(const uint4*)(pd - j * T + seg_off(sb, p.dl_bs, sl));
+      rg = *(const uint4*)(pg - j * T + seg_off(sb, p.do_bs, sl));
+      if (has_z) rz = *(const uint4*)(pz - j * T + seg_off(sb, p.z_bs, sl));
     } else if (tn + CH <= L || tn + j * T + T <= L) {
       ru = *(const uint4*)(pu + tn);
       rd = *(const uint4*)(pd + tn);
@@ -492,7 +484,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     if (!full) {
 #pragma unroll
       for (int i = 0; i < T; ++i)
-        if (!(t0 + j * T + i < L)) { dl[i] = 0.0f; dsp[i] = 0.0f; }
+        if (!(t0 + j * T + i < L)) { dl[i] = 0.0f; dsp[i] = 0.0f; if (FOLD) go[i] = 0.0f; }   // FOLD: those lanes loaded step 0
     }
     if (!row_ok) {  // clamped duplicate rows must not add into the shared dB/dC tile
 #pragma unroll

@@ -478,7 +478,10 @@ int mxvl_scan_fold_ok(int batch, int seqlen, int dstate) {
   if (batch < 2 || seqlen < 8 || seqlen % 8 != 0 || dstate != 16) return 0;
   if ((uint64_t)batch * (uint64_t)seqlen * (uint64_t)seqlen >= (1ull << 32)) return 0;   // multiply-high division by seqlen stays exact
   const int padded = (seqlen + kCkptLen - 1) / kCkptLen * kCkptLen;
-  return (padded - seqlen) * 8 >= padded;          // >= 12.5 % of the computed steps are padding
+  // >= 12.5 % of the computed steps are padding, or one-chunk rows (a workgroup per row is all prologue: at 128 steps the folded
+  // backward is 16 % faster and the folded forward 25 % slower, -7 % for the pair; from 256 steps on the pair does not gain,
+  // profiles/r03_scan_fold.txt)
+  return (padded - seqlen) * 8 >= padded || seqlen <= 128;
 }
 // checkpoint slots per channel of a folded call: ckpt = (dim, slots, dstate) fp32
 int mxvl_scan_fold_slots(int batch, int seqlen, int dim, int n_groups) {

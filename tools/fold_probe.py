@@ -19,7 +19,9 @@ def timed(f, iters=10):
 
 
 from medical_image_analysis_amd import selective_scan_interface as ssi
-for (B, L, fold) in ((64, 200, True), (64, 200, False), (2, 6400, True), (256, 144, True), (256, 144, False)):
+import sys
+SHAPES = ((64, 200), (256, 144)) if len(sys.argv) < 2 else tuple((int(a.split('x')[0]), int(a.split('x')[1])) for a in sys.argv[1:])
+for (B, L, fold) in [(b, l, f) for (b, l) in SHAPES for f in (True, False)]:
     ssi.FOLD_SHORT_ROWS = fold
     G, D, N = 4, 8192, 16
     g = torch.Generator().manual_seed(0)
@@ -34,4 +36,4 @@ for (B, L, fold) in ((64, 200, True), (64, 200, False), (2, 6400, True), (256, 1
     dB = torch.zeros(Bm.shape, dtype=torch.float32, device=dev); dC = torch.zeros_like(dB)
     tf = timed(lambda: scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, want_ckpt=True))
     tb = timed(lambda: scan_bwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, ckpt, dout, dB=dB, dC=dC))
-    print(f"B={B:3d} L={L:6d} D={D} G={G} folded={ckpt.dim() == 3}: fwd {tf:8.1f} us   bwd {tb:8.1f} us")
+    print(f"B={B:3d} L={L:6d} D={D} G={G} folded={ckpt is not None and ckpt.dim() == 3}: fwd {tf:8.1f} us   bwd {tb:8.1f} us")
