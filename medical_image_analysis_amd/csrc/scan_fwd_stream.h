@@ -218,7 +218,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   auto row_fetch = [&](const io_t* q, int t0, float (&v)[T], int64_t bs) {
     if constexpr (FOLD) {
       ldT(q - j * T + bs, v);            // FOLD: `bs` carries the lane's (segment, step) element offset of this chunk (clamped)
-    } else if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+    } else if (t0 + CH <= L) {           // wave-uniform (see ud_fetch)
+      ldT(q + t0, v);
+    } else if (VEC && t0 + j * T + T <= L) {
       ldT(q + t0, v);
     } else {
 #pragma unroll
@@ -228,9 +230,30 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   auto ud_fetch = [&](int t0, float (&vu)[T], float (&vd)[T]) {
     if constexpr (FOLD) {   // lanes past the end read step 0 (see bc_fetch): delta is forced to 0 for them below, nothing is stored
       const int tv = t0 + j * T < L ? t0 + j * T : 0, sb = seg_of(tv), sl = tv - sb * SL;
-      ldT(pu - j * T + seg_off(sb, p.u_bs, sl), vu);
-      ldT(pd - j * T + seg_off(sb, p.dl_bs, sl), vd);
-    } else if (t0 + CH <= L || (VEC && t0 + j * T + T <= L)) {
+      const io_t* qu = pu - j * T + seg_off(sb, p.u_bs, sl);
+      const io_t* qd = pd - j * T + seg_off(sb, p.dl_bs, sl);
+      if constexpr (T == 8 && sizeof(io_t) == 2) {
+        // both rows requested before either is converted: with two ldT calls hipcc waited for u before it asked for delta
+        // (an extra HBM round trip per chunk, +25 % on the folded forward)
+        uint4 ra = *(const uint4*)qu, rb = *(const uint4*)qd;
+        // (an empty asm that "uses" all eight registers: the scheduler otherwise converts u before it issues the load of delta)
+        asm volatile("" : "+v"(ra.x), "+v"(ra.y), "+v"(ra.z), "+v"(ra.w), "+v"(rb.x), "+v"(rb.y), "+v"(rb.z), "+v"(rb.w));
+        io_t ta[T], tb[T];
+        *(uint4*)ta = ra;
+        *(uint4*)tb = rb;
+#pragma unroll
+        for (int i = 0; i < T; ++i) { vu[i] = io::ld(ta + i); vd[i] = io::ld(tb + i); }
+      } else {
+        ldT(qu, vu);
+        ldT(qd, vd);
+      }
+    } else if (t0 + CH <= L) {
+      // the full-chunk test alone is wave-uniform -- a scalar branch.  Merged with the per-lane "whole lane inside the row" test
+      // it became an exec-masked region whose other side writes the same registers, and hipcc then waits for the loads right
+      // there: the prefetch of chunk c + 1 never overlapped the state loop of chunk c
+      ldT(pu + t0, vu);
+      ldT(pd + t0, vd);
+    } else if (VEC && t0 + j * T + T <= L) {
       ldT(pu + t0, vu);
       ldT(pd + t0, vd);
     } else {
@@ -250,8 +273,31 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   const long long clk0 = 0, wall0 = 0;
 #endif
   float un[T], dn[T];
+  // 16-bit aligned rows: u / delta of the next chunk stay PACKED (2 x 16 bytes) across the state loop and are converted at the
+  // top of the next iteration, z of this chunk until the loop is over -- converted where they are loaded, hipcc waits for them in
+  // front of the loop: no overlap at all (folded forward 714 -> 688 us, profiles/r03_scan_fold.txt)
+  constexpr bool RAWPF = VEC && T == 8 && sizeof(io_t) == 2;
+  uint4 ru = make_uint4(0, 0, 0, 0), rd = ru;
+  auto raw_row = [&](const io_t* q, int t0) {          // 8 steps of a plain (not folded) row; beyond L: zeros
+    if (t0 + CH <= L) return *(const uint4*)(q + t0);   // wave-uniform: every full chunk takes this path, nothing per lane
+    uint16_t e[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) e[i] = (t0 + j * T + i < L) ? *(const uint16_t*)(q + t0 + i) : (uint16_t)0;
+    return make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                      (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+  };
+  auto raw_ud = [&](int t0) {
+    if constexpr (FOLD) {
+      const int tv = t0 + j * T < L ? t0 + j * T : 0, sb = seg_of(tv), sl = tv - sb * SL;
+      ru = *(const uint4*)(pu - j * T + seg_off(sb, p.u_bs, sl));
+      rd = *(const uint4*)(pd - j * T + seg_off(sb, p.dl_bs, sl));
+    } else {
+      ru = raw_row(pu, t0);
+      rd = raw_row(pd, t0);
+    }
+  };
   bc_fetch(0);
-  ud_fetch(0, un, dn);
+  if constexpr (RAWPF) raw_ud(0); else ud_fetch(0, un, dn);
   bc_commit(0);
 
   for (int c = 0; c < nchunks; ++c) {
@@ -264,6 +310,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     // flag tests stay OUTSIDE the per-step loops: a uniform branch per step serialises the 8 exp -> log -> rcp chains
 #pragma unroll
     for (int i = 0; i < T; ++i) dl[i] = dn[i] + bias;
+    if constexpr (RAWPF) {
+      io_t ta[T], tb[T];
+      *(uint4*)ta = ru;
+      *(uint4*)tb = rd;
+#pragma unroll
+      for (int i = 0; i < T; ++i) { un[i] = io::ld(ta + i); dl[i] = io::ld(tb + i) + bias; }
+    }
     if (p.softplus) {
 #pragma unroll
       for (int i = 0; i < T; ++i) dl[i] = softplus(dl[i]);
@@ -280,7 +333,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     // requests for the next chunk (and this chunk's z) go out before the long state loop
     if (more) {
       bc_fetch(t0 + CH);
-      ud_fetch(t0 + CH, un, dn);
+      if constexpr (RAWPF) raw_ud(t0 + CH); else ud_fetch(t0 + CH, un, dn);
     }
     // FOLD: (segment, step) of this lane's 8 steps in chunk c, once for z, the reset test and the output store
     int csb = 0, csl = 0;
@@ -289,7 +342,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       csb = seg_of(tv);
       csl = tv - csb * SL;
     }
-    if (has_z) row_fetch(pz, t0, zz, FOLD ? seg_off(csb, p.z_bs, csl) : 0);
+    uint4 rz = make_uint4(0, 0, 0, 0);       // RAWPF: z of this chunk stays packed until the state loop is over
+    if (has_z) {
+      if constexpr (RAWPF && FOLD) rz = *(const uint4*)(pz - j * T + seg_off(csb, p.z_bs, csl));
+      else if constexpr (RAWPF) rz = raw_row(pz, t0);
+      else row_fetch(pz, t0, zz, FOLD ? seg_off(csb, p.z_bs, csl) : 0);
+    }
 
     float dsum = 0.0f;
 #pragma unroll
@@ -396,6 +454,12 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 
     if (more) bc_commit((c + 1) & 1);
     if (has_z) {
+      if constexpr (RAWPF) {
+        io_t tz[T];
+        *(uint4*)tz = rz;
+#pragma unroll
+        for (int i = 0; i < T; ++i) zz[i] = io::ld(tz + i);
+      }
 #pragma unroll
       for (int i = 0; i < T; ++i) y[i] *= silu(zz[i]);
     }
