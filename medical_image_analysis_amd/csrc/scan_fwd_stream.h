@@ -115,8 +115,17 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   auto qpos = [](int e) { const int q = (e % T) >> 2; return q * (LPR * 4) + ((((e / T) * 4) + (q & 1) * SWZ) & (LPR * 4 - 1)) + (e & 3); };
 
   // ---- B/C tile fetch (global -> registers) and commit (registers -> LDS buffer) ------------------
-  float4 bq[VEC ? BCV : 1], cq[VEC ? BCV : 1];
+  // 16-bit aligned rows: the quarters stay PACKED (8 bytes) until the commit after the state loop -- converted at the load,
+  // hipcc waits for the whole tile in front of the loop
+  constexpr bool RAWBC = VEC && sizeof(io_t) == 2;
+  float4 bq[(VEC && !RAWBC) ? BCV : 1], cq[(VEC && !RAWBC) ? BCV : 1];
+  uint2 bqr[RAWBC ? BCV : 1], cqr[RAWBC ? BCV : 1];
   float bs[VEC ? 1 : BCS], cs[VEC ? 1 : BCS];
+  auto q_unpack = [](uint2 r) {
+    io_t t[4];
+    *(uint2*)t = r;
+    return make_float4(io::ld(t), io::ld(t + 1), io::ld(t + 2), io::ld(t + 3));
+  };
   auto bc_fetch = [&](int t0) {
     const bool full = t0 + CH <= L;
     if constexpr (VEC) {
@@ -135,6 +144,30 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
       for (int k = 0; k < BCV; ++k) {
         const int n = tid / CQ + k * RSTEP;
+        if constexpr (RAWBC) {
+          bqr[k] = make_uint2(0, 0);
+          cqr[k] = bqr[k];
+          if (n < N) {
+            if constexpr (FOLD) {
+              bqr[k] = *(const uint2*)(Bp + (int64_t)n * p.B_ns + fB);
+              cqr[k] = *(const uint2*)(Cp + (int64_t)n * p.C_ns + fC);
+            } else if (full) {
+              bqr[k] = *(const uint2*)(Bp + (int64_t)n * p.B_ns + t0 + e4);
+              cqr[k] = *(const uint2*)(Cp + (int64_t)n * p.C_ns + t0 + e4);
+            } else {
+              uint16_t tb[4] = {0, 0, 0, 0}, tc[4] = {0, 0, 0, 0};
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (t0 + e4 + q < L) {
+                  tb[q] = *(const uint16_t*)(Bp + (int64_t)n * p.B_ns + t0 + e4 + q);
+                  tc[q] = *(const uint16_t*)(Cp + (int64_t)n * p.C_ns + t0 + e4 + q);
+                }
+              bqr[k] = make_uint2((uint32_t)tb[0] | ((uint32_t)tb[1] << 16), (uint32_t)tb[2] | ((uint32_t)tb[3] << 16));
+              cqr[k] = make_uint2((uint32_t)tc[0] | ((uint32_t)tc[1] << 16), (uint32_t)tc[2] | ((uint32_t)tc[3] << 16));
+            }
+          }
+          continue;
+        }
         bq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         cq[k] = bq[k];
         if (n < N) {
@@ -183,8 +216,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       for (int k = 0; k < BCV; ++k) {
         const int n = tid / CQ + k * RSTEP;
         if (n < N) {
-          *(float4*)(dB + n * CH + pos) = bq[k];
-          *(float4*)(dC + n * CH + pos) = cq[k];
+          if constexpr (RAWBC) {
+            *(float4*)(dB + n * CH + pos) = q_unpack(bqr[k]);
+            *(float4*)(dC + n * CH + pos) = q_unpack(cqr[k]);
+          } else {
+            *(float4*)(dB + n * CH + pos) = bq[k];
+            *(float4*)(dC + n * CH + pos) = cq[k];
+          }
         }
       }
     } else {
