@@ -180,6 +180,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   // per-step outputs; in registers (32 VGPRs) they push the loop to the 256-VGPR limit, where the compiler re-computes the 8
   // v_exp_f32 of a_t in the second pass instead of keeping them (17 instead of 9 transcendentals per state).
   io_t* sPark = (io_t*)(smem + (((sDump + NT + N) - smem + 3) & ~3));     // [4][NT][T], 16-byte aligned
+  // DMABC: the B/C tile of the NEXT chunk to be processed (c - 1) arrives by LDS-DMA, raw io dtype [B|C][N][CH], while chunk c is
+  // in its state loop; at the top of a chunk the staging pass converts it LDS -> LDS.  Staged from global memory at the top of the
+  // chunk (as before, and still for run-time dstate / unaligned rows) the tile cost one fully exposed HBM round trip per chunk:
+  // the one workgroup of a CU has nothing else to run meanwhile.  The checkpoint of chunk c - 1 is prefetched into a register.
+  // (A/B in one process, profiles/r03_scan_fold.txt: 1157.7 -> 1128.0 us at the pre-training shape; the folded walk got SLOWER,
+  //  895.7 -> 943.3 us at B64 x L200, and keeps the global staging)
+  constexpr bool DMABC = VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD;     // (fp32 rows: the parked rows already fill the LDS)
+  io_t* sRawBC = sPark + (size_t)4 * NT * T;                               // [2][N][CH] io dtype (DMABC)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = __builtin_amdgcn_readfirstlane(wave);     // the wave index as a scalar: flush addresses are SGPR + lane
@@ -352,6 +360,48 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   };
 
   const int nchunks = (L + CH - 1) / CH;
+  // one DMA instruction = 64 lanes x 16 bytes = 1 KB of the raw tile; lane -> (array, state row, first step) of its 16 bytes
+  constexpr int EPL = 16 / (int)sizeof(io_t);                   // elements per lane and instruction
+  constexpr int NDMA = 2 * 16 * CH * (int)sizeof(io_t) / 1024;  // instructions per tile (dstate 16): 8 (16-bit) / 16 (fp32)
+  constexpr int DPW = (NDMA + NWAVES - 1) / NWAVES;             // per wave
+  auto bc_dma = [&](int t0) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)((char*)sRawBC);
+#pragma unroll
+    for (int k = 0; k < DPW; ++k) {
+      const int q = wq * DPW + k;                                // wave-uniform 1 KB block of the raw tile
+      if (q < NDMA) {
+        const int e0 = q * (1024 / (int)sizeof(io_t)) + lane * EPL;   // element index inside [B|C][16][CH]
+        const int arr = e0 / (16 * CH), n = (e0 / CH) & 15, st = e0 & (CH - 1);
+        int tv = t0 + st;
+        tv = tv < L ? tv : 0;                                    // past the end: step 0 (finite values under delta = 0)
+        const io_t* g = arr ? Cp + (int64_t)n * p.C_ns : Bp + (int64_t)n * p.B_ns;
+        if constexpr (FOLD) g += fold_off(tv, arr ? p.C_bs : p.B_bs); else g += tv;
+        const unsigned dst = lds0 + (unsigned)q * 1024u;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %[keep], m0\n\t"
+            "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g], off\n\t"
+            "s_mov_b32 m0, %[keep]"
+            : [keep] "=&s"(keep)
+            : [dst] "s"(dst), [g] "v"(g)
+            : "memory", "scc");
+      }
+    }
+  };
+  float ck_next = 0.0f;                                          // checkpoint (row, state) = lane of this wave, for the next chunk
+  auto ckpt_prefetch = [&](int c) {
+    const int rr = lane / N, n = lane - rr * N;                  // RPW * N == 64: one entry per lane
+    const int dd = d0 + wave * RPW + rr;
+    ck_next = 0.0f;
+    if (c > 0 && dd < d_end) {
+      const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
+      ck_next = p.ckpt[slot * N + n];
+    }
+  };
+  if constexpr (DMABC) {
+    bc_dma((nchunks - 1) * CH);
+    ckpt_prefetch(nchunks - 1);
+  }
   if constexpr (PF) raw_prefetch((nchunks - 1) * CH);
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
@@ -401,7 +451,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * CH;
     const bool full = t0 + CH <= L;
-    __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible)
+    if constexpr (DMABC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the B/C DMA has landed ...
+    __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible); ... and everybody's share
     // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
     float uu[T], dl[T], zz[T], go[T];
     if constexpr (PF) {
@@ -413,7 +464,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       rows_fetch(t0, uu, dl, go, zz);
     }
     // ---- B/C tile of this chunk + state entering the chunk ---------------------------------------------
-    if (FOLD || (VEC && full)) {
+    if constexpr (DMABC) {       // the raw tile landed before the barrier that opened this chunk
+      for (int i = tid; i < N * (CH / 4); i += NT) {
+        const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
+        const float4 bv = ld4<io_t>(sRawBC + n * CH + e);
+        const float4 cv = ld4<io_t>(sRawBC + 16 * CH + n * CH + e);
+        const int pos = n * CH + ((e >> 2) & 1) * 64 + (((e >> 3) * 4 + ((e >> 2) & 1) * 16) & 63);
+        *(float4*)(sB + pos) = bv;
+        *(float4*)(sC + pos) = cv;
+      }
+      sAC[(wave * RPW + lane / N) * NP + (lane % N)].y = ck_next;
+    } else if (FOLD || (VEC && full)) {
       for (int i = tid; i < N * (CH / 4); i += NT) {   // 16-byte loads, 4 consecutive steps per thread
         const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), cv = bv;
@@ -444,19 +505,27 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         sC[pos] = cv;
       }
     }
-    for (int i = lane; i < RPW * N; i += 64) {
-      const int rr = i / N, n = i - rr * N;
-      const int dd = d0 + wave * RPW + rr;
-      float h0 = 0.0f;
-      if (c > 0 && dd < d_end) {
-        const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
-        h0 = p.ckpt[slot * N + n];
+    if constexpr (!DMABC) {
+      for (int i = lane; i < RPW * N; i += 64) {
+        const int rr = i / N, n = i - rr * N;
+        const int dd = d0 + wave * RPW + rr;
+        float h0 = 0.0f;
+        if (c > 0 && dd < d_end) {
+          const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
+          h0 = p.ckpt[slot * N + n];
+        }
+        sAC[(wave * RPW + rr) * NP + n].y = h0;
       }
-      sAC[(wave * RPW + rr) * NP + n].y = h0;
     }
     __syncthreads();
     if constexpr (PF) {
       if (c > 0) raw_prefetch(t0 - CH);     // chunk c-1 is always a full chunk
+    }
+    if constexpr (DMABC) {                  // the raw tile has been read: the next one may overwrite it while this chunk computes
+      if (c > 0) {
+        bc_dma(t0 - CH);
+        ckpt_prefetch(c - 1);
+      }
     }
 
     {
@@ -714,7 +783,8 @@ template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1) +
-                                      (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t);
+                                      (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t) +
+                     ((VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD) ? (size_t)2 * 16 * CH * sizeof(io_t) : 0);      // + the raw B/C tile of the LDS-DMA prefetch
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
   auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS, FOLD>;
   if (lds > 64 * 1024) {
