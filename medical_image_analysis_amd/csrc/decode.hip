@@ -82,24 +82,14 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     const int n = n_first + (p.swiglu ? item >> 1 : item) * TW;
     return ((p.swiglu && (item & 1)) ? p.W2 : p.W) + (size_t)n * K;
   };
-  uint4 pre[PF];
-  if (n_items > 0) {
-    const uint16_t* w = row_ptr(0);
-#pragma unroll
-    for (int j = 0; j < PF; ++j) pre[j] = ldw(w, lane * 8 + j * 512, K);
-  }
-
-  // Stage x (or RMSNorm(x)*g, Qwen2RMSNorm hybrid_decoder_layer.py:193-198: bf16(bf16(x*rstd) * g)) in LDS.  One
-  // 16-byte global load per thread per (row, 8192-column block), ALL issued before the first use: the prologue costs
-  // one L2 round trip, not one per element.
-  if (MXVL_ABL(p.ablate == 2)) return;
-  if (!MXVL_ABL(p.ablate == 3))
-  for (int c0 = 0; c0 < K; c0 += 8192) {
-    const int kk = c0 + tid * 8;
-    const bool on = kk < K;
-    uint4 xr[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) xr[m] = on ? *(const uint4*)(p.x + (size_t)m * K + kk) : make_uint4(0, 0, 0, 0);
+  // Stage x (or RMSNorm(x)*g, Qwen2RMSNorm hybrid_decoder_layer.py:193-198: bf16(bf16(x*rstd) * g)) in LDS, one 16-byte load per
+  // thread per (row, 8192-column block).  Order of the requests (round 3; loads return in order, so the order IS the latency chain):
+  // the activations and the norm weight of the first block go out FIRST, the wave's first weight row right behind them, and
+  // only then is anything waited for -- x arrives after one round trip and the norm / LDS staging runs while the weight row is
+  // still streaming in.  Before, the weight row was requested first and the staging loop's header made hipcc wait for ALL
+  // outstanding loads before it even asked for x (a loop-carried write-after-write on the x registers): weight round trip, then
+  // x round trip, then the norm weight's -- three serialised latencies in front of the first dot product of every launch.
+  auto stage = [&](int kk, bool on, const uint4 (&xr)[M], uint4 gv) {
     if (!p.g) {
       if (on) {
 #pragma unroll
@@ -116,11 +106,10 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
           const float a = bf2f((uint16_t)w[j]), b = bf2f((uint16_t)(w[j] >> 16));
           s = fmaf(a, a, fmaf(b, b, s));
         }
-        s = wave_sum(s);
+        s = wave_sum(on ? s : 0.0f);
         if (lane == 0) s_part[m][wave] = s;
       }
       __syncthreads();
-      const uint4 gv = on ? *(const uint4*)(p.g + kk) : make_uint4(0, 0, 0, 0);
       const uint32_t gw[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
       for (int m = 0; m < M; ++m) {
@@ -139,6 +128,39 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
         if (on) *(uint4*)(sx + (size_t)m * K + kk) = make_uint4(o[0], o[1], o[2], o[3]);
       }
     }
+  };
+  if (MXVL_ABL(p.ablate == 2)) return;
+  uint4 pre[PF];
+  {
+    const int kk = tid * 8;
+    const bool on = kk < K;
+    // UNCONDITIONAL loads (threads past the row read its first 16 bytes again; their values are never stored and are masked out
+    // of the norm's sum): behind a per-lane `if` hipcc waits for a load on the spot
+    const int kc = on ? kk : 0;
+    uint4 xr[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) xr[m] = *(const uint4*)(p.x + (size_t)m * K + kc);
+    // branch-free: no norm -> the activations' first bytes stand in for the (unused) norm weight; a wave without a row, or a
+    // lane past the end of a short row, re-reads the start of a valid row (every consumer tests kk < K / n_items).  With any
+    // branch between the requests hipcc loses count of what is in flight and waits for everything at the join.
+    const uint4 gv = *(const uint4*)((p.g ? p.g : p.x) + kc);
+    {
+      const uint16_t* w = n_items > 0 ? row_ptr(0) : p.W;
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int kj = lane * 8 + j * 512;
+        pre[j] = ldnt(w + (kj < K ? kj : 0));
+      }
+    }
+    if (!MXVL_ABL(p.ablate == 3)) stage(kk, on, xr, gv);
+  }
+  for (int c0 = 8192; c0 < K; c0 += 8192) {      // rows longer than one block (down projection: K = 11008); never with a norm
+    const int kk = c0 + tid * 8;
+    const bool on = kk < K;
+    uint4 xr[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) xr[m] = on ? *(const uint4*)(p.x + (size_t)m * K + kk) : make_uint4(0, 0, 0, 0);
+    if (!MXVL_ABL(p.ablate == 3)) stage(kk, on, xr, make_uint4(0, 0, 0, 0));
   }
   __syncthreads();
 
@@ -188,8 +210,14 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     }
     if (item + 1 < n_items) {  // next row's head goes in flight before this row's reduction
       const uint16_t* wn = row_ptr(item + 1);
+      if (K >= PF * 512) {
+        const uint16_t* wl = wn + lane * 8;
 #pragma unroll
-      for (int j = 0; j < PF; ++j) pre[j] = ldw(wn, lane * 8 + j * 512, K);
+        for (int j = 0; j < PF; ++j) pre[j] = ldnt(wl + j * 512);
+      } else {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) pre[j] = ldw(wn, lane * 8 + j * 512, K);
+      }
     }
     const int n = n_first + (p.swiglu ? item >> 1 : item) * TW;
 #pragma unroll
