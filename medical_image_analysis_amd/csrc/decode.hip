@@ -188,13 +188,10 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     // request in flight and the down projection (K = 11008) streamed at 3.9 TB/s against 5.0 for the 4096-column rows
     // (profiles/r03_decode_timeline.txt)
     for (int k0 = PF * 512; k0 < K; k0 += PF * 512) {
-      if (k0 + PF * 512 <= K) {            // uniform: a whole batch, one lane address + immediate offsets
-        const uint16_t* wl = w + k0 + lane * 8;
 #pragma unroll
-        for (int j = 0; j < PF; ++j) pre[j] = ldnt(wl + j * 512);
-      } else {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) pre[j] = ldw(w, k0 + lane * 8 + j * 512, K);
+      for (int j = 0; j < PF; ++j) {          // branch-free, as above
+        const int kj = k0 + lane * 8 + j * 512;
+        pre[j] = ldnt(w + (kj < K ? kj : 0));
       }
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
@@ -210,13 +207,10 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
     }
     if (item + 1 < n_items) {  // next row's head goes in flight before this row's reduction
       const uint16_t* wn = row_ptr(item + 1);
-      if (K >= PF * 512) {
-        const uint16_t* wl = wn + lane * 8;
 #pragma unroll
-        for (int j = 0; j < PF; ++j) pre[j] = ldnt(wl + j * 512);
-      } else {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) pre[j] = ldw(wn, lane * 8 + j * 512, K);
+      for (int j = 0; j < PF; ++j) {          // branch-free (lanes past a short row re-read its start; consumers test kk < K)
+        const int kj = lane * 8 + j * 512;
+        pre[j] = ldnt(wn + (kj < K ? kj : 0));
       }
     }
     const int n = n_first + (p.swiglu ? item >> 1 : item) * TW;
