@@ -285,24 +285,33 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
   const uint16_t* q = p.qkv + row + (size_t)h * D;
   const uint16_t* kn = p.qkv + row + (size_t)(p.H + hk) * D;
   const uint16_t* vn = p.qkv + row + (size_t)(p.H + p.Hkv + hk) * D;
-  for (int t = tid; t <= pos; t += kAttnWaves * 64)
-    ssl[t] = p.mask[(size_t)m * T + t] != 0 ? p.slot[(size_t)m * T + t] : -1;
+  // every request of the prologue goes out before anything is used, none behind a per-lane branch: as `mask ? slot : -1` and
+  // `d < half ? -q[d + half] : q[d - half]` the loads sat in exec-masked blocks and hipcc waited for each of them in turn -- eight
+  // serialised round trips in front of a kernel whose whole body is a handful of them (8.9 us per launch, 32 launches per token)
+  for (int t = tid; t <= pos; t += kAttnWaves * 64) {
+    const int64_t mk = p.mask[(size_t)m * T + t];
+    const int sl = p.slot[(size_t)m * T + t];
+    ssl[t] = mk != 0 ? sl : -1;
+  }
   // RoPE (hybrid_decoder_layer.py:284-322): x*cos + rotate_half(x)*sin, computed in the activation dtype (bf16)
   if (tid < D) {
     const int d = tid, half = D / 2;
-    const float c = bf2f(f2bf(p.cosv[(size_t)m * D + d])), s = bf2f(f2bf(p.sinv[(size_t)m * D + d]));
-    const float qd = bf2f(q[d]), qo = d < half ? -bf2f(q[d + half]) : bf2f(q[d - half]);
-    const float kd = bf2f(kn[d]), ko = d < half ? -bf2f(kn[d + half]) : bf2f(kn[d - half]);
+    const int dp = d < half ? d + half : d - half;
+    const uint16_t rq = q[d], rqo = q[dp], rk = kn[d], rko = kn[dp], rv = vn[d];
+    const float rc = p.cosv[(size_t)m * D + d], rs = p.sinv[(size_t)m * D + d];
+    const float c = bf2f(f2bf(rc)), s = bf2f(f2bf(rs));
+    const float qd = bf2f(rq), qo = d < half ? -bf2f(rqo) : bf2f(rqo);
+    const float kd = bf2f(rk), ko = d < half ? -bf2f(rko) : bf2f(rko);
     const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * s))));
     const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * s))));
     sq[d] = qr * p.scale;
     if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
     sk[d] = kr;
-    sv[d] = bf2f(vn[d]);
+    sv[d] = bf2f(rv);
     if (h % group == 0) {  // one head of the group appends to the cache (slot m owns position pos of beam m)
       const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
       p.kc[o] = f2bf(kr);
-      p.vc[o] = vn[d];
+      p.vc[o] = rv;
     }
   }
   __syncthreads();
