@@ -224,6 +224,29 @@ typedef struct mxvl_decode_cross_attn_desc {
   void *out;                /* (rows, n_heads * head_dim) bf16, must not alias text_state */
 } mxvl_decode_cross_attn_desc;
 
+/*
+ * mxvl_decode_prologue (ABI v5): everything a generation step does before the decoder stack, as one launch -- what HF `generate`
+ * spreads over its cache re-ordering, embedding lookup and rotary module per token (MambaXrayVL_DownStream.py:292-301):
+ *   pos = *cur + prompt_len - 1;  slot_table[r][:] = slot_table[beam_src[r]][:];  slot_table[r][pos] = r;  mask[r][pos] = 1;
+ *   x[r] = embed[tok[r]];  cos[r] / sin[r] = cos_table / sin_table[n_real[r] + *cur - 1];  *pos_out = pos
+ * The tables are filled by the caller with its own rotary module for positions 0 .. table_len - 1 (so the values are the
+ * module's own bits).  tok / beam_src / cur are the search state's device tensors (mxvl_beam_step updates them in place).
+ */
+typedef struct mxvl_decode_prologue_desc {
+  int32_t rows, hidden, max_len, head_dim, prompt_len, table_len;
+  const void *tok;          /* (rows) int64 */
+  const void *beam_src;     /* (rows) int64: parent row of every row */
+  const void *cur;          /* device int64 scalar: tokens generated so far (the step being fed is cur - 1) */
+  const void *n_real;       /* (rows) int64: RoPE position of the first generated token */
+  const void *embed;        /* (vocab, hidden) bf16 */
+  const void *cos_table, *sin_table;   /* (table_len, head_dim) fp32 */
+  void *slot_table;         /* (rows, max_len) int32, in place */
+  void *mask;               /* (rows, max_len) int64, in place */
+  void *x;                  /* (rows, hidden) bf16 out */
+  void *cos, *sin;          /* (rows, head_dim) fp32 out */
+  void *pos;                /* device int64 scalar out */
+} mxvl_decode_prologue_desc;
+int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);
 int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
 int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc *desc, void *hip_stream);

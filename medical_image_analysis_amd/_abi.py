@@ -33,7 +33,7 @@ SYMBOLS = [
     "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
-    "mxvl_decode_cross_attn",
+    "mxvl_decode_cross_attn", "mxvl_decode_prologue",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss",
@@ -138,6 +138,16 @@ class DecodeCrossAttnDesc(ctypes.Structure):
     ]
 
 
+class DecodePrologueDesc(ctypes.Structure):
+    _fields_ = [
+        ("rows", c_int32), ("hidden", c_int32), ("max_len", c_int32), ("head_dim", c_int32), ("prompt_len", c_int32),
+        ("table_len", c_int32),
+        ("tok", c_void_p), ("beam_src", c_void_p), ("cur", c_void_p), ("n_real", c_void_p), ("embed", c_void_p),
+        ("cos_table", c_void_p), ("sin_table", c_void_p), ("slot_table", c_void_p), ("mask", c_void_p), ("x", c_void_p),
+        ("cos", c_void_p), ("sin", c_void_p), ("pos", c_void_p),
+    ]
+
+
 class AddLnDesc(ctypes.Structure):
     _fields_ = [
         ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
@@ -226,6 +236,8 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_beam_step.restype = c_int
     lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
+    lib.mxvl_decode_prologue.restype = c_int
+    lib.mxvl_decode_prologue.argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

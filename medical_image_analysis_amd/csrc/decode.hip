@@ -500,6 +500,52 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(cons
   }
 }
 
+// Everything a generation step does BEFORE the decoder stack, as one launch (it was 22 small torch kernels, 65 us + 100 us of
+// gaps per token inside the hipGraph): the position of the step from the search state's counter, the beam re-ordering of the
+// slot table (a thread owns a column: it reads the column of every parent row, then writes it), the new position's slot and
+// mask bit, the token embeddings, and the RoPE cos / sin rows from a table the caller filled with its own rotary module.
+struct PrologueArgs {
+  int rows, hidden, max_len, D, prompt_len, table_len;
+  const int64_t *tok, *beam, *cur, *n_real;
+  const uint16_t* embed;
+  const float *cos_t, *sin_t;
+  int* slot;
+  int64_t* mask;
+  uint16_t* x;
+  float *cosv, *sinv;
+  int64_t* pos;
+};
+__global__ __launch_bounds__(1024) void decode_prologue_kernel(const PrologueArgs p) {
+  const int tid = threadIdx.x;
+  const int64_t cur = *p.cur;
+  const int pos = (int)(cur + p.prompt_len - 1), step = (int)(cur - 1);
+  int parent[kMaxRows];
+#pragma unroll
+  for (int r = 0; r < kMaxRows; ++r) parent[r] = r < p.rows ? (int)p.beam[r] : 0;
+  for (int t = tid; t < p.max_len; t += 1024) {
+    int v[kMaxRows];
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) v[r] = r < p.rows ? p.slot[(size_t)parent[r] * p.max_len + t] : 0;
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r)
+      if (r < p.rows) p.slot[(size_t)r * p.max_len + t] = t == pos ? r : v[r];
+  }
+  if (tid < p.rows && pos < p.max_len) p.mask[(size_t)tid * p.max_len + pos] = 1;
+  const int per_row = p.hidden / 8;
+  for (int i = tid; i < p.rows * per_row; i += 1024) {
+    const int r = i / per_row, c = (i - r * per_row) * 8;
+    *(uint4*)(p.x + (size_t)r * p.hidden + c) = *(const uint4*)(p.embed + (size_t)p.tok[r] * p.hidden + c);
+  }
+  for (int i = tid; i < p.rows * p.D; i += 1024) {
+    const int r = i / p.D, d = i - r * p.D;
+    int64_t q = p.n_real[r] + step;
+    q = q < 0 ? 0 : (q >= p.table_len ? p.table_len - 1 : q);
+    p.cosv[i] = p.cos_t[(size_t)q * p.D + d];
+    p.sinv[i] = p.sin_t[(size_t)q * p.D + d];
+  }
+  if (tid == 0) *p.pos = pos;
+}
+
 static int dec_check() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
@@ -576,6 +622,22 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
     case 256: hipLaunchKernelGGL(decode_attn_kernel<256>, grid, block, lds, s, a); break;
     default: return MXVL_ERR_UNSUPPORTED;
   }
+  return dec_check();
+}
+
+int mxvl_decode_prologue(const mxvl_decode_prologue_desc* d, void* hip_stream) {
+  if (!d || !d->tok || !d->beam_src || !d->cur || !d->n_real || !d->embed || !d->cos_table || !d->sin_table || !d->slot_table ||
+      !d->mask || !d->x || !d->cos || !d->sin || !d->pos)
+    return MXVL_ERR_NULL;
+  if (d->rows <= 0 || d->rows > kMaxRows || d->hidden <= 0 || d->hidden % 8 || d->max_len <= 0 || d->head_dim <= 0 || d->table_len <= 0)
+    return MXVL_ERR_SHAPE;
+  PrologueArgs a;
+  a.rows = d->rows; a.hidden = d->hidden; a.max_len = d->max_len; a.D = d->head_dim; a.prompt_len = d->prompt_len; a.table_len = d->table_len;
+  a.tok = (const int64_t*)d->tok; a.beam = (const int64_t*)d->beam_src; a.cur = (const int64_t*)d->cur; a.n_real = (const int64_t*)d->n_real;
+  a.embed = (const uint16_t*)d->embed; a.cos_t = (const float*)d->cos_table; a.sin_t = (const float*)d->sin_table;
+  a.slot = (int*)d->slot_table; a.mask = (int64_t*)d->mask; a.x = (uint16_t*)d->x; a.cosv = (float*)d->cos; a.sinv = (float*)d->sin;
+  a.pos = (int64_t*)d->pos;
+  hipLaunchKernelGGL(decode_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, a);
   return dec_check();
 }
 

@@ -95,6 +95,9 @@ class _SearchFusion:
     sstate = None
 
     def _search_body(self, state):
+        if getattr(self, "fused_prologue", False):        # the kernel stepper reads the search state's tensors itself
+            state.advance(self._body(state.tok, state.beam_src, state.cur))
+            return
         self.tok.copy_(state.tok)
         self.beam.copy_(state.beam_src)
         self.step_no.copy_((state.cur - 1).view(1))
@@ -388,7 +391,11 @@ class _KernelStepper(_SearchFusion):
         self.tok = torch.zeros(rows, dtype=torch.long, device=dev)
         self.beam = torch.arange(rows, device=dev)
         self.pos = torch.zeros(1, dtype=torch.long, device=dev)
-        self.step_no = torch.zeros(1, dtype=torch.long, device=dev)
+        self.cur = torch.zeros(1, dtype=torch.long, device=dev)
+        # RoPE rows of every position a generation can reach, from the model's own rotary module (so they are its bits)
+        with torch.no_grad():
+            ct, st = model.model.rotary_emb(self.cos, torch.arange(self.max_len + 1, device=dev)[None])
+        self.cos_table, self.sin_table = ct[0].float().contiguous(), st[0].float().contiguous()
         self.graph = None
         self.reset(prompt_mask, dyn_cache)
 
@@ -456,15 +463,24 @@ class _KernelStepper(_SearchFusion):
         d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), y.data_ptr()
         self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
 
-    def _body(self):
+    fused_prologue = True
+
+    def _prologue(self, tok, beam, cur):
+        """slot-table re-ordering, new position's slot / mask bit, token embeddings, RoPE rows: ONE launch (mxvl_decode_prologue)
+        instead of 22 small torch kernels per token."""
+        d = self._abi.DecodePrologueDesc()
+        d.rows, d.hidden, d.max_len, d.head_dim = self.rows, self.hidden, self.max_len, self.D
+        d.prompt_len, d.table_len = self.P, self.cos_table.shape[0]
+        d.tok, d.beam_src, d.cur, d.n_real = tok.data_ptr(), beam.data_ptr(), cur.data_ptr(), self.n_real.data_ptr()
+        d.embed = self.model.model.embed_tokens.weight.data_ptr()
+        d.cos_table, d.sin_table = self.cos_table.data_ptr(), self.sin_table.data_ptr()
+        d.slot_table, d.mask, d.x = self.slot.data_ptr(), self.mask.data_ptr(), self.x.data_ptr()
+        d.cos, d.sin, d.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
+        self._abi.check(self.lib.mxvl_decode_prologue(self._ct.byref(d), self._abi.stream_ptr(self.x.device)), "mxvl_decode_prologue")
+
+    def _body(self, tok, beam, cur):
         m = self.model
-        self.slot.copy_(self.slot.index_select(0, self.beam))
-        self.slot.index_copy_(1, self.pos, self.own)
-        self.mask.index_fill_(1, self.pos, 1)
-        self.x.copy_(m.model.embed_tokens(self.tok))
-        cos, sin = m.model.rotary_emb(self.cos, self.n_real + self.step_no)   # fp32 (rows, 1, D)
-        self.cos.copy_(cos[:, 0])
-        self.sin.copy_(sin[:, 0])
+        self._prologue(tok, beam, cur)
         a = self._abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
         a.scale = self.D ** -0.5
@@ -494,14 +510,13 @@ class _KernelStepper(_SearchFusion):
     def step(self, tok, beam_idx, k):
         self.tok.copy_(tok)
         self.beam.copy_(beam_idx)
-        self.pos.fill_(self.P + k)
-        self.step_no.fill_(k)
+        self.cur.fill_(k + 1)               # the prologue kernel derives the position and the RoPE step from it
         if self.graph is None:
-            out = self._body().clone()      # eager first token = the warm-up hipGraph capture needs
+            out = self._body(self.tok, self.beam, self.cur).clone()      # eager first token = the warm-up hipGraph capture needs
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self._body()
+                self._body(self.tok, self.beam, self.cur)
             return out
         self.graph.replay()
         return self.logits

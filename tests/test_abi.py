@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
                                               ("mxvl_gemv_desc", _abi.GemvDesc), ("mxvl_decode_attn_desc", _abi.DecodeAttnDesc),
                                               ("mxvl_dir_perm_desc", _abi.DirPermDesc), ("mxvl_beam_desc", _abi.BeamDesc),
                                               ("mxvl_add_ln_desc", _abi.AddLnDesc), ("mxvl_add_ln_bwd_desc", _abi.AddLnBwdDesc),
-                                              ("mxvl_image_desc", _abi.ImageDesc), ("mxvl_gemm_swiglu_desc", _abi.GemmSwigluDesc)])
+                                              ("mxvl_image_desc", _abi.ImageDesc), ("mxvl_gemm_swiglu_desc", _abi.GemmSwigluDesc),
+                                              ("mxvl_decode_prologue_desc", _abi.DecodePrologueDesc)])
 def test_ctypes_struct_mirrors_header(cstruct, pystruct):
     m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
