@@ -648,7 +648,7 @@ def main():
                        "kernel": _abi.load().mxvl_last_scan_kernel().decode()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("scan_bwd_kernel + scan_bwd_reduce_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
+                         "kernel": ("scan_bwd_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
                                     if backward else "scan_fwd_stream_kernel"),
                          "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms,
                          "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},

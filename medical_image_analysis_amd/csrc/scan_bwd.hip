@@ -20,6 +20,7 @@
 // du, ddelta, dz are fully written; dA, dB, dC, dD, ddelta_bias are accumulated into caller-zeroed fp32.
 
 #include "mxvl_common.h"
+#include <type_traits>
 
 namespace mxvl {
 
@@ -149,7 +150,7 @@ __device__ __forceinline__ void lane16_swap_x4(float (&s)[8]) {                 
 // sequence of nb * SL steps, last chunk first.  The first step of every segment has a_t = 0 (and the lane product P = 0): no
 // state enters a segment in the recomputation, no adjoint leaves it towards the previous one, and dA / ddelta see h_{-1} = 0.
 // Addresses of a lane's 8 steps, of a staging quarter and of a flush lane's step come from one multiply-high each.
-template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false>
+template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false, bool DMAR = false>
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
   constexpr int FG = 4;                    // states per dB/dC flush group
@@ -187,7 +188,19 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   // (A/B in one process, profiles/r03_scan_fold.txt: 1157.7 -> 1128.0 us at the pre-training shape; the folded walk got SLOWER,
   //  895.7 -> 943.3 us at B64 x L200, and keeps the global staging)
   constexpr bool DMABC = VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD;     // (fp32 rows: the parked rows already fill the LDS)
-  io_t* sRawBC = sPark + (size_t)4 * NT * T;                               // [2][N][CH] io dtype (DMABC)
+  // DMAR (16-bit rows, L % 8 == 0, io-dtype dout; the launcher decides): the ROWS of the next chunk (u, delta, z, dout) and its
+  // checkpoint arrive by LDS-DMA as well, into the park buffer -- a wave requests exactly the 16 bytes per lane it will read
+  // back, so only its own vmcnt orders them -- while the rows of the CURRENT chunk stay packed in 16 VGPRs (read from the park
+  // buffer at the top of the chunk, unpacked there and again after the state loop; a second park buffer does not fit: 165 KB).
+  // No compiler-visible load is left in the chunk loop: hipcc waited for the register prefetch (`s_waitcnt vmcnt(1)` right
+  // behind the loads: they sit under a per-lane condition) and again for everything outstanding (`vmcnt(0)`) before the state
+  // loop, so nothing of the next chunk was in flight while it ran.  The one wait of a chunk sits AFTER the state loop, where the
+  // requests are ~30 us old, and no longer at the chunk top, where it also waited for the acknowledgements of the previous
+  // chunk's stores and atomics.
+  static_assert(!DMAR || DMABC, "row DMA rides on the B/C DMA path");
+  constexpr int PARKN = 4 * NT * T;                                        // elements of one park buffer
+  io_t* sRawBC = sPark + (size_t)PARKN;                   // [2][N][CH] io dtype (DMABC)
+  float* sCk = (float*)(sRawBC + 2 * 16 * CH);                             // [NT] checkpoint entries of the next chunk (DMAR)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = __builtin_amdgcn_readfirstlane(wave);     // the wave index as a scalar: flush addresses are SGPR + lane
@@ -209,7 +222,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   const io_t* __restrict__ pz = p.z ? (const io_t*)p.z + (int64_t)b * p.z_bs + (int64_t)dc * p.z_ds + j * T : nullptr;
   const int64_t pg_off = (int64_t)b * p.do_bs + (int64_t)dc * p.do_ds + j * T;   // element offset into dout (io dtype, or fp32)
   const io_t* __restrict__ pg = (const io_t*)p.dout + pg_off;                       // io-dtype view (not used when dout is fp32)
-  const bool of32 = p.out_f32 != 0;
+  // An fp32 dout (i16o32) is loaded by ordinary register loads around the state loop.  The folded and the row-DMA
+  // instantiations exclude it at COMPILE time (their launchers refuse such calls): s_waitcnt insertion is static, so the mere
+  // presence of that branch put a `vmcnt(0)` at the first use of its registers after the join -- on every call, where it waited
+  // for the LDS-DMA of the next chunk before the state loop had even started.
+  const bool of32 = (FOLD || DMAR) ? false : p.out_f32 != 0;
   io_t* __restrict__ qdu = (io_t*)p.du + (int64_t)b * p.du_bs + (int64_t)dc * p.du_ds + j * T;
   io_t* __restrict__ qdd = (io_t*)p.ddelta + (int64_t)b * p.dd_bs + (int64_t)dc * p.dd_ds + j * T;
   io_t* __restrict__ qdz = p.dz ? (io_t*)p.dz + (int64_t)b * p.dz_bs + (int64_t)dc * p.dz_ds + j * T : nullptr;
@@ -398,11 +415,44 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       ck_next = p.ckpt[slot * N + n];
     }
   };
-  if constexpr (DMABC) {
+  auto dma_to = [&](unsigned dst, const void* g, auto wide) {     // one LDS-DMA instruction: lane i -> dst + i * (16 | 4) bytes
+    unsigned keep;
+    if constexpr (decltype(wide)::value) {
+      asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[g], off\n\ts_mov_b32 m0, %[keep]"
+                   : [keep] "=&s"(keep) : [dst] "s"(dst), [g] "v"(g) : "memory", "scc");
+    } else {
+      asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dword %[g], off\n\ts_mov_b32 m0, %[keep]"
+                   : [keep] "=&s"(keep) : [dst] "s"(dst), [g] "v"(g) : "memory", "scc");
+    }
+  };
+  auto lds_addr = [](const void* q) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)q; };
+  // rows of chunk [tn, tn + CH) into park buffer `buf`, layout [array][thread][T]: a wave's lanes are 16 bytes apart
+  auto rows_dma = [&](int tn) {
+    const int off = (tn + j * T + T <= L) ? tn : -j * T;    // L % 8 == 0: a lane is inside the row or past it as a whole; past the
+                                                            // end it reads step 0 (finite; delta, d softplus, dout zeroed at use)
+    const unsigned w0 = lds_addr(sPark) + (unsigned)wq * 1024u;
+    dma_to(w0, pu + off, std::true_type{});
+    dma_to(w0 + NT * 16u, pd + off, std::true_type{});
+    if (has_z) dma_to(w0 + 2u * NT * 16u, pz + off, std::true_type{});
+    if (!of32) dma_to(w0 + 3u * NT * 16u, pg + off, std::true_type{});
+  };
+  auto ckpt_dma = [&](int c) {                              // checkpoint entering chunk c > 0: (row, state) = lane of this wave
+    const int rr = lane / N, n = lane - rr * N;
+    int dd = d0 + wave * RPW + rr;
+    dd = dd < d_end ? dd : d_end - 1;
+    dma_to(lds_addr(sCk) + (unsigned)wq * 256u, p.ckpt + (((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n, std::false_type{});
+  };
+  if constexpr (DMAR) {
+    rows_dma((nchunks - 1) * CH);
     bc_dma((nchunks - 1) * CH);
-    ckpt_prefetch(nchunks - 1);
+    if (nchunks > 1) ckpt_dma(nchunks - 1);
+  } else {
+    if constexpr (DMABC) {
+      bc_dma((nchunks - 1) * CH);
+      ckpt_prefetch(nchunks - 1);
+    }
+    if constexpr (PF) raw_prefetch((nchunks - 1) * CH);
   }
-  if constexpr (PF) raw_prefetch((nchunks - 1) * CH);
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
@@ -451,10 +501,23 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   for (int c = nchunks - 1; c >= 0; --c) {
     const int t0 = c * CH;
     const bool full = t0 + CH <= L;
-    if constexpr (DMABC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the B/C DMA has landed ...
+    if constexpr (DMABC) {     // this wave's share of the B/C DMA has landed ... (DMAR: waited for after the previous state loop)
+      if (!DMAR || c == nchunks - 1 || (MXVL_EXP & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible); ... and everybody's share
     // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
     float uu[T], dl[T], zz[T], go[T];
+    auto unpark = [&](int arr, float (&v)[T]) {
+      const io_t* q = sPark + ((size_t)arr * NT + tid) * T;
+      const float4 a0 = ld4<io_t>(q), a1 = ld4<io_t>(q + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    };
+    if constexpr (DMAR) {        // the DMA of the previous chunk's state loop landed here; from now on the rows live in ru .. rz
+      ru = *(const uint4*)(sPark + ((size_t)0 * NT + tid) * T);
+      rd = *(const uint4*)(sPark + ((size_t)1 * NT + tid) * T);
+      rg = *(const uint4*)(sPark + ((size_t)3 * NT + tid) * T);
+      if (has_z) rz = *(const uint4*)(sPark + ((size_t)2 * NT + tid) * T);
+    }
     if constexpr (PF) {
       unpack(ru, uu);
       unpack(rd, dl);
@@ -473,7 +536,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         *(float4*)(sB + pos) = bv;
         *(float4*)(sC + pos) = cv;
       }
-      sAC[(wave * RPW + lane / N) * NP + (lane % N)].y = ck_next;
+      if constexpr (DMAR) sAC[(wave * RPW + lane / N) * NP + (lane % N)].y = c > 0 ? sCk[tid] : 0.0f;
+      else sAC[(wave * RPW + lane / N) * NP + (lane % N)].y = ck_next;
     } else if (FOLD || (VEC && full)) {
       for (int i = tid; i < N * (CH / 4); i += NT) {   // 16-byte loads, 4 consecutive steps per thread
         const int n = i / (CH / 4), e = (i % (CH / 4)) * 4;
@@ -518,17 +582,25 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       }
     }
     __syncthreads();
-    if constexpr (PF) {
-      if (c > 0) raw_prefetch(t0 - CH);     // chunk c-1 is always a full chunk
-    }
-    if constexpr (DMABC) {                  // the raw tile has been read: the next one may overwrite it while this chunk computes
+    if constexpr (DMAR) {
       if (c > 0) {
+        rows_dma(t0 - CH);
         bc_dma(t0 - CH);
-        ckpt_prefetch(c - 1);
+        if (c > 1) ckpt_dma(c - 1);
+      }
+    } else {
+      if constexpr (PF) {
+        if (c > 0) raw_prefetch(t0 - CH);     // chunk c-1 is always a full chunk
+      }
+      if constexpr (DMABC) {                  // the raw tile has been read: the next one may overwrite it while this chunk computes
+        if (c > 0) {
+          bc_dma(t0 - CH);
+          ckpt_prefetch(c - 1);
+        }
       }
     }
 
-    {
+    if constexpr (!DMAR) {
       auto park = [&](int arr, const float (&v)[T]) {
         io_t* q = sPark + ((size_t)arr * NT + tid) * T;
         st4<io_t>(q, make_float4(v[0], v[1], v[2], v[3]));
@@ -553,7 +625,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     if (!full) {
 #pragma unroll
       for (int i = 0; i < T; ++i)
-        if (!(t0 + j * T + i < L)) { dl[i] = 0.0f; dsp[i] = 0.0f; if (FOLD) go[i] = 0.0f; }   // FOLD: those lanes loaded step 0
+        if (!(t0 + j * T + i < L)) { dl[i] = 0.0f; dsp[i] = 0.0f; if (FOLD || DMAR) go[i] = 0.0f; }   // FOLD / DMAR: those lanes loaded step 0
     }
     if (!row_ok) {  // clamped duplicate rows must not add into the shared dB/dC tile
 #pragma unroll
@@ -710,6 +782,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       }
     }
 
+    if constexpr (DMAR && !(MXVL_EXP & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's tiles, requested before the state loop
     {
       {     // the last group's shares
         float fpart[FK * NWAVES];
@@ -717,16 +790,18 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
         flush_add(NGRP - 1, fpart);
         if (!VEC) __syncthreads();       // unaligned rows: the store transpose tile sO aliases buffer 0
       }
-      auto unpark = [&](int arr, float (&v)[T]) {
-        const io_t* q = sPark + ((size_t)arr * NT + tid) * T;
-        const float4 a0 = ld4<io_t>(q), a1 = ld4<io_t>(q + 4);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-      };
       float raw[T];
-      unpark(0, uu);
-      unpark(1, raw);
-      if (of32) dout_fetch(t0, go); else unpark(3, go);
-      if (has_z) unpark(2, zz);
+      if constexpr (DMAR) {
+        unpack(ru, uu);
+        unpack(rd, raw);
+        unpack(rg, go);
+        if (has_z) unpack(rz, zz);
+      } else {
+        unpark(0, uu);
+        unpark(1, raw);
+        if (of32) dout_fetch(t0, go); else unpark(3, go);
+        if (has_z) unpark(2, zz);
+      }
 #pragma unroll
       for (int i = 0; i < T; ++i) {
         const float rb = raw[i] + bias;
@@ -779,14 +854,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 static thread_local int g_bwd_hip_error = 0;
 extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
-template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false>
+template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false, bool DMAR = false>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1) +
                                       (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t) +
-                     ((VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD) ? (size_t)2 * 16 * CH * sizeof(io_t) : 0);      // + the raw B/C tile of the LDS-DMA prefetch
+                     ((VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD) ? (size_t)2 * 16 * CH * sizeof(io_t) : 0) +      // + the raw B/C tile of the LDS-DMA prefetch
+                     (DMAR ? (size_t)NT * sizeof(float) : 0);                                                           // + its checkpoint entries
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
-  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS, FOLD>;
+  auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS, FOLD, DMAR>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
@@ -801,6 +877,11 @@ static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
 // dstate 16 (every Mamba block of the reference) takes the instantiation with the unrolled state loop
 template <typename io_t, int NWAVES, bool VEC>
 static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  if constexpr (VEC && sizeof(io_t) == 2 && NWAVES == 8) {     // rows by LDS-DMA: whole 8-step lanes only.  (The 4-wave kernel, 4 flush
+    // elements per thread, spills row pointers at 256 VGPRs and reloads them between the DMA requests: every reload waits for the
+    // requests before it.)
+    if (a.N == 16 && a.L % 8 == 0 && !a.out_f32 && !(MXVL_EXP & 1)) return launch_bwd1<io_t, NWAVES, VEC, 16, false, true>(a, stream);
+  }
   return a.N == 16 ? launch_bwd1<io_t, NWAVES, VEC, 16>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, 0>(a, stream);
 }
 
