@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   // the one workgroup of a CU has nothing else to run meanwhile.  The checkpoint of chunk c - 1 is prefetched into a register.
   // (A/B in one process, profiles/r03_scan_fold.txt: 1157.7 -> 1128.0 us at the pre-training shape; the folded walk got SLOWER,
   //  895.7 -> 943.3 us at B64 x L200, and keeps the global staging)
-  constexpr bool DMABC = VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD;     // (fp32 rows: the parked rows already fill the LDS)
+  constexpr bool DMABC = VEC && NS == 16 && sizeof(io_t) == 2 && (!FOLD || DMAR);     // (fp32 rows: the parked rows already fill the LDS)
   // DMAR (16-bit rows, L % 8 == 0, io-dtype dout; the launcher decides): the ROWS of the next chunk (u, delta, z, dout) and its
   // checkpoint arrive by LDS-DMA as well, into the park buffer -- a wave requests exactly the 16 bytes per lane it will read
   // back, so only its own vmcnt orders them -- while the rows of the CURRENT chunk stay packed in 16 VGPRs (read from the park
@@ -381,18 +381,29 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   constexpr int EPL = 16 / (int)sizeof(io_t);                   // elements per lane and instruction
   constexpr int NDMA = 2 * 16 * CH * (int)sizeof(io_t) / 1024;  // instructions per tile (dstate 16): 8 (16-bit) / 16 (fp32)
   constexpr int DPW = (NDMA + NWAVES - 1) / NWAVES;             // per wave
+  // (array, state row, first step) of a lane's 16 bytes do not depend on the chunk: the row pointer and the batch stride are set
+  // up once (read inside the loop, two of these kernel arguments came back as VECTOR loads from the kernarg segment, each with
+  // a vmcnt wait that also waited for the DMA requests issued just before)
+  const io_t* bc_g[DPW];
+  int64_t bc_bs[DPW];
+#pragma unroll
+  for (int k = 0; k < DPW; ++k) {
+    const int q = wq * DPW + k;                                  // wave-uniform 1 KB block of the raw tile
+    const int e0 = q * (1024 / (int)sizeof(io_t)) + lane * EPL;  // element index inside [B|C][16][CH]
+    const int arr = e0 / (16 * CH), n = (e0 / CH) & 15;
+    bc_g[k] = arr ? Cp + (int64_t)n * p.C_ns : Bp + (int64_t)n * p.B_ns;
+    bc_bs[k] = arr ? p.C_bs : p.B_bs;
+  }
   auto bc_dma = [&](int t0) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)((char*)sRawBC);
 #pragma unroll
     for (int k = 0; k < DPW; ++k) {
-      const int q = wq * DPW + k;                                // wave-uniform 1 KB block of the raw tile
+      const int q = wq * DPW + k;
       if (q < NDMA) {
-        const int e0 = q * (1024 / (int)sizeof(io_t)) + lane * EPL;   // element index inside [B|C][16][CH]
-        const int arr = e0 / (16 * CH), n = (e0 / CH) & 15, st = e0 & (CH - 1);
-        int tv = t0 + st;
+        int tv = t0 + ((q * (1024 / (int)sizeof(io_t)) + lane * EPL) & (CH - 1));
         tv = tv < L ? tv : 0;                                    // past the end: step 0 (finite values under delta = 0)
-        const io_t* g = arr ? Cp + (int64_t)n * p.C_ns : Bp + (int64_t)n * p.B_ns;
-        if constexpr (FOLD) g += fold_off(tv, arr ? p.C_bs : p.B_bs); else g += tv;
+        const io_t* g = bc_g[k];
+        if constexpr (FOLD) g += fold_off(tv, bc_bs[k]); else g += tv;
         const unsigned dst = lds0 + (unsigned)q * 1024u;
         unsigned keep;
         asm volatile(
@@ -428,19 +439,30 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   auto lds_addr = [](const void* q) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)q; };
   // rows of chunk [tn, tn + CH) into park buffer `buf`, layout [array][thread][T]: a wave's lanes are 16 bytes apart
   auto rows_dma = [&](int tn) {
-    const int off = (tn + j * T + T <= L) ? tn : -j * T;    // L % 8 == 0: a lane is inside the row or past it as a whole; past the
-                                                            // end it reads step 0 (finite; delta, d softplus, dout zeroed at use)
+    // L % 8 == 0: a lane is inside the row or past it as a whole; past the end it reads step 0 (finite; delta, d softplus and
+    // dout are zeroed at use)
     const unsigned w0 = lds_addr(sPark) + (unsigned)wq * 1024u;
-    dma_to(w0, pu + off, std::true_type{});
-    dma_to(w0 + NT * 16u, pd + off, std::true_type{});
-    if (has_z) dma_to(w0 + 2u * NT * 16u, pz + off, std::true_type{});
-    if (!of32) dma_to(w0 + 3u * NT * 16u, pg + off, std::true_type{});
+    if constexpr (FOLD) {
+      const int tv = tn + j * T < L ? tn + j * T : 0;
+      const int sb = seg_of(tv), sl = tv - sb * SL;       // (the row pointers already carry + j * T)
+      dma_to(w0, pu - j * T + seg_off(sb, p.u_bs, sl), std::true_type{});
+      dma_to(w0 + NT * 16u, pd - j * T + seg_off(sb, p.dl_bs, sl), std::true_type{});
+      if (has_z) dma_to(w0 + 2u * NT * 16u, pz - j * T + seg_off(sb, p.z_bs, sl), std::true_type{});
+      dma_to(w0 + 3u * NT * 16u, pg - j * T + seg_off(sb, p.do_bs, sl), std::true_type{});
+    } else {
+      const int off = (tn + j * T + T <= L) ? tn : -j * T;
+      dma_to(w0, pu + off, std::true_type{});
+      dma_to(w0 + NT * 16u, pd + off, std::true_type{});
+      if (has_z) dma_to(w0 + 2u * NT * 16u, pz + off, std::true_type{});
+      dma_to(w0 + 3u * NT * 16u, pg + off, std::true_type{});
+    }
   };
   auto ckpt_dma = [&](int c) {                              // checkpoint entering chunk c > 0: (row, state) = lane of this wave
     const int rr = lane / N, n = lane - rr * N;
     int dd = d0 + wave * RPW + rr;
     dd = dd < d_end ? dd : d_end - 1;
-    dma_to(lds_addr(sCk) + (unsigned)wq * 256u, p.ckpt + (((int64_t)b * p.dim + dd) * p.n_ckpt + c) * N + n, std::false_type{});
+    const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
+    dma_to(lds_addr(sCk) + (unsigned)wq * 256u, p.ckpt + slot * N + n, std::false_type{});
   };
   if constexpr (DMAR) {
     rows_dma((nchunks - 1) * CH);
@@ -859,7 +881,7 @@ static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
   const size_t lds = sizeof(float) * ((size_t)2 * a.N * CH + (size_t)DT * 2 * 2 * CH + (size_t)3 * (DT + 1) * (a.N + 1) + (size_t)DT * (a.N + 1) +
                                       (size_t)NT + a.N) + 16 + (size_t)4 * NT * 8 * sizeof(io_t) +
-                     ((VEC && NS == 16 && sizeof(io_t) == 2 && !FOLD) ? (size_t)2 * 16 * CH * sizeof(io_t) : 0) +      // + the raw B/C tile of the LDS-DMA prefetch
+                     ((VEC && NS == 16 && sizeof(io_t) == 2 && (!FOLD || DMAR)) ? (size_t)2 * 16 * CH * sizeof(io_t) : 0) +      // + the raw B/C tile of the LDS-DMA prefetch
                      (DMAR ? (size_t)NT * sizeof(float) : 0);                                                           // + its checkpoint entries
   if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
   auto kern = scan_bwd_kernel<io_t, NWAVES, VEC, NS, FOLD, DMAR>;
@@ -904,7 +926,12 @@ static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
       if (bs >= (1ll << 32)) return MXVL_ERR_UNSUPPORTED;    // seg_off: 32-bit batch strides
     const long parts = (a.batch + a.fold_bpp - 1) / a.fold_bpp;
     const long tiles32 = parts * a.G * ((a.dim / a.G + 31) / 32);
-    if ((a.dim / a.G) % 32 == 0 && tiles32 >= 256) return launch_bwd1<io_t, 8, true, 16, true>(a, stream);
+    if ((a.dim / a.G) % 32 == 0 && tiles32 >= 256) {
+      if constexpr (sizeof(io_t) == 2) {
+        if (!(MXVL_EXP & 4)) return launch_bwd1<io_t, 8, true, 16, true, true>(a, stream);
+      }
+      return launch_bwd1<io_t, 8, true, 16, true>(a, stream);
+    }
     return launch_bwd1<io_t, 4, true, 16, true>(a, stream);
   }
   const int variant = mxvl_scan_bwd_variant();   // tests / A-B measurements: 0 automatic
