@@ -209,6 +209,146 @@ __global__ __launch_bounds__(256) void dir_merge_short_kernel(const PermArgs p) 
   }
 }
 
+// ---- short rows, 16-bit io, 16-byte rows on the stacked side ---------------------------------------------------------------
+// The stacked tensor is K times the bytes of the row tensors and its rows are Lp = a multiple of 8 elements long: the kernels
+// below move it with 16-byte accesses (a 16-bit element per lane is 128 bytes per wave instruction: the element-wise kernels
+// above spent 16 (merge) / 32 (gather) such instructions per thread on it), keep the tile in LDS in the io dtype and take 8
+// channels per workgroup.  The row side (L = 197 elements, 2-byte aligned rows with arbitrary strides) stays element-wise,
+// coalesced across the lanes.  Results are bit-identical to the kernels above (same fp32 sum order, one rounding).
+constexpr int kVecRows = 8;
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void dir_gather_vec_kernel(const PermArgs p) {
+  static_assert(sizeof(io_t) == 2, "16-bit io");
+  constexpr int RPB = kVecRows;
+  __shared__ __attribute__((aligned(16))) io_t srow[RPB][256];           // entries >= L are zero: the padding reads them
+  __shared__ __attribute__((aligned(16))) uint8_t sidx[kMaxDirs][256];    // perm[k][l], l >= L -> 255 (a zero entry; L <= 248 here)
+  using io = Io<io_t>;
+  const int d0 = blockIdx.x * RPB, b = blockIdx.y, t = threadIdx.x;
+  const bool live = t < p.L;
+  const int tc = live ? t : 0;
+  int ixv[kMaxDirs];
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) ixv[k] = p.idx[(k < p.K ? k : 0) * p.L + tc];
+  // ungated: the gate / pre loads go to the source rows instead (values unused): no branch around a load, see dir_merge_vec_kernel
+  const bool gated = p.gate != nullptr;
+  const io_t* gz = (const io_t*)(gated ? p.gate : p.src);
+  const io_t* gp = (const io_t*)(gated ? p.pre : p.src);
+  const long long gbs = gated ? p.g_bs : p.x_bs, gds = gated ? p.g_ds : p.x_ds, pbs = gated ? p.p_bs : p.x_bs, pds = gated ? p.p_ds : p.x_ds;
+  io_t vr[RPB], zr[RPB], pr[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    const int d = min(d0 + r, p.D - 1);
+    vr[r] = *((const io_t*)p.src + (long long)b * p.x_bs + (long long)d * p.x_ds + tc);
+    zr[r] = *(gz + (long long)b * gbs + (long long)d * gds + tc);
+    pr[r] = *(gp + (long long)b * pbs + (long long)d * pds + tc);
+  }
+  float v[RPB], zv[RPB], pre[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) { v[r] = io::ld(&vr[r]); zv[r] = io::ld(&zr[r]); pre[r] = io::ld(&pr[r]); }
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) asm volatile("" : "+v"(v[r]), "+v"(zv[r]), "+v"(pre[r]));   // (keeps a load from being sunk into the gated branch)
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) sidx[k][t] = live ? (uint8_t)ixv[k] : (uint8_t)255;
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    float x = v[r];
+    if (gated) {   // backward of the gated merge: x is d(out)
+      const float g = x * p.scale, sg = sigmoid(zv[r]);
+      x = g * (zv[r] * sg);
+      if (live && d0 + r < p.D)
+        io::st((io_t*)p.dgate + (long long)b * p.dg_bs + (long long)(d0 + r) * p.dg_ds + t, g * pre[r] * (sg * fmaf(zv[r], 1.0f - sg, 1.0f)));
+    }
+    asm volatile("" : "+v"(x));     // round the product to fp32 first, like the element-wise kernel (which parks it in LDS as fp32):
+                                    // hipcc otherwise folds the last multiply into the fp16 conversion (v_fma_mixlo_f16, one rounding)
+    io::st(&srow[r][t], live ? x : 0.0f);
+  }
+  __syncthreads();
+  const int cpr = p.Lp >> 3;                       // 16-byte vectors per stacked row
+  const int nvec = p.K * RPB * cpr;
+  for (int vv = t; vv < nvec; vv += 256) {
+    const int c = vv % cpr, rk = vv / cpr, r = rk % RPB, k = rk / RPB;
+    if (d0 + r >= p.D) continue;
+    const uint2 ib = *(const uint2*)&sidx[k][c * 8];
+    const uint16_t* row = (const uint16_t*)srow[r];
+    uint4 o;
+    o.x = (uint32_t)row[ib.x & 255u] | ((uint32_t)row[(ib.x >> 8) & 255u] << 16);
+    o.y = (uint32_t)row[(ib.x >> 16) & 255u] | ((uint32_t)row[ib.x >> 24] << 16);
+    o.z = (uint32_t)row[ib.y & 255u] | ((uint32_t)row[(ib.y >> 8) & 255u] << 16);
+    o.w = (uint32_t)row[(ib.y >> 16) & 255u] | ((uint32_t)row[ib.y >> 24] << 16);
+    io_t* X = (io_t*)p.dst + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)(d0 + r) * p.X_ds;
+    *(uint4*)(X + c * 8) = o;
+  }
+}
+
+template <typename io_t>
+__global__ __launch_bounds__(256) void dir_merge_vec_kernel(const PermArgs p) {
+  static_assert(sizeof(io_t) == 2, "16-bit io");
+  constexpr int RPB = kVecRows;
+  __shared__ __attribute__((aligned(16))) io_t sy[kMaxDirs][RPB][256];
+  using io = Io<io_t>;
+  const int d0 = blockIdx.x * RPB, b = blockIdx.y, t = threadIdx.x;
+  const bool live = t < p.L;
+  const int tc = live ? t : 0;
+  const int cpr = p.Lp >> 3;
+  const int nvec = p.K * RPB * cpr;
+  // every global load of the thread is requested before the first use: the stacked tile (up to 5 vectors), its K indices and
+  // its element of the 8 gate rows
+  constexpr int MAXV = (kMaxDirs * RPB * 32 + 255) / 256;     // Lp <= 256: at most 32 vectors per row
+  uint4 yv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vv = min(t + i * 256, nvec - 1);
+    const int c = vv % cpr, rk = vv / cpr, r = rk % RPB, k = rk / RPB;
+    const int d = min(d0 + r, p.D - 1);
+    yv[i] = *(const uint4*)((const io_t*)p.src + (long long)b * p.X_bs + (long long)k * p.X_ks + (long long)d * p.X_ds + c * 8);
+  }
+  int ixv[kMaxDirs];
+#pragma unroll
+  for (int k = 0; k < kMaxDirs; ++k) ixv[k] = p.idx[(k < p.K ? k : 0) * p.L + tc];
+  io_t zr[RPB];
+  {
+    // the gate rows, or (ungated merge) any valid address with the same strides zeroed: no branch around a load -- hipcc waits
+    // for a load at the join of the branch it sits in, which made a chain of 8 serialised round trips out of these
+    const io_t* gz = (const io_t*)(p.gate ? p.gate : p.src);
+    const long long gbs = p.gate ? p.g_bs : 0, gds = p.gate ? p.g_ds : 0;
+#pragma unroll
+    for (int r = 0; r < RPB; ++r) zr[r] = gz[(long long)b * gbs + (long long)min(d0 + r, p.D - 1) * gds + (p.gate ? tc : 0)];
+  }
+  // pin: all of the above are requested before the first of them is waited for (the compiler otherwise sinks each tile load
+  // into the `vv < nvec` block of its LDS store: load, wait, store, six times in a row)
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) asm volatile("" : "+v"(yv[i].x), "+v"(yv[i].y), "+v"(yv[i].z), "+v"(yv[i].w));
+  float zv[RPB];
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) zv[r] = io::ld(&zr[r]);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vv = t + i * 256;
+    if (vv < nvec) {
+      const int c = vv % cpr, rk = vv / cpr, r = rk % RPB, k = rk / RPB;
+      *(uint4*)&sy[k][r][c * 8] = yv[i];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < RPB; ++r) {
+    if (d0 + r >= p.D) break;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxDirs; ++k)
+      if (k < p.K) acc += io::ld(&sy[k][r][ixv[k]]);          // k ascending, like the generic kernel
+    io_t* out = (io_t*)p.dst + (long long)b * p.x_bs + (long long)(d0 + r) * p.x_ds;
+    if (p.gate) {
+      if (p.pre) io::st((io_t*)p.pre + (long long)b * p.p_bs + (long long)(d0 + r) * p.p_ds + t, acc);
+      io::st(out + t, acc * silu(zv[r]) * p.scale);
+    } else {
+      io::st(out + t, acc);
+    }
+  }
+}
+
 static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   if (!d || !d->rows || !d->stacked || !d->index) return MXVL_ERR_NULL;
   if (d->batch <= 0 || d->dim <= 0 || d->seqlen <= 0 || d->n_dirs <= 0 || d->padded_len < d->seqlen) return MXVL_ERR_SHAPE;
@@ -226,9 +366,20 @@ static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   const size_t lds = sizeof(float) * (size_t)a.L;
   hipStream_t s = (hipStream_t)stream;
   const bool short_rows = a.Lp <= 256 && a.K <= kMaxDirs;
+  // 16-byte accesses on the stacked side: 16-bit io, rows of whole 8-element vectors at 16-byte aligned addresses
+  const bool vec_rows = short_rows && d->io_dtype != MXVL_F32 && a.Lp % 8 == 0 && a.L <= 248 && !(MXVL_EXP & 8) &&
+                        ((uintptr_t)d->stacked % 16 == 0) && a.X_bs % 8 == 0 && a.X_ks % 8 == 0 && a.X_ds % 8 == 0;
+  const dim3 vgrid((a.D + kVecRows - 1) / kVecRows, a.B);
   const dim3 ggrid((a.D + kRowsPerBlock - 1) / kRowsPerBlock, a.B), mgrid((a.D + kRowsPerBlock / 2 - 1) / (kRowsPerBlock / 2), a.B);
 #define MXVL_PERM(T)                                                                                   \
   do {                                                                                                  \
+    if constexpr (sizeof(T) == 2) {                                                                     \
+      if (vec_rows) {                                                                                   \
+        if (merge) hipLaunchKernelGGL(dir_merge_vec_kernel<T>, vgrid, dim3(256), 0, s, a);              \
+        else hipLaunchKernelGGL(dir_gather_vec_kernel<T>, vgrid, dim3(256), 0, s, a);                   \
+        break;                                                                                          \
+      }                                                                                                 \
+    }                                                                                                   \
     if (short_rows && merge) hipLaunchKernelGGL(dir_merge_short_kernel<T>, mgrid, dim3(256), 0, s, a);   \
     else if (short_rows) hipLaunchKernelGGL(dir_gather_short_kernel<T>, ggrid, dim3(256), 0, s, a);      \
     else if (merge) hipLaunchKernelGGL(dir_merge_kernel<T>, grid, dim3(256), lds, s, a);                \

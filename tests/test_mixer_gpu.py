@@ -173,6 +173,47 @@ def test_dir_merge_gate_equals_torch_restatement(dtype):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K", [4, 6])
+def test_dir_perm_16_byte_kernels_equal_the_element_wise_kernels_bitwise(dtype, K):
+    """csrc/dir_perm.hip: 16-bit stacked tensors with 16-byte aligned rows take dir_gather_vec / dir_merge_vec (16-byte
+    accesses, 8 channels per workgroup); a stacked view that starts 8 bytes into its rows takes the element-wise short-row
+    kernels.  Same fp32 sum order, same rounding points: every output must agree bit for bit (plain and gated, ragged D)."""
+    from medical_image_analysis_amd.mamba_simple import _dir_perm
+    B, D, L, Lp = 3, 43, 197, 200
+    g = torch.Generator().manual_seed(K)
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(K)]).to(DEV, torch.int32)
+    inv = torch.argsort(perm.long(), dim=1).to(torch.int32)
+    xz = torch.randn(B, 2 * D, L, generator=g).to(DEV, dtype)
+    x, z = xz[:, :D], xz[:, D:]
+    dout = torch.randn(B, D, L, generator=g).to(DEV, dtype)
+    y = torch.randn(B, K, D, Lp, generator=g).to(DEV, dtype)
+
+    def stacked(aligned, fill=None):
+        t = torch.zeros(B, K, D, Lp + 8, dtype=dtype, device=DEV)
+        v = t[..., :Lp] if aligned else t[..., 4:4 + Lp]
+        if fill is not None:
+            v.copy_(fill)
+        return v
+
+    res = []
+    for aligned in (True, False):
+        X, dy = stacked(aligned), stacked(aligned)
+        ys = stacked(aligned, y)
+        out, pre, dz, dx = (torch.empty(B, D, L, dtype=dtype, device=DEV) for _ in range(4))
+        _dir_perm(False, x, X, perm, L, Lp)
+        _dir_perm(True, out, ys, inv, L, Lp, gate=z, pre=pre, scale=0.25)
+        _dir_perm(False, dout, dy, perm, L, Lp, gate=z, pre=pre, dgate=dz, scale=0.25)
+        _dir_perm(True, dx, ys, inv, L, Lp)
+        res.append([t.clone() for t in (X, out, pre, dy, dz, dx)])
+    for name, a, b in zip(("X", "out", "pre", "dy", "dz", "dx"), *res):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), name
+    ref = torch.zeros(B, K, D, Lp, dtype=dtype, device=DEV)
+    for k in range(K):
+        ref[:, k, :, :L] = x[:, :, perm[k].long()]
+    assert torch.equal(res[0][0], ref)
+
+
 def test_v4_layer_scale_scales_out_only():
     """bimamba v4 + init_layer_scale: the reference multiplies `out` by gamma and returns `out_d` unscaled
     (arm/Finetuning/mamba_simple.py:710-713)."""
