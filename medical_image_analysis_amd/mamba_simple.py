@@ -178,8 +178,10 @@ class _MultiDirMixerFn(torch.autograd.Function):
         _dir_perm(False, x, X, perm, L, Lp)
         needs_grad = any(ctx.needs_input_grad)
         y, saved, ctx.meta = mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad)
-        out = torch.empty((B, D, L), dtype=y.dtype, device=y.device)
-        pre = torch.empty((B, D, L), dtype=y.dtype, device=y.device) if needs_grad else None
+        # channel-major (D, B, L) storage: proj_out reads it as the (D, B*L) operand of ONE GEMM and hands d(out) back in the same
+        # layout (batch-major, F.linear copied `out` to token-major and the backward copied d(out) back: two tensor passes a layer)
+        out = torch.empty((D, B, L), dtype=y.dtype, device=y.device).permute(1, 0, 2)
+        pre = torch.empty((D, B, L), dtype=y.dtype, device=y.device).permute(1, 0, 2) if needs_grad else None
         _dir_perm(True, out, y, inv, L, Lp, gate=z, pre=pre, scale=scale)
         ctx.save_for_backward(xz, perm, inv, pre, *saved)
         ctx.dims = (Lp, scale)
@@ -325,8 +327,7 @@ class Mamba(nn.Module):
                 torch.stack([m[1].weight for m in mods]), torch.stack([m[2].weight for m in mods]),
                 -torch.exp(torch.cat([m[3].float() for m in mods], dim=0)), torch.cat([m[4].float() for m in mods], dim=0),
                 torch.cat([m[2].bias.float() for m in mods], dim=0))
-            return F.linear(gated.transpose(1, 2), self.out_proj.weight.to(gated.dtype),
-                            None if self.out_proj.bias is None else self.out_proj.bias.to(gated.dtype))
+            return _ssi.proj_out(gated, self.out_proj.weight, self.out_proj.bias)
         x, z = _SplitHalves.apply(xz)       # the gradient of xz is written once, channel-major (proj_in's layout)
         sfxs = ["", "_b", "_c", "_c_b"]
         x_d = None
