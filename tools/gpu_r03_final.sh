@@ -25,8 +25,9 @@ prof bwd_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 prof fwd_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES -d $P/fwd_sq -o r -- $FW
 prof gemm_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -d $P/gemm_sq -o r -- python $R/tools/gemm_swiglu_bench.py 1
 prof pretrain_stats --kernel-trace --stats -d $P/pretrain_stats -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
+prof encoder_stats --kernel-trace --stats -d $P/encoder_stats -o r -- python $R/bench.py --workload arm_encoder_large_224 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 cd $R
-for n in bwd_fetch bwd_write fwd_fetch fwd_write bwd_sq bwd_sq2 fwd_sq gemm_sq pretrain_stats; do
+for n in bwd_fetch bwd_write fwd_fetch fwd_write bwd_sq bwd_sq2 fwd_sq gemm_sq pretrain_stats encoder_stats; do
   python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -70 | cut -c1-170 > $O/prof_${TAG}_$n.txt
 done
 rm -f $O/${TAG}_pmc_traffic.json
@@ -40,4 +41,5 @@ done
 (timeout 300 python tools/scan_r03_bench.py all 2 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_scan_variants.txt
 (timeout 300 python tools/gemm_swiglu_bench.py 3 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_gemm_swiglu_bench.txt
 (timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_attn_bench.txt
+(timeout 300 python tools/dir_perm_bench.py 2 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_dir_perm_bench.txt
 cat $O/${TAG}_pytest_gpu_tail.log $O/${TAG}_smoke.log $O/${TAG}_pmc_traffic.log; for f in $O/${TAG}_bench_*.json; do echo "== $f"; cut -c1-330 $f; done
