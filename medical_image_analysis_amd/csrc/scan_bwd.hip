@@ -926,7 +926,8 @@ static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
       if (bs >= (1ll << 32)) return MXVL_ERR_UNSUPPORTED;    // seg_off: 32-bit batch strides
     const long parts = (a.batch + a.fold_bpp - 1) / a.fold_bpp;
     const long tiles32 = parts * a.G * ((a.dim / a.G + 31) / 32);
-    if ((a.dim / a.G) % 32 == 0 && tiles32 >= 256) {
+    const int fv = mxvl_scan_bwd_variant();       // tests: 1 forces the 8-wave walk at small sizes, 2 the 4-wave walk
+    if ((a.dim / a.G) % 32 == 0 && (fv == 1 || (fv != 2 && tiles32 >= 256))) {
       if constexpr (sizeof(io_t) == 2) {
         if (!(MXVL_EXP & 4)) return launch_bwd1<io_t, 8, true, 16, true, true>(a, stream);
       }

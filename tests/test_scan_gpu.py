@@ -389,6 +389,42 @@ def test_scan_bwd_workgroup_shapes_agree(shape):
             _check_grads(got[v], ref, f"variant {v}: ")
 
 
+@pytest.mark.parametrize("B,D,L,has_z,G,fold", [(2, 64, 8, True, 1, False),     # one 8-step chunk: no checkpoint, 15 of 16 lanes past the end
+                                               (2, 64, 128, True, 1, False),   # exactly one full chunk
+                                               (3, 96, 136, True, 1, False),   # a full chunk + an 8-step one
+                                               (2, 64, 392, False, 2, False),  # no gate, two groups, 4 chunks with a ragged last one
+                                               (2, 32, 1024, True, 1, False),  # 8 full chunks: 7 DMA hand-overs
+                                               (5, 64, 200, True, 1, True),    # folded walk: segments straddle chunks
+                                               (7, 32, 8, True, 1, True),      # folded walk: 16 segments per chunk
+                                               (24, 64, 144, False, 2, True)])  # folded walk: grouped B / C, no gate
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_scan_bwd_dma_walk_vs_oracle(B, D, L, has_z, G, fold, dtype, tol, monkeypatch):
+    """The 8-wave 16-bit backward walk whose next chunk (rows, B/C tile, checkpoint) arrives by LDS-DMA (csrc/scan_bwd.hip,
+    DMAR: L % 8 == 0, dstate 16), plain and batch-folded, forced by variant 1 at small sizes, against the C oracle on the same
+    rounded inputs.  fp16 keeps the comparison tight (2^-11 output rounding); the fp32 accumulators (dA, dD, ddelta_bias) are held
+    to 1e-3."""
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    from oracle import oracle as orc
+    monkeypatch.setattr(ssi, "FOLD_SHORT_ROWS", fold)
+    cpu = scan_inputs(B, D, L, 16, G, has_z, True, True, seed=L, dtype=dtype)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(L + 1)).to(dtype)
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"],
+                                     cpu["delta_bias"], True, dout)
+    lib = _abi.load()
+    try:
+        lib.mxvl_set_scan_variant(1 << 8)
+        got = _grads_via_autograd(_to(cpu, _dev()), True, dout.to(_dev()))
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    for k, r in ref.items():
+        if r is None:
+            continue
+        scale = max(1.0, float(r.abs().max()))
+        t = tol if k not in ("dA", "dD", "ddelta_bias") else max(1e-3, tol / 8)
+        assert_close(got[k], r, t * scale, t, k)
+
+
 def test_scan_bwd_linearity_full_size():
     """Size-independent property at BASELINE configs[1] full size: the gradient is linear in dout."""
     dev = _dev()
