@@ -133,19 +133,24 @@ template <typename E> struct Pol16 {
   template <int D, int ROWS, int NT> struct Stage {
     static constexpr int UPR = D / 8, N = ROWS * UPR / NT;
     uint4 v[N];
+    int nv;
+    // Unconditional loads (rows past the end re-read the last valid row, nvalid >= 1) and the zero-fill at STORE time: behind
+    // `if (row < nvalid) v = load` hipcc waits for the load at the join of the branch, i.e. at once -- the tile that was meant to
+    // be in flight under the multiplications of the previous one was waited for before they started.
     __device__ __forceinline__ void load(const E* base, int64_t ts, int nvalid, int tid) {
+      nv = nvalid;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int c = tid + i * NT, row = c / UPR, u = c % UPR;
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (row < nvalid) v[i] = *(const uint4*)(base + (int64_t)row * ts + u * 8);
+        const int rc = row < nvalid ? row : nvalid - 1;
+        v[i] = *(const uint4*)(base + (int64_t)rc * ts + u * 8);
       }
     }
     __device__ __forceinline__ void store(char* tile, int tid) const {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int c = tid + i * NT, row = c / UPR, u = c % UPR;
-        *(uint4*)(tile + unit_off<D>(row, u)) = v[i];
+        *(uint4*)(tile + unit_off<D>(row, u)) = row < nv ? v[i] : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -171,12 +176,14 @@ struct Pol32 {
   template <int D, int ROWS, int NT> struct Stage {
     static constexpr int QPR = D / 4, N = ROWS * QPR / NT;
     float4 v[N];
-    __device__ __forceinline__ void load(const float* base, int64_t ts, int nvalid, int tid) {
+    int nv;
+    __device__ __forceinline__ void load(const float* base, int64_t ts, int nvalid, int tid) {     // see Pol16::Stage
+      nv = nvalid;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int c = tid + i * NT, row = c / QPR, u = c % QPR;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nvalid) v[i] = *(const float4*)(base + (int64_t)row * ts + u * 4);
+        const int rc = row < nvalid ? row : nvalid - 1;
+        v[i] = *(const float4*)(base + (int64_t)rc * ts + u * 4);
       }
     }
     __device__ __forceinline__ void store(char* tile, int tid) const {
@@ -185,7 +192,8 @@ struct Pol32 {
       for (int i = 0; i < N; ++i) {
         const int c = tid + i * NT, row = c / QPR, u = c % QPR;
         float* d = t + row * (D + 1) + u * 4;
-        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        const float4 w = row < nv ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
       }
     }
   };
@@ -260,20 +268,24 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   const E* kb = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
   const E* vb = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs;
   typename Pol::template Stage<D, KT, NT> stK, stV;
-  float mreg = 0.f;
+  int mraw = 0, mkey = 0;
+  // (the key-mask byte: an unconditional load from a clamped position -- of the K tensor itself when there is no mask -- decided
+  // at commit; see Pol16::Stage for why no load of the prefetch may sit behind a condition)
+  const uint8_t* const mbase = p.kmask ? p.kmask + (int64_t)b * p.Lk : (const uint8_t*)kb;
   auto fetch = [&](int kt) {
     const int k0 = kt * KT;
     stK.load(kb + (int64_t)k0 * p.k_ts, p.k_ts, p.Lk - k0, tid);
     stV.load(vb + (int64_t)k0 * p.v_ts, p.v_ts, p.Lk - k0, tid);
     if constexpr (EXTRA) {
-      if (tid < KT) mreg = (k0 + tid < p.Lk && (!p.kmask || p.kmask[(int64_t)b * p.Lk + k0 + tid])) ? 0.f : kNegInf;
+      mkey = k0 + (tid & (KT - 1));
+      mraw = mbase[mkey < p.Lk ? mkey : p.Lk - 1];
     }
   };
   auto commit = [&](int buf) {
     stK.store(smem + (2 * buf) * TB, tid);
     stV.store(smem + (2 * buf + 1) * TB, tid);
     if constexpr (EXTRA) {
-      if (tid < KT) sMaskAll[buf * KT + tid] = mreg;
+      if (tid < KT) sMaskAll[buf * KT + tid] = (mkey < p.Lk && (!p.kmask || mraw)) ? 0.f : kNegInf;
     }
   };
   if (ntiles > 0) fetch(0);
@@ -305,6 +317,20 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
   float m = kNegInf, l = 0.f;
+  // The Q-side fragments are consumed HERE, before the loop: s_waitcnt insertion is static, and with their loads still pending
+  // at the loop header hipcc put `s_waitcnt vmcnt(0)` in front of the first MFMA of the loop BODY -- executed every iteration,
+  // right behind the loads of tile kt + 1 (head_dim 128 causal: 321 -> 302 us forward, 924 -> 868 us backward; head_dim 32: 94 -> 79 us)
+#pragma unroll
+  for (int ks = 0; ks < NKD; ++ks) {
+    if constexpr (sizeof(E) == 2) {
+      asm volatile("" : "+v"(qf[ks].x), "+v"(qf[ks].y), "+v"(qf[ks].z), "+v"(qf[ks].w));
+      if constexpr (DQ) asm volatile("" : "+v"(dof[ks].x), "+v"(dof[ks].y), "+v"(dof[ks].z), "+v"(dof[ks].w));
+    } else {
+      asm volatile("" : "+v"(qf[ks]));
+      if constexpr (DQ) asm volatile("" : "+v"(dof[ks]));
+    }
+  }
+  if constexpr (DQ) asm volatile("" : "+v"(lse), "+v"(delta));
 
   if (ntiles > 0) commit(0);
   __syncthreads();
@@ -556,6 +582,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(const AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[qb][dt][r] = 0.f;
   float m[2] = {kNegInf, kNegInf}, l[2] = {0.f, 0.f};
+  // NOTE (profiles/r03_attn_wait_ab.txt): with the Q fragment loads still pending at the loop header, hipcc puts a
+  // `s_waitcnt vmcnt(0)` in front of the first MFMA of the loop body (s_waitcnt insertion is static), i.e. behind the DMA request
+  // of tile kt + 2.  Consuming the fragments before the loop removes that wait -- and measured 2 % SLOWER here and in the dQ pass
+  // (374 vs 366 us; two co-resident workgroups cover each other's wait and stay staggered), while the same fix gained 6-19 % in
+  // attn_q_kernel and the dK/dV pass.  Left as the compiler emits it.
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int k0 = kt * KT;
@@ -854,8 +885,14 @@ __global__ __launch_bounds__(256, 2) void attn_dq64_kernel(const AttnArgs p) {
 
 // ---- dK / dV ----------------------------------------------------------------------------------------------------------
 // One workgroup per 128-key tile (a lane owns a key); walks the query tiles that can see it, Q / dO tiles double-buffered.
-template <typename E, int D, int NW, bool EXTRA>
+// DMAQ (head_dim 64, 16-bit, no key mask / bias, 16-byte aligned q / dout rows; the launcher decides): the Q / dO tile of the
+// NEXT query tile, its lse and delta rows arrive by LDS-DMA (global_load_lds_dwordx4 / _dword from inline asm, the XOR swizzle of
+// unit_off<64> on the source address as in attn_fwd64_kernel) while the current tile is multiplied; one vmcnt(0) + one barrier per
+// tile.  The register-staged form below was meant to do the same, but hipcc puts `s_waitcnt vmcnt(0)` in front of the first MFMA
+// of the iteration that issued the loads (profiles/r03_attn_dkv_dma.txt): every tile's latency was exposed.
+template <typename E, int D, int NW, bool EXTRA, bool DMAQ = false>
 __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void attn_bwd_dkv_kernel(const AttnArgs p) {
+  static_assert(!DMAQ || (D == 64 && sizeof(E) == 2 && NW == 4 && !EXTRA), "DMAQ: head_dim 64, 16-bit, 4 waves, no mask / bias");
   typedef typename PolOf<E>::type Pol;
   typedef typename Pol::Frag Frag;
   constexpr int KTW = NW * 32, QT = kKT, NKD = D / Pol::KSTEP, NKR = 32 / Pol::KSTEP, NDT = D / 32, NT = NW * 64;
@@ -883,18 +920,18 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
 
   typename Pol::template Stage<D, QT, NT> stQ, stO;
   float r_lse = 0.f, r_delta = 0.f;
-  int r_klim = 0;
+  int r_q = 0;
   auto fetch = [&](int it) {
     const int hq = hk * grp + it / per_head, q0 = (qt0 + it % per_head) * QT;
     stQ.load((const E*)p.q + (int64_t)b * p.q_bs + (int64_t)hq * p.q_hs + (int64_t)q0 * p.q_ts, p.q_ts, p.Lq - q0, tid);
     stO.load((const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)hq * p.do_hs + (int64_t)q0 * p.do_ts, p.do_ts, p.Lq - q0, tid);
-    if (tid < QT) {
-      const int q = q0 + tid;
-      const bool ok = q < p.Lq;
+    {   // every thread loads (clamped, unconditional: see Pol16::Stage); threads >= QT and rows past Lq are sorted out at commit
+      const int q = q0 + (tid & (QT - 1));
       const int64_t ro = ((int64_t)b * p.H + hq) * p.Lq;
-      r_lse = ok ? p.lse[ro + q] : __builtin_inff();
-      r_delta = ok ? p.delta[ro + q] : 0.f;
-      r_klim = key_limit(p, q);
+      const int qc = q < p.Lq ? q : p.Lq - 1;
+      r_lse = p.lse[ro + qc];
+      r_delta = p.delta[ro + qc];
+      r_q = q;
     }
   };
   auto commit = [&](int buf) {
@@ -902,12 +939,70 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
     stO.store(smem + (2 * buf + 1) * TB, tid);
     if (tid < QT) {
       float* r = sRow + buf * 3 * QT;
-      r[tid] = r_lse;
-      r[QT + tid] = r_delta;
-      ((int*)r)[2 * QT + tid] = r_klim;
+      const bool ok = r_q < p.Lq;
+      r[tid] = ok ? r_lse : __builtin_inff();
+      r[QT + tid] = ok ? r_delta : 0.f;
+      ((int*)r)[2 * QT + tid] = key_limit(p, r_q);
     }
   };
-  if (nit > 0) fetch(0);
+  // ---- DMAQ: this wave moves rows 16 wave .. 16 wave + 15 of the Q tile and of the dO tile (2 x 1 KB each); wave 0 also the
+  // 64 lse and delta entries.  address = (tile base, wave-uniform, SGPRs) + (per-lane 32-bit byte offset)
+  const int wq = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_row = [&](int i) { return 16 * wq + 8 * i + (lane >> 3); };
+  auto dma_unit = [&](int row) { return ((lane & 7) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) * 8; };   // Pol16::unit_off<64>
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
+  const unsigned ldsRow = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)((char*)sRow);
+  auto issue = [&](int it) {
+    const int hq = hk * grp + it / per_head, q0 = (qt0 + it % per_head) * QT, buf = it & 1;
+    const E* gq = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)hq * p.q_hs + (int64_t)q0 * p.q_ts;
+    const E* go = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)hq * p.do_hs + (int64_t)q0 * p.do_ts;
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {      // rows past Lq re-read row Lq - 1 (finite values under lse = +inf, i.e. probability 0)
+      const int row = dma_row(i), unit = dma_unit(row);
+      const int r = q0 + row < p.Lq ? row : p.Lq - 1 - q0;
+      o[i] = (unsigned)(((int64_t)r * p.q_ts + unit) * 2);
+      o[2 + i] = (unsigned)(((int64_t)r * p.do_ts + unit) * 2);
+    }
+    const unsigned dst = lds0 + (unsigned)(2 * buf * TB + wq * 2048);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o0], %[gq]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o1], %[gq]\n\t"
+        "s_add_u32 m0, m0, 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o2], %[go]\n\t"
+        "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[o3], %[go]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep)
+        : [dst] "s"(dst), [gq] "s"(gq), [go] "s"(go), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3])
+        : "memory", "scc");
+    if (wq == 0) {
+      const int q = q0 + lane;
+      const unsigned oq = (unsigned)((q < p.Lq ? q : p.Lq - 1) * 4);
+      const float* gl = p.lse + ((int64_t)b * p.H + hq) * p.Lq;
+      const float* gd = p.delta + ((int64_t)b * p.H + hq) * p.Lq;
+      const unsigned dr = ldsRow + (unsigned)(buf * 3 * QT * 4);
+      asm volatile(
+          "s_mov_b32 %[keep], m0\n\t"
+          "s_mov_b32 m0, %[dr]\n\ts_nop 0\n\tglobal_load_lds_dword %[oq], %[gl]\n\t"
+          "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %[oq], %[gd]\n\t"
+          "s_mov_b32 m0, %[keep]"
+          : [keep] "=&s"(keep)
+          : [dr] "s"(dr), [gl] "s"(gl), [gd] "s"(gd), [oq] "v"(oq)
+          : "memory", "scc");
+    }
+  };
+  auto landed = [&](int it) {      // after this wave's vmcnt(0): key limits, and lse = +inf / delta = 0 for query rows past Lq
+    if (wq == 0) {
+      const int q = (qt0 + it % per_head) * QT + lane;
+      float* r = sRow + (it & 1) * 3 * QT;
+      ((int*)r)[2 * QT + lane] = key_limit(p, q);
+      if (q >= p.Lq) { r[lane] = __builtin_inff(); r[QT + lane] = 0.f; }
+    }
+  };
+  if (nit > 0) {
+    if constexpr (DMAQ) issue(0); else fetch(0);
+  }
 
   const E* kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs + kr * p.k_ts;
   const E* vp = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs + kr * p.v_ts;
@@ -923,7 +1018,26 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
 
-  if (nit > 0) commit(0);
+  // The K / V fragments are consumed here, on every path into the loop: s_waitcnt insertion is static, and with their loads
+  // possibly pending at the loop header (the nit == 0 path skips the waits below) hipcc put a vmcnt(0) in front of the FIRST
+  // MFMA of the loop body -- executed every iteration, it waited for the tile requested a few instructions earlier.
+#pragma unroll
+  for (int ks = 0; ks < NKD; ++ks) {
+    if constexpr (sizeof(E) == 2) {
+      asm volatile("" : "+v"(kf[ks].x), "+v"(kf[ks].y), "+v"(kf[ks].z), "+v"(kf[ks].w));
+      asm volatile("" : "+v"(vf[ks].x), "+v"(vf[ks].y), "+v"(vf[ks].z), "+v"(vf[ks].w));
+    } else {
+      asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+    }
+  }
+  if (nit > 0) {
+    if constexpr (DMAQ) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      landed(0);
+    } else {
+      commit(0);
+    }
+  }
   __syncthreads();
 
   for (int it = 0; it < nit; ++it) {
@@ -934,7 +1048,9 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
     const float* sDelta = sLse + QT;
     const int* sKlim = (const int*)(sLse + 2 * QT);
     const bool more = it + 1 < nit;
-    if (more) fetch(it + 1);
+    if (more) {
+      if constexpr (DMAQ) issue(it + 1); else fetch(it + 1);       // DMAQ: buffer buf ^ 1 was last read before the barrier above
+    }
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       f32x16 s, dp;
@@ -980,7 +1096,14 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
         }
       }
     }
-    if (more) commit(buf ^ 1);
+    if (more) {
+      if constexpr (DMAQ) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(it + 1);
+      } else {
+        commit(buf ^ 1);
+      }
+    }
     __syncthreads();
   }
   if (!kv) return;
@@ -1046,18 +1169,23 @@ static int launch_q(const AttnArgs& a, hipStream_t s) {
   return (a.kmask || a.bias) ? launch_q1<E, D, DQ, true>(a, s) : launch_q1<E, D, DQ, false>(a, s);
 }
 
-template <typename E, int D, bool EXTRA>
+template <typename E, int D, bool EXTRA, bool DMAQ = false>
 static int launch_dkv1(const AttnArgs& a, hipStream_t s);
 template <typename E, int D>
 static int launch_dkv(const AttnArgs& a, hipStream_t s) {
+  if constexpr (D == 64 && sizeof(E) == 2) {      // Q / dO tiles by LDS-DMA: 16-byte aligned rows, 32-bit in-tile offsets
+    const bool aligned = a.q_ts % 8 == 0 && a.do_ts % 8 == 0 && a.q_hs % 8 == 0 && a.do_hs % 8 == 0 && a.q_bs % 8 == 0 && a.do_bs % 8 == 0 &&
+                         ((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 && a.q_ts < (1 << 24) && a.do_ts < (1 << 24);
+    if (!a.kmask && !a.bias && aligned && a.Lq > 0 && !(MXVL_EXP & 16)) return launch_dkv1<E, D, false, true>(a, s);
+  }
   return (a.kmask || a.bias) ? launch_dkv1<E, D, true>(a, s) : launch_dkv1<E, D, false>(a, s);
 }
-template <typename E, int D, bool EXTRA>
+template <typename E, int D, bool EXTRA, bool DMAQ>
 static int launch_dkv1(const AttnArgs& a, hipStream_t s) {
   typedef typename PolOf<E>::type Pol;
   constexpr int NW = 4;
   const size_t lds = 4 * (size_t)Pol::tile_bytes(kKT, D) + 6 * kKT * sizeof(float);
-  auto kern = attn_bwd_dkv_kernel<E, D, NW, EXTRA>;
+  auto kern = attn_bwd_dkv_kernel<E, D, NW, EXTRA, DMAQ>;
   int rc = raise_lds(kern, lds);
   if (rc != MXVL_OK) return rc;
   dim3 grid(a.Hkv * a.batch, (a.Lk + NW * 32 - 1) / (NW * 32), 1);
