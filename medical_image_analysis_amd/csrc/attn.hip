@@ -293,21 +293,23 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   const E* qp = (const E*)p.q + (int64_t)b * p.q_bs + (int64_t)h * p.q_hs + qr * p.q_ts;
   Frag qf[NKD];
 #pragma unroll
-  for (int ks = 0; ks < NKD; ++ks) qf[ks] = qv ? Pol::ldg(qp, ks, hi) : Pol::zero();
-  Frag dof[DQ ? NKD : 1];
-  float lse = 0.f, delta = 0.f;
+  for (int ks = 0; ks < NKD; ++ks) qf[ks] = Pol::ldg(qp, ks, hi);     // unconditional (qr is clamped to a valid row): all the
+  Frag dof[DQ ? NKD : 1];                                              // loads of this prologue are in flight together; rows
+  float lse = 0.f, delta = 0.f;                                        // without a query are zeroed after the pin below
   if constexpr (DQ) {
     const E* dop = (const E*)p.dout + (int64_t)b * p.do_bs + (int64_t)h * p.do_hs + qr * p.do_ts;
     const E* op = (const E*)p.o + (int64_t)b * p.o_bs + (int64_t)h * p.o_hs + qr * p.o_ts;
+    const int64_t ro = ((int64_t)b * p.H + h) * p.Lq + qr;
+    Frag of[NKD];
 #pragma unroll
     for (int ks = 0; ks < NKD; ++ks) {
-      dof[ks] = qv ? Pol::ldg(dop, ks, hi) : Pol::zero();
-      const Frag of = qv ? Pol::ldg(op, ks, hi) : Pol::zero();
-      delta += Pol::dot(dof[ks], of);
+      dof[ks] = Pol::ldg(dop, ks, hi);
+      of[ks] = Pol::ldg(op, ks, hi);
     }
+    lse = p.lse[ro];
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) delta += Pol::dot(dof[ks], of[ks]);
     delta = pair_sum(delta);
-    const int64_t ro = ((int64_t)b * p.H + h) * p.Lq + qr;
-    lse = qv ? p.lse[ro] : __builtin_inff();
     if (qv && hi == 0) p.delta[ro] = delta;
   }
 
@@ -331,6 +333,15 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
     }
   }
   if constexpr (DQ) asm volatile("" : "+v"(lse), "+v"(delta));
+  if (!qv) {
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) {
+      qf[ks] = Pol::zero();
+      if constexpr (DQ) dof[ks] = Pol::zero();
+    }
+    lse = __builtin_inff();
+    delta = 0.f;
+  }
 
   if (ntiles > 0) commit(0);
   __syncthreads();
@@ -1008,9 +1019,9 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
   const E* vp = (const E*)p.v + (int64_t)b * p.v_bs + (int64_t)hk * p.v_hs + kr * p.v_ts;
   Frag kf[NKD], vf[NKD];
 #pragma unroll
-  for (int ks = 0; ks < NKD; ++ks) {
-    kf[ks] = kv ? Pol::ldg(kp, ks, hi) : Pol::zero();
-    vf[ks] = kv ? Pol::ldg(vp, ks, hi) : Pol::zero();
+  for (int ks = 0; ks < NKD; ++ks) {     // unconditional (kr is clamped to a valid row); lanes without a key are zeroed after the pin below
+    kf[ks] = Pol::ldg(kp, ks, hi);
+    vf[ks] = Pol::ldg(vp, ks, hi);
   }
   f32x16 dk[NDT], dv[NDT];
 #pragma unroll
@@ -1029,6 +1040,10 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
     } else {
       asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
     }
+  }
+  if (!kv) {
+#pragma unroll
+    for (int ks = 0; ks < NKD; ++ks) { kf[ks] = Pol::zero(); vf[ks] = Pol::zero(); }
   }
   if (nit > 0) {
     if constexpr (DMAQ) {
@@ -1176,7 +1191,7 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
   if constexpr (D == 64 && sizeof(E) == 2) {      // Q / dO tiles by LDS-DMA: 16-byte aligned rows, 32-bit in-tile offsets
     const bool aligned = a.q_ts % 8 == 0 && a.do_ts % 8 == 0 && a.q_hs % 8 == 0 && a.do_hs % 8 == 0 && a.q_bs % 8 == 0 && a.do_bs % 8 == 0 &&
                          ((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 && a.q_ts < (1 << 24) && a.do_ts < (1 << 24);
-    if (!a.kmask && !a.bias && aligned && a.Lq > 0 && !(MXVL_EXP & 16)) return launch_dkv1<E, D, false, true>(a, s);
+    if (!a.kmask && !a.bias && aligned && a.Lq > 0) return launch_dkv1<E, D, false, true>(a, s);
   }
   return (a.kmask || a.bias) ? launch_dkv1<E, D, true>(a, s) : launch_dkv1<E, D, false>(a, s);
 }

@@ -367,7 +367,7 @@ static int perm_launch(bool merge, const mxvl_dir_perm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool short_rows = a.Lp <= 256 && a.K <= kMaxDirs;
   // 16-byte accesses on the stacked side: 16-bit io, rows of whole 8-element vectors at 16-byte aligned addresses
-  const bool vec_rows = short_rows && d->io_dtype != MXVL_F32 && a.Lp % 8 == 0 && a.L <= 248 && !(MXVL_EXP & 8) &&
+  const bool vec_rows = short_rows && d->io_dtype != MXVL_F32 && a.Lp % 8 == 0 && a.L <= 248 &&
                         ((uintptr_t)d->stacked % 16 == 0) && a.X_bs % 8 == 0 && a.X_ks % 8 == 0 && a.X_ds % 8 == 0;
   const dim3 vgrid((a.D + kVecRows - 1) / kVecRows, a.B);
   const dim3 ggrid((a.D + kRowsPerBlock - 1) / kRowsPerBlock, a.B), mgrid((a.D + kRowsPerBlock / 2 - 1) / (kRowsPerBlock / 2), a.B);

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
     const int t0 = c * CH;
     const bool full = t0 + CH <= L;
     if constexpr (DMABC) {     // this wave's share of the B/C DMA has landed ... (DMAR: waited for after the previous state loop)
-      if (!DMAR || c == nchunks - 1 || (MXVL_EXP & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!DMAR || c == nchunks - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();  // previous chunk: accumulators flushed, B/C tile free (first pass: init visible); ... and everybody's share
     // row data first: their HBM latency overlaps the B/C staging below (one exposed round trip per chunk, not two)
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       }
     }
 
-    if constexpr (DMAR && !(MXVL_EXP & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's tiles, requested before the state loop
+    if constexpr (DMAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's tiles, requested before the state loop
     {
       {     // the last group's shares
         float fpart[FK * NWAVES];
@@ -902,7 +902,7 @@ static int launch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   if constexpr (VEC && sizeof(io_t) == 2 && NWAVES == 8) {     // rows by LDS-DMA: whole 8-step lanes only.  (The 4-wave kernel, 4 flush
     // elements per thread, spills row pointers at 256 VGPRs and reloads them between the DMA requests: every reload waits for the
     // requests before it.)
-    if (a.N == 16 && a.L % 8 == 0 && !a.out_f32 && !(MXVL_EXP & 1)) return launch_bwd1<io_t, NWAVES, VEC, 16, false, true>(a, stream);
+    if (a.N == 16 && a.L % 8 == 0 && !a.out_f32) return launch_bwd1<io_t, NWAVES, VEC, 16, false, true>(a, stream);
   }
   return a.N == 16 ? launch_bwd1<io_t, NWAVES, VEC, 16>(a, stream) : launch_bwd1<io_t, NWAVES, VEC, 0>(a, stream);
 }
@@ -928,10 +928,8 @@ static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
     const long tiles32 = parts * a.G * ((a.dim / a.G + 31) / 32);
     const int fv = mxvl_scan_bwd_variant();       // tests: 1 forces the 8-wave walk at small sizes, 2 the 4-wave walk
     if ((a.dim / a.G) % 32 == 0 && (fv == 1 || (fv != 2 && tiles32 >= 256))) {
-      if constexpr (sizeof(io_t) == 2) {
-        if (!(MXVL_EXP & 4)) return launch_bwd1<io_t, 8, true, 16, true, true>(a, stream);
-      }
-      return launch_bwd1<io_t, 8, true, 16, true>(a, stream);
+      if constexpr (sizeof(io_t) == 2) return launch_bwd1<io_t, 8, true, 16, true, true>(a, stream);     // rows by LDS-DMA
+      else return launch_bwd1<io_t, 8, true, 16, true>(a, stream);
     }
     return launch_bwd1<io_t, 4, true, 16, true>(a, stream);
   }
