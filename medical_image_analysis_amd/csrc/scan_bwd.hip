@@ -1001,6 +1001,15 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
     const void* ptrs[] = {f->u, f->delta, f->z, d->du, d->ddelta, d->dz, f->B, f->C};
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
     ok = ok && (((uintptr_t)d->dout) % (4 * (a.out_f32 ? 4 : esz)) == 0);
+    // 16-bit rows take kernels that move B / C (and, at L % 8 == 0, the rows) in 16-byte LDS-DMA units: those need 16-byte aligned
+    // addresses.  Rows that are only 8-byte aligned (a view that starts 4 elements into its storage) take the element-wise path.
+    if (ok && esz == 2) {
+      const int64_t s8[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,
+                            a.out_f32 ? 0 : d->dout_bs, a.out_f32 ? 0 : d->dout_ds, f->B_bs, f->B_gs, f->B_ns, f->C_bs, f->C_gs, f->C_ns};
+      for (int64_t s : s8) ok = ok && (s % 8 == 0);
+      const void* p16[] = {f->u, f->delta, f->z, a.out_f32 ? nullptr : d->dout, f->B, f->C};
+      for (const void* q : p16) ok = ok && (((uintptr_t)q) % 16 == 0);
+    }
     a.vec_ok = ok ? 1 : 0;
   }
   hipStream_t stream = (hipStream_t)hip_stream;
