@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 5
+#define MXVL_ABI_VERSION 6
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -159,13 +159,16 @@ typedef struct mxvl_conv1d_bwd_desc {
 
 /*
  * Single-token decoder step of the report generator (bf16 weights and activations, fp32 accumulation), rows =
- * batch * beams <= 8.  Replaces per-token HF `LlamaForCausalLM.forward` + cuBLAS GEMVs
+ * batch * beams <= 80.  Replaces per-token HF `LlamaForCausalLM.forward` + cuBLAS GEMVs
  * (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301; layer arithmetic as restated in
  * EMRRG/models/hybrid_decoder_layer.py:185-199, 266-337, 392-457).
  *
  * mxvl_decode_gemv:  y[m][n] = epi( sum_k W[n][k] * xhat[m][k] ),  xhat = x, or RMSNorm(x; norm_weight, eps) when
  * norm_weight != NULL.  epi: + bias[n]; + residual[m][n]; swiglu = 1: y = silu(W xhat) * (W2 xhat); out_f32: fp32 y.
- * W, W2: (N, K) row-major bf16 (nn.Linear layout).  rows * K * 2 bytes must fit in LDS (<= 150 KiB).
+ * W, W2: (N, K) row-major bf16 (nn.Linear layout).
+ * rows <= 8: one GEMV kernel, activations staged in LDS (rows * K * 2 bytes <= 150 KiB, K <= 8192 with norm_weight).
+ * rows 9..80 (ABI v6): v_mfma_f32_16x16x32_bf16 with the weight tile as the A operand, loaded from HBM straight into the MFMA
+ * registers; K >= 32; norm_weight must be NULL (mxvl_decode_rmsnorm first).  Same epilogues, same rounding points.
  */
 typedef struct mxvl_gemv_desc {
   int32_t rows, K, N;
@@ -246,6 +249,21 @@ typedef struct mxvl_decode_prologue_desc {
   void *cos, *sin;          /* (rows, head_dim) fp32 out */
   void *pos;                /* device int64 scalar out */
 } mxvl_decode_prologue_desc;
+/*
+ * mxvl_decode_rmsnorm (ABI v6): y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * weight ), fp32 statistics -- Qwen2RMSNorm / LlamaRMSNorm
+ * (EMRRG/models/hybrid_decoder_layer.py:185-199) of the (rows, K) activations ahead of a projection.  mxvl_decode_gemv fuses this
+ * for rows <= 8 (norm_weight); for 9..80 rows -- the reference's own decode batches: val_batch_size 6 x beam 3 = 18
+ * (launch/launch_mambaclip_chexpert.sh:23), 8 x 3 = 24 (launch_mambaclip_test_cheXpert.sh:26), 16 x 5 = 80
+ * (launch_mambaclip_test_iu.sh:26-27) -- the projection runs on the matrix cores and takes already-normalised rows.
+ */
+typedef struct mxvl_rmsnorm_desc {
+  int32_t rows, K;          /* K % 8 == 0, K <= 16384 */
+  float eps;
+  const void *x;            /* (rows, K) bf16 */
+  const void *weight;       /* (K) bf16 */
+  void *y;                  /* (rows, K) bf16, may alias x */
+} mxvl_rmsnorm_desc;
+int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);
 int mxvl_decode_attn(const mxvl_decode_attn_desc *desc, void *hip_stream);
@@ -300,7 +318,7 @@ int mxvl_dir_merge(const mxvl_dir_perm_desc *desc, void *hip_stream);
 /* One beam-search update of report generation (what HF `generate(num_beams>1)` does between two decoder steps; call site
  * CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301): log-softmax, repetition penalty, min-new-tokens,
  * top-`keep` over beams*vocab, live-beam / finished-pool bookkeeping, early-stop heuristic.  All state tensors are updated
- * in place; *cur is incremented; *unfinished = decoding continues.  beams <= 4, keep <= 8.  Dtypes: logits, scores, tables
+ * in place; *cur is incremented; *unfinished = decoding continues.  beams <= 8, keep <= 16 (beam 5 of launch_mambaclip_test_iu.sh:27).  Dtypes: logits, scores, tables
  * fp32; sequences, cur, eos, tok, beam_src int64; fin_done, heur_open, unfinished 1-byte booleans. */
 typedef struct mxvl_beam_desc {
   int32_t batch, beams, vocab, max_new, min_new, n_eos, early_stopping, keep; /* early_stopping: 1 = True, 0 = False/"never" */
@@ -315,6 +333,8 @@ typedef struct mxvl_beam_desc {
   const void *len_tab, *hyp_tab;   /* (max_new): (t+1)^length_penalty, hypothesis-length^length_penalty */
   void *tok, *beam_src;            /* (batch*beams): next token, parent row of every live beam */
   void *unfinished;                /* scalar */
+  void *scratch;                   /* ABI v6, optional: (1) uint32, zero before the first call (the kernel leaves it zero): when
+                                      given, one workgroup per batch element instead of one workgroup walking the batch */
 } mxvl_beam_desc;
 int mxvl_beam_step(const mxvl_beam_desc *desc, void *hip_stream);
 

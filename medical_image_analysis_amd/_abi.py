@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -33,7 +33,7 @@ SYMBOLS = [
     "mxvl_scan_bwd_workspace_bytes",
     "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_conv1d_update", "mxvl_state_update",
     "mxvl_last_hip_error", "mxvl_set_scan_variant", "mxvl_last_scan_kernel", "mxvl_decode_gemv", "mxvl_decode_attn",
-    "mxvl_decode_cross_attn", "mxvl_decode_prologue",
+    "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss",
@@ -116,6 +116,10 @@ class GemvDesc(ctypes.Structure):
     ]
 
 
+class RmsNormDesc(ctypes.Structure):
+    _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p)]
+
+
 class DecodeAttnDesc(ctypes.Structure):
     _fields_ = [
         ("rows", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32), ("max_len", c_int32),
@@ -192,7 +196,7 @@ class BeamDesc(ctypes.Structure):
         ("repetition_penalty", ctypes.c_float), ("reserved0", c_int32),
         ("logits", c_void_p), ("run_seq", c_void_p), ("fin_seq", c_void_p), ("run_score", c_void_p), ("fin_score", c_void_p),
         ("fin_done", c_void_p), ("heur_open", c_void_p), ("cur", c_void_p), ("eos", c_void_p), ("len_tab", c_void_p),
-        ("hyp_tab", c_void_p), ("tok", c_void_p), ("beam_src", c_void_p), ("unfinished", c_void_p),
+        ("hyp_tab", c_void_p), ("tok", c_void_p), ("beam_src", c_void_p), ("unfinished", c_void_p), ("scratch", c_void_p),
     ]
 
 
@@ -236,8 +240,9 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_beam_step.restype = c_int
     lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
-    lib.mxvl_decode_prologue.restype = c_int
-    lib.mxvl_decode_prologue.argtypes = [c_void_p, c_void_p]
+    for name in ("mxvl_decode_prologue", "mxvl_decode_rmsnorm"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

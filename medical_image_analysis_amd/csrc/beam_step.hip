@@ -7,7 +7,11 @@
 // Same arithmetic, same order of the fp32 operations as report_decoder._BeamState.advance (the torch restatement that is
 // checked token-exact against HF): this kernel is tested against that function.
 //
-// One workgroup (512 threads) walks the batch elements.  Per element: (1) online max / sum-exp of every beam row (32
+// One workgroup (512 threads) per batch element when the caller provides the arrival word (`scratch`; rows > 8 in the stepper:
+// 6 / 8 / 16 samples x beams), else one workgroup walks the batch elements.  The workgroups meet in ONE returning atomicAdd
+// whose addend packs "arrived / any heuristic open / all candidates stopped / all pools full": the last arriver owns the
+// totals, writes *unfinished and *cur and clears the word (no fence: nothing but the atomic's own value crosses workgroups).
+// Per element: (1) online max / sum-exp of every beam row (32
 // independent loads in flight per thread: a single workgroup is latency-, not bandwidth-limited on 384 KB of logits), (2) every
 // thread keeps the `keep` best penalised candidates of its strided share, history membership through an LDS bitmap,
 // (3) `keep` rounds of a block arg-max merge them, (4) a few lanes do the bookkeeping on the `keep` survivors.
@@ -18,7 +22,8 @@
 
 namespace mxvl {
 
-constexpr int kBeamThreads = 512, kBeamWaves = kBeamThreads / 64, kMaxKeep = 8, kMaxBeams = 4, kMaxEos = 4, kMaxSurv = 256;   // 8 waves: 256 VGPRs each
+constexpr int kBeamThreads = 512, kBeamWaves = kBeamThreads / 64, kMaxKeep = 16, kMaxBeams = 8, kMaxEos = 4, kMaxSurv = 256;   // 8 waves: 256 VGPRs each
+// (num_beams 5 of launch_mambaclip_test_iu.sh:27 keeps 2 x 5 = 10 candidates)
 
 struct BeamArgs {
   int batch, nb, V, max_new, min_new, n_eos, early, keep, ablate;   // early: 1 = early_stopping True
@@ -32,6 +37,7 @@ struct BeamArgs {
   const float *len_tab, *hyp_tab;      // (max_new)
   long long *tok, *beam_src;           // (batch*nb)
   unsigned char* unfinished;           // scalar
+  unsigned int* ticket;                // optional: arrival word of a multi-workgroup launch (zero between launches)
 };
 
 __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
 #pragma unroll
   for (int e = 0; e < kMaxEos; ++e) eos32[e] = e < p.n_eos ? (int)p.eos[e] : -1;
 
-  for (int b = 0; b < p.batch; ++b) {
+  for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
     __syncthreads();
     const float* lg = p.logits + (size_t)b * nb * V;
     long long* rs = p.run_seq + (size_t)b * nb * max_new;
@@ -345,10 +351,22 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
   }
   __syncthreads();
   if (tid == 0) {
-    bool unf = s_any_open && !s_all_hits;
-    if (p.early == 1) unf = unf && !s_all_done;
-    *p.unfinished = unf ? 1 : 0;
-    *p.cur = cur + 1;
+    bool any_open = s_any_open != 0, all_hits = s_all_hits != 0, all_done = s_all_done != 0, last = true;
+    if (gridDim.x > 1) {
+      const unsigned int inc = 1u | (any_open ? 1u << 8 : 0u) | (all_hits ? 1u << 16 : 0u) | (all_done ? 1u << 24 : 0u);
+      const unsigned int tot = atomicAdd(p.ticket, inc) + inc;
+      last = (tot & 0xffu) == gridDim.x;
+      any_open = ((tot >> 8) & 0xffu) != 0;
+      all_hits = ((tot >> 16) & 0xffu) == gridDim.x;
+      all_done = ((tot >> 24) & 0xffu) == gridDim.x;
+      if (last) atomicExch(p.ticket, 0u);
+    }
+    if (last) {       // every workgroup read *cur at its start, before it arrived
+      bool unf = any_open && !all_hits;
+      if (p.early == 1) unf = unf && !all_done;
+      *p.unfinished = unf ? 1 : 0;
+      *p.cur = cur + 1;
+    }
   }
 }
 
@@ -373,9 +391,11 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   a.heur_open = (unsigned char*)d->heur_open; a.cur = (long long*)d->cur; a.eos = (const long long*)d->eos;
   a.len_tab = (const float*)d->len_tab; a.hyp_tab = (const float*)d->hyp_tab; a.tok = (long long*)d->tok;
   a.beam_src = (long long*)d->beam_src; a.unfinished = (unsigned char*)d->unfinished;
+  a.ticket = (unsigned int*)d->scratch;
+  const int grid = (a.ticket && d->batch > 1) ? (d->batch < 255 ? d->batch : 255) : 1;
   const size_t words = (size_t)(a.V + 31) / 32;
   const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
   if (lds > 60 * 1024) return MXVL_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(beam_step_kernel, dim3(1), dim3(kBeamThreads), lds, (hipStream_t)hip_stream, a);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(grid), dim3(kBeamThreads), lds, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

@@ -568,6 +568,8 @@ static int launch_gemv(const GemvArgs& a, hipStream_t s) {
   return MXVL_OK;
 }
 
+int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s);   // decode_gemm.hip: 9..80 rows on the matrix cores
+
 }  // namespace mxvl
 
 using namespace mxvl;
@@ -576,7 +578,8 @@ extern "C" {
 
 int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (!d || !d->x || !d->W || !d->y) return MXVL_ERR_NULL;
-  if (d->rows <= 0 || d->rows > kMaxRows || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
+  if (d->rows > kMaxRows) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
+  if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
   if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;

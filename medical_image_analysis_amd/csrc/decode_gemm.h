@@ -1,0 +1,217 @@
+// decode_gemm.h -- the decoder step's projections for 9..80 rows (batch x beams) on the matrix cores, gfx950 only.
+//
+// The reference decodes reports at val_batch_size 6 x beam 3 = 18 rows (CXPMRG_Bench_MambaXray_VL/launch/launch_mambaclip_chexpert.sh:23),
+// 8 x 3 = 24 (launch_mambaclip_test_cheXpert.sh:26) and 16 x 5 = 80 (launch_mambaclip_test_iu.sh:26-27) through
+// models/MambaXrayVL_DownStream.py:292-301 -> HF generate -> one cuBLAS GEMM per nn.Linear and token.  At those row counts a
+// projection is still a stream of its bf16 weight matrix (13.5 GB per token for Llama-2-7B) against 18..80 activation rows that
+// live in L2: HBM-bound, ~2 % of the MFMA rate.  So the kernel is shaped by the weight stream, not by the matrix cores:
+//
+//   y[m][n] = epi( sum_k W[n][k] * x[m][k] )        W (N, K) bf16 row-major (nn.Linear), x (rows, K) bf16, fp32 accumulate
+//
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand (16 output columns n x 32 k) and the activations as B
+//     (32 k x 16 rows m): the A fragment of lane l is 16 contiguous bytes of weight row n0 + l%16 at k0 + 8*(l/16) -- it is
+//     loaded from HBM straight into the MFMA's registers (non-temporal 16-byte loads, 16 rows x 64 contiguous bytes per
+//     instruction), never through LDS.  B fragments are the same pattern on the activation rows (L2 hits).
+//   * a workgroup owns R 16-column tiles over the WHOLE K; its NW waves split K, so the weight rows of a tile are read as NW
+//     contiguous segments, PF k-steps (PF x (R + MT) 16-byte loads per lane) in flight per wave, no barrier and no LDS in the loop.
+//     One LDS reduction over the NW partial tiles at the end, then the epilogue of mxvl_decode_gemv (bias, bf16 rounding before
+//     the residual add, SwiGLU across the gate / up tiles of one workgroup, fp32 logits).  No split-K across workgroups: a
+//     cross-workgroup seam costs 5-13 us (agent-scope fences) on kernels that run 7-40 us.
+//   * activation traffic from L2 per weight byte = MT / R (MT = 16-row activation tiles): R is chosen by the host from N.
+#pragma once
+#include "mxvl_common.h"
+
+namespace mxvl {
+
+typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dg_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int dg_u32x4 __attribute__((ext_vector_type(4)));
+
+struct DecodeGemmArgs {
+  int rows, K, N, swiglu, out_f32;
+  const uint16_t *x, *W, *W2, *bias, *res;
+  void* y;
+};
+
+__device__ inline float dg_bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ inline uint16_t dg_f2bf(float x) {
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// MT: 16-row activation tiles (rows <= 16 * MT), R: 16-column weight tiles per workgroup (with SwiGLU: R/2 gate tiles + the
+// R/2 up tiles of the same columns), NW: waves per workgroup (they split K), PF: k-steps in flight per wave.
+template <int MT, int R, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float dg_red[];   // [NW][TPR][MT][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N;
+  const int cols_per_wg = (p.swiglu ? R / 2 : R) * 16;
+  const int n0 = blockIdx.x * cols_per_wg;
+
+  // per-lane row bases (rows past the end re-read the last valid row: their results are never stored)
+  const uint16_t* wrow[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
+    const uint16_t* base = (p.swiglu && r >= R / 2) ? p.W2 : p.W;
+    int n = n0 + t * 16 + l16;
+    n = n < N ? n : N - 1;
+    wrow[r] = base + (size_t)n * K + q * 8;
+  }
+  const uint16_t* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = mt * 16 + l16;
+    m = m < p.rows ? m : p.rows - 1;
+    xrow[mt] = p.x + (size_t)m * K + q * 8;
+  }
+  // k-steps of 32 columns, dealt to the waves in contiguous runs
+  const int steps = (K + 31) >> 5;
+  const int spw = (steps + NW - 1) / NW;
+  const int s_begin = wave * spw;
+  const int s_end = s_begin + spw < steps ? s_begin + spw : steps;
+  const int iters = (spw + PF - 1) / PF;        // the same trip count for every wave
+
+  dg_u32x4 a[PF][R], b[PF][MT];
+  dg_f32x4 acc[R][MT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = dg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // every load is unconditional (an invalid step re-reads the row's first bytes and its weight fragment is zeroed before the
+  // MFMA): behind a per-lane or run-time-uniform branch hipcc's static s_waitcnt placement waits for a load where it is issued
+  auto issue = [&](int slot, int s) {
+    const bool ok = s < s_end && (s * 32 + q * 8) < K;
+    const int off = ok ? s * 32 : 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[slot][r] = __builtin_nontemporal_load((const dg_u32x4*)(wrow[r] + off));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[slot][mt] = *(const dg_u32x4*)(xrow[mt] + off);
+  };
+  auto consume = [&](int slot, int s) {
+    const bool ok = s < s_end && (s * 32 + q * 8) < K;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const dg_u32x4 av = ok ? a[slot][r] : dg_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dg_bf16x8, av), __builtin_bit_cast(dg_bf16x8, b[slot][mt]),
+                                                             acc[r][mt], 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    issue(j, s_begin + j);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int i = 0; i + 1 < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int s = s_begin + i * PF + j;
+      consume(j, s);
+      issue(j, s + PF);
+      __builtin_amdgcn_sched_barrier(0);      // keep the slots' requests in slot order: loads return in order, and hipcc otherwise
+    }                                         // clusters them by operand, which puts slot 0's activations behind every weight load
+  }
+#pragma unroll
+  for (int j = 0; j < PF; ++j) consume(j, s_begin + (iters - 1) * PF + j);
+
+  // ---- reduction over the K split + epilogue, one round per output tile (SwiGLU: per gate / up tile pair) ------------------------
+  constexpr int TPR = 2;                                   // tiles per round (the second one only with SwiGLU)
+  const int rounds = p.swiglu ? R / 2 : R;
+  for (int rd = 0; rd < rounds; ++rd) {
+    if (rd) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ts = p.swiglu ? (r >= R / 2 ? 1 : 0) : 0;
+      const int tr = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
+      if (tr == rd) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *(dg_f32x4*)(dg_red + ((size_t)((wave * TPR + ts) * MT + mt) * 64 + lane) * 4) = acc[r][mt];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * 256; e += NW * 64) {
+      const int m = e >> 4, nl = e & 15;
+      const int n = n0 + rd * 16 + nl;
+      if (m >= p.rows || n >= N) continue;
+      const int mt = m >> 4, src_lane = (m & 15) + 16 * (nl >> 2), v = nl & 3;
+      float s0 = 0.0f, s1 = 0.0f;
+      const float* part = dg_red + ((size_t)mt * 64 + src_lane) * 4 + v;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s0 += part[(size_t)(w * TPR) * MT * 256];
+      if (p.swiglu) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s1 += part[(size_t)(w * TPR + 1) * MT * 256];
+      }
+      const size_t o = (size_t)m * N + n;
+      if (p.swiglu) {   // bf16(bf16(silu(gate)) * up), gate / up rounded to bf16 first (what the torch modules do)
+        const float gte = dg_bf2f(dg_f2bf(s0)), up = dg_bf2f(dg_f2bf(s1));
+        ((uint16_t*)p.y)[o] = dg_f2bf(dg_bf2f(dg_f2bf(gte * sigmoid(gte))) * up);
+      } else {
+        float val = s0;
+        if (p.bias) val += dg_bf2f(p.bias[n]);
+        if (p.res) val = dg_bf2f(dg_f2bf(val)) + dg_bf2f(p.res[o]);   // the linear output rounds to bf16 before the residual add
+        if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = dg_f2bf(val);
+      }
+    }
+  }
+}
+
+// RMSNorm of the activation rows ahead of a projection (Qwen2RMSNorm / LlamaRMSNorm, EMRRG/models/hybrid_decoder_layer.py:185-199):
+// y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * g ), statistics in fp32.  One workgroup per row.  (At <= 8 rows the GEMV kernel
+// does this in its prologue, redundantly per workgroup; at 18..80 rows that redundancy would cost more than the weight stream.)
+struct RmsNormArgs {
+  int rows, K;
+  float eps;
+  const uint16_t *x, *g;
+  uint16_t* y;
+};
+__global__ __launch_bounds__(256) void decode_rmsnorm_kernel(const RmsNormArgs p) {
+  __shared__ float s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
+  const uint16_t* x = p.x + (size_t)m * p.K;
+  constexpr int MAXV = 8;                       // 8 x 256 x 8 columns: K <= 16384
+  uint4 xr[MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int k = (i * 256 + tid) * 8;
+    xr[i] = k < p.K ? *(const uint4*)(x + k) : make_uint4(0, 0, 0, 0);
+    const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = dg_bf2f((uint16_t)w[j]), b = dg_bf2f((uint16_t)(w[j] >> 16));
+      s = fmaf(a, a, fmaf(b, b, s));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) s_part[wave] = s;
+  __syncthreads();
+  const float tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  const float rstd = rsqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int k = (i * 256 + tid) * 8;
+    if (k < p.K) {
+      const uint4 gv = *(const uint4*)(p.g + k);
+      const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = dg_bf2f(dg_f2bf(dg_bf2f((uint16_t)w[j]) * rstd)) * dg_bf2f((uint16_t)gw[j]);
+        const float b = dg_bf2f(dg_f2bf(dg_bf2f((uint16_t)(w[j] >> 16)) * rstd)) * dg_bf2f((uint16_t)(gw[j] >> 16));
+        o[j] = (uint32_t)dg_f2bf(a) | ((uint32_t)dg_f2bf(b) << 16);
+      }
+      *(uint4*)(p.y + (size_t)m * p.K + k) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+}  // namespace mxvl

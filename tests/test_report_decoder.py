@@ -457,6 +457,79 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("K,N,mode", [(4096, 4096, "plain"), (4096, 12288, "bias"), (4096, 11008, "swiglu"),
+                                      (11008, 4096, "residual"), (4096, 32000, "f32"), (1408, 520, "residual"),
+                                      (512, 2056, "f32"), (72, 24, "swiglu"), (64, 16, "bias")])
+@pytest.mark.parametrize("rows", [18, 9, 16, 24, 33, 48, 80])
+def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows):
+    """mxvl_decode_gemv at the row counts the reference's launch scripts decode with (val 6 x beam 3 = 18, test 8 x 3 = 24,
+    config default 16 x 3 = 48, IU test 16 x beam 5 = 80): decode_gemm_kernel (csrc/decode_gemm.h, 16x16x32 MFMA, weight tile
+    loaded from HBM into the A operand, K split over the waves of a workgroup).  Every epilogue the stepper uses, Llama-2-7B
+    matrix shapes plus ragged ones (N not a multiple of 16, K not a multiple of 32 x waves).  Reference: fp32 torch on the
+    same bf16 inputs with the modules' bf16 rounding points."""
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    lib = _abi.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(K * 7 + N + rows)
+    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(torch.bfloat16).to(dev)
+    x, W = bf(rows, K), bf(N, K, sc=K ** -0.5)
+    W2 = bf(N, K, sc=K ** -0.5) if "swiglu" in mode else None
+    bias = bf(N, sc=0.5) if "bias" in mode else None
+    res = bf(rows, N) if "residual" in mode else None
+    f32 = "f32" in mode
+    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    d = _abi.GemvDesc()
+    d.rows, d.K, d.N = rows, K, N
+    d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(f32), 0.0
+    d.x, d.norm_weight, d.W = x.data_ptr(), None, W.data_ptr()
+    d.W2, d.bias, d.residual, d.y = _abi.ptr(W2), _abi.ptr(bias), _abi.ptr(res), y.data_ptr()
+    _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv")
+    torch.cuda.synchronize()
+    xf = x.float()
+    r16 = lambda t: t.to(torch.bfloat16).float()
+    ref = xf @ W.float().t()
+    if W2 is not None:
+        ref = r16(torch.nn.functional.silu(r16(ref))) * r16(xf @ W2.float().t())
+    if bias is not None:
+        ref = ref + bias.float()
+    if res is not None:
+        ref = r16(ref) + res.float()
+    scale = float(ref.abs().max())
+    tol = (3e-5 if f32 else 1e-3) * scale
+    assert_close(y.float(), ref, tol, 1e-5 if f32 else 2.0 ** -7, f"gemm K={K} N={N} rows={rows} {mode}")
+    # a norm prologue is the GEMV kernel's (rows <= 8): refused here, never silently skipped
+    d.norm_weight = x.data_ptr()
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(18, 4096), (80, 4096), (3, 11008), (24, 512), (9, 72), (1, 16384)])
+def test_decode_rmsnorm_kernel_matches_module_rounding(rows, K):
+    """mxvl_decode_rmsnorm == Qwen2RMSNorm (hybrid_decoder_layer.py:185-199) bit for bit up to the order of the fp32 sum:
+    fp32 statistics, bf16(x * rstd), times the bf16 gain, bf16."""
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd.hybrid_decoder_layer import Qwen2RMSNorm
+    lib = _abi.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(rows * 31 + K)
+    x = (2.0 * torch.randn(rows, K, generator=g)).to(torch.bfloat16).to(dev)
+    mod = Qwen2RMSNorm(K, eps=1e-6).to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        mod.weight.copy_((1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16))
+    y = torch.empty_like(x)
+    d = _abi.RmsNormDesc()
+    d.rows, d.K, d.eps = rows, K, 1e-6
+    d.x, d.weight, d.y = x.data_ptr(), mod.weight.data_ptr(), y.data_ptr()
+    _abi.check(lib.mxvl_decode_rmsnorm(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_rmsnorm")
+    ref = mod(x)
+    diff = (y.float() - ref.float()).abs()
+    # a different summation order can move rstd by an fp32 ulp, which flips at most isolated bf16 roundings
+    assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= 2.0 ** -7 * float(ref.float().abs().max()), float(diff.max())
+
+
+@pytest.mark.gpu
 def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning():
     """A captured decode graph holds weight addresses and the unconditioned layer structure: after the parameters move
     (.to() re-creates their storage) generate() must capture anew -- and still give the same tokens --, and a
