@@ -515,35 +515,39 @@ struct PrologueArgs {
   float *cosv, *sinv;
   int64_t* pos;
 };
-__global__ __launch_bounds__(1024) void decode_prologue_kernel(const PrologueArgs p) {
-  const int tid = threadIdx.x;
+// Workgroup b of G owns the slot-table columns t = b * 256 + tid (+ G * 256 ...): a column is read for every parent row, then
+// written, so the in-place re-ordering needs no second table and no cross-workgroup order.  MAXR bounds the per-thread column
+// (registers): 8 for the GEMV row counts, 32 / 80 for the batched ones (6 x 3 ... 16 x 5 rows).
+template <int MAXR>
+__global__ __launch_bounds__(256) void decode_prologue_kernel(const PrologueArgs p) {
+  __shared__ int s_parent[MAXR];
+  const int tid = threadIdx.x, gtid = blockIdx.x * 256 + tid, gsz = gridDim.x * 256;
   const int64_t cur = *p.cur;
   const int pos = (int)(cur + p.prompt_len - 1), step = (int)(cur - 1);
-  int parent[kMaxRows];
+  if (tid < MAXR) s_parent[tid] = tid < p.rows ? (int)p.beam[tid] : 0;
+  __syncthreads();
+  for (int t = gtid; t < p.max_len; t += gsz) {
+    int v[MAXR];
 #pragma unroll
-  for (int r = 0; r < kMaxRows; ++r) parent[r] = r < p.rows ? (int)p.beam[r] : 0;
-  for (int t = tid; t < p.max_len; t += 1024) {
-    int v[kMaxRows];
+    for (int r = 0; r < MAXR; ++r) v[r] = r < p.rows ? p.slot[(size_t)s_parent[r] * p.max_len + t] : 0;
 #pragma unroll
-    for (int r = 0; r < kMaxRows; ++r) v[r] = r < p.rows ? p.slot[(size_t)parent[r] * p.max_len + t] : 0;
-#pragma unroll
-    for (int r = 0; r < kMaxRows; ++r)
+    for (int r = 0; r < MAXR; ++r)
       if (r < p.rows) p.slot[(size_t)r * p.max_len + t] = t == pos ? r : v[r];
   }
-  if (tid < p.rows && pos < p.max_len) p.mask[(size_t)tid * p.max_len + pos] = 1;
+  if (gtid < p.rows && pos < p.max_len) p.mask[(size_t)gtid * p.max_len + pos] = 1;
   const int per_row = p.hidden / 8;
-  for (int i = tid; i < p.rows * per_row; i += 1024) {
+  for (int i = gtid; i < p.rows * per_row; i += gsz) {
     const int r = i / per_row, c = (i - r * per_row) * 8;
     *(uint4*)(p.x + (size_t)r * p.hidden + c) = *(const uint4*)(p.embed + (size_t)p.tok[r] * p.hidden + c);
   }
-  for (int i = tid; i < p.rows * p.D; i += 1024) {
+  for (int i = gtid; i < p.rows * p.D; i += gsz) {
     const int r = i / p.D, d = i - r * p.D;
     int64_t q = p.n_real[r] + step;
     q = q < 0 ? 0 : (q >= p.table_len ? p.table_len - 1 : q);
     p.cosv[i] = p.cos_t[(size_t)q * p.D + d];
     p.sinv[i] = p.sin_t[(size_t)q * p.D + d];
   }
-  if (tid == 0) *p.pos = pos;
+  if (gtid == 0) *p.pos = pos;
 }
 
 static int dec_check() {
@@ -632,7 +636,7 @@ int mxvl_decode_prologue(const mxvl_decode_prologue_desc* d, void* hip_stream) {
   if (!d || !d->tok || !d->beam_src || !d->cur || !d->n_real || !d->embed || !d->cos_table || !d->sin_table || !d->slot_table ||
       !d->mask || !d->x || !d->cos || !d->sin || !d->pos)
     return MXVL_ERR_NULL;
-  if (d->rows <= 0 || d->rows > kMaxRows || d->hidden <= 0 || d->hidden % 8 || d->max_len <= 0 || d->head_dim <= 0 || d->table_len <= 0)
+  if (d->rows <= 0 || d->rows > 80 || d->hidden <= 0 || d->hidden % 8 || d->max_len <= 0 || d->head_dim <= 0 || d->table_len <= 0)
     return MXVL_ERR_SHAPE;
   PrologueArgs a;
   a.rows = d->rows; a.hidden = d->hidden; a.max_len = d->max_len; a.D = d->head_dim; a.prompt_len = d->prompt_len; a.table_len = d->table_len;
@@ -640,7 +644,13 @@ int mxvl_decode_prologue(const mxvl_decode_prologue_desc* d, void* hip_stream) {
   a.embed = (const uint16_t*)d->embed; a.cos_t = (const float*)d->cos_table; a.sin_t = (const float*)d->sin_table;
   a.slot = (int*)d->slot_table; a.mask = (int64_t*)d->mask; a.x = (uint16_t*)d->x; a.cosv = (float*)d->cos; a.sinv = (float*)d->sin;
   a.pos = (int64_t*)d->pos;
-  hipLaunchKernelGGL(decode_prologue_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, a);
+  hipStream_t s = (hipStream_t)hip_stream;
+  // enough workgroups that the embedding rows (rows x hidden x 2 bytes) and the table columns are one trip per thread
+  const int work = std::max(a.rows * a.hidden / 8, a.max_len);
+  const dim3 grid(std::max(1, std::min(64, (work + 255) / 256)));
+  if (a.rows <= 8) hipLaunchKernelGGL(decode_prologue_kernel<8>, grid, dim3(256), 0, s, a);
+  else if (a.rows <= 32) hipLaunchKernelGGL(decode_prologue_kernel<32>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(decode_prologue_kernel<80>, grid, dim3(256), 0, s, a);
   return dec_check();
 }
 

@@ -209,6 +209,7 @@ class _BeamState:
         self.tok = torch.zeros(B * nb, dtype=torch.long, device=dev)
         self.beam_src = torch.zeros(B * nb, dtype=torch.long, device=dev)
         self.unfinished = torch.ones((), dtype=torch.bool, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # arrival word of the multi-workgroup beam kernel
         self.reset()
 
     def reset(self):
@@ -225,7 +226,7 @@ class _BeamState:
     def _hip_supported(self, logits):
         words = (self.V + 31) // 32
         lds = 4 * ((self.nb * words + 1) & ~1) + 16 * self.nb * self.max_new
-        return (logits.is_cuda and self.nb <= 4 and self.keep <= 8 and self.eos_t.numel() <= 4 and lds <= 60 * 1024 and logits.dtype == torch.float32
+        return (logits.is_cuda and self.nb <= 8 and self.keep <= 16 and self.eos_t.numel() <= 4 and lds <= 60 * 1024 and logits.dtype == torch.float32
                 and logits.is_contiguous())
 
     def _advance_hip(self, logits):
@@ -241,6 +242,7 @@ class _BeamState:
         d.heur_open, d.cur, d.eos = self.heur_open.data_ptr(), self.cur.data_ptr(), _abi.ptr(self.eos_t if self.eos_t.numel() else None)
         d.len_tab, d.hyp_tab = self.len_tab.data_ptr(), self.hyp_tab.data_ptr()
         d.tok, d.beam_src, d.unfinished = self.tok.data_ptr(), self.beam_src.data_ptr(), self.unfinished.data_ptr()
+        d.scratch = self.ticket.data_ptr() if self.B > 1 else None        # one workgroup per sample
         with torch.cuda.device(logits.device):
             _abi.check(lib.mxvl_beam_step(ctypes.byref(d), _abi.stream_ptr(logits.device)), "mxvl_beam_step")
 
@@ -351,9 +353,12 @@ class _KernelStepper(_SearchFusion):
             # there (as the reference does, hybrid_decoder_layer.py:631-640) -- the kernel path must not decode without the gate
             if "warmup" in at.gating_type and not hasattr(at, "cross_attn_warm_up_gate"):
                 return False
-        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and rows <= 8 and D in (64, 128, 256)
-                and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0
-                and rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024)
+        # rows <= 8: GEMV kernels with the activations of all rows in LDS; 9..80 rows (the reference's decode batches: 6 x 3,
+        # 8 x 3, 16 x 3, 16 x 5 -- launch/*.sh, configs/config.py:11-12,50): MFMA projections (csrc/decode_gemm.h)
+        fits = rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024 if rows <= 8 else \
+            (rows <= 80 and min(cfg.hidden_size, cfg.intermediate_size) >= 32 and cfg.hidden_size <= 16384)
+        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and D in (64, 128, 256)
+                and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and fits)
 
     def __init__(self, model, rows, prompt_mask, dyn_cache, max_new, dtype):
         import ctypes
@@ -375,6 +380,7 @@ class _KernelStepper(_SearchFusion):
         self.vc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
         self.x = torch.zeros(rows, self.hidden, **bf)
         self.x2 = torch.zeros(rows, self.hidden, **bf)
+        self.xn = torch.zeros(rows, self.hidden, **bf) if rows > 8 else None      # RMSNorm output ahead of an MFMA projection
         self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
         self.att = torch.zeros(rows, self.H * self.D, **bf)
         self.att2 = torch.zeros(rows, self.H * self.D, **bf)      # self-attention output + gated image context
@@ -456,6 +462,12 @@ class _KernelStepper(_SearchFusion):
         self._abi.check(self.lib.mxvl_decode_cross_attn(self._ct.byref(d), sp), "mxvl_decode_cross_attn")
 
     def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False):
+        if norm is not None and self.rows > 8:       # the GEMV kernel normalises in its prologue; the MFMA kernel takes normalised rows
+            n = self._abi.RmsNormDesc()
+            n.rows, n.K, n.eps = self.rows, K, eps
+            n.x, n.weight, n.y = x.data_ptr(), norm.data_ptr(), self.xn.data_ptr()
+            self._abi.check(self.lib.mxvl_decode_rmsnorm(self._ct.byref(n), self._abi.stream_ptr(x.device)), "mxvl_decode_rmsnorm")
+            x, norm = self.xn, None
         d = self._abi.GemvDesc()
         d.rows, d.K, d.N = self.rows, K, N
         d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), eps
@@ -673,8 +685,17 @@ class ReportDecoder(nn.Module):
                    _KernelStepper.cond_signature(self))
             stepper = getattr(self, "_steppers", {}).get(key)
             if stepper is None:
-                cls = _KernelStepper if (use_graph != "torch" and _KernelStepper.supported(
-                    self, B * nb, inputs_embeds.dtype, dev)) else _GraphStepper
+                cls = _GraphStepper
+                if use_graph != "torch":
+                    # ONE decode path on a HIP device: the kernels, or an error naming what they cannot serve -- the torch-module
+                    # stepper is an explicit request (use_graph="torch": CPU-parity experiments), never a silent substitute
+                    if not _KernelStepper.supported(self, B * nb, inputs_embeds.dtype, dev):
+                        raise RuntimeError(
+                            f"report decoding on {dev}: the HIP decode kernels serve bf16 models with head_dim 64/128/256 and "
+                            f"batch * beams <= 80 (got rows={B * nb}, dtype={inputs_embeds.dtype}, head_dim="
+                            f"{self.config.hidden_size // self.config.num_attention_heads}); pass use_graph=\"torch\" for the "
+                            f"torch-module stepper or use_graph=False for the eager loop")
+                    cls = _KernelStepper
                 stepper = cls(self, B * nb, attention_mask, cache, max_new_tokens, inputs_embeds.dtype)
                 self.__dict__.setdefault("_steppers", {})[key] = stepper
             else:

@@ -832,6 +832,102 @@ def gen_decode_keyed(name):
          **{"cfg_" + k: np.array(v) for k, v in shape.items()})
 
 
+def gen_decode_batched():
+    """The row counts the reference's launch scripts decode at, HF-exact: batch 6 x beam 3 = 18 rows
+    (launch/launch_mambaclip_chexpert.sh:23, launch_mambaclip_mimic.sh:25) and batch 16 x beam 5 = 80 rows
+    (launch_mambaclip_test_iu.sh:26-27), plus greedy at 16 rows, on the decode_llama_hd128 configuration with RAGGED prompts
+    (left padding, as HF batches them: MambaXrayVL_DownStream.py:268-301).  Beam search is independent per sample, so the
+    robustness search runs per prompt (HF fp32 == HF bf16 == this package's bf16 CPU path == HF under injected logit noise, for
+    greedy, beam 3 and beam 5) and the batches are assembled from 16 robust prompts; the batched HF runs are the goldens and
+    must reproduce the per-prompt streams."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import LlamaConfig, LlamaForCausalLM, LogitsProcessor, LogitsProcessorList
+    from keyed_fill import keyed_fill_llama_
+    shape = DECODE_KEYED["decode_llama_hd128"]
+    hid = shape["hidden_size"]
+
+    class Noise(LogitsProcessor):
+        def __init__(self, seed, amp):
+            self.g, self.amp = torch.Generator().manual_seed(seed), amp
+
+        def __call__(self, input_ids, scores):
+            return scores + self.amp * torch.randn(scores.shape, generator=self.g)
+
+    cfg = LlamaConfig(max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                      attention_bias=False, tie_word_embeddings=False, **shape)
+    P, NEW = 9, 16
+    kws = {"greedy": dict(num_beams=1, min_new_tokens=4, max_new_tokens=NEW),
+           "beam3": dict(num_beams=3, min_new_tokens=6, max_new_tokens=NEW),
+           "beam5": dict(num_beams=5, min_new_tokens=6, max_new_tokens=NEW)}
+    weight_seed = 1
+    m = keyed_fill_llama_(LlamaForCausalLM(cfg).eval(), weight_seed)
+    mb = LlamaForCausalLM(cfg).eval()
+    mb.load_state_dict(m.state_dict())
+    mb = mb.to(torch.bfloat16)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    rd = ReportDecoder(rms_norm_eps=1e-6, max_position_embeddings=128, **shape)
+    keyed_fill_llama_(rd, weight_seed)
+    rd = rd.to(torch.bfloat16).eval()
+    eq = lambda x, y: x.shape == y.shape and torch.equal(x, y)
+    gen = dict(do_sample=False, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+    embs, lens, single = [], [], []
+    seed = 0
+    while len(embs) < 16:
+        seed += 1
+        g = torch.Generator().manual_seed(7000 + seed)
+        n_real = 4 + (seed * 5) % 6                      # 4 .. 9 real tokens, left-padded to P
+        emb = torch.zeros(1, P, hid)
+        emb[0, P - n_real:] = (0.5 * torch.randn(n_real, hid, generator=g)).to(torch.bfloat16).float()
+        att = torch.zeros(1, P, dtype=torch.long)
+        att[0, P - n_real:] = 1
+        common = dict(inputs_embeds=emb, attention_mask=att, **gen)
+        ok, outs = True, {}
+        with torch.no_grad():
+            gr = m.generate(output_logits=True, return_dict_in_generate=True, **kws["greedy"], **common)
+            sl = torch.stack(gr.logits, dim=1)
+            scale = float(sl.abs().max())
+            top2 = sl.topk(2, dim=-1).values
+            if float((top2[..., 0] - top2[..., 1]).min()) <= 0.012 * scale:
+                continue
+            outs["greedy"] = gr.sequences
+            for name in ("beam3", "beam5"):
+                outs[name] = m.generate(**kws[name], **common)
+            cb = dict(common, inputs_embeds=emb.to(torch.bfloat16))
+            kw = dict(attention_mask=att, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+            for name in kws:
+                ok = ok and eq(outs[name], mb.generate(**kws[name], **cb)) and eq(outs[name], rd.generate(emb.to(torch.bfloat16), **kws[name], **kw))
+                for t in range(3):
+                    if not ok:
+                        break
+                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.0024 * scale)])
+                    ok = eq(m.generate(logits_processor=lp, **kws[name], **common), outs[name])
+        print(f"decode_batched prompt seed {seed} ({n_real} real tokens): robust={ok}")
+        if ok:
+            embs.append(emb)
+            lens.append(n_real)
+            single.append(outs)
+    emb = torch.cat(embs)
+    att = (torch.arange(P)[None, :] >= (P - torch.tensor(lens))[:, None]).long()
+    out = {}
+    with torch.no_grad():
+        for name, nb, B in (("greedy_b16", "greedy", 16), ("beam3_b6", "beam3", 6), ("beam5_b16", "beam5", 16), ("beam3_b16", "beam3", 16)):
+            seqs = m.generate(inputs_embeds=emb[:B], attention_mask=att[:B], **gen, **kws[nb])
+            for i in range(B):                    # the batch reproduces every prompt's own stream (up to the batch's padding)
+                one = single[i][nb][0]
+                assert torch.equal(seqs[i, :one.numel()], one) and bool((seqs[i, one.numel():] == 0).all() | (seqs[i, one.numel():] == 2).all()), (name, i)
+            assert eq(seqs, mb.generate(inputs_embeds=emb[:B].to(torch.bfloat16), attention_mask=att[:B], **gen, **kws[nb])), name
+            assert eq(seqs, rd.generate(emb[:B].to(torch.bfloat16), attention_mask=att[:B], repetition_penalty=2.0, length_penalty=2.0,
+                                        pad_token_id=0, eos_token_id=2, **kws[nb])), name
+            out[name] = seqs.numpy().copy()
+            print(name, seqs.tolist())
+    save("decode_llama_hd128_batched", weight_seed=np.array(weight_seed), inputs_embeds_bf16=emb.to(torch.bfloat16).view(torch.int16).numpy().copy(),
+         attention_mask=att.numpy().copy(), max_new_tokens=np.array(NEW),
+         weight_checksum=np_(sum(v.double().abs().sum() for v in m.state_dict().values()).float()),
+         **{"cfg_" + k: np.array(v) for k, v in shape.items()}, **out)
+
+
 def gen_vmamba(scan_ref):
     """VMamba / SS2D (R2GenCSR/VMamba/classification/models/vmamba.py) on CPU.  The vendored CUDA extension
     `selective_scan_cuda_oflex` is replaced by a stub that evaluates the reference's own selective_scan_ref (forward)
@@ -1131,7 +1227,9 @@ def gen_qformer():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "qformer":
+    if len(sys.argv) > 1 and sys.argv[1] == "decode_batched":
+        gen_decode_batched()
+    elif len(sys.argv) > 1 and sys.argv[1] == "qformer":
         gen_qformer()
     elif len(sys.argv) > 1 and sys.argv[1] == "text":
         gen_clean_report()

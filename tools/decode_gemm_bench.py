@@ -1,6 +1,7 @@
 """Per-kernel timing of the 9..80-row decoder projections (csrc/decode_gemm.h) at Llama-2-7B shapes, next to the library
 GEMM torch would run for the same nn.Linear.  GPU only.   python tools/decode_gemm_bench.py [rows ...]"""
-import ctypes, sys, torch
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medical_image_analysis_amd import _abi
 
 lib = _abi.load()
