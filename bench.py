@@ -111,6 +111,15 @@ DECODE_WORKLOADS = {
     "decode_llama7b_128": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 1,
                            "configs[3]: report generation with a Llama-2-7B-shaped decoder (random-init bf16 weights), 230-embedding "
                            "prompt [bos, prompt, 197 image tokens, prompt], beam 3, 128 new tokens (min = max = 128), repetition/length penalty 2.0"),
+    # the batches the reference's launch scripts decode at (rows = batch x beams): validation 6 x 3 (launch_mambaclip_chexpert.sh:23,
+    # launch_mambaclip_mimic.sh:25), test 8 x 3 (launch_mambaclip_test_cheXpert.sh:26), IU test 16 x beam 5 (launch_mambaclip_test_iu.sh:26-27)
+    "decode_llama7b_b6x3": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 6,
+                            "configs[3] at the reference's validation batch: val_batch_size 6 x beam 3 = 18 rows per decoder step, Llama-2-7B-shaped "
+                            "decoder (random-init bf16), 230-embedding prompts, 128 new tokens (min = max = 128), repetition/length penalty 2.0"),
+    "decode_llama7b_b8x3": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 8,
+                            "configs[3] at the reference's test batch: test_batch_size 8 x beam 3 = 24 rows per decoder step, otherwise as decode_llama7b_b6x3"),
+    "decode_llama7b_b16x5": (32000, 4096, 11008, 32, 32, 32, 230, 128, 5, 16,
+                             "configs[3] at the reference's IU-Xray test batch: 16 x beam 5 = 80 rows per decoder step, otherwise as decode_llama7b_b6x3"),
 }
 DEFAULT_WORKLOAD = "arm_pretrain_large_1024"
 
@@ -222,7 +231,11 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
         "config": {"workload": f"{workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "decode step = 129 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": ("decode step = 129 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)"
+                                if B * beams <= 8 else
+                                "decode step = 129 decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + 65 decode_rmsnorm_kernel "
+                                "+ 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)"),
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}
 
 

@@ -180,6 +180,12 @@ typedef struct mxvl_gemv_desc {
   const void *bias;         /* (N) bf16, optional */
   const void *residual;     /* (rows, N) bf16, optional */
   void *y;                  /* (rows, N) bf16, or fp32 when out_f32 */
+  void *split_acc;          /* ABI v6, rows > 8 only, optional: (rows, N) fp32, ZERO on entry.  K is split over k_splits workgroups per
+                               column block and the partial sums are added here atomically; no epilogue runs (swiglu / bias /
+                               residual / out_f32 must be unset, y is ignored): mxvl_decode_rmsnorm folds the sums (acc).  For the
+                               projections with few columns (o_proj, down_proj: N = hidden) that cannot fill the chip otherwise */
+  int32_t k_splits;         /* 1..16 with split_acc */
+  int32_t reserved0;
 } mxvl_gemv_desc;
 
 /*
@@ -199,6 +205,10 @@ typedef struct mxvl_decode_attn_desc {
   void *out;                /* (rows, n_heads * head_dim) bf16 */
   void *q_rope;             /* ABI v3, optional: (rows, n_heads * head_dim) bf16, the rotated (unscaled) query -- the input of
                                mxvl_decode_cross_attn for hybrid layers conditioned on image tokens */
+  int32_t beams;            /* ABI v6: 0 / 1 = a workgroup per (head, row).  2..5 (rows % beams == 0; rows b * beams .. are the beams of
+                               sample b): a workgroup per (head, sample) -- cache positions on which the beams' slot-table entries agree
+                               (the prompt, the common generated prefix) are read once for all of them */
+  int32_t reserved0;
 } mxvl_decode_attn_desc;
 
 /*
@@ -259,9 +269,13 @@ typedef struct mxvl_decode_prologue_desc {
 typedef struct mxvl_rmsnorm_desc {
   int32_t rows, K;          /* K % 8 == 0, K <= 16384 */
   float eps;
-  const void *x;            /* (rows, K) bf16 */
+  const void *x;            /* (rows, K) bf16; ignored in fold mode */
   const void *weight;       /* (K) bf16 */
   void *y;                  /* (rows, K) bf16, may alias x */
+  void *acc;                /* optional, fold mode: (rows, K) fp32 sums of a split projection (mxvl_gemv_desc.split_acc).  The row
+                               normalised is  x_out = bf16(acc) + residual  (the modules' `residual + linear(...)`), acc is zeroed */
+  const void *residual;     /* (rows, K) bf16, with acc */
+  void *x_out;              /* (rows, K) bf16, with acc; may alias residual */
 } mxvl_rmsnorm_desc;
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);

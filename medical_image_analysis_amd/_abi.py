@@ -112,12 +112,13 @@ class GemvDesc(ctypes.Structure):
         ("rows", c_int32), ("K", c_int32), ("N", c_int32), ("swiglu", c_int32), ("out_f32", c_int32),
         ("eps", ctypes.c_float),
         ("x", c_void_p), ("norm_weight", c_void_p), ("W", c_void_p), ("W2", c_void_p), ("bias", c_void_p),
-        ("residual", c_void_p), ("y", c_void_p),
+        ("residual", c_void_p), ("y", c_void_p), ("split_acc", c_void_p), ("k_splits", c_int32), ("reserved0", c_int32),
     ]
 
 
 class RmsNormDesc(ctypes.Structure):
-    _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p)]
+    _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p),
+                ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p)]
 
 
 class DecodeAttnDesc(ctypes.Structure):
@@ -126,6 +127,7 @@ class DecodeAttnDesc(ctypes.Structure):
         ("scale", ctypes.c_float),
         ("qkv", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p),
         ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p), ("out", c_void_p), ("q_rope", c_void_p),
+        ("beams", c_int32), ("reserved0", c_int32),
     ]
 
 

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
   long long* old_run = (long long*)(smem_u + ((nb * words + 1) & ~1));   // [nb][max_new]
   long long* old_fin = old_run + nb * max_new;                     // [nb][max_new]
   const int cur = (int)*p.cur;
+  // a search that has already stopped stays stopped: the stepper enqueues token k + 1 before the host has read token k's flag
+  // (report_decoder._search_lookahead), and that speculative launch must leave the state as the last real one left it
+  if (*p.unfinished == 0) return;
   if (tid == 0) { s_any_open = 0; s_all_hits = 1; s_all_done = 1; }
   int eos32[kMaxEos];                  // the EOS ids live in registers: they are tested against every candidate
 #pragma unroll

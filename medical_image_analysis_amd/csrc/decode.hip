@@ -259,6 +259,7 @@ struct CrossAttnArgs {
   uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
+constexpr int kBeamAttnWaves = 16;   // the beams kernel: a workgroup reads nb rows' worth of cache -- twice the position groups per trip
 constexpr int kAttnWaves = 8;    // (16 waves x 8 positions per group -- one trip of cache loads for a 358-position report instead of
                                  //  three -- measured slower: 9.7 vs 8.9 us per launch, profiles/r03_decode_timeline.txt)
 
@@ -388,6 +389,193 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
       den = fmaf(w, gl[i], den);
     }
     p.out[(size_t)m * p.H * D + (size_t)h * D + tid] = f2bf(num / den);
+  }
+}
+
+// The same step for the nb beams of ONE sample in one workgroup (grid: head x sample).  Beams continue a common ancestor: the prompt
+// (whose slots the stepper points at one physical copy) and usually the first generated tokens name the SAME cache lines for every
+// beam -- 230 of ~300 positions at the reference's settings.  With a workgroup per (head, row) those lines were fetched nb times
+// (three workgroups asking for a line at the same moment are three fabric reads: measured, the shared slots alone bought nothing);
+// here positions [0, n_shared) -- the longest prefix on which all beams agree -- are loaded ONCE and folded into nb running
+// softmax states, the rest per beam as before.  18 rows x 32 heads x 300 positions: 88 MB -> 41 MB of cache reads per layer.
+template <int D, int NB, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnArgs p) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW, NT = NW * 64;
+  extern __shared__ float sm[];
+  const int T = p.max_len;
+  float* sq = sm;                      // [NB][D] rotated, scaled queries
+  float* sk = sq + NB * D;             // [NB][D] rotated new keys
+  float* sv = sk + NB * D;             // [NB][D] new values
+  float* wm = sv + NB * D;             // [NB][NW] per-wave maxima
+  float* wl = wm + NB * NW;            // [NB][NW] per-wave sums
+  float* wo = wl + NB * NW;            // [NB][NW][D] per-wave outputs
+  int* ssl = (int*)(wo + NB * NW * D); // [NB][T] slot of each position, -1 = masked
+  __shared__ int s_nsh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, m0 = blockIdx.y * NB;
+  const int group = p.H / p.Hkv, hk = h / group;
+  const int pos = (int)*p.pos;
+  if (tid == 0) s_nsh = pos;
+  __syncthreads();
+  for (int t = tid; t <= pos; t += NT) {
+    int64_t mk[NB];
+    int sl[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      mk[r] = p.mask[(size_t)(m0 + r) * T + t];
+      sl[r] = p.slot[(size_t)(m0 + r) * T + t];
+    }
+    bool same = true;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int v = mk[r] != 0 ? sl[r] : -1;
+      ssl[r * T + t] = v;
+      same = same && v == (mk[0] != 0 ? sl[0] : -1);
+    }
+    if (!same && t < pos) atomicMin(&s_nsh, t);
+  }
+  // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group
+  for (int i = tid; i < NB * D; i += NT) {
+    const int r = i / D, d = i - r * D, half = D / 2, m = m0 + r;
+    const int dp = d < half ? d + half : d - half;
+    const size_t row = (size_t)m * (p.H + 2 * p.Hkv) * D;
+    const uint16_t* q = p.qkv + row + (size_t)h * D;
+    const uint16_t* kn = p.qkv + row + (size_t)(p.H + hk) * D;
+    const uint16_t* vn = p.qkv + row + (size_t)(p.H + p.Hkv + hk) * D;
+    const uint16_t rq = q[d], rqo = q[dp], rk = kn[d], rko = kn[dp], rv = vn[d];
+    const float rc = p.cosv[(size_t)m * D + d], rs = p.sinv[(size_t)m * D + d];
+    const float c = bf2f(f2bf(rc)), sn = bf2f(f2bf(rs));
+    const float qd = bf2f(rq), qo = d < half ? -bf2f(rqo) : bf2f(rqo);
+    const float kd = bf2f(rk), ko = d < half ? -bf2f(rko) : bf2f(rko);
+    const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * sn))));
+    const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * sn))));
+    sq[i] = qr * p.scale;
+    if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
+    sk[i] = kr;
+    sv[i] = bf2f(rv);
+    if (h % group == 0) {
+      const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
+      p.kc[o] = f2bf(kr);
+      p.vc[o] = rv;
+    }
+  }
+  __syncthreads();
+  const int nsh = s_nsh;
+  const int sub = lane % LPR, g = wave * RPW + lane / LPR;
+  float qv[NB][8], mx[NB], l[NB], o[NB][8];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    mx[r] = -1e30f;
+    l[r] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qv[r][j] = sq[r * D + sub * 8 + j]; o[r][j] = 0.0f; }
+  }
+  auto fold = [&](int r, bool live, const float* kf, const float* vf) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s = fmaf(qv[r][j], kf[j], s);
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    const float mn = live ? fmaxf(mx[r], s) : mx[r];
+    const float corr = fast_exp(mx[r] - mn), pr = live ? fast_exp(s - mn) : 0.0f;
+    mx[r] = mn;
+    l[r] = fmaf(l[r], corr, pr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[r][j] = fmaf(o[r][j], corr, pr * vf[j]);
+  };
+  auto unpack = [](const uint4 v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = __builtin_bit_cast(float, w[j] << 16);
+      f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+    }
+  };
+  // ---- positions every beam shares: one load, nb folds ------------------------------------------------------------------------
+  constexpr int U = 4;
+  for (int t0 = g; t0 < nsh; t0 += NG * U) {
+    uint4 kq[U], vq[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG;
+      const int sl = t < nsh ? ssl[t] : -1;
+      live[u] = sl >= 0;
+      const size_t a = (((size_t)(live[u] ? sl : m0) * p.Hkv + hk) * T + (live[u] ? t : 0)) * D + sub * 8;   // unconditional loads
+      kq[u] = *(const uint4*)(p.kc + a);
+      vq[u] = *(const uint4*)(p.vc + a);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kf[8], vf[8];
+      unpack(kq[u], kf);
+      unpack(vq[u], vf);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) fold(r, live[u], kf, vf);
+    }
+  }
+  // ---- positions on which the beams differ: per beam -----------------------------------------------------------------------------
+  for (int t = nsh + g; t < pos; t += NG) {
+    uint4 kq[NB], vq[NB];
+    bool live[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int sl = ssl[r * T + t];
+      live[r] = sl >= 0;
+      const size_t a = (((size_t)(live[r] ? sl : m0) * p.Hkv + hk) * T + t) * D + sub * 8;
+      kq[r] = *(const uint4*)(p.kc + a);
+      vq[r] = *(const uint4*)(p.vc + a);
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      float kf[8], vf[8];
+      unpack(kq[r], kf);
+      unpack(vq[r], vf);
+      fold(r, live[r], kf, vf);
+    }
+  }
+  if (g == 0) {  // the fresh position of every beam
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      float kf[8], vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kf[j] = sk[r * D + sub * 8 + j]; vf[j] = sv[r * D + sub * 8 + j]; }
+      fold(r, ssl[r * T + pos] >= 0, kf, vf);
+    }
+  }
+  // ---- merge: the position groups of a wave by shuffles, the waves through LDS -------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      const float m2 = __shfl_xor(mx[r], off, 64), l2 = __shfl_xor(l[r], off, 64);
+      const float mn = fmaxf(mx[r], m2);
+      const float c1 = fast_exp(mx[r] - mn), c2 = fast_exp(m2 - mn);
+      l[r] = l[r] * c1 + l2 * c2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[r][j] = o[r][j] * c1 + __shfl_xor(o[r][j], off, 64) * c2;
+      mx[r] = mn;
+    }
+    if (lane < LPR) {
+      if (sub == 0) { wm[r * NW + wave] = mx[r]; wl[r * NW + wave] = l[r]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wo[(r * NW + wave) * D + sub * 8 + j] = o[r][j];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NB * D; i += NT) {
+    const int r = i / D, d = i - r * D;
+    float gmax = -1e30f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gmax = fmaxf(gmax, wm[r * NW + w]);
+    float num = 0.0f, den = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float c = fast_exp(wm[r * NW + w] - gmax);
+      num = fmaf(c, wo[(r * NW + w) * D + d], num);
+      den = fmaf(c, wl[r * NW + w], den);
+    }
+    p.out[(size_t)(m0 + r) * p.H * D + (size_t)h * D + d] = f2bf(num / den);
   }
 }
 
@@ -581,8 +769,9 @@ using namespace mxvl;
 extern "C" {
 
 int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
-  if (!d || !d->x || !d->W || !d->y) return MXVL_ERR_NULL;
+  if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
   if (d->rows > kMaxRows) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
+  if (d->split_acc) return MXVL_ERR_UNSUPPORTED;      // the GEMV kernel (rows <= 8) never splits K
   if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
   if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
@@ -618,11 +807,40 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
   a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
   a.q_rope = (uint16_t*)d->q_rope;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (d->beams > 1) {       // the beams of a sample share a workgroup (and every cache line they have in common)
+    if (d->beams > 5 || d->rows % d->beams != 0) return MXVL_ERR_UNSUPPORTED;
+    const int nb = d->beams;
+    const size_t lds = sizeof(float) * ((size_t)3 * nb * a.D + 2 * nb * kBeamAttnWaves + (size_t)nb * kBeamAttnWaves * a.D + (size_t)nb * a.max_len);
+    if (lds > 150 * 1024) return MXVL_ERR_UNSUPPORTED;
+    const dim3 grid(a.H, a.rows / nb), block(kBeamAttnWaves * 64);
+#define MXVL_ATTN_BEAMS(DD, NB)                                                                                                    \
+  do {                                                                                                                             \
+    auto kern = decode_attn_beams_kernel<DD, NB, kBeamAttnWaves>;                                                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return MXVL_ERR_LAUNCH;                                                                                                      \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                                                              \
+  } while (0)
+#define MXVL_ATTN_BEAMS_D(NB)                                                                                                      \
+  switch (a.D) {                                                                                                                   \
+    case 64: MXVL_ATTN_BEAMS(64, NB); break;                                                                                       \
+    case 128: MXVL_ATTN_BEAMS(128, NB); break;                                                                                     \
+    default: MXVL_ATTN_BEAMS(256, NB); break;                                                                                      \
+  }
+    switch (nb) {
+      case 2: MXVL_ATTN_BEAMS_D(2); break;
+      case 3: MXVL_ATTN_BEAMS_D(3); break;
+      case 4: MXVL_ATTN_BEAMS_D(4); break;
+      default: MXVL_ATTN_BEAMS_D(5); break;
+    }
+#undef MXVL_ATTN_BEAMS_D
+#undef MXVL_ATTN_BEAMS
+    return dec_check();
+  }
   const int NG = kAttnWaves * 64 / (a.D / 8);
   const size_t lds = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
   if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
   const dim3 grid(a.H, a.rows), block(kAttnWaves * 64);
-  hipStream_t s = (hipStream_t)hip_stream;
   switch (a.D) {
     case 64: hipLaunchKernelGGL(decode_attn_kernel<64>, grid, block, lds, s, a); break;
     case 128: hipLaunchKernelGGL(decode_attn_kernel<128>, grid, block, lds, s, a); break;

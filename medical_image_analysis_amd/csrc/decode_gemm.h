@@ -31,6 +31,7 @@ struct DecodeGemmArgs {
   int rows, K, N, swiglu, out_f32;
   const uint16_t *x, *W, *W2, *bias, *res;
   void* y;
+  float* split_acc;     // K split over gridDim.y workgroups: fp32 (rows, N) sums, added to atomically; the epilogue is the consumer's
 };
 
 __device__ inline float dg_bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
@@ -38,6 +39,56 @@ __device__ inline uint16_t dg_f2bf(float x) {
   uint32_t u = __builtin_bit_cast(uint32_t, x);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
+}
+
+// Reduction over the waves' K split + the epilogue of mxvl_decode_gemv, one round per output tile (SwiGLU: per gate / up pair).
+// acc[r][mt] is lane (col = l%16 -> activation row, 4 * (l/16) + v -> weight row) of the 16x16 tile (weight tile r, row tile mt).
+template <int MT, int R, int NW>
+__device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, const dg_f32x4 (&acc)[R][MT], float* dg_red, int n0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N;
+  constexpr int TPR = 2;                                   // tiles per round (the second one only with SwiGLU)
+  const int rounds = p.swiglu ? R / 2 : R;
+  for (int rd = 0; rd < rounds; ++rd) {
+    if (rd) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ts = p.swiglu ? (r >= R / 2 ? 1 : 0) : 0;
+      const int tr = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
+      if (tr == rd) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *(dg_f32x4*)(dg_red + ((size_t)((wave * TPR + ts) * MT + mt) * 64 + lane) * 4) = acc[r][mt];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < MT * 256; e += NW * 64) {
+      const int m = e >> 4, nl = e & 15;
+      const int n = n0 + rd * 16 + nl;
+      if (m >= p.rows || n >= N) continue;
+      const int mt = m >> 4, src_lane = (m & 15) + 16 * (nl >> 2), v = nl & 3;
+      float s0 = 0.0f, s1 = 0.0f;
+      const float* part = dg_red + ((size_t)mt * 64 + src_lane) * 4 + v;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s0 += part[(size_t)(w * TPR) * MT * 256];
+      if (p.swiglu) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s1 += part[(size_t)(w * TPR + 1) * MT * 256];
+      }
+      const size_t o = (size_t)m * N + n;
+      if (p.split_acc) {
+        atomicAdd(p.split_acc + o, s0);
+      } else if (p.swiglu) {   // bf16(bf16(silu(gate)) * up), gate / up rounded to bf16 first (what the torch modules do)
+        const float gte = dg_bf2f(dg_f2bf(s0)), up = dg_bf2f(dg_f2bf(s1));
+        ((uint16_t*)p.y)[o] = dg_f2bf(dg_bf2f(dg_f2bf(gte * sigmoid(gte))) * up);
+      } else {
+        float val = s0;
+        if (p.bias) val += dg_bf2f(p.bias[n]);
+        if (p.res) val = dg_bf2f(dg_f2bf(val)) + dg_bf2f(p.res[o]);   // the linear output rounds to bf16 before the residual add
+        if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = dg_f2bf(val);
+      }
+    }
+  }
 }
 
 // MT: 16-row activation tiles (rows <= 16 * MT), R: 16-column weight tiles per workgroup (with SwiGLU: R/2 gate tiles + the
@@ -70,8 +121,9 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmAr
   }
   // k-steps of 32 columns, dealt to the waves in contiguous runs
   const int steps = (K + 31) >> 5;
-  const int spw = (steps + NW - 1) / NW;
-  const int s_begin = wave * spw;
+  const int nsl = NW * gridDim.y;                  // K slices: the waves of the gridDim.y workgroups that share these columns
+  const int spw = (steps + nsl - 1) / nsl;
+  const int s_begin = (blockIdx.y * NW + wave) * spw;
   const int s_end = s_begin + spw < steps ? s_begin + spw : steps;
   const int iters = (spw + PF - 1) / PF;        // the same trip count for every wave
 
@@ -120,69 +172,189 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmAr
 #pragma unroll
   for (int j = 0; j < PF; ++j) consume(j, s_begin + (iters - 1) * PF + j);
 
-  // ---- reduction over the K split + epilogue, one round per output tile (SwiGLU: per gate / up tile pair) ------------------------
-  constexpr int TPR = 2;                                   // tiles per round (the second one only with SwiGLU)
-  const int rounds = p.swiglu ? R / 2 : R;
-  for (int rd = 0; rd < rounds; ++rd) {
-    if (rd) __syncthreads();
+  dg_reduce_epilogue<MT, R, NW>(p, acc, dg_red, n0);
+}
+
+// ---- K % 64 == 0: the weight stream through LDS-DMA -------------------------------------------------------------------------------
+// Same decomposition (a workgroup owns R tiles over its K slice, the waves split it, one reduction at the end), but the weight
+// tiles never touch a VGPR on their way in: a wave owns a ring of PF stages in LDS, a stage = R tiles x (16 rows x 128 bytes = 64
+// columns); one global_load_lds_dwordx4 covers 8 rows x 128 contiguous bytes (lane i: row i / 8, 16-byte unit i % 8, stored at
+// unit ^ key(row) so the ds_read_b128 fragment reads are conflict-free).  Measured on the weight stream alone
+// (tools/ubench/wstream_probe.hip, N = 32000): 6.0-6.3 TB/s against 5.5 for the 16 rows x 64 bytes of the direct loads, and the
+// registers the direct ring needed go to R = 4 tiles (activation re-reads per weight byte = MT / 4).
+// The activation fragments of a stage are requested right behind its DMA, ALSO from inline asm: vmcnt counts DMA and loads in
+// issue order, and hipcc -- which cannot see the DMA -- would wait for a compiler-visible fragment load with a count that drains
+// the whole ring.  So every vector-memory wait of the loop is the explicit one in front of a stage's first MFMA.
+__device__ __forceinline__ int dg_key(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+template <int N> __device__ __forceinline__ void dg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MT, int R, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dg_smem[];
+  constexpr int STAGE = R * 2048, OPS = 2 * R + 2 * MT;          // vector-memory operations per stage
+  static_assert((PF - 1) * OPS <= 63, "vmcnt is a 6-bit field");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N;
+  const int cols_per_wg = (p.swiglu ? R / 2 : R) * 16;
+  const int n0 = blockIdx.x * cols_per_wg;
+  char* ring = dg_smem + wave * PF * STAGE;
+
+  const char* src[R][2];                    // DMA sources: call h of tile r covers rows 8 h .. 8 h + 7
+  {
+    const int rl = lane >> 3, ul = lane & 7;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int ts = p.swiglu ? (r >= R / 2 ? 1 : 0) : 0;
-      const int tr = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
-      if (tr == rd) {
+      const int t = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
+      const uint16_t* base = (p.swiglu && r >= R / 2) ? p.W2 : p.W;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          *(dg_f32x4*)(dg_red + ((size_t)((wave * TPR + ts) * MT + mt) * 64 + lane) * 4) = acc[r][mt];
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < MT * 256; e += NW * 64) {
-      const int m = e >> 4, nl = e & 15;
-      const int n = n0 + rd * 16 + nl;
-      if (m >= p.rows || n >= N) continue;
-      const int mt = m >> 4, src_lane = (m & 15) + 16 * (nl >> 2), v = nl & 3;
-      float s0 = 0.0f, s1 = 0.0f;
-      const float* part = dg_red + ((size_t)mt * 64 + src_lane) * 4 + v;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) s0 += part[(size_t)(w * TPR) * MT * 256];
-      if (p.swiglu) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s1 += part[(size_t)(w * TPR + 1) * MT * 256];
-      }
-      const size_t o = (size_t)m * N + n;
-      if (p.swiglu) {   // bf16(bf16(silu(gate)) * up), gate / up rounded to bf16 first (what the torch modules do)
-        const float gte = dg_bf2f(dg_f2bf(s0)), up = dg_bf2f(dg_f2bf(s1));
-        ((uint16_t*)p.y)[o] = dg_f2bf(dg_bf2f(dg_f2bf(gte * sigmoid(gte))) * up);
-      } else {
-        float val = s0;
-        if (p.bias) val += dg_bf2f(p.bias[n]);
-        if (p.res) val = dg_bf2f(dg_f2bf(val)) + dg_bf2f(p.res[o]);   // the linear output rounds to bf16 before the residual add
-        if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = dg_f2bf(val);
+      for (int h = 0; h < 2; ++h) {
+        const int row = h * 8 + rl;
+        int n = n0 + t * 16 + row;
+        n = n < N ? n : N - 1;
+        src[r][h] = (const char*)(base + (size_t)n * K) + ((ul ^ dg_key(row)) << 4);
       }
     }
   }
+  const uint16_t* xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = mt * 16 + l16;
+    m = m < p.rows ? m : p.rows - 1;
+    xrow[mt] = p.x + (size_t)m * K + q * 8;
+  }
+  const int chunks = K >> 6;                       // 64 columns = 128 bytes of a weight row
+  const int nsl = NW * gridDim.y;
+  const int cpw = (chunks + nsl - 1) / nsl;
+  const int c_begin = (blockIdx.y * NW + wave) * cpw;
+  const int c_end = c_begin + cpw < chunks ? c_begin + cpw : chunks;
+  const int n_it = (cpw + PF - 1) / PF;            // the same trip count for every wave
+
+  dg_f32x4 acc[R][MT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = dg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  dg_u32x4 xb[PF][2][MT];
+
+  auto issue = [&](int slot, int c) {
+    const int cc = c < c_end ? c : 0;              // a chunk past the wave's run re-reads chunk 0; its activations are zeroed
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + slot * STAGE));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const char* g0 = src[r][0] + (size_t)cc * 128;
+      const char* g1 = src[r][1] + (size_t)cc * 128;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(dst + r * 2048), "v"(g0), "v"(g1) : "memory", "scc");
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[slot][ks][mt]) : "v"(xrow[mt] + cc * 64 + ks * 32) : "memory");
+  };
+  auto consume = [&](int slot, int c) {
+    // (the wait for this stage was issued by the caller: its count depends on how many younger stages are in flight)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        asm volatile("" : "+v"(xb[slot][ks][mt]));           // the fragments are defined HERE, behind the wait
+        if (c >= c_end) xb[slot][ks][mt] = dg_u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int unit = (ks * 4 + q) ^ dg_key(l16);
+        const dg_u32x4 av = *(const dg_u32x4*)(ring + slot * STAGE + r * 2048 + l16 * 128 + (unit << 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dg_bf16x8, av), __builtin_bit_cast(dg_bf16x8, xb[slot][ks][mt]),
+                                                               acc[r][mt], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's fragment reads have returned: it may be refilled
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j) issue(j, c_begin + j);
+  for (int i = 0; i + 1 < n_it; ++i) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int c = c_begin + i * PF + j;
+      dg_wait_vm<(PF - 1) * OPS>();
+      consume(j, c);
+      issue(j, c + PF);
+    }
+  }
+  {
+    const int c = c_begin + (n_it - 1) * PF;
+    if constexpr (PF >= 1) { dg_wait_vm<(PF - 1) * OPS>(); consume(0, c); }
+    if constexpr (PF >= 2) { dg_wait_vm<(PF - 2) * OPS>(); consume(1, c + 1); }
+    if constexpr (PF >= 3) { dg_wait_vm<(PF - 3) * OPS>(); consume(2, c + 2); }
+    if constexpr (PF >= 4) { dg_wait_vm<(PF - 4) * OPS>(); consume(3, c + 3); }
+    static_assert(PF <= 4, "tail is written out for PF <= 4");
+  }
+  __syncthreads();                                            // every wave is done with its ring: the reduction reuses the memory
+  dg_reduce_epilogue<MT, R, NW>(p, acc, (float*)dg_smem, n0);
 }
 
 // RMSNorm of the activation rows ahead of a projection (Qwen2RMSNorm / LlamaRMSNorm, EMRRG/models/hybrid_decoder_layer.py:185-199):
 // y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * g ), statistics in fp32.  One workgroup per row.  (At <= 8 rows the GEMV kernel
 // does this in its prologue, redundantly per workgroup; at 18..80 rows that redundancy would cost more than the weight stream.)
+// Fold mode (acc != NULL): the row is first completed from a K-split projection's fp32 sums -- x = bf16(acc) + residual, the two
+// roundings of `residual + linear(...)` in the modules -- written to x_out, and acc is cleared for the next projection.  That is the
+// epilogue of o_proj / down_proj (N = 4096: too few columns to fill 256 CUs without splitting K) in the kernel that has to follow
+// them anyway, instead of a cross-workgroup seam (agent-scope fences, 5-13 us) inside a 7-20 us projection.
 struct RmsNormArgs {
   int rows, K;
   float eps;
   const uint16_t *x, *g;
   uint16_t* y;
+  float* acc;
+  const uint16_t* res;
+  uint16_t* x_out;
 };
 __global__ __launch_bounds__(256) void decode_rmsnorm_kernel(const RmsNormArgs p) {
   __shared__ float s_part[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
   const uint16_t* x = p.x + (size_t)m * p.K;
   constexpr int MAXV = 8;                       // 8 x 256 x 8 columns: K <= 16384
-  uint4 xr[MAXV];
+  uint4 xr[MAXV], gr[MAXV];
   float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {              // the gain goes out with the row: one memory round trip for the kernel, not two
+    const int k = (i * 256 + tid) * 8;
+    gr[i] = *(const uint4*)(p.g + (k < p.K ? k : 0));
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int k = (i * 256 + tid) * 8;
-    xr[i] = k < p.K ? *(const uint4*)(x + k) : make_uint4(0, 0, 0, 0);
+    if (p.acc) {
+      xr[i] = make_uint4(0, 0, 0, 0);
+      if (k < p.K) {
+        float* ap = p.acc + (size_t)m * p.K + k;
+        const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
+        const uint4 rv = *(const uint4*)(p.res + (size_t)m * p.K + k);
+        *(float4*)ap = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(ap + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = dg_bf2f(dg_f2bf(av[2 * j])) + dg_bf2f((uint16_t)rw[j]);
+          const float hi = dg_bf2f(dg_f2bf(av[2 * j + 1])) + dg_bf2f((uint16_t)(rw[j] >> 16));
+          o[j] = (uint32_t)dg_f2bf(lo) | ((uint32_t)dg_f2bf(hi) << 16);
+        }
+        xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        *(uint4*)(p.x_out + (size_t)m * p.K + k) = xr[i];
+      }
+    } else {
+      xr[i] = k < p.K ? *(const uint4*)(x + k) : make_uint4(0, 0, 0, 0);
+    }
     const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -200,7 +372,7 @@ __global__ __launch_bounds__(256) void decode_rmsnorm_kernel(const RmsNormArgs p
   for (int i = 0; i < MAXV; ++i) {
     const int k = (i * 256 + tid) * 8;
     if (k < p.K) {
-      const uint4 gv = *(const uint4*)(p.g + k);
+      const uint4 gv = gr[i];
       const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
       uint32_t o[4];
 #pragma unroll

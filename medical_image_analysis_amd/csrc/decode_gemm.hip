@@ -5,30 +5,54 @@
 
 namespace mxvl {
 
-constexpr int kGemmWaves = 8;
-
-template <int MT, int R>
-static int launch_decode_gemm(const DecodeGemmArgs& a, hipStream_t s) {
-  constexpr int PF = (R + MT <= 4) ? 4 : ((R + MT <= 6) ? 3 : 2);
+// ---- launchers ----------------------------------------------------------------------------------------------------------------------
+// K % 64 == 0 (every real decoder: 4096 / 11008 / 3584 / 18944): LDS-DMA weight stream, 4 waves x R tiles, two workgroups per CU.
+template <int MT, int R, int NW, int PF>
+static int launch_dma(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   const int cols_per_wg = (a.swiglu ? R / 2 : R) * 16;
-  const int grid = (a.N + cols_per_wg - 1) / cols_per_wg;
-  const size_t lds = (size_t)kGemmWaves * 2 * MT * 64 * 4 * sizeof(float);
-  auto kern = decode_gemm_kernel<MT, R, kGemmWaves, PF>;
+  const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
+  const size_t ring = (size_t)NW * PF * R * 2048, red = (size_t)NW * 2 * MT * 1024;
+  const size_t lds = ring > red ? ring : red;
+  auto kern = decode_gemm_dma_kernel<MT, R, NW, PF>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return MXVL_ERR_LAUNCH;   // per call: the attribute is per device
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kGemmWaves * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+  return MXVL_OK;
+}
+
+// any K % 8 == 0: fragments loaded straight into the MFMA operands
+template <int MT, int R>
+static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
+  constexpr int NW = 8, PF = (R + MT <= 4) ? 4 : ((R + MT <= 6) ? 3 : 2);
+  const int cols_per_wg = (a.swiglu ? R / 2 : R) * 16;
+  const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
+  const size_t lds = (size_t)NW * 2 * MT * 1024;
+  auto kern = decode_gemm_kernel<MT, R, NW, PF>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return MXVL_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
   return MXVL_OK;
 }
 
 template <int MT>
-static int launch_decode_gemm_r(const DecodeGemmArgs& a, hipStream_t s) {
+static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   // R = weight tiles per workgroup: the activation re-read from L2 per weight byte is MT / R, the number of workgroups
-  // N / (16 R): keep at least ~1.5 workgroups per CU (256 CUs), then take the widest R
+  // N / (16 R) x splits -- keep the 256 CUs covered, then take the widest R
   const int tiles = (a.N + 15) / 16;
-  if (a.swiglu) return tiles >= 768 ? launch_decode_gemm<MT, 4>(a, s) : launch_decode_gemm<MT, 2>(a, s);
-  if (tiles >= 1536) return launch_decode_gemm<MT, 4>(a, s);
-  if (tiles >= 512) return launch_decode_gemm<MT, 2>(a, s);
-  return launch_decode_gemm<MT, 1>(a, s);
+  const long wgs4 = (long)(a.swiglu ? (tiles + 1) / 2 : (tiles + 3) / 4) * splits;
+  if (a.K % 64 == 0 && a.K >= 256) {
+    constexpr int PFN = MT <= 2 ? 4 : 2;       // narrow workgroups: deeper rings while the activation fragments fit the registers
+    if (wgs4 >= 256) return launch_dma<MT, 4, 4, 2>(a, splits, s);
+    if (a.swiglu) return launch_dma<MT, 2, 4, PFN>(a, splits, s);
+    const long wgs3 = (long)((tiles + 2) / 3) * splits;
+    if (wgs3 >= 256) return launch_dma<MT, 3, 4, 2>(a, splits, s);
+    if ((long)((tiles + 1) / 2) * splits >= 256) return launch_dma<MT, 2, 4, PFN>(a, splits, s);
+    return launch_dma<MT, 1, 8, PFN>(a, splits, s);
+  }
+  if (a.swiglu) return tiles >= 768 ? launch_direct<MT, 4>(a, splits, s) : launch_direct<MT, 2>(a, splits, s);
+  if (tiles >= 1536) return launch_direct<MT, 4>(a, splits, s);
+  if (tiles >= 512) return launch_direct<MT, 2>(a, splits, s);
+  return launch_direct<MT, 1>(a, splits, s);
 }
 
 int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
@@ -41,13 +65,19 @@ int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32;
   a.x = (const uint16_t*)d->x; a.W = (const uint16_t*)d->W; a.W2 = (const uint16_t*)d->W2;
   a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
+  a.split_acc = (float*)d->split_acc;
+  int splits = 1;
+  if (a.split_acc) {        // the caller folds the fp32 sums itself (mxvl_decode_rmsnorm): no epilogue here
+    if (d->swiglu || d->bias || d->residual || d->out_f32 || d->k_splits < 1 || d->k_splits > 16) return MXVL_ERR_UNSUPPORTED;
+    splits = d->k_splits;
+  }
   int rc;
   switch ((d->rows + 15) / 16) {
-    case 1: rc = launch_decode_gemm_r<1>(a, s); break;
-    case 2: rc = launch_decode_gemm_r<2>(a, s); break;
-    case 3: rc = launch_decode_gemm_r<3>(a, s); break;
-    case 4: rc = launch_decode_gemm_r<4>(a, s); break;
-    default: rc = launch_decode_gemm_r<5>(a, s); break;
+    case 1: rc = launch_decode_gemm<1>(a, splits, s); break;
+    case 2: rc = launch_decode_gemm<2>(a, splits, s); break;
+    case 3: rc = launch_decode_gemm<3>(a, splits, s); break;
+    case 4: rc = launch_decode_gemm<4>(a, splits, s); break;
+    default: rc = launch_decode_gemm<5>(a, splits, s); break;
   }
   if (rc != MXVL_OK) return rc;
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
@@ -58,12 +88,14 @@ int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
 using namespace mxvl;
 
 extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream) {
-  if (!d || !d->x || !d->weight || !d->y) return MXVL_ERR_NULL;
+  if (!d || !d->weight || !d->y) return MXVL_ERR_NULL;
+  if (d->acc ? (!d->residual || !d->x_out) : !d->x) return MXVL_ERR_NULL;
   if (d->rows <= 0 || d->K <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0 || d->K > 16384) return MXVL_ERR_UNSUPPORTED;
   RmsNormArgs a;
   a.rows = d->rows; a.K = d->K; a.eps = d->eps;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->weight; a.y = (uint16_t*)d->y;
+  a.acc = (float*)d->acc; a.res = (const uint16_t*)d->residual; a.x_out = (uint16_t*)d->x_out;
   hipLaunchKernelGGL(decode_rmsnorm_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

@@ -381,6 +381,8 @@ class _KernelStepper(_SearchFusion):
         self.x = torch.zeros(rows, self.hidden, **bf)
         self.x2 = torch.zeros(rows, self.hidden, **bf)
         self.xn = torch.zeros(rows, self.hidden, **bf) if rows > 8 else None      # RMSNorm output ahead of an MFMA projection
+        # fp32 sums of the K-split o_proj / down_proj (zero between uses: the folding norm clears what it reads)
+        self.acc = torch.zeros(rows, self.hidden, dtype=torch.float32, device=dev) if rows > 8 else None
         self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
         self.att = torch.zeros(rows, self.H * self.D, **bf)
         self.att2 = torch.zeros(rows, self.H * self.D, **bf)      # self-attention output + gated image context
@@ -415,6 +417,11 @@ class _KernelStepper(_SearchFusion):
         self.mask[:, :self.P] = prompt_mask.repeat_interleave(rep, dim=0)
         self.n_real.copy_(self.mask[:, :self.P].sum(-1, keepdim=True))
         self.slot.copy_(self.own.expand(-1, self.max_len))
+        # the beams of a sample continue the SAME prompt: their prompt positions name one physical copy (the sample's first row), so
+        # the other beams' attention reads of it are L2 hits (same head -> same XCD) instead of HBM reads of identical bytes --
+        # at 6 x 3 rows and a 230-token prompt that is half of the cache traffic of a step
+        self.slot[:, :self.P] = (self.own // rep) * rep
+        self.beams = rep
         self._project_image_tokens()
 
     @torch.no_grad()
@@ -461,19 +468,34 @@ class _KernelStepper(_SearchFusion):
         d.gate_weight, d.gate_bias, d.warm_up_gate = c["gate_w"].data_ptr(), c["gate_b"].data_ptr(), self._abi.ptr(c["warm"])
         self._abi.check(self.lib.mxvl_decode_cross_attn(self._ct.byref(d), sp), "mxvl_decode_cross_attn")
 
-    def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False):
-        if norm is not None and self.rows > 8:       # the GEMV kernel normalises in its prologue; the MFMA kernel takes normalised rows
-            n = self._abi.RmsNormDesc()
-            n.rows, n.K, n.eps = self.rows, K, eps
-            n.x, n.weight, n.y = x.data_ptr(), norm.data_ptr(), self.xn.data_ptr()
-            self._abi.check(self.lib.mxvl_decode_rmsnorm(self._ct.byref(n), self._abi.stream_ptr(x.device)), "mxvl_decode_rmsnorm")
-            x, norm = self.xn, None
+    def _rmsnorm(self, x, norm, eps, K, fold_res=None, x_out=None):
+        """rows > 8: RMSNorm ahead of an MFMA projection (the GEMV kernel, rows <= 8, normalises in its own prologue).  With
+        fold_res the row is first completed from the split projection's fp32 sums: x_out = bf16(acc) + fold_res; acc is cleared."""
+        n = self._abi.RmsNormDesc()
+        n.rows, n.K, n.eps = self.rows, K, eps
+        n.x, n.weight, n.y = self._abi.ptr(x), norm.data_ptr(), self.xn.data_ptr()
+        if fold_res is not None:
+            n.acc, n.residual, n.x_out = self.acc.data_ptr(), fold_res.data_ptr(), x_out.data_ptr()
+        self._abi.check(self.lib.mxvl_decode_rmsnorm(self._ct.byref(n), self._abi.stream_ptr(self.x.device)), "mxvl_decode_rmsnorm")
+        return self.xn
+
+    def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False, split=0):
         d = self._abi.GemvDesc()
         d.rows, d.K, d.N = self.rows, K, N
         d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), eps
         d.x, d.norm_weight, d.W = x.data_ptr(), self._abi.ptr(norm), W.data_ptr()
-        d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), y.data_ptr()
+        d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), self._abi.ptr(y)
+        if split:
+            d.split_acc, d.k_splits = self.acc.data_ptr(), split
         self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
+
+    @staticmethod
+    def _k_splits(N, K):
+        """Workgroups of 64 columns: split K until ~256 of them exist (o_proj / down_proj: N = hidden), a wave keeping >= 4 chunks of 64."""
+        s = max(1, min(8, 256 // max(1, -(-N // 64))))
+        while s > 1 and K // 64 < 4 * 4 * s:
+            s //= 2
+        return s
 
     fused_prologue = True
 
@@ -496,13 +518,22 @@ class _KernelStepper(_SearchFusion):
         a = self._abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
         a.scale = self.D ** -0.5
+        a.beams = self.beams if 2 <= self.beams <= 5 else 0      # the beams of a sample share a workgroup and their common cache lines
         a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
+        batched = self.rows > 8          # MFMA projections: explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
+        so, sd = (self._k_splits(self.hidden, self.H * self.D), self._k_splits(self.hidden, self.inter)) if batched else (0, 0)
         for i, layer in enumerate(m.model.layers):
             at = layer.self_attn
-            self._gemv(self.x, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], norm=layer.input_layernorm.weight,
-                       eps=layer.input_layernorm.variance_epsilon, bias=at.qkv_bias)
+            ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
+            if batched:
+                xin = self._rmsnorm(self.x, ln1.weight, ln1.variance_epsilon, self.hidden,
+                                    fold_res=self.x2 if i else None, x_out=self.x)      # layer i - 1's down_proj sums + residual
+                self._gemv(xin, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], bias=at.qkv_bias)
+            else:
+                self._gemv(self.x, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], norm=ln1.weight, eps=ln1.variance_epsilon,
+                           bias=at.qkv_bias)
             a.k_cache, a.v_cache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
             a.q_rope = self.q_rope.data_ptr() if i in self.cond else None
             self._abi.check(self.lib.mxvl_decode_attn(self._ct.byref(a), sp), "mxvl_decode_attn")
@@ -510,13 +541,22 @@ class _KernelStepper(_SearchFusion):
             if i in self.cond:                       # gated image cross-attention on the rotated query, before o_proj
                 self._cross_attn(i, sp)
                 att = self.att2
-            self._gemv(att, at.o_proj.weight, self.x2, self.H * self.D, self.hidden, res=self.x)
-            self._gemv(self.x2, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter,
-                       norm=layer.post_attention_layernorm.weight, eps=layer.post_attention_layernorm.variance_epsilon,
-                       W2=layer.mlp.up_proj.weight)
-            self._gemv(self.act, layer.mlp.down_proj.weight, self.x, self.inter, self.hidden, res=self.x2)
-        self._gemv(self.x, m.lm_head.weight, self.logits, self.hidden, self.V, norm=m.model.norm.weight,
-                   eps=m.model.norm.variance_epsilon, out_f32=True)
+            if batched:
+                self._gemv(att, at.o_proj.weight, None, self.H * self.D, self.hidden, split=so)
+                xin = self._rmsnorm(None, ln2.weight, ln2.variance_epsilon, self.hidden, fold_res=self.x, x_out=self.x2)
+                self._gemv(xin, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter, W2=layer.mlp.up_proj.weight)
+                self._gemv(self.act, layer.mlp.down_proj.weight, None, self.inter, self.hidden, split=sd)
+            else:
+                self._gemv(att, at.o_proj.weight, self.x2, self.H * self.D, self.hidden, res=self.x)
+                self._gemv(self.x2, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter,
+                           norm=ln2.weight, eps=ln2.variance_epsilon, W2=layer.mlp.up_proj.weight)
+                self._gemv(self.act, layer.mlp.down_proj.weight, self.x, self.inter, self.hidden, res=self.x2)
+        if batched:
+            xin = self._rmsnorm(None, m.model.norm.weight, m.model.norm.variance_epsilon, self.hidden, fold_res=self.x2, x_out=self.x)
+            self._gemv(xin, m.lm_head.weight, self.logits, self.hidden, self.V, out_f32=True)
+        else:
+            self._gemv(self.x, m.lm_head.weight, self.logits, self.hidden, self.V, norm=m.model.norm.weight,
+                       eps=m.model.norm.variance_epsilon, out_f32=True)
         return self.logits
 
     def step(self, tok, beam_idx, k):
@@ -647,6 +687,30 @@ class ReportDecoder(nn.Module):
             emb = self.model.embed_tokens(tok)[:, None, :].to(dtype)
             logits = self.forward(emb, attention_mask=attn, past_key_values=cache)[:, -1]
 
+    @staticmethod
+    def _search_lookahead(stepper, state):
+        """Token loop without a host round trip per token: replay k + 1 is enqueued BEFORE the host has seen `unfinished` of replay k
+        (copied to pinned memory behind it).  If k was the last token, replay k + 1 is a no-op for the search state -- mxvl_beam_step
+        returns at once when *unfinished is already 0 -- so the result is what the synchronous loop returns; the ~45 us the
+        device idled per token while the host read one byte are gone."""
+        if not bool(state.unfinished):
+            return
+        flags = [torch.empty(1, dtype=torch.bool).pin_memory() for _ in range(2)]
+        events = [torch.cuda.Event() for _ in range(2)]
+        stepper.step_search(state)                       # (the first call runs eagerly and captures the graph)
+        k = 0
+        flags[0].copy_(state.unfinished.view(1), non_blocking=True)
+        events[0].record()
+        while True:
+            stepper.step_search(state)                   # speculative: a no-op if the previous step finished the search
+            flags[1 - k].copy_(state.unfinished.view(1), non_blocking=True)
+            events[1 - k].record()
+            events[k].synchronize()
+            if not bool(flags[k][0]):
+                break
+            k = 1 - k
+        torch.cuda.current_stream().synchronize()
+
     @torch.no_grad()
     def generate(self, inputs_embeds, attention_mask=None, num_beams=1, do_sample=False, min_new_tokens=0,
                  max_new_tokens=20, repetition_penalty=1.0, length_penalty=1.0, eos_token_id=None, pad_token_id=None,
@@ -681,7 +745,7 @@ class ReportDecoder(nn.Module):
             if self.__dict__.get("_stepper_weights") != ident:
                 self.__dict__["_steppers"] = {}
                 self.__dict__["_stepper_weights"] = ident
-            key = (B * nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph), conditioned,
+            key = (B * nb, nb, attention_mask.shape[1], max_new_tokens, inputs_embeds.dtype, str(dev), str(use_graph), conditioned,
                    _KernelStepper.cond_signature(self))
             stepper = getattr(self, "_steppers", {}).get(key)
             if stepper is None:
@@ -718,6 +782,8 @@ class ReportDecoder(nn.Module):
         if stepper is None:
             cache.expand(nb)
             attn = attention_mask.repeat_interleave(nb, dim=0)
+        if isinstance(stepper, _KernelStepper) and state.use_hip and state._hip_supported(stepper.logits):
+            self._search_lookahead(stepper, state)
         while bool(state.unfinished):
             if stepper is not None:
                 stepper.step_search(state)                       # decoder step + search update, one hipGraph replay

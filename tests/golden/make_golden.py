@@ -889,7 +889,7 @@ def gen_decode_batched():
             sl = torch.stack(gr.logits, dim=1)
             scale = float(sl.abs().max())
             top2 = sl.topk(2, dim=-1).values
-            if float((top2[..., 0] - top2[..., 1]).min()) <= 0.012 * scale:
+            if float((top2[..., 0] - top2[..., 1]).min()) <= 0.012 * scale:     # cheap pre-filter; the noise draws below decide
                 continue
             outs["greedy"] = gr.sequences
             for name in ("beam3", "beam5"):
@@ -898,10 +898,10 @@ def gen_decode_batched():
             kw = dict(attention_mask=att, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
             for name in kws:
                 ok = ok and eq(outs[name], mb.generate(**kws[name], **cb)) and eq(outs[name], rd.generate(emb.to(torch.bfloat16), **kws[name], **kw))
-                for t in range(3):
+                for t in range(6):
                     if not ok:
                         break
-                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.0024 * scale)])
+                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.005 * scale)])   # sigma 0.5 % of the scale: the HIP bf16 path sits ~0.3 % (max 1 %) from HF
                     ok = eq(m.generate(logits_processor=lp, **kws[name], **common), outs[name])
         print(f"decode_batched prompt seed {seed} ({n_real} real tokens): robust={ok}")
         if ok:

@@ -29,7 +29,7 @@ for p in range(n):
     tot_k += dur
     tot_g += gap
     name = steps[0][p][0].split("(")[0].replace("void mxvl::", "")[:40]
-    a = agg.setdefault((name, round(dur / 2) * 2 if "gemv" in name else 0), [0, 0.0, 0.0])
+    a = agg.setdefault((name, round(dur / 2) * 2 if ("gemv" in name or "gemm" in name) else 0), [0, 0.0, 0.0])
     a[0] += 1
     a[1] += dur
     a[2] += gap
