@@ -27,6 +27,11 @@
  *   D, delta_bias    : (dim) fp32
  * "io" tensors (u, delta, z, out, B, C and their gradients) share one dtype
  * (fp32 / bf16 / fp16); weights, state and accumulators are always fp32.
+ * Alignment and speed: any element-aligned view is accepted.  The vector kernels need every row of every io tensor to start on
+ * a 4-element boundary (fp32: 16 bytes) and, for the 16-bit dtypes, on a 16-byte boundary (8 elements: strides % 8 == 0,
+ * pointers % 16 == 0) -- forward and backward apply the same rule; rows that are only 8-byte aligned (e.g. seqlen % 8 == 4, or a
+ * view starting 4 elements into its storage) run on the element-wise kernels (same results, several times slower), and
+ * MXVL_SCAN_FOLD_BATCH returns MXVL_ERR_UNSUPPORTED for them.
  */
 #ifndef MXVL_H_
 #define MXVL_H_

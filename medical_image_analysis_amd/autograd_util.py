@@ -1,0 +1,25 @@
+"""Grad mode at the time a custom autograd Function is APPLIED.
+
+Inside `Function.forward` autograd has already switched grad mode off and `ctx.needs_input_grad` mirrors the inputs'
+`requires_grad` whatever the caller's mode was: under `torch.no_grad()` (evaluation of a model whose parameters still require
+grad) a forward that asks only `any(ctx.needs_input_grad)` keeps writing the tensors its backward would need.  `apply(fn, ...)`
+records the caller's mode for the duration of the call; `wants_grad(ctx)` is what the forwards ask instead."""
+import threading
+
+import torch
+
+_state = threading.local()
+
+
+def apply(fn, *args):
+    prev = getattr(_state, "on", True)
+    _state.on = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _state.on = prev
+
+
+def wants_grad(ctx, upto=None) -> bool:
+    need = ctx.needs_input_grad if upto is None else ctx.needs_input_grad[:upto]
+    return getattr(_state, "on", True) and any(need)

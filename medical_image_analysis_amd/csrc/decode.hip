@@ -748,14 +748,9 @@ static int launch_gemv(const GemvArgs& a, hipStream_t s) {
   const int grid = std::max(1, std::min(256, (a.N + 15) / 16));
   const size_t lds = (size_t)M * a.K * sizeof(uint16_t);
   if (lds > 150 * 1024) return MXVL_ERR_UNSUPPORTED;  // rows * K bf16 must fit one CU's LDS
-  if (lds > 64 * 1024) {
-    static bool raised = false;  // per template instance
-    if (!raised) {
-      if (hipFuncSetAttribute((const void*)gemv_bf16_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-        return MXVL_ERR_LAUNCH;
-      raised = true;
-    }
-  }
+  // per call: the attribute belongs to the (kernel, device) pair, and a process may drive several devices
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)gemv_bf16_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+    return MXVL_ERR_LAUNCH;
   hipLaunchKernelGGL(gemv_bf16_kernel<M>, dim3(grid), dim3(1024), lds, s, a);
   return MXVL_OK;
 }

@@ -321,11 +321,8 @@ template <typename E>
 static int launch_gemm_swiglu(const GemmSwigluArgs& a, hipStream_t s) {
   auto kern = gemm_swiglu_kernel<E>;
   const size_t lds = (size_t)GS_SLOTS * GS_STAGE;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MXVL_ERR_LAUNCH;
-    raised = true;
-  }
+  // per call: the attribute belongs to the (kernel, device) pair, and a process may drive several devices
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MXVL_ERR_LAUNCH;
   // one persistent workgroup per CU (256 CUs; LDS and the 2-waves-per-SIMD register budget admit exactly one), fewer for small grids
   const int tiles = 8 * a.ntm_x * a.ntn;
   hipLaunchKernelGGL(kern, dim3(tiles < 256 ? tiles : 256), dim3(GS_NT), lds, s, a);

@@ -1002,7 +1002,9 @@ extern "C" int mxvl_scan_bwd(const mxvl_scan_bwd_desc* d, void* hip_stream) {
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
     ok = ok && (((uintptr_t)d->dout) % (4 * (a.out_f32 ? 4 : esz)) == 0);
     // 16-bit rows take kernels that move B / C (and, at L % 8 == 0, the rows) in 16-byte LDS-DMA units: those need 16-byte aligned
-    // addresses.  Rows that are only 8-byte aligned (a view that starts 4 elements into its storage) take the element-wise path.
+    // addresses.  Rows that are only 8-byte aligned (a view that starts 4 elements into its storage, L % 8 == 4) take the
+    // element-wise path: a third, non-DMA vector instantiation of this 1000-line kernel per (dtype, waves, fold) for views that no
+    // model of the reference produces was judged not worth its compile time -- the cliff is documented in mxvl.h instead.
     if (ok && esz == 2) {
       const int64_t s8[] = {f->u_bs, f->u_ds, f->delta_bs, f->delta_ds, f->z ? f->z_bs : 0, f->z ? f->z_ds : 0,
                             a.out_f32 ? 0 : d->dout_bs, a.out_f32 ? 0 : d->dout_ds, f->B_bs, f->B_gs, f->B_ns, f->C_bs, f->C_gs, f->C_ns};

@@ -548,6 +548,15 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
     const void* ptrs[] = {d->u, d->delta, d->B, d->C, d->z};
     for (const void* q : ptrs) ok = ok && (((uintptr_t)q) % (4 * esz) == 0);
     ok = ok && (((uintptr_t)d->out) % (4 * (a.out_f32 ? 4 : esz)) == 0);
+    // 16-bit rows: the vector kernels read u / delta / z eight steps (16 bytes) at a time (scan_fwd_stream.h raw_row, and every
+    // folded walk): those rows must start on 16-byte boundaries -- the same rule mxvl_scan_bwd applies.  A view that is only
+    // 8-byte aligned takes the element-wise kernels (and MXVL_SCAN_FOLD_BATCH is refused for it, as mxvl.h documents).
+    if (ok && esz == 2) {
+      const int64_t s8[] = {d->u_bs, d->u_ds, d->delta_bs, d->delta_ds, d->z ? d->z_bs : 0, d->z ? d->z_ds : 0};
+      for (int64_t s : s8) ok = ok && (s % 8 == 0);
+      const void* p16[] = {d->u, d->delta, d->z};
+      for (const void* q : p16) ok = ok && (((uintptr_t)q) % 16 == 0);
+    }
     a.vec_ok = ok ? 1 : 0;
   }
   hipStream_t stream = (hipStream_t)hip_stream;

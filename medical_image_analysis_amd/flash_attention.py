@@ -244,15 +244,20 @@ def supported(q, *others) -> bool:
     return D == 256 and q.dtype != torch.float32 and not needs_grad
 
 
-def require(q, what: str, dropout_p: float = 0.0) -> bool:
+def require(q, what: str, dropout_p: float = 0.0, *others) -> bool:
     """The one dispatch rule of every attention call site: True -> HIP tensors, run the MFMA kernel; False -> CPU tensors, the
     caller evaluates its torch reference expression (host-side tests, golden generation).  A HIP tensor the kernels cannot
-    serve RAISES -- there is no library attention fallback on the GPU."""
+    serve RAISES -- there is no library attention fallback on the GPU.  `others` = the k / v tensors of the call: head_dim 256 is
+    forward-only, and a call where only k / v need gradients must be refused HERE, not inside backward.
+    Restriction (documented, deliberate): attention dropout > 0 raises on a HIP device.  Every configuration the reference ships
+    trains with attn_drop = 0 / attention_dropout = 0.0 (models_pretrain.py CrossAttention default, Qwen2 / Llama configs); a config
+    that sets it needs the dropout mask inside the kernel, which is not built -- an eager softmax-dropout path would be a second,
+    silent attention implementation."""
     if not q.is_cuda:
         return False
     if dropout_p != 0.0:
         raise RuntimeError(f"{what}: attention dropout is not implemented by the HIP kernels (the reference trains with attn_drop = 0)")
-    if not supported(q):
+    if not supported(q, *others):
         raise RuntimeError(f"{what}: head_dim {q.shape[-1]} / dtype {q.dtype} has no HIP attention kernel (head_dim <= 128 for "
                            "fp32 / bf16 / fp16 forward + backward; 256: bf16 / fp16 forward only)")
     return True

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from . import _abi
+from . import _abi, autograd_util
 
 _LN_DTYPES = {(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
               (torch.float32, torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16, torch.bfloat16)}
@@ -178,7 +178,7 @@ class _LinearSwiGLU(torch.autograd.Function):
         cd = _compute_dtype(x)
         x2 = x.reshape(-1, x.shape[-1]).to(cd)
         w = weight.to(cd)
-        needs_grad = any(ctx.needs_input_grad)
+        needs_grad = autograd_util.wants_grad(ctx)
         H = w.shape[0] // 2
         # ONE MFMA kernel: GEMM + bias + gate (csrc/gemm_swiglu.hip).  Measured per ARM layer (profiles/r03_gemm_swiglu_bench.txt):
         # without the pre-activations (no gradient) it beats library GEMM + gate kernel at every shape (0.73 vs 0.85 ms at 65 280
@@ -226,7 +226,7 @@ class _LinearSwiGLU(torch.autograd.Function):
 def linear_swiglu(x, weight, bias=None):
     """silu(x w1^T + b1) * (x w2^T + b2) for weight = [w1; w2] (2H, K), bias = [b1 | b2]."""
     _abi.require_gpu(x, weight, bias)
-    return _LinearSwiGLU.apply(x, weight, bias)
+    return autograd_util.apply(_LinearSwiGLU, x, weight, bias)
 
 
 def swiglu(ab):

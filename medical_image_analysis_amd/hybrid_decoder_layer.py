@@ -124,7 +124,7 @@ class ScaleDotProductCrossAttention(nn.Module):
         (both cross-attention variants build it that way): then the MFMA flash kernel runs, image K/V tiles staged in LDS,
         grouped-query heads served without repeat_kv."""
         p = self.dropout_p if self.training else 0.0
-        if flash.require(q, "ScaleDotProductCrossAttention", p):
+        if flash.require(q, "ScaleDotProductCrossAttention", p, k, v):
             if attn_mask is not None:
                 raise RuntimeError("ScaleDotProductCrossAttention: a query-dependent (B, Lq, Lk) mask has no HIP kernel; both "
                                    "cross-attention variants of the reference pass a per-key mask (key_mask)")
@@ -261,7 +261,7 @@ class Qwen2HybridAttention(nn.Module):
             k, v = past_key_value.update(k, v, self.layer_idx, {"sin": sin, "cos": cos, "cache_position": cache_position})
         kv_len = k.shape[-2]
         p_drop = self.attention_dropout if self.training else 0.0
-        if flash.require(q, "Qwen2HybridAttention", p_drop):
+        if flash.require(q, "Qwen2HybridAttention", p_drop, k, v):
             # MFMA flash attention: causal aligned to the END of the key sequence (decode with a cache) + the (B, kv_len)
             # padding mask as a key mask; grouped-query heads without repeat_kv
             if attention_mask is not None and attention_mask.dim() != 2:

@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd_util
 from .causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 from .selective_scan_interface import _SplitHalves, bimamba_inner_fn, mamba_inner_fn, proj_in, selective_scan_fn
 from .selective_state_update import selective_state_update
@@ -142,7 +143,7 @@ class _DirMergeGate(torch.autograd.Function):
             y = y.contiguous()
         z = _rows_view(z)
         out = torch.empty((B, D, L), dtype=y.dtype, device=y.device)
-        pre = torch.empty((B, D, L), dtype=y.dtype, device=y.device) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        pre = torch.empty((B, D, L), dtype=y.dtype, device=y.device) if autograd_util.wants_grad(ctx, 2) else None
         _dir_perm(True, out, y, inv, L, Lp, gate=z, pre=pre, scale=scale)
         ctx.save_for_backward(perm, z, pre)
         ctx.meta = (K, Lp, scale)
@@ -176,7 +177,7 @@ class _MultiDirMixerFn(torch.autograd.Function):
         x, z = xz[:, :D], xz[:, D:]
         X = torch.empty((K, D, B, Lp), dtype=xz.dtype, device=xz.device).permute(2, 0, 1, 3)
         _dir_perm(False, x, X, perm, L, Lp)
-        needs_grad = any(ctx.needs_input_grad)
+        needs_grad = autograd_util.wants_grad(ctx)
         y, saved, ctx.meta = mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad)
         # channel-major (D, B, L) storage: proj_out reads it as the (D, B*L) operand of ONE GEMM and hands d(out) back in the same
         # layout (batch-major, F.linear copied `out` to token-major and the backward copied d(out) back: two tensor passes a layer)
@@ -321,8 +322,8 @@ class Mamba(nn.Module):
                 and xz.dtype in (torch.float32, torch.bfloat16, torch.float16)):
             # v3 on the GPU: gather -> conv -> x_proj -> dt_proj -> scan -> gated merge as ONE node, batch-of-K GEMMs
             mods = [self._dir(s) for s in ["", "_b", "_c", "_c_b"]]
-            gated = _MultiDirMixerFn.apply(
-                xz, fwd32, inv32, (L + 7) // 8 * 8, 0.25, torch.cat([m[0].weight for m in mods], dim=0),
+            gated = autograd_util.apply(
+                _MultiDirMixerFn, xz, fwd32, inv32, (L + 7) // 8 * 8, 0.25, torch.cat([m[0].weight for m in mods], dim=0),
                 torch.cat([m[0].bias for m in mods], dim=0) if mods[0][0].bias is not None else None,
                 torch.stack([m[1].weight for m in mods]), torch.stack([m[2].weight for m in mods]),
                 -torch.exp(torch.cat([m[3].float() for m in mods], dim=0)), torch.cat([m[4].float() for m in mods], dim=0),
@@ -366,7 +367,7 @@ class Mamba(nn.Module):
                               delta_bias=dbias, delta_softplus=True).view(Bz, K, D, L)
         # merge: direction k's output at step l belongs to token perm_k[l]  (:522-529)
         if hip_perm and xd is None:   # v3: merge + silu(z) gate + /4 in one kernel
-            gated = _DirMergeGate.apply(y, z, inv32, fwd32, L_true, 0.25)
+            gated = autograd_util.apply(_DirMergeGate, y, z, inv32, fwd32, L_true, 0.25)
             return F.linear(gated.transpose(1, 2), self.out_proj.weight.to(io),
                             None if self.out_proj.bias is None else self.out_proj.bias.to(io))
         if hip_perm:

@@ -91,7 +91,7 @@ class CrossAttention(nn.Module):
         p = self.attn_drop.p if self.training else 0.0
         q = self.q(q).reshape(B, N, H, C // H).transpose(1, 2)                 # (B, H, N, dh) view, no copy
         kv = self.kv(kv).reshape(B, N, 2, H, C // H)                           # packed (B, N, 2, H, dh)
-        if flash.require(q, "pre-training CrossAttention", p):
+        if flash.require(q, "pre-training CrossAttention", p, kv):
             # hand-written MFMA flash attention (csrc/attn.hip): the block-lower-triangular mask of mask_generate is a kernel
             # mode that never visits the tiles above the diagonal; any other mask tensor goes in as an additive bias
             if flash.is_block_causal_mask(mask, 16):

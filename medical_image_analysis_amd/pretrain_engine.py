@@ -6,14 +6,20 @@ Host-side mirror of the reference's hand-rolled loop:
   CXPMRG_Bench_MambaXray_VL/pretrain/engine_pretrain.py:37-62  autocast(bf16) forward -> loss.mean() -> backward ->
                                                                clip_grad_norm_(3.0) -> step -> all_reduce_mean(loss)
   CXPMRG_Bench_MambaXray_VL/pretrain/utils/misc.py:211-233     env:// NCCL(=RCCL) init
-bf16 autocast needs no loss scaling, so the reference's GradScaler (misc.py:236-256) is an identity here and is
-not instantiated; gradients stay fp32 (params are fp32 under autocast) exactly as in the reference.
+bf16 autocast needs no loss scaling, so the reference's GradScaler (misc.py:236-256) is an identity there and is
+not instantiated; gradients stay fp32 (params are fp32 under autocast) exactly as in the reference.  The ViT-MAE stage
+(HD_Xray_Pretrain_MAE/pretrain/main.py:211-213,317) trains under fp16 autocast WITH the scaler: amp_dtype=torch.float16
+instantiates it (scale -> backward -> unscale_ -> clip -> step -> update, misc.py NativeScalerWithGradNormCount).
+Gradient accumulation and the per-iteration schedule of engine_pretrain.py:28-52 / utils/lr_sched.py are part of step():
+accum_iter micro-batches per optimizer update (loss / accum_iter, DDP no_sync() on the micro-steps that do not update),
+half-cycle cosine with linear warm-up evaluated at data_iter_step / iters_per_epoch + epoch on every update boundary.
 Gradient exchange: torch DDP over RCCL with 256 MiB buckets (ARM-large = 1.16 GiB of fp32 grads -> 5 large
 reduce-scatter+all-gather rounds that use all 7 xGMI links per GPU, overlapped with backward) and
 gradient_as_bucket_view (no extra copy).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -68,12 +74,38 @@ def param_groups_weight_decay(model: nn.Module, weight_decay: float = 0.05, skip
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
+def cosine_lr(epoch: float, lr: float, min_lr: float, warmup_epochs: float, epochs: float) -> float:
+    """utils/lr_sched.py adjust_learning_rate: linear warm-up, then half-cycle cosine down to min_lr (epoch is fractional)."""
+    import math
+    if epoch < warmup_epochs:
+        return lr * epoch / warmup_epochs
+    return min_lr + (lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch - warmup_epochs) / (epochs - warmup_epochs)))
+
+
+def adjust_learning_rate(optimizer, epoch: float, lr: float, min_lr: float, warmup_epochs: float, epochs: float) -> float:
+    """Same side effect as the reference's: every param group gets lr (x its "lr_scale" when it has one)."""
+    v = cosine_lr(epoch, lr, min_lr, warmup_epochs, epochs)
+    for g in optimizer.param_groups:
+        g["lr"] = v * g["lr_scale"] if "lr_scale" in g else v
+    return v
+
+
 class PretrainEngine:
     """model(imgs) -> per-token loss; one call of step() = forward + backward + clip + AdamW step."""
 
     def __init__(self, model: nn.Module, lr: float = 1.5e-4, weight_decay: float = 0.05, clip_grad: float | None = 3.0,
-                 amp_dtype: torch.dtype | None = torch.bfloat16, bucket_cap_mb: int = 256, device=None):
+                 amp_dtype: torch.dtype | None = torch.bfloat16, bucket_cap_mb: int = 256, device=None, accum_iter: int = 1,
+                 schedule: dict | None = None, iters_per_epoch: int | None = None):
+        """schedule = dict(min_lr=, warmup_epochs=, epochs=) switches the per-iteration cosine schedule on (peak = lr); it needs
+        iters_per_epoch = len(data_loader).  accum_iter micro-batches feed one optimizer update."""
         self.device = device
+        self.accum_iter, self.lr, self.schedule, self.iters_per_epoch = int(accum_iter), lr, schedule, iters_per_epoch
+        if schedule is not None and not iters_per_epoch:
+            raise ValueError("a schedule needs iters_per_epoch (the reference evaluates it at data_iter_step / len(data_loader) + epoch)")
+        self.data_iter_step = 0
+        on_gpu = device is not None and torch.device(device).type == "cuda"
+        # fp16 autocast trains with dynamic loss scaling (MAE: main.py:317 NativeScaler); bf16 / fp32 never needed one
+        self.scaler = torch.amp.GradScaler("cuda" if on_gpu else "cpu") if amp_dtype == torch.float16 else None
         self.tuned_gemms = enable_tuned_gemms() if (device is not None and torch.device(device).type == "cuda") else False
         self.amp_dtype = amp_dtype
         self.clip_grad = clip_grad
@@ -89,25 +121,53 @@ class PretrainEngine:
         else:
             self.model = model
 
-    def step(self, imgs: torch.Tensor) -> torch.Tensor:
-        dev_type = imgs.device.type
-        with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            loss = self.model(imgs)
-        loss = loss.mean()
-        # misc.all_reduce_mean(loss_value) (engine_pretrain.py:62) is part of every reference step: issued here, on the
-        # collective stream, so the 4-byte all-reduce rides under the backward pass instead of costing a host round trip
-        reduced, work = loss.detach().clone(), None
-        if self.world > 1:
-            work = dist.all_reduce(reduced, async_op=True)
+    def start_epoch(self):
+        """engine_pretrain.py:31 `optimizer.zero_grad()` + the iteration counter the schedule and the accumulation window read."""
+        self.data_iter_step = 0
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        if self.clip_grad is not None:
-            nn.utils.clip_grad_norm_(self.raw_model.parameters(), self.clip_grad)
-        self.optimizer.step()
+
+    def step(self, imgs: torch.Tensor, epoch: int = 0) -> torch.Tensor:
+        """One iteration of train_one_epoch (engine_pretrain.py:36-62): a micro-batch forward + backward; on the last micro-batch of
+        an accumulation window also clip, optimizer step and zero_grad.  Returns misc.all_reduce_mean(loss) of this micro-batch."""
+        dev_type = imgs.device.type
+        it, acc = self.data_iter_step, self.accum_iter
+        if self.schedule is not None and it % acc == 0:
+            adjust_learning_rate(self.optimizer, it / self.iters_per_epoch + epoch, self.lr, **self.schedule)
+        update = (it + 1) % acc == 0
+        ddp = self.world > 1
+        # micro-steps that do not update keep their gradients local: the all-reduce of the window rides on its last backward
+        sync = self.model.no_sync() if (ddp and not update) else contextlib.nullcontext()
+        with sync:
+            with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                loss = self.model(imgs)
+            loss = loss.mean()
+            # misc.all_reduce_mean(loss_value) (engine_pretrain.py:62) is part of every reference step: issued here, on the
+            # collective stream, so the 4-byte all-reduce rides under the backward pass instead of costing a host round trip
+            reduced, work = loss.detach().clone(), None
+            if ddp:
+                work = dist.all_reduce(reduced, async_op=True)
+            if acc == 1:
+                self.optimizer.zero_grad(set_to_none=True)
+            back = loss / acc if acc > 1 else loss
+            (self.scaler.scale(back) if self.scaler is not None else back).backward()
+        if update:
+            if self.scaler is not None:
+                if self.clip_grad is not None:
+                    self.scaler.unscale_(self.optimizer)
+                    nn.utils.clip_grad_norm_(self.raw_model.parameters(), self.clip_grad)
+                self.scaler.step(self.optimizer)
+                self.scaler.update()
+            else:
+                if self.clip_grad is not None:
+                    nn.utils.clip_grad_norm_(self.raw_model.parameters(), self.clip_grad)
+                self.optimizer.step()
+            if acc > 1:
+                self.optimizer.zero_grad(set_to_none=True)
         if work is not None:
             work.wait()
             reduced /= self.world
         self.last_local_loss = loss.detach()
+        self.data_iter_step = it + 1
         return reduced
 
     def reduced_loss(self, loss: torch.Tensor) -> float:

@@ -19,7 +19,7 @@ import ctypes
 
 import torch
 
-from . import _abi
+from . import _abi, autograd_util
 
 
 # bench.py sets this to a list to collect (kind, start_event, end_event, algorithmic_bytes) per kernel launch;
@@ -247,7 +247,7 @@ class SelectiveScanFn(torch.autograd.Function):
         dev, u, delta, A, B, C, D, z, delta_bias = _prep(u, delta, A, B, C, D, z, delta_bias)
         # grad mode is off inside Function.forward: the copies _prep makes (.contiguous() / .float()) never require grad, so
         # ask autograd about the ORIGINAL arguments
-        needs_grad = any(ctx.needs_input_grad[:8])
+        needs_grad = autograd_util.wants_grad(ctx, 8)
         out, last, ckpt = scan_fwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus,
                                        want_last_state=return_last_state, want_ckpt=needs_grad)
         ctx.delta_softplus = delta_softplus
@@ -278,7 +278,7 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
                       return_last_state=False):
     """out = selective scan of u (B,D,L); with z the output is gated by silu(z).
     Returns out, or (out, last_state (B,D,N) fp32) when return_last_state."""
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    return autograd_util.apply(SelectiveScanFn, u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -535,7 +535,7 @@ class _MambaInnerFn(torch.autograd.Function):
         if C_proj_bias is not None:
             Cm = Cm + C_proj_bias.to(io)[None, :, None]
         _, u_, dt_, A_, B_, C_, D_, z_, bias_ = _prep(xc, dt, A, Bm, Cm, D, z, delta_bias)
-        needs_grad = any(ctx.needs_input_grad[:10])
+        needs_grad = autograd_util.wants_grad(ctx, 10)
         out, _, ckpt = scan_fwd_raw(u_, dt_, A_, B_, C_, D_, z_, bias_, delta_softplus, want_ckpt=needs_grad)
         ctx.meta = (delta_softplus, conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype,
                     dt_proj_w.dtype, A.dtype, None if D is None else D.dtype, None if delta_bias is None else delta_bias.dtype,
@@ -660,7 +660,7 @@ def mamba_inner_fn_no_out_proj(xz, conv1d_weight, conv1d_bias, x_proj_weight, de
     N = A.shape[1]
     R = delta_proj_weight.shape[1]
     if _use_mixer_node(xz):
-        return _MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
+        return autograd_util.apply(_MambaInnerFn, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias,
                                    B_proj_bias, C_proj_bias, delta_softplus)
     x, z = _SplitHalves.apply(xz) if xz.requires_grad else (xz[:, :d_inner], xz[:, d_inner:])   # views: strided rows
     xc = causal_conv1d_fn(x, conv1d_weight, conv1d_bias, "silu")  # (b, d, l)

@@ -928,6 +928,26 @@ def gen_decode_batched():
          **{"cfg_" + k: np.array(v) for k, v in shape.items()}, **out)
 
 
+def gen_lr_sched():
+    """CXPMRG_Bench_MambaXray_VL/pretrain/utils/lr_sched.py adjust_learning_rate, executed: the learning rates of the stage-1 run
+    (pretrain.sh: blr 1.5e-4 x 4096 / 256 -> lr, min_lr 0, warmup 5 / 100 epochs style settings) on a grid of fractional epochs,
+    and a second setting with min_lr > 0; a param group with lr_scale rides along."""
+    mod = _load(os.path.join(REF, "CXPMRG_Bench_MambaXray_VL/pretrain/utils/lr_sched.py"), "_ref_lr_sched")
+    out = {}
+    for tag, a in (("a", dict(lr=2.4e-3, min_lr=0.0, warmup_epochs=5, epochs=100)), ("b", dict(lr=1e-3, min_lr=1e-5, warmup_epochs=2, epochs=40))):
+        args = types.SimpleNamespace(**a)
+        opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.65}])
+        ep = np.concatenate([np.linspace(0, a["warmup_epochs"], 23), np.linspace(a["warmup_epochs"], a["epochs"], 57)])
+        lr0, lr1 = [], []
+        for e in ep:
+            mod.adjust_learning_rate(opt, float(e), args)
+            lr0.append(opt.param_groups[0]["lr"])
+            lr1.append(opt.param_groups[1]["lr"])
+        out.update({f"{tag}_epoch": ep, f"{tag}_lr": np.array(lr0), f"{tag}_lr_scaled": np.array(lr1),
+                    f"{tag}_args": np.array([a["lr"], a["min_lr"], a["warmup_epochs"], a["epochs"]])})
+    save("lr_sched", **out)
+
+
 def gen_vmamba(scan_ref):
     """VMamba / SS2D (R2GenCSR/VMamba/classification/models/vmamba.py) on CPU.  The vendored CUDA extension
     `selective_scan_cuda_oflex` is replaced by a stub that evaluates the reference's own selective_scan_ref (forward)
@@ -1227,7 +1247,9 @@ def gen_qformer():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "decode_batched":
+    if len(sys.argv) > 1 and sys.argv[1] == "lr_sched":
+        gen_lr_sched()
+    elif len(sys.argv) > 1 and sys.argv[1] == "decode_batched":
         gen_decode_batched()
     elif len(sys.argv) > 1 and sys.argv[1] == "qformer":
         gen_qformer()
