@@ -189,7 +189,8 @@ typedef struct mxvl_gemv_desc {
                                column block and the partial sums are added here atomically; no epilogue runs (swiglu / bias /
                                residual / out_f32 must be unset, y is ignored): mxvl_decode_rmsnorm folds the sums (acc).  For the
                                projections with few columns (o_proj, down_proj: N = hidden) that cannot fill the chip otherwise */
-  int32_t k_splits;         /* 1..16 with split_acc */
+  int32_t k_splits;         /* 0: kernel by row count (rows <= 8: GEMV).  != 0: the matrix-core kernels at any row count; 1..16 with
+                               split_acc, 1 without */
   int32_t reserved0;
 } mxvl_gemv_desc;
 

@@ -765,8 +765,8 @@ extern "C" {
 
 int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
-  if (d->rows > kMaxRows) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
-  if (d->split_acc) return MXVL_ERR_UNSUPPORTED;      // the GEMV kernel (rows <= 8) never splits K
+  // k_splits != 0 asks for the matrix-core kernels at any row count (1 = no split); 0 = by row count
+  if (d->rows > kMaxRows || d->k_splits != 0 || d->split_acc) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
   if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
   if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers

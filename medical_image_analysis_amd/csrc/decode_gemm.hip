@@ -67,6 +67,7 @@ int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
   a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
   a.split_acc = (float*)d->split_acc;
   int splits = 1;
+  if (!a.split_acc && d->k_splits > 1) return MXVL_ERR_UNSUPPORTED;    // a split needs the accumulator
   if (a.split_acc) {        // the caller folds the fp32 sums itself (mxvl_decode_rmsnorm): no epilogue here
     if (d->swiglu || d->bias || d->residual || d->out_f32 || d->k_splits < 1 || d->k_splits > 16) return MXVL_ERR_UNSUPPORTED;
     splits = d->k_splits;

@@ -380,9 +380,11 @@ class _KernelStepper(_SearchFusion):
         self.vc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
         self.x = torch.zeros(rows, self.hidden, **bf)
         self.x2 = torch.zeros(rows, self.hidden, **bf)
-        self.xn = torch.zeros(rows, self.hidden, **bf) if rows > 8 else None      # RMSNorm output ahead of an MFMA projection
+        import os
+        self.batched = rows > int(os.environ.get("MXVL_DECODE_GEMV_MAX_ROWS", "8")) or rows > 8
+        self.xn = torch.zeros(rows, self.hidden, **bf) if self.batched else None      # RMSNorm output ahead of an MFMA projection
         # fp32 sums of the K-split o_proj / down_proj (zero between uses: the folding norm clears what it reads)
-        self.acc = torch.zeros(rows, self.hidden, dtype=torch.float32, device=dev) if rows > 8 else None
+        self.acc = torch.zeros(rows, self.hidden, dtype=torch.float32, device=dev) if self.batched else None
         self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
         self.att = torch.zeros(rows, self.H * self.D, **bf)
         self.att2 = torch.zeros(rows, self.H * self.D, **bf)      # self-attention output + gated image context
@@ -487,6 +489,8 @@ class _KernelStepper(_SearchFusion):
         d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), self._abi.ptr(y)
         if split:
             d.split_acc, d.k_splits = self.acc.data_ptr(), split
+        elif self.batched:
+            d.k_splits = 1
         self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
 
     @staticmethod
@@ -522,7 +526,7 @@ class _KernelStepper(_SearchFusion):
         a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
-        batched = self.rows > 8          # MFMA projections: explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
+        batched = self.batched           # MFMA projections: explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
         so, sd = (self._k_splits(self.hidden, self.H * self.D), self._k_splits(self.hidden, self.inter)) if batched else (0, 0)
         for i, layer in enumerate(m.model.layers):
             at = layer.self_attn

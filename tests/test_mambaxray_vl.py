@@ -105,8 +105,8 @@ def test_downstream_loss_generate_and_delta(tmp_path):
     from medical_image_analysis_amd import mambaxray_vl as mx
     torch.manual_seed(0)
     args = mx.default_args(vision_model="Base-None", max_length=16, min_new_tokens=4, max_new_tokens=8)
-    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=4,
-                                       num_key_value_heads=4, max_position_embeddings=512), dtype=torch.bfloat16)
+    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+                                       num_key_value_heads=2, max_position_embeddings=512), dtype=torch.bfloat16)   # head_dim 64: a width the HIP decode kernels serve
     m = mx.MambaXrayVLDownStream(args, tokenizer=WordTokenizer(), llm=llm).to(DEV)
     assert m.visual_encoder.num_features == 768                       # 'B' in vision_model -> arm_base_pz16
     assert not any(p.requires_grad for p in m.llama_model.parameters()) and not any(p.requires_grad for p in m.visual_encoder.parameters())
@@ -179,8 +179,8 @@ def test_r2gencsr_context_residuals_loss_and_generate():
     torch.manual_seed(0)
     enc = VSSM(depths=[1, 1, 2, 1], dims=32, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
                mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0)
-    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=4,
-                                       num_key_value_heads=4, max_position_embeddings=1024), dtype=torch.bfloat16)
+    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+                                       num_key_value_heads=2, max_position_embeddings=1024), dtype=torch.bfloat16)
     args = mx.default_args(max_length=16, min_new_tokens=4, max_new_tokens=8, context_pair=3, freeze_vm=False, llm_freeze=True,
                            positive="Note: <Img><ImageHere></Img> with disease .", negative="Note: <Img><ImageHere></Img> is healthy .",
                            use_feature_mean=True, instruction="Generate a report .")
@@ -224,8 +224,8 @@ def test_r2gencsr_qformer_projector():
     torch.manual_seed(0)
     enc = VSSM(depths=[1, 1, 2, 1], dims=32, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
                mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0)
-    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=4,
-                                       num_key_value_heads=4, max_position_embeddings=1024), dtype=torch.bfloat16)
+    llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+                                       num_key_value_heads=2, max_position_embeddings=1024), dtype=torch.bfloat16)
     args = mx.default_args(max_length=16, min_new_tokens=4, max_new_tokens=8, context_pair=0, freeze_vm=True, llm_freeze=True,
                            proj="qformer", instruction="Generate a report .")
     m = R2GenCSR(args, tokenizer=WordTokenizer(), llm=llm, encoder=enc).to(DEV)

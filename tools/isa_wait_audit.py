@@ -1,6 +1,6 @@
 """Dev tool (round 3): static audit of the compiled kernels for waits that defeat a prefetch.  No GPU needed.
 
-    python tools/isa_wait_audit.py [file.hip ...]            # default: every csrc/*.hip; compiles with -save-temps into build_tmp/
+    python tools/isa_wait_audit.py [file.hip ...]            # default: every csrc/*.hip; compiles with -save-temps into /tmp/mxvl_isa_audit
     python tools/isa_wait_audit.py --trace scan_bwd.hip <kernel-name-substring>     # loads / waits / barriers / MFMA blocks in order
 
 hipcc (SIInsertWaitcnts) places `s_waitcnt vmcnt(N)` statically.  Three source patterns made it wait for a load right where the
@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "medical_image_analysis_amd", "csrc")
-TMP = os.path.join(ROOT, "build_tmp")
+TMP = os.environ.get("MXVL_ISA_TMP", "/tmp/mxvl_isa_audit")     # outside the repository: -save-temps dumps are 40+ MB and every gpurun pushes the tree
 
 
 def compile_s(src):
