@@ -380,8 +380,9 @@ class _KernelStepper(_SearchFusion):
         self.vc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
         self.x = torch.zeros(rows, self.hidden, **bf)
         self.x2 = torch.zeros(rows, self.hidden, **bf)
-        import os
-        self.batched = rows > int(os.environ.get("MXVL_DECODE_GEMV_MAX_ROWS", "8")) or rows > 8
+        # rows > 8 need the matrix-core projections; below that they are still ~3 % faster per token than the GEMV kernels wherever
+        # their LDS-DMA form applies (K % 64 == 0: every real decoder width) -- 5.2-6.2 TB/s against 4.4-5 of the weight stream
+        self.batched = rows > 8 or (self.hidden % 64 == 0 and self.inter % 64 == 0 and (self.H * self.D) % 64 == 0)
         self.xn = torch.zeros(rows, self.hidden, **bf) if self.batched else None      # RMSNorm output ahead of an MFMA projection
         # fp32 sums of the K-split o_proj / down_proj (zero between uses: the folding norm clears what it reads)
         self.acc = torch.zeros(rows, self.hidden, dtype=torch.float32, device=dev) if self.batched else None
@@ -522,7 +523,9 @@ class _KernelStepper(_SearchFusion):
         a = self._abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
         a.scale = self.D ** -0.5
-        a.beams = self.beams if 2 <= self.beams <= 5 else 0      # the beams of a sample share a workgroup and their common cache lines
+        # the beams of a sample share a workgroup (and the cache lines they have in common) once head x sample workgroups fill the
+        # chip; below that a workgroup per (head, row) keeps more requests in flight (batch 1 x beam 3: 9 vs 15 us per layer)
+        a.beams = self.beams if (2 <= self.beams <= 5 and self.H * (self.rows // self.beams) >= 128) else 0
         a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
