@@ -362,7 +362,8 @@ int mxvl_beam_step(const mxvl_beam_desc *desc, void *hip_stream);
  * 110-116 `x + mixer(norm1(x))`, `x + mlp(norm2(x))`; the reference's fused_add_norm path pairs them the same way):
  *   h = x + branch (branch may be NULL: h is x and is not written);  n = (h - mean) * rstd * gamma + beta.
  * res_dtype is the dtype of x, h, dx, dh; branch_dtype of branch / dbranch; out_dtype of n / dn (MXVL_F32 | MXVL_BF16,
- * combinations f32/f32/f32, f32/bf16/bf16, f32/f32/bf16, bf16/bf16/bf16); cols % 256 == 0, cols <= 2048.
+ * combinations f32/f32/f32, f32/bf16/bf16, f32/f32/bf16, bf16/bf16/bf16, and for fp16 autocast f32/f16/f16, f32/f32/f16);
+ * cols % 256 == 0, cols <= 2048.
  * Backward: dx = dh + LN'(dn) (dh may be NULL), optionally also written in the branch dtype to dbranch; dgamma/dbeta
  * leave as n_partials = mxvl_add_layernorm_partials(rows) partial rows the caller sums. */
 typedef struct mxvl_add_ln_desc {

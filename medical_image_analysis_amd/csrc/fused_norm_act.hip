@@ -450,6 +450,9 @@ static int dispatch_ln(bool bwd, const void* args, int rows, int C, int res_dt, 
   if (res_dt == MXVL_F32 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<float, bf16_t, bf16_t>(bwd, args, rows, C, s);
   if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_BF16) return dispatch_k<float, float, bf16_t>(bwd, args, rows, C, s);
   if (res_dt == MXVL_BF16 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<bf16_t, bf16_t, bf16_t>(bwd, args, rows, C, s);
+  // fp16 autocast (the ViT-MAE recipe: HD_Xray_Pretrain_MAE/pretrain/main.py:211-213,317): fp32 residual stream, fp16 branch / n
+  if (res_dt == MXVL_F32 && br_dt == MXVL_F16 && out_dt == MXVL_F16) return dispatch_k<float, f16_t, f16_t>(bwd, args, rows, C, s);
+  if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_F16) return dispatch_k<float, float, f16_t>(bwd, args, rows, C, s);
   return MXVL_ERR_DTYPE;
 }
 

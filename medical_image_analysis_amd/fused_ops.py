@@ -15,7 +15,8 @@ import torch
 from . import _abi, autograd_util
 
 _LN_DTYPES = {(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
-              (torch.float32, torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16, torch.bfloat16)}
+              (torch.float32, torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16, torch.bfloat16),
+              (torch.float32, torch.float16, torch.float16), (torch.float32, torch.float32, torch.float16)}     # fp16 autocast (ViT-MAE)
 
 
 def add_layer_norm_supported(x, cols):

@@ -121,3 +121,52 @@ def test_mae_patch_loss_kernel_matches_reference_forward_loss(N, C, HW, p, dtype
     (ref * w).sum().backward()
     tol = 1e-6 if dtype == torch.float32 else (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10)
     assert_close(pa.grad, pb.grad, tol * float(pb.grad.float().abs().max()), tol, "d pred")
+
+
+@pytest.mark.gpu
+def test_mae_under_fp16_autocast_and_grad_scaler_like_the_reference_recipe():
+    """HD_Xray_Pretrain_MAE/pretrain/main.py:211-213,317: the ViT-MAE stage trains under torch.cuda.amp.autocast() (fp16) with a
+    GradScaler.  Forward under fp16 autocast against the reference's fp32 golden (mae_d2_1280) within fp16 resolution -- the HIP
+    kernels on the path (flash attention f16, add + LayerNorm f32/f16/f16, index / patch-loss kernels) have fp16 instantiations --
+    then engine steps with amp_dtype=float16: finite loss, live scaler, parameters move."""
+    from medical_image_analysis_amd.mae import MaskedAutoencoderViT, SmallPatchEmbed
+    from medical_image_analysis_amd.pretrain_engine import PretrainEngine
+    import torch.nn as nn
+    g = load_golden("mae_d2_1280")
+    m = MaskedAutoencoderViT(embed_dim=64, depth=2, num_heads=4, decoder_embed_dim=64, decoder_depth=1,
+                             decoder_num_heads=4, norm_pix_loss=True)
+    m.patch_embed = SmallPatchEmbed(1, 64, 32)
+    m.load_state_dict(_sd(g), strict=True)
+    m = m.to(DEV).eval()
+    img = torch.randn(1, 1, 1280, 1280, generator=torch.Generator().manual_seed(int(g["img_seed"]))).to(DEV)
+    for tag in ("rand", "yiliao"):
+        mt, ro, ri, seed = g[f"{tag}_args"].tolist()
+        mt, seed = int(mt), int(seed)
+        torch.manual_seed(seed)
+        if mt == 1:
+            idx_out, idx_in = m.region_indices(400, "cpu")
+            noise = (torch.rand(1, idx_out.numel()).to(DEV), torch.rand(1, idx_in.numel()).to(DEV))
+        else:
+            noise = torch.rand(1, 400).to(DEV)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, mask = m(img, mt, ro, ri, noise)
+        assert torch.equal(mask.cpu(), g[f"{tag}_mask"]), f"{tag}: the mask is index work: bit-exact under any autocast"
+        assert_close(loss.float(), g[f"{tag}_loss"], 2e-2, 2e-2, f"{tag}: loss under fp16 autocast")
+
+    class MaeLoss(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            loss, mask = self.net(x, 1, 0.85, 0.95)
+            return ((loss * mask).sum() / mask.sum()).reshape(1)
+
+    model = MaeLoss(m).train()
+    eng = PretrainEngine(model, lr=1e-3, amp_dtype=torch.float16, device=DEV)
+    assert eng.scaler is not None
+    before = m.blocks[0].mlp.fc1.weight.detach().clone()
+    x = torch.randn(2, 1, 1280, 1280, device=DEV)
+    losses = [float(eng.step(x)) for _ in range(3)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert eng.scaler.get_scale() > 0 and not torch.equal(before, m.blocks[0].mlp.fc1.weight.detach())
