@@ -95,7 +95,7 @@ PRETRAIN_WORKLOADS = {
 }
 MAE_WORKLOADS = {
     # name: (per-GPU batch, description)
-    "mae_vit_large_1280": (128, "HD_Xray_Pretrain_MAE: mae_vit_large_patch16 (1280x1280 1-channel X-rays, 64x64 patches -> 400 tokens, "
+    "mae_vit_large_1280": (256, "HD_Xray_Pretrain_MAE: mae_vit_large_patch16 (1280x1280 1-channel X-rays, 64x64 patches -> 400 tokens, "
                                 "encoder 1024x24x16h, decoder 512x8x16h), chest-region masking (mask_type 1, ratios 0.85 / 0.95), the reference's "
                                 "arithmetic: fp16 autocast + GradScaler (pretrain/main.py:211-213,317); per-GPU batch sized for the 288 GB of an "
                                 "MI355X (the reference's default of 2 per 24 GB card leaves the 47-token encoder GEMMs launch-bound)"),

@@ -259,7 +259,7 @@ struct CrossAttnArgs {
   uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
-constexpr int kBeamAttnWaves = 16;   // the beams kernel: a workgroup reads nb rows' worth of cache -- twice the position groups per trip
+constexpr int kBeamAttnWaves = 8;    // (16 waves = 128 VGPRs per lane: the nb running softmax states spill; measured 17.8 vs 16.7 us even before that)
 constexpr int kAttnWaves = 8;    // (16 waves x 8 positions per group -- one trip of cache loads for a 358-position report instead of
                                  //  three -- measured slower: 9.7 vs 8.9 us per launch, profiles/r03_decode_timeline.txt)
 
@@ -416,6 +416,22 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
   const int group = p.H / p.Hkv, hk = h / group;
   const int pos = (int)*p.pos;
   if (tid == 0) s_nsh = pos;
+  // raw RoPE operands of this thread's (row, dim) items: unconditional loads (clamped index), consumed after the slot sweep
+  constexpr int RI = (NB * D + NT - 1) / NT;
+  uint16_t rope_q[RI], rope_qo[RI], rope_k[RI], rope_ko[RI], rope_v[RI];
+  float rope_c[RI], rope_s[RI];
+#pragma unroll
+  for (int it = 0; it < RI; ++it) {
+    const int i = tid + it * NT < NB * D ? tid + it * NT : 0;
+    const int r = i / D, d = i - r * D, half = D / 2, m = m0 + r;
+    const int dp = d < half ? d + half : d - half;
+    const size_t row = (size_t)m * (p.H + 2 * p.Hkv) * D;
+    const uint16_t* q = p.qkv + row + (size_t)h * D;
+    const uint16_t* kn = p.qkv + row + (size_t)(p.H + hk) * D;
+    const uint16_t* vn = p.qkv + row + (size_t)(p.H + p.Hkv + hk) * D;
+    rope_q[it] = q[d]; rope_qo[it] = q[dp]; rope_k[it] = kn[d]; rope_ko[it] = kn[dp]; rope_v[it] = vn[d];
+    rope_c[it] = p.cosv[(size_t)m * D + d]; rope_s[it] = p.sinv[(size_t)m * D + d];
+  }
   __syncthreads();
   for (int t = tid; t <= pos; t += NT) {
     int64_t mk[NB];
@@ -434,29 +450,27 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
     }
     if (!same && t < pos) atomicMin(&s_nsh, t);
   }
-  // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group
-  for (int i = tid; i < NB * D; i += NT) {
-    const int r = i / D, d = i - r * D, half = D / 2, m = m0 + r;
-    const int dp = d < half ? d + half : d - half;
-    const size_t row = (size_t)m * (p.H + 2 * p.Hkv) * D;
-    const uint16_t* q = p.qkv + row + (size_t)h * D;
-    const uint16_t* kn = p.qkv + row + (size_t)(p.H + hk) * D;
-    const uint16_t* vn = p.qkv + row + (size_t)(p.H + p.Hkv + hk) * D;
-    const uint16_t rq = q[d], rqo = q[dp], rk = kn[d], rko = kn[dp], rv = vn[d];
-    const float rc = p.cosv[(size_t)m * D + d], rs = p.sinv[(size_t)m * D + d];
-    const float c = bf2f(f2bf(rc)), sn = bf2f(f2bf(rs));
-    const float qd = bf2f(rq), qo = d < half ? -bf2f(rqo) : bf2f(rqo);
-    const float kd = bf2f(rk), ko = d < half ? -bf2f(rko) : bf2f(rko);
-    const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * sn))));
-    const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * sn))));
-    sq[i] = qr * p.scale;
-    if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
-    sk[i] = kr;
-    sv[i] = bf2f(rv);
-    if (h % group == 0) {
-      const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
-      p.kc[o] = f2bf(kr);
-      p.vc[o] = rv;
+  // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group.  (The raw operands were
+  // requested BEFORE the slot-table sweep above: one memory round trip for both instead of two in a row.)
+#pragma unroll
+  for (int it = 0; it < RI; ++it) {
+    const int i = tid + it * NT;
+    if (i < NB * D) {
+      const int r = i / D, d = i - r * D, half = D / 2, m = m0 + r;
+      const float c = bf2f(f2bf(rope_c[it])), sn = bf2f(f2bf(rope_s[it]));
+      const float qd = bf2f(rope_q[it]), qo = d < half ? -bf2f(rope_qo[it]) : bf2f(rope_qo[it]);
+      const float kd = bf2f(rope_k[it]), ko = d < half ? -bf2f(rope_ko[it]) : bf2f(rope_ko[it]);
+      const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * sn))));
+      const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * sn))));
+      sq[i] = qr * p.scale;
+      if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
+      sk[i] = kr;
+      sv[i] = bf2f(rope_v[it]);
+      if (h % group == 0) {
+        const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
+        p.kc[o] = f2bf(kr);
+        p.vc[o] = rope_v[it];
+      }
     }
   }
   __syncthreads();
@@ -491,8 +505,23 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
     }
   };
+  // the first trip over the positions on which the beams differ is requested NOW and folded after the shared positions: its
+  // round trip hides behind theirs (a lane group without such a position re-reads the sample's first cache line)
+  uint4 okq[NB], ovq[NB];
+  bool olive[NB];
+  {
+    const int t = nsh + g;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int sl = t < pos ? ssl[r * T + t] : -1;
+      olive[r] = sl >= 0;
+      const size_t a = (((size_t)(olive[r] ? sl : m0) * p.Hkv + hk) * T + (olive[r] ? t : 0)) * D + sub * 8;
+      okq[r] = *(const uint4*)(p.kc + a);
+      ovq[r] = *(const uint4*)(p.vc + a);
+    }
+  }
   // ---- positions every beam shares: one load, nb folds ------------------------------------------------------------------------
-  constexpr int U = 4;
+  constexpr int U = 4;                   // (8 positions in flight per lane group measured slower: 18.9 vs 16.6 us per layer at 6 x 3 rows)
   for (int t0 = g; t0 < nsh; t0 += NG * U) {
     uint4 kq[U], vq[U];
     bool live[U];
@@ -515,7 +544,14 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
     }
   }
   // ---- positions on which the beams differ: per beam -----------------------------------------------------------------------------
-  for (int t = nsh + g; t < pos; t += NG) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    float kf[8], vf[8];
+    unpack(okq[r], kf);
+    unpack(ovq[r], vf);
+    fold(r, olive[r], kf, vf);
+  }
+  for (int t = nsh + g + NG; t < pos; t += NG) {
     uint4 kq[NB], vq[NB];
     bool live[NB];
 #pragma unroll
