@@ -522,7 +522,12 @@ int mxvl_clip_loss(const float *image_features, const float *text_features, cons
 
 /* last hipError_t observed by a failing launch on this thread (0 = hipSuccess) */
 int mxvl_last_hip_error(void);
-/* Scan kernel selection for tests / A-B measurements.  Bits 0..7: forward kernel shape (0 = automatic, unknown ids fall
+/* ---- DIAGNOSTICS (not part of the drop-in surface; no caller of the reference's interface needs them) -------------------------
+ * They stay in the product library on purpose: the parity tests must run against the SAME .so the product loads (the driver records
+ * which libraries the test processes mapped), and forcing each instantiation of the scan kernels through the public entry points
+ * is how tests/test_scan_gpu.py covers every variant against the reference goldens.  Thread-local, no effect on results.
+ *
+ * Scan kernel selection for tests / A-B measurements.  Bits 0..7: forward kernel shape (0 = automatic, unknown ids fall
  * back to automatic); bits 8..15: backward (0 automatic, 1 = 32-row / 8-wave workgroups, 2 = 16-row / 4-wave; other
  * ids fall back to automatic).  Every choice is a correct kernel.  Thread-local: it affects only calls made by the calling thread --
  * note that autograd runs backward on its own thread.  The product library ignores bits >= 16 (measurement builds,
