@@ -428,7 +428,7 @@ def run_pretrain(args, rank, world, dev, dist):
                    else args.workload)
     if secondary is not None:
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-                                                      "dtype", "config", "roofline")}
+                                                      "dtype", "config", "roofline", "cpu_baseline") if k in secondary}
     if cpu_sd is not None:
         out["cpu_baseline"] = cpu_baseline_pretrain(cpu_sd, img, patch, depth, cpu_trainable)
     print(json.dumps(out))

@@ -200,7 +200,6 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
   const int cols_per_wg = (p.swiglu ? R / 2 : R) * 16;
   const int n0 = blockIdx.x * cols_per_wg;
   char* ring = dg_smem + wave * PF * STAGE;
-
   const char* src[R][2];                    // DMA sources: call h of tile r covers rows 8 h .. 8 h + 7
   {
     const int rl = lane >> 3, ul = lane & 7;
@@ -317,44 +316,59 @@ struct RmsNormArgs {
   const uint16_t* res;
   uint16_t* x_out;
 };
-__global__ __launch_bounds__(256) void decode_rmsnorm_kernel(const RmsNormArgs p) {
-  __shared__ float s_part[4];
+// (Tried and removed, profiles/r04_decode_fused_norm_rejected_timeline.txt: for rows <= 8 the norm -- and the fold -- in the PROLOGUE of the
+//  consuming projection, rows in LDS, no RMSNorm launches at all: 164 instead of 229 launches per token, but every workgroup of
+//  every projection then starts with a memory round trip + two barriers while its weight ring is already full -- gate / up 32 -> 42 us,
+//  qkv 17.5 -> 24 us, the token 3.13 -> 3.39 ms.  A launch boundary costs less than a stalled stream on 256 CUs.)
+// 1024 threads per row, 8 columns per thread and trip (K <= 16384 in two trips): EVERY load of the row -- the fp32 sums, the
+// residual, the gain -- is requested before anything is stored or reduced; the first version walked the row in 256-thread trips of
+// load -> store -> load, three to four serialised round trips in a kernel that runs 65 times per token (4.9 us each in the
+// step's trace, a tenth of the batch-1 token).
+__global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs p) {
+  constexpr int NT = 1024, MAXV = 2;
+  __shared__ float s_part[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
-  const uint16_t* x = p.x + (size_t)m * p.K;
-  constexpr int MAXV = 8;                       // 8 x 256 x 8 columns: K <= 16384
-  uint4 xr[MAXV], gr[MAXV];
-  float s = 0.0f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {              // the gain goes out with the row: one memory round trip for the kernel, not two
-    const int k = (i * 256 + tid) * 8;
-    gr[i] = *(const uint4*)(p.g + (k < p.K ? k : 0));
-  }
+  uint4 xr[MAXV], gr[MAXV], rr[MAXV];
+  float4 a0[MAXV], a1[MAXV];
+  bool on[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 256 + tid) * 8;
+    const int k = (i * NT + tid) * 8;
+    on[i] = k < p.K;
+    const int kc = on[i] ? k : 0;                       // unconditional loads (clamped): nothing waits behind a branch
+    gr[i] = *(const uint4*)(p.g + kc);
     if (p.acc) {
-      xr[i] = make_uint4(0, 0, 0, 0);
-      if (k < p.K) {
+      const float* ap = p.acc + (size_t)m * p.K + kc;
+      a0[i] = *(const float4*)ap;
+      a1[i] = *(const float4*)(ap + 4);
+      rr[i] = *(const uint4*)(p.res + (size_t)m * p.K + kc);
+    } else {
+      xr[i] = *(const uint4*)(p.x + (size_t)m * p.K + kc);
+    }
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (p.acc) {
+      const float av[8] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w, a1[i].x, a1[i].y, a1[i].z, a1[i].w};
+      const uint32_t rw[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = dg_bf2f(dg_f2bf(av[2 * j])) + dg_bf2f((uint16_t)rw[j]);
+        const float hi = dg_bf2f(dg_f2bf(av[2 * j + 1])) + dg_bf2f((uint16_t)(rw[j] >> 16));
+        o[j] = (uint32_t)dg_f2bf(lo) | ((uint32_t)dg_f2bf(hi) << 16);
+      }
+      xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+      if (on[i]) {
+        const int k = (i * NT + tid) * 8;
         float* ap = p.acc + (size_t)m * p.K + k;
-        const float4 a0 = *(const float4*)ap, a1 = *(const float4*)(ap + 4);
-        const uint4 rv = *(const uint4*)(p.res + (size_t)m * p.K + k);
         *(float4*)ap = make_float4(0.f, 0.f, 0.f, 0.f);
         *(float4*)(ap + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float lo = dg_bf2f(dg_f2bf(av[2 * j])) + dg_bf2f((uint16_t)rw[j]);
-          const float hi = dg_bf2f(dg_f2bf(av[2 * j + 1])) + dg_bf2f((uint16_t)(rw[j] >> 16));
-          o[j] = (uint32_t)dg_f2bf(lo) | ((uint32_t)dg_f2bf(hi) << 16);
-        }
-        xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
         *(uint4*)(p.x_out + (size_t)m * p.K + k) = xr[i];
       }
-    } else {
-      xr[i] = k < p.K ? *(const uint4*)(x + k) : make_uint4(0, 0, 0, 0);
     }
+    if (!on[i]) xr[i] = make_uint4(0, 0, 0, 0);
     const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -366,14 +380,15 @@ __global__ __launch_bounds__(256) void decode_rmsnorm_kernel(const RmsNormArgs p
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane == 0) s_part[wave] = s;
   __syncthreads();
-  const float tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+  float tot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) tot += s_part[w];
   const float rstd = rsqrtf(tot / (float)p.K + p.eps);
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int k = (i * 256 + tid) * 8;
-    if (k < p.K) {
-      const uint4 gv = gr[i];
-      const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+    if (on[i]) {
+      const int k = (i * NT + tid) * 8;
+      const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w}, gw[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w};
       uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

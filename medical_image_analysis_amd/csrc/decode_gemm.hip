@@ -58,8 +58,8 @@ static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s
 int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
   if (d->rows <= 0 || d->rows > 80 || d->K < 32 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;                      // 16-byte fragments
-  if (d->norm_weight) return MXVL_ERR_UNSUPPORTED;                      // rows > 8: mxvl_decode_rmsnorm runs ahead of the projection
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
+  if (d->norm_weight) return MXVL_ERR_UNSUPPORTED;                      // the matrix-core kernels take rows mxvl_decode_rmsnorm normalised
   if ((long long)d->N * d->K > 0x7fffffffLL * 16) return MXVL_ERR_SHAPE;
   DecodeGemmArgs a;
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32;
@@ -97,6 +97,6 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
   a.rows = d->rows; a.K = d->K; a.eps = d->eps;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->weight; a.y = (uint16_t*)d->y;
   a.acc = (float*)d->acc; a.res = (const uint16_t*)d->residual; a.x_out = (uint16_t*)d->x_out;
-  hipLaunchKernelGGL(decode_rmsnorm_kernel, dim3(d->rows), dim3(256), 0, (hipStream_t)hip_stream, a);
+  hipLaunchKernelGGL(decode_rmsnorm_kernel, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
