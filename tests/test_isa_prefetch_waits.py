@@ -1,7 +1,7 @@
 """Static guard (no GPU): the kernels that keep the next tile in flight must not wait for it before the work it is meant to hide.
 
 hipcc places `s_waitcnt vmcnt` statically, and three source patterns made it wait directly behind a prefetch in every kernel of
-this repo that had one (DESIGN.md "Round 3" table; tools/isa_wait_audit.py).  The fixes are source idioms a later edit can undo
+this repo that had one (docs/DESIGN_HISTORY.md "Round 3" table; tools/isa_wait_audit.py).  The fixes are source idioms a later edit can undo
 without failing any numerical test -- the results do not change, only the overlap does -- so the compiled ISA is checked here:
 between the requests of the next tile inside the main loop and the first `vmcnt` wait after them there must be the loop's
 arithmetic (MFMAs, or the scan's state loop)."""
