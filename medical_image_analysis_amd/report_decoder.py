@@ -355,7 +355,9 @@ class _KernelStepper(_SearchFusion):
                 return False
         # rows <= 8: GEMV kernels with the activations of all rows in LDS; 9..80 rows (the reference's decode batches: 6 x 3,
         # 8 x 3, 16 x 3, 16 x 5 -- launch/*.sh, configs/config.py:11-12,50): MFMA projections (csrc/decode_gemm.h)
-        fits = rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024 if rows <= 8 else \
+        # (rows <= 8 on the MFMA kernels as well wherever every K is a multiple of 64: no LDS bound on the activations there)
+        mfma8 = cfg.hidden_size % 64 == 0 and cfg.intermediate_size % 64 == 0 and cfg.hidden_size <= 16384
+        fits = (mfma8 or rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024) if rows <= 8 else \
             (rows <= 80 and min(cfg.hidden_size, cfg.intermediate_size) >= 32 and cfg.hidden_size <= 16384)
         return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and D in (64, 128, 256)
                 and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and fits)
@@ -702,8 +704,9 @@ class ReportDecoder(nn.Module):
         device idled per token while the host read one byte are gone."""
         if not bool(state.unfinished):
             return
-        flags = [torch.empty(1, dtype=torch.bool).pin_memory() for _ in range(2)]
-        events = [torch.cuda.Event() for _ in range(2)]
+        if getattr(state, "_look", None) is None:          # pinned flags + events live with the (cached) search state
+            state._look = ([torch.empty(1, dtype=torch.bool).pin_memory() for _ in range(2)], [torch.cuda.Event() for _ in range(2)])
+        flags, events = state._look
         stepper.step_search(state)                       # (the first call runs eagerly and captures the graph)
         k = 0
         flags[0].copy_(state.unfinished.view(1), non_blocking=True)
