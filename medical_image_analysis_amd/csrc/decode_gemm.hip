@@ -36,18 +36,30 @@ static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
 
 template <int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
-  // R = weight tiles per workgroup: the activation re-read from L2 per weight byte is MT / R, the number of workgroups
-  // N / (16 R) x splits -- keep the 256 CUs covered, then take the widest R
+  // R = weight tiles per workgroup.  Two effects, both measured (tools/decode_gemm_bench.py A/B at 18 rows, profiles/r04_decode_gemm_r_sweep.txt):
+  // (1) a CU streams ~28 GB/s whatever it holds, so the workgroups must fill whole rounds of the 256 CUs -- 344 workgroups (gate / up
+  //     at R = 4: 88 CUs with two, 168 with one) run at 4.7 TB/s, 688 (R = 2) at 5.3, 256 (qkv at R = 3) at 5.2 against 4.3 for 384;
+  // (2) the activation re-read from L2 per weight byte is MT / R: at equal fill R = 4 beats R = 2 by 6 % (lm_head 5.73 vs 5.37 TB/s).
+  // score = fill of the last round x 1 / (1 + 0.06 MT / R); SwiGLU needs an even R (gate and up tiles of the same columns).
   const int tiles = (a.N + 15) / 16;
-  const long wgs4 = (long)(a.swiglu ? (tiles + 1) / 2 : (tiles + 3) / 4) * splits;
+  auto score = [&](int R) {
+    const long wgs = (long)(a.swiglu ? (tiles + R / 2 - 1) / (R / 2) : (tiles + R - 1) / R) * splits;
+    const long rounds = (wgs + 255) / 256;
+    return (double)wgs / (double)(rounds * 256) / (1.0 + 0.06 * MT / R);
+  };
   if (a.K % 64 == 0 && a.K >= 256) {
     constexpr int PFN = MT <= 2 ? 4 : 2;       // narrow workgroups: deeper rings while the activation fragments fit the registers
-    if (wgs4 >= 256) return launch_dma<MT, 4, 4, 2>(a, splits, s);
-    if (a.swiglu) return launch_dma<MT, 2, 4, PFN>(a, splits, s);
-    const long wgs3 = (long)((tiles + 2) / 3) * splits;
-    if (wgs3 >= 256) return launch_dma<MT, 3, 4, 2>(a, splits, s);
-    if ((long)((tiles + 1) / 2) * splits >= 256) return launch_dma<MT, 2, 4, PFN>(a, splits, s);
-    return launch_dma<MT, 1, 8, PFN>(a, splits, s);
+    int best = a.swiglu ? 2 : 1;
+    for (int R : {2, 3, 4}) {
+      if (a.swiglu && (R & 1)) continue;
+      if (score(R) > score(best) + 1e-9) best = R;
+    }
+    switch (best) {
+      case 4: return launch_dma<MT, 4, 4, 2>(a, splits, s);
+      case 3: return launch_dma<MT, 3, 4, 2>(a, splits, s);
+      case 2: return launch_dma<MT, 2, 4, PFN>(a, splits, s);
+      default: return launch_dma<MT, 1, 8, PFN>(a, splits, s);
+    }
   }
   if (a.swiglu) return tiles >= 768 ? launch_direct<MT, 4>(a, splits, s) : launch_direct<MT, 2>(a, splits, s);
   if (tiles >= 1536) return launch_direct<MT, 4>(a, splits, s);

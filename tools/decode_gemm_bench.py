@@ -4,6 +4,8 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medical_image_analysis_amd import _abi
 
+if os.environ.get('MXVL_LIB'):
+    _abi.LIB_PATH = os.environ['MXVL_LIB']
 lib = _abi.load()
 dev = "cuda:0"
 rows_list = [int(a) for a in sys.argv[1:]] or [18, 24, 48, 80]
@@ -39,7 +41,7 @@ def timeit(fn, n=48):
 
 
 bf = dict(dtype=torch.bfloat16, device=dev)
-shapes = [("qkv", 4096, 12288, False), ("o+res", 4096, 4096, False), ("gate/up swiglu", 4096, 11008, True),
+shapes = [("plain22016", 4096, 22016, False), ("qkv", 4096, 12288, False), ("o+res", 4096, 4096, False), ("gate/up swiglu", 4096, 11008, True),
           ("down+res", 11008, 4096, False), ("lm_head f32", 4096, 32000, False)]
 NL = 8   # rotate over NL weight copies so the 256 MB MALL does not serve re-reads
 for rows in rows_list:
@@ -63,7 +65,7 @@ for rows in rows_list:
             if swi: torch.nn.functional.linear(x, W2s[j])
         us_t = timeit(fl, 48)
         print(f"rows={rows:3d} {name:16s} K={K:6d} N={N:6d}: {us:8.1f} us  {byt / us / 1e3:8.1f} GB/s   | torch linear {us_t:8.1f} us {byt / us_t / 1e3:8.1f} GB/s")
-        mult = 32 if name != "lm_head f32" else 1
+        mult = 0 if name == "plain22016" else (32 if name != "lm_head f32" else 1)     # (plain22016: the gate + up bytes without the SwiGLU epilogue, not part of a token)
         tot_us += us * mult; tot_b += byt * mult
         del Ws, W2s
     x = torch.randn(rows, 4096, **bf); g = torch.ones(4096, **bf); y = torch.empty_like(x)
