@@ -376,6 +376,9 @@ typedef struct mxvl_add_ln_bwd_desc {
   int32_t rows, cols, res_dtype, branch_dtype, out_dtype, n_partials;
   const void *dn, *dh, *h, *gamma, *mean, *rstd;
   void *dx, *dbranch, *partial_dgamma, *partial_dbeta; /* partials: (n_partials, cols) fp32 */
+  void *partial_dbranch;    /* ABI v6, optional (n_partials, cols) fp32: column sums of the branch gradient AS WRITTEN (rounded to the
+                               branch dtype when dbranch is given, else dx) = the bias gradient of the linear layer whose output was
+                               the branch (models_mamba.py:110-116: mixer out_proj / SwiGLU w3) */
 } mxvl_add_ln_bwd_desc;
 int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc *desc, void *hip_stream);
 int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc *desc, void *hip_stream);

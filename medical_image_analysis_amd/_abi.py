@@ -177,6 +177,7 @@ class AddLnBwdDesc(ctypes.Structure):
         ("n_partials", c_int32),
         ("dn", c_void_p), ("dh", c_void_p), ("h", c_void_p), ("gamma", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
         ("dx", c_void_p), ("dbranch", c_void_p), ("partial_dgamma", c_void_p), ("partial_dbeta", c_void_p),
+        ("partial_dbranch", c_void_p),
     ]
 
 

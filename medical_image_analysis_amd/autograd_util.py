@@ -23,3 +23,15 @@ def apply(fn, *args):
 def wants_grad(ctx, upto=None) -> bool:
     need = ctx.needs_input_grad if upto is None else ctx.needs_input_grad[:upto]
     return getattr(_state, "on", True) and any(need)
+
+
+def cast_param(w, dtype):
+    """w in `dtype` for a GEMM.  A parameter whose low-precision copy was refreshed right after the optimizer step
+    (pretrain_engine.PretrainEngine._refresh_casts: ONE multi-tensor kernel for all weights instead of one cast launch per weight
+    and forward) and has not changed since (`_version`) is served from that copy."""
+    if w.dtype == dtype:
+        return w
+    lp = getattr(w, "_mxvl_lp", None)
+    if lp is not None and lp[0] == w._version and lp[1].dtype == dtype:
+        return lp[1]
+    return w.to(dtype)

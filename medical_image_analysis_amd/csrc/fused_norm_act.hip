@@ -28,6 +28,8 @@ struct NormBwdArgs {
   const float *gamma, *mean, *rstd;
   void *dx, *dbr;              // grad wrt x (res dtype), optional copy in the branch dtype
   float *pgamma, *pbeta;       // (gridDim.x, C) partial sums
+  float* pdbr;                 // optional (gridDim.x, C): column sums of the branch gradient as written (= the bias gradient of the
+                               // linear that produced the branch: its backward no longer re-reads rows x C to sum it)
 };
 
 __device__ inline float wsum(float v) {
@@ -99,17 +101,23 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const NormArgs p) {
   }
 }
 
+template <typename T> __device__ inline float ln_round_trip(float v) {   // value after a round trip through dtype T
+  if constexpr (sizeof(T) == 4) return v;
+  else if constexpr (__is_same(T, bf16_t)) return __builtin_bit_cast(float, cvt_pk_bf16(v, 0.0f) << 16);
+  else return (float)(_Float16)v;
+}
+
 template <typename res_t, typename br_t, typename out_t, int K>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
-  __shared__ float sred[2][4][K * 256];   // [gamma|beta][wave][column]
+  __shared__ float sred[2][4][K * 256];   // [gamma|beta][wave][column]; re-used for the branch-gradient sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = p.C;
-  float g[K][4], ag[K][4], ab[K][4];
+  float g[K][4], ag[K][4], ab[K][4], ad[K][4];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     ld4v<float>(p.gamma + (k * 64 + lane) * 4, g[k]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { ag[k][j] = 0.0f; ab[k][j] = 0.0f; }
+    for (int j = 0; j < 4; ++j) { ag[k][j] = 0.0f; ab[k][j] = 0.0f; ad[k][j] = 0.0f; }
   }
   for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
     const float mean = p.mean[row], rstd = p.rstd[row];
@@ -146,6 +154,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
       }
       st4v<res_t>(dxr + (k * 64 + lane) * 4, o);
       if (p.dbr) st4v<br_t>((br_t*)p.dbr + (size_t)row * C + (k * 64 + lane) * 4, o);
+      if (p.pdbr) {      // uniform: the sum of the values the consumer will read (the branch dtype's rounding of dx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad[k][j] += p.dbr ? ln_round_trip<br_t>(o[j]) : ln_round_trip<res_t>(o[j]);
+      }
     }
   }
 #pragma unroll
@@ -157,6 +169,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
   for (int c = threadIdx.x; c < C; c += 256) {
     p.pgamma[(size_t)blockIdx.x * C + c] = (sred[0][0][c] + sred[0][1][c]) + (sred[0][2][c] + sred[0][3][c]);
     p.pbeta[(size_t)blockIdx.x * C + c] = (sred[1][0][c] + sred[1][1][c]) + (sred[1][2][c] + sred[1][3][c]);
+  }
+  if (p.pdbr) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) *(float4*)&sred[0][wave][(k * 64 + lane) * 4] = make_float4(ad[k][0], ad[k][1], ad[k][2], ad[k][3]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      p.pdbr[(size_t)blockIdx.x * C + c] = (sred[0][0][c] + sred[0][1][c]) + (sred[0][2][c] + sred[0][3][c]);
   }
 }
 
@@ -479,7 +499,7 @@ int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc* d, void* hip_stream) {
   NormBwdArgs a;
   a.rows = d->rows; a.C = d->cols; a.dn = d->dn; a.dh = d->dh; a.h = d->h; a.gamma = (const float*)d->gamma;
   a.mean = (const float*)d->mean; a.rstd = (const float*)d->rstd; a.dx = d->dx; a.dbr = d->dbranch;
-  a.pgamma = (float*)d->partial_dgamma; a.pbeta = (float*)d->partial_dbeta;
+  a.pgamma = (float*)d->partial_dgamma; a.pbeta = (float*)d->partial_dbeta; a.pdbr = (float*)d->partial_dbranch;
   return dispatch_ln(true, &a, d->rows, d->cols, d->res_dtype, d->branch_dtype, d->out_dtype, (hipStream_t)hip_stream);
 }
 

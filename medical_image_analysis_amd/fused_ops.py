@@ -79,13 +79,15 @@ class _AddLayerNorm(torch.autograd.Function):
         dx = torch.empty_like(h)
         dbr = torch.empty((rows, C), dtype=br_dtype, device=h.device) if has_br and br_dtype != h.dtype else None
         n_part = lib.mxvl_add_layernorm_partials(rows)
-        pgb = torch.empty((2, n_part, C), dtype=torch.float32, device=h.device)     # dgamma | dbeta partials: ONE reduction below
+        # dgamma | dbeta | (with a branch) column sums of the branch gradient: partials, ONE reduction below
+        pgb = torch.empty((3 if has_br else 2, n_part, C), dtype=torch.float32, device=h.device)
         pg, pb = pgb[0], pgb[1]
         d = _abi.AddLnBwdDesc()
         d.rows, d.cols, d.n_partials = rows, C, n_part
         d.res_dtype, d.branch_dtype, d.out_dtype = _abi.dtype_code(h.dtype), _abi.dtype_code(br_dtype), _abi.dtype_code(out_dtype)
         d.dn, d.dh, d.h, d.gamma, d.mean, d.rstd = dn2.data_ptr(), _abi.ptr(dh2), h.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         d.dx, d.dbranch, d.partial_dgamma, d.partial_dbeta = dx.data_ptr(), _abi.ptr(dbr), pg.data_ptr(), pb.data_ptr()
+        d.partial_dbranch = pgb[2].data_ptr() if has_br else None
         with torch.cuda.device(h.device):
             _abi.check(lib.mxvl_add_layernorm_bwd(ctypes.byref(d), _abi.stream_ptr(h.device)), "mxvl_add_layernorm_bwd")
         gb = pgb.sum(1)
@@ -97,6 +99,10 @@ class _AddLayerNorm(torch.autograd.Function):
             dbranch = (dbr if dbr is not None else dx).view(shape)
             if dbranch.dtype != br_orig:
                 dbranch = dbranch.to(br_orig)
+            else:
+                # the linear layer that produced the branch needs sum_rows(dbranch) for its bias: it rides on the tensor it belongs to
+                # (selective_scan_interface.bias_grad reads it; a tensor autograd had to accumulate into is a new object without it)
+                dbranch._mxvl_colsum = gb[2]
         return dx_v, dbranch, dgamma, dbeta, None, None
 
 
@@ -178,7 +184,7 @@ class _LinearSwiGLU(torch.autograd.Function):
         lib = _abi.load()
         cd = _compute_dtype(x)
         x2 = x.reshape(-1, x.shape[-1]).to(cd)
-        w = weight.to(cd)
+        w = autograd_util.cast_param(weight, cd)
         needs_grad = autograd_util.wants_grad(ctx)
         H = w.shape[0] // 2
         # ONE MFMA kernel: GEMM + bias + gate (csrc/gemm_swiglu.hip).  Measured per ARM layer (profiles/r03_gemm_swiglu_bench.txt):

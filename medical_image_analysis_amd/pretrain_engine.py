@@ -114,12 +114,26 @@ class PretrainEngine:
         skip = model.no_weight_decay() if hasattr(model, "no_weight_decay") else ()
         self.optimizer = torch.optim.AdamW(param_groups_weight_decay(model, weight_decay, skip), lr=lr, betas=(0.9, 0.95),
                                            fused=bool(device is not None and torch.device(device).type == "cuda"))
+        self._cast_params = [p for p in model.parameters() if p.requires_grad and p.ndim >= 2 and p.is_cuda]
+        self._cast_shadow = None
         if self.world > 1:
             ids = [torch.device(device).index] if (device is not None and torch.device(device).type == "cuda") else None
             self.model = nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
                                                              gradient_as_bucket_view=True, broadcast_buffers=False)
         else:
             self.model = model
+
+    @torch.no_grad()
+    def _refresh_casts(self):
+        """Low-precision copies of every >= 2-D parameter (the GEMM weights) in ONE multi-tensor launch, right after the optimizer
+        step; the projections pick them up through autograd_util.cast_param (one cast kernel per weight and forward before)."""
+        if self.amp_dtype not in (torch.bfloat16, torch.float16) or not self._cast_params:
+            return
+        if self._cast_shadow is None:
+            self._cast_shadow = [torch.empty_like(p, dtype=self.amp_dtype) for p in self._cast_params]
+        torch._foreach_copy_(self._cast_shadow, self._cast_params)
+        for p, s_ in zip(self._cast_params, self._cast_shadow):
+            p._mxvl_lp = (p._version, s_)
 
     def start_epoch(self):
         """engine_pretrain.py:31 `optimizer.zero_grad()` + the iteration counter the schedule and the accumulation window read."""
@@ -161,6 +175,7 @@ class PretrainEngine:
                 if self.clip_grad is not None:
                     nn.utils.clip_grad_norm_(self.raw_model.parameters(), self.clip_grad)
                 self.optimizer.step()
+            self._refresh_casts()
             if acc > 1:
                 self.optimizer.zero_grad(set_to_none=True)
         if work is not None:

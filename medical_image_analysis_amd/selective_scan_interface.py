@@ -194,13 +194,16 @@ def scan_bwd_raw(u, delta, A, B, C, D, z, delta_bias, delta_softplus, ckpt, dout
     if dz is None and z is not None:
         dz = torch.empty_like(z)
     # accumulated-into buffers start at zero (reference contract, selective_scan.cpp:321-327)
-    dA = torch.zeros_like(A)
+    # dA | dD | ddelta_bias: one zero-fill for the three (they are tiny; three fill launches per layer were not)
+    nA = A.numel()
+    small = torch.zeros(nA + (dim if D is not None else 0) + (dim if delta_bias is not None else 0), dtype=torch.float32, device=u.device)
+    dA = small[:nA].view(A.shape)
     if dB is None:
         dB = torch.zeros(B.shape, dtype=torch.float32, device=u.device)
     if dC is None:
         dC = torch.zeros(C.shape, dtype=torch.float32, device=u.device)
-    dD = torch.zeros_like(D) if D is not None else None
-    dbias = torch.zeros(dim, dtype=torch.float32, device=u.device) if delta_bias is not None else None
+    dD = small[nA:nA + dim] if D is not None else None
+    dbias = small[small.numel() - dim:] if delta_bias is not None else None
     fold = ckpt is not None and ckpt.dim() == 3          # the forward folded the batch into the sequence (scan_fwd_raw)
     if fold and not _rows_16b(dout):
         dout = dout.contiguous()
@@ -370,6 +373,20 @@ def splitk_wgrad_cm(a_mk, b_kn, out_dtype):
     return part.sum(0, dtype=torch.float32).to(out_dtype)
 
 
+COLSUM_HITS = 0      # (tests) how many bias gradients came from a producer's column sums
+
+
+def bias_grad(dy, d2, bdt, dim=0):
+    """sum over the token axis of the incoming gradient.  When dy is the branch gradient an add+LayerNorm backward just wrote
+    (fused_ops._AddLayerNorm.backward), that kernel has already summed exactly these (rounded) values: no second pass over rows x C."""
+    global COLSUM_HITS
+    cs = getattr(dy, "_mxvl_colsum", None)
+    if cs is not None and dim == 0 and cs.numel() == d2.shape[1] and dy.dtype == d2.dtype:
+        COLSUM_HITS += 1
+        return cs.to(bdt)
+    return d2.sum(dim, dtype=torch.float32).to(bdt)
+
+
 class _LinearSplitK(torch.autograd.Function):
     """F.linear for token-major activations with the split-K weight gradient above (SwiGLU w1|w2 and w3)."""
 
@@ -377,7 +394,7 @@ class _LinearSplitK(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         cd = _compute_dtype(x)
         x2 = x.reshape(-1, x.shape[-1]).to(cd)
-        w = weight.to(cd)
+        w = autograd_util.cast_param(weight, cd)
         y = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -390,7 +407,7 @@ class _LinearSplitK(torch.autograd.Function):
         d2 = dy.reshape(-1, dy.shape[-1]).to(w.dtype)
         dx = torch.matmul(d2, w).view(shape).to(xdt)
         dw = splitk_wgrad(d2, x2, wdt)
-        db = d2.sum(0, dtype=torch.float32).to(bdt) if bdt is not None else None
+        db = bias_grad(dy, d2, bdt) if bdt is not None else None
         return dx, dw, db
 
 
@@ -406,7 +423,7 @@ class _ProjIn(torch.autograd.Function):
         Bz, L, K = x.shape
         cd = _compute_dtype(x)
         x2 = x.reshape(Bz * L, K).to(cd)
-        w = weight.to(cd)
+        w = autograd_util.cast_param(weight, cd)
         y2 = torch.matmul(w, x2.t())
         if bias is not None:
             y2 = y2 + bias.to(cd)[:, None]
@@ -421,7 +438,7 @@ class _ProjIn(torch.autograd.Function):
         dy2 = _dmajor_2d(dy.to(w.dtype))
         dx = torch.matmul(dy2.t(), w).view(Bz, L, K).to(xdt)
         dw = splitk_wgrad_cm(dy2, x2, wdt)
-        db = dy2.float().sum(1).to(bdt) if has_b else None
+        db = dy2.sum(1, dtype=torch.float32).to(bdt) if has_b else None
         return dx, dw, db
 
 
@@ -433,7 +450,7 @@ class _ProjOut(torch.autograd.Function):
         Bz, D, L = y.shape
         cd = _compute_dtype(y)
         y2 = _dmajor_2d(y.to(cd))
-        w = weight.to(cd)
+        w = autograd_util.cast_param(weight, cd)
         o2 = torch.matmul(y2.t(), w.t())
         if bias is not None:
             o2 = o2 + bias.to(cd)
@@ -448,7 +465,7 @@ class _ProjOut(torch.autograd.Function):
         d2 = do.reshape(Bz * L, -1).to(w.dtype)
         dy = _from_2d(torch.matmul(w.t(), d2.t()), Bz, L).to(ydt)
         dw = splitk_wgrad_cm(y2, d2, wdt).t()      # (D, Mout)^T: the same split GEMM with the roles swapped
-        db = d2.float().sum(0).to(bdt) if has_b else None
+        db = bias_grad(do, d2, bdt) if has_b else None
         return dy, dw, db
 
 
@@ -595,7 +612,7 @@ def mdir_core_forward(X, conv_w, conv_b, Wx, Wdt, A, Dv, dbias, needs_grad):
     b32 = conv_b.detach().float().contiguous() if conv_b is not None else None
     Xc = conv1d_fwd_raw(Xf, w32, b32, 1)                           # same (channel-major) layout
     io = Xc.dtype
-    wx, wdt = Wx.detach().to(io), Wdt.detach().to(io)
+    wx, wdt = autograd_util.cast_param(Wx, io).detach(), autograd_util.cast_param(Wdt, io).detach()
     with torch.autocast(device_type="cuda", enabled=False):       # io-dtype GEMMs whatever the ambient autocast (see _MambaInnerFn)
         x_dbl = torch.bmm(wx, Xc.permute(1, 0, 2).reshape(K, D, T))                # (K, R+2N, T)
         dt = torch.bmm(wdt, x_dbl[:, :R]).view(K * D, B, Lp).permute(1, 0, 2)      # (B, K*D, Lp)
