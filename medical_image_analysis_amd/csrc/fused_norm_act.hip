@@ -445,9 +445,14 @@ static int dispatch_swiglu(const void* ab, const void* dy, void* out, int rows, 
   }
 }
 
+// backward workgroups = partial rows of dgamma | dbeta | d-branch sums the caller reduces: 1024 = one round of 4 workgroups per CU
+// (32 KB of LDS each).  With 2048 the three (2048, C) partial tensors cost a 41 us reduce_kernel per add+LN backward (2 ms of the
+// ARM-large step) on top of a kernel that is bandwidth-bound either way.
+constexpr int kLnBwdPartials = 1024;
+
 template <typename R, typename B, typename O, int K>
 static void launch_ln(bool bwd, const void* args, int rows, hipStream_t s) {
-  const int wgs = std::min((rows + 3) / 4, 2048);
+  const int wgs = std::min((rows + 3) / 4, bwd ? kLnBwdPartials : 2048);
   if (bwd) hipLaunchKernelGGL((add_ln_bwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormBwdArgs*)args);
   else hipLaunchKernelGGL((add_ln_fwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormArgs*)args);
 }
@@ -495,7 +500,7 @@ int mxvl_add_layernorm_fwd(const mxvl_add_ln_desc* d, void* hip_stream) {
 int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc* d, void* hip_stream) {
   if (!d || !d->dn || !d->h || !d->gamma || !d->mean || !d->rstd || !d->dx || !d->partial_dgamma || !d->partial_dbeta) return MXVL_ERR_NULL;
   if (d->rows <= 0 || d->cols <= 0) return MXVL_ERR_SHAPE;
-  if (d->n_partials != std::min((d->rows + 3) / 4, 2048)) return MXVL_ERR_SHAPE;
+  if (d->n_partials != std::min((d->rows + 3) / 4, kLnBwdPartials)) return MXVL_ERR_SHAPE;
   NormBwdArgs a;
   a.rows = d->rows; a.C = d->cols; a.dn = d->dn; a.dh = d->dh; a.h = d->h; a.gamma = (const float*)d->gamma;
   a.mean = (const float*)d->mean; a.rstd = (const float*)d->rstd; a.dx = d->dx; a.dbr = d->dbranch;
@@ -503,7 +508,7 @@ int mxvl_add_layernorm_bwd(const mxvl_add_ln_bwd_desc* d, void* hip_stream) {
   return dispatch_ln(true, &a, d->rows, d->cols, d->res_dtype, d->branch_dtype, d->out_dtype, (hipStream_t)hip_stream);
 }
 
-int mxvl_add_layernorm_partials(int rows) { return std::min((rows + 3) / 4, 2048); }
+int mxvl_add_layernorm_partials(int rows) { return std::min((rows + 3) / 4, kLnBwdPartials); }
 
 int mxvl_swiglu_fwd(const void* ab, void* y, int rows, int hidden, int io_dtype, void* hip_stream) {
   if (!ab || !y) return MXVL_ERR_NULL;
