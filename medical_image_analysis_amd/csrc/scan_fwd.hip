@@ -529,7 +529,7 @@ int mxvl_scan_fwd(const mxvl_scan_desc* d, void* hip_stream) {
   a.out = d->out; a.last_state = (float*)d->last_state; a.ckpt = (float*)d->ckpt;
   a.dl_ratio = d->delta_group_ratio > 1 ? d->delta_group_ratio : 1;
   a.dl_magic = delta_magic(a.dl_ratio);
-  a.ablate = MXVL_ABL(true) ? (g_variant >> 16) & 0xff : 0;
+  a.ablate = MXVL_ABL(true) ? (g_variant >> 16) & 0xfff : 0;
   a.fold_magic = 0; a.fold_bpp = 0; a.fold_cpp = 0;
   if (d->flags & MXVL_SCAN_FOLD_BATCH) {
     if (!mxvl_scan_fold_ok(d->batch, d->seqlen, d->dstate) || d->last_state) return MXVL_ERR_UNSUPPORTED;

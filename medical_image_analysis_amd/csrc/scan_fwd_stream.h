@@ -369,9 +369,15 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       y[i] = Dv * un[i];
     }
     // requests for the next chunk (and this chunk's z) go out before the long state loop
+    // (measurement build: ablate & 32 = NO global loads after chunk 0 -- every chunk re-uses stale rows and the B / C tile of chunk 0;
+    //  & 64 / 128 / 256 drop one class only: the B / C tile, z, u / delta.  With & 8 no stores either: all of the VALU / LDS work,
+    //  none of the HBM traffic)
+    const int abl = MXVL_ABL(p.ablate);
     if (more) {
-      bc_fetch(t0 + CH);
-      if constexpr (RAWPF) raw_ud(t0 + CH); else ud_fetch(t0 + CH, un, dn);
+      if (!(abl & (32 | 64))) bc_fetch(t0 + CH);
+      if (!(abl & (32 | 256))) {
+        if constexpr (RAWPF) raw_ud(t0 + CH); else ud_fetch(t0 + CH, un, dn);
+      }
     }
     // FOLD: (segment, step) of this lane's 8 steps in chunk c, once for z, the reset test and the output store
     int csb = 0, csl = 0;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       csl = tv - csb * SL;
     }
     uint4 rz = make_uint4(0, 0, 0, 0);       // RAWPF: z of this chunk stays packed until the state loop is over
-    if (has_z) {
+    if (has_z && !((abl & (32 | 128)) && c > 0)) {
       if constexpr (RAWPF && FOLD) rz = *(const uint4*)(pz - j * T + seg_off(csb, p.z_bs, csl));
       else if constexpr (RAWPF) rz = raw_row(pz, t0);
       else row_fetch(pz, t0, zz, FOLD ? seg_off(csb, p.z_bs, csl) : 0);

@@ -41,9 +41,11 @@ def run(B, D, L, N, dtype, variants=(10, 15, 16), iters=10, rounds=5):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
-        for ab in (0, 1, 2, 4, 8, 1 | 4, 1 | 4 | 8):
-            print("ablate bits", ab, "(1=no n-loop 2=half n-loop 4=no softplus/silu 8=no out store)")
-            run(8, 1536, 4096, 16, torch.float32, variants=[10 | (ab << 16)], rounds=3)
+        if os.environ.get("MXVL_LIB"):
+            _abi.LIB_PATH = os.environ["MXVL_LIB"]
+        for ab in (0, 1, 8, 32, 64, 128, 256, 32 | 8, 1 | 32 | 8):
+            print("ablate bits", ab, "(1=no n-loop 2=half n-loop 4=no softplus/silu 8=no out store 32=no global loads after chunk 0; one class only: 64=B/C tile 128=z 256=u/delta)")
+            run(8, 1536, 4096, 16, torch.float32, variants=[14 | (ab << 16)], rounds=3)
     elif len(sys.argv) > 1:
         B, D, L, N = map(int, sys.argv[1:5]); dt = getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32
         run(B, D, L, N, dt)
