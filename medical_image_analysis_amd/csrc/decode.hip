@@ -14,6 +14,7 @@
 //   decode_attn_kernel   RoPE on q/k, append k/v to the cache, one-query attention over the cached positions with a
 //                        per-beam slot table (beam re-ordering moves 4-byte slot ids, never the cache itself).
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "mxvl_common.h"
@@ -245,6 +246,7 @@ struct AttnArgs {
   const int64_t* mask;       // (rows, max_len), nonzero = attend
   uint16_t* out;             // (rows, H * D)
   uint16_t* q_rope;          // optional (rows, H * D): the rotated, UNscaled query (what the hybrid layers' image cross-attention reads)
+  int ablate;                // measurement build only (MXVL_ATTN_ABLATE): the beams kernel returns after phase 1 .. 4
 };
 
 struct CrossAttnArgs {
@@ -259,16 +261,44 @@ struct CrossAttnArgs {
   uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
+// measurement knob (tools/decode_attn_probe.py): MXVL_ATTN_DEPTH = 2 / 4 / 8 pins the ring depth of the beams kernel; unset = automatic
+static int attn_depth_env() {
+  static const int v = [] { const char* e = getenv("MXVL_ATTN_DEPTH"); const int d = e ? atoi(e) : 0; return (d == 2 || d == 4 || d == 8) ? d : 0; }();
+  return v;
+}
+static int attn_waves_env() {   // MXVL_ATTN_WAVES = 8 / 16 pins the workgroup size of the self-attention kernels; unset = automatic
+  static const int v = [] { const char* e = getenv("MXVL_ATTN_WAVES"); const int d = e ? atoi(e) : 0; return (d == 8 || d == 16) ? d : 0; }();
+  return v;
+}
 constexpr int kBeamAttnWaves = 8;    // (16 waves = 128 VGPRs per lane: the nb running softmax states spill; measured 17.8 vs 16.7 us even before that)
+// Sum over the LPR lanes that share a cache row (LPR = head_dim / 8 consecutive lanes), result in every lane.  DPP moves inside a
+// 16-lane row -- quad_perm for the partners at distance 1 and 2, row_half_mirror / row_mirror for the other half of 8 / 16 (every
+// lane of a half already holds the same partial sum, so the mirrored partner is as good as the xor one and the additions are the
+// same additions: bit-identical to the __shfl_xor butterfly) -- instead of ds_bpermute_b32: four DEPENDENT LDS-crossbar round trips
+// per (position, beam) score were the attention kernels' critical path (round 4: 230 shared positions cost 1 us per trip of 32).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float s) {
+  auto mv = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  s += mv(s, std::integral_constant<int, 0xB1>{});                          // quad_perm [1,0,3,2]
+  s += mv(s, std::integral_constant<int, 0x4E>{});                          // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) s += mv(s, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  if constexpr (LPR >= 16) s += mv(s, std::integral_constant<int, 0x140>{});  // row_mirror
+  if constexpr (LPR >= 32) s += __shfl_xor(s, 16, 64);                      // the other row (head_dim 256 only)
+  static_assert(LPR == 8 || LPR == 16 || LPR == 32, "8 columns per lane, head_dim 64 / 128 / 256");
+  return s;
+}
+
 constexpr int kAttnWaves = 8;    // (16 waves x 8 positions per group -- one trip of cache loads for a 358-position report instead of
                                  //  three -- measured slower: 9.7 vs 8.9 us per launch, profiles/r03_decode_timeline.txt)
 
 // One workgroup per (head, row).  A cached K or V line of D bf16 is read by LPR = D/8 lanes with one 16-byte load
 // each, so a wave covers 64/LPR positions per load and the workgroup 8 x 64/LPR; K and V of a position are loaded
 // together and folded into a running (max, sum, out[8]) per lane group (one-pass softmax), merged once at the end.
-template <int D>
-__global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const AttnArgs p) {
-  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = kAttnWaves * RPW;
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW;
   extern __shared__ float sm[];
   const int T = p.max_len;
   float* sq = sm;                 // [D] rotated query
@@ -289,7 +319,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
   // every request of the prologue goes out before anything is used, none behind a per-lane branch: as `mask ? slot : -1` and
   // `d < half ? -q[d + half] : q[d - half]` the loads sat in exec-masked blocks and hipcc waited for each of them in turn -- eight
   // serialised round trips in front of a kernel whose whole body is a handful of them (8.9 us per launch, 32 launches per token)
-  for (int t = tid; t <= pos; t += kAttnWaves * 64) {
+  for (int t = tid; t <= pos; t += NW * 64) {
     const int64_t mk = p.mask[(size_t)m * T + t];
     const int sl = p.slot[(size_t)m * T + t];
     ssl[t] = mk != 0 ? sl : -1;
@@ -327,8 +357,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s = fmaf(qv[j], kf[j], s);
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    s = group_sum<LPR>(s);
     const float mn = live ? fmaxf(mx, s) : mx;
     const float corr = fast_exp(mx - mn), pr = live ? fast_exp(s - mn) : 0.0f;
     mx = mn;
@@ -398,12 +427,13 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_attn_kernel(const Attn
 // (three workgroups asking for a line at the same moment are three fabric reads: measured, the shared slots alone bought nothing);
 // here positions [0, n_shared) -- the longest prefix on which all beams agree -- are loaded ONCE and folded into nb running
 // softmax states, the rest per beam as before.  18 rows x 32 heads x 300 positions: 88 MB -> 41 MB of cache reads per layer.
-template <int D, int NB, int NW>
+template <int D, int NB, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnArgs p) {
   constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW, NT = NW * 64;
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = p.max_len;
-  float* sq = sm;                      // [NB][D] rotated, scaled queries
+  char* ring_all = (char*)sm;          // [NW][DEPTH][K 1 KB | V 1 KB]: the landing ring of the cache rows (see below)
+  float* sq = sm + NW * DEPTH * 512;   // [NB][D] rotated, scaled queries
   float* sk = sq + NB * D;             // [NB][D] rotated new keys
   float* sv = sk + NB * D;             // [NB][D] new values
   float* wm = sv + NB * D;             // [NB][NW] per-wave maxima
@@ -441,6 +471,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       mk[r] = p.mask[(size_t)(m0 + r) * T + t];
       sl[r] = p.slot[(size_t)(m0 + r) * T + t];
     }
+    __builtin_amdgcn_sched_barrier(0);   // all 2 nb loads in flight before the first is looked at (hipcc interleaved them: two round trips)
     bool same = true;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
@@ -448,7 +479,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       ssl[r * T + t] = v;
       same = same && v == (mk[0] != 0 ? sl[0] : -1);
     }
-    if (!same && t < pos) atomicMin(&s_nsh, t);
+    // the first position on which the beams differ: t grows with the lane, so the lowest set lane of the ballot has the wave's minimum
+    // (one LDS atomic per wave: with one per differing position the ~70 generated positions serialised on the same LDS word)
+    const unsigned long long differ = __ballot(!same && t < pos);
+    if (differ != 0 && lane == __ffsll(differ) - 1) atomicMin(&s_nsh, t);
   }
   // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group.  (The raw operands were
   // requested BEFORE the slot-table sweep above: one memory round trip for both instead of two in a row.)
@@ -474,6 +508,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
     }
   }
   __syncthreads();
+  if (MXVL_ABL(p.ablate == 1)) return;      // launch + slot sweep + RoPE + cache append
   const int nsh = s_nsh;
   const int sub = lane % LPR, g = wave * RPW + lane / LPR;
   float qv[NB][8], mx[NB], l[NB], o[NB][8];
@@ -488,8 +523,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) s = fmaf(qv[r][j], kf[j], s);
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+    s = group_sum<LPR>(s);
     const float mn = live ? fmaxf(mx[r], s) : mx[r];
     const float corr = fast_exp(mx[r] - mn), pr = live ? fast_exp(s - mn) : 0.0f;
     mx[r] = mn;
@@ -505,71 +539,90 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
     }
   };
-  // the first trip over the positions on which the beams differ is requested NOW and folded after the shared positions: its
-  // round trip hides behind theirs (a lane group without such a position re-reads the sample's first cache line)
-  uint4 okq[NB], ovq[NB];
-  bool olive[NB];
-  {
-    const int t = nsh + g;
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const int sl = t < pos ? ssl[r * T + t] : -1;
-      olive[r] = sl >= 0;
-      const size_t a = (((size_t)(olive[r] ? sl : m0) * p.Hkv + hk) * T + (olive[r] ? t : 0)) * D + sub * 8;
-      okq[r] = *(const uint4*)(p.kc + a);
-      ovq[r] = *(const uint4*)(p.vc + a);
+  // The cache rows land in LDS, not in registers (round 4): every wave owns a ring of DEPTH trips; a trip = one
+  // global_load_lds_dwordx4 of K and one of V, each lane moving the 16 bytes IT will read back (LDS address = lane * 16: no
+  // swizzle, no cross-lane traffic, no barrier) -- LDS as the register file of the loads in flight, so the depth costs no VGPRs.
+  // Trips are numbered over the whole job: ns trips over the positions every beam shares, then nt per beam over the positions
+  // on which they differ; vmcnt retires in order, so the wait in front of trip j is the constant 2 * (DEPTH - 1) while the
+  // ring is full and 0 on the last DEPTH - 1 trips (all requested long before).
+  // What the phase ablation of this kernel showed (profiles/r04_attn_phase_ablation.txt): it is bound by INSTRUCTION ISSUE, not by
+  // memory -- 0.45 us per one-fold trip, 0.82 us per three-fold trip at two waves per SIMD, the same at every ring depth.  So the
+  // per-trip bookkeeping is kept to a handful of instructions: 32-bit element offsets (sl * c1 + t * D + a per-lane constant; the
+  // launcher checks the cache fits), scalar trip counters instead of a division, liveness carried in a per-lane bit ring instead
+  // of a second LDS lookup, and the cross-lane score sum by DPP (group_sum).
+  static_assert((DEPTH & (DEPTH - 1)) == 0, "ring slots are picked with a mask");
+  const int ns = (nsh + NG - 1) / NG, nt = (pos - nsh + NG - 1) / NG, ntrips = ns + NB * nt;
+  char* ring = ring_all + wave * (DEPTH * 2048);
+  const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  const uint32_t c1 = (uint32_t)p.Hkv * (uint32_t)T * D;                    // elements per cache row (slot)
+  const uint32_t lane_off = (uint32_t)hk * (uint32_t)T * D + sub * 8;
+  const uint32_t dummy = (uint32_t)m0 * c1 + lane_off;                       // a masked / out-of-range group re-reads the sample's first line
+  uint32_t livebits = 0;                                                    // bit (j & 31): trip j of this lane group carries an attended position
+  int iss = 0, iss_r = 0, iss_i = 0;                                        // next trip to request; (beam, trip of the beam) once past the shared ones
+  int nx_t = 0, nx_sl = -1;                                                 // its position and slot: looked up one trip EARLY (an LDS round
+  bool nx_in = false;                                                       //  trip in front of every request was a tenth of the loop)
+  auto prep = [&]() {
+    if (iss >= ntrips) return;
+    int lim;
+    const int* sp;
+    if (iss < ns) {
+      nx_t = g + iss * NG; lim = nsh; sp = ssl;
+    } else {
+      nx_t = nsh + g + iss_i * NG; lim = pos; sp = ssl + iss_r * T;
+      if (++iss_i == nt) { iss_i = 0; ++iss_r; }
     }
-  }
+    nx_in = nx_t < lim;
+    nx_sl = sp[nx_in ? nx_t : 0];
+  };
+  auto issue = [&]() {
+    if (iss >= ntrips) return;
+    const bool live = nx_in && nx_sl >= 0;
+    const uint32_t off = live ? (uint32_t)nx_sl * c1 + (uint32_t)nx_t * D + lane_off : dummy;
+    const int bit = iss & 31;
+    livebits = (livebits & ~(1u << bit)) | ((uint32_t)live << bit);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(iss & (DEPTH - 1)) * 2048u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(p.kc + off), "v"(p.vc + off) : "memory", "scc");
+    ++iss;
+    prep();
+  };
+  auto take = [&](int j, float* kf, float* vf) -> bool {
+    if (j + DEPTH <= ntrips) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* slot = ring + (j & (DEPTH - 1)) * 2048 + lane * 16;
+    const uint4 kq = *(const uint4*)slot, vq = *(const uint4*)(slot + 1024);
+    const bool live = (livebits >> (j & 31)) & 1u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // both rows are in registers: the slot may be refilled
+    issue();
+    unpack(kq, kf);
+    unpack(vq, vf);
+    return live;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the counts above are counts of ring trips only
+  prep();
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j) issue();
   // ---- positions every beam shares: one load, nb folds ------------------------------------------------------------------------
-  constexpr int U = 4;                   // (8 positions in flight per lane group measured slower: 18.9 vs 16.6 us per layer at 6 x 3 rows)
-  for (int t0 = g; t0 < nsh; t0 += NG * U) {
-    uint4 kq[U], vq[U];
-    bool live[U];
+  for (int j = 0; j < ns; ++j) {
+    float kf[8], vf[8];
+    const bool live = take(j, kf, vf);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 + u * NG;
-      const int sl = t < nsh ? ssl[t] : -1;
-      live[u] = sl >= 0;
-      const size_t a = (((size_t)(live[u] ? sl : m0) * p.Hkv + hk) * T + (live[u] ? t : 0)) * D + sub * 8;   // unconditional loads
-      kq[u] = *(const uint4*)(p.kc + a);
-      vq[u] = *(const uint4*)(p.vc + a);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float kf[8], vf[8];
-      unpack(kq[u], kf);
-      unpack(vq[u], vf);
-#pragma unroll
-      for (int r = 0; r < NB; ++r) fold(r, live[u], kf, vf);
-    }
+    for (int r = 0; r < NB; ++r) fold(r, live, kf, vf);
   }
+  if (MXVL_ABL(p.ablate == 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }   // + shared positions
   // ---- positions on which the beams differ: per beam -----------------------------------------------------------------------------
+  int jt = ns;
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    float kf[8], vf[8];
-    unpack(okq[r], kf);
-    unpack(ovq[r], vf);
-    fold(r, olive[r], kf, vf);
-  }
-  for (int t = nsh + g + NG; t < pos; t += NG) {
-    uint4 kq[NB], vq[NB];
-    bool live[NB];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const int sl = ssl[r * T + t];
-      live[r] = sl >= 0;
-      const size_t a = (((size_t)(live[r] ? sl : m0) * p.Hkv + hk) * T + t) * D + sub * 8;
-      kq[r] = *(const uint4*)(p.kc + a);
-      vq[r] = *(const uint4*)(p.vc + a);
-    }
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
+    for (int i = 0; i < nt; ++i, ++jt) {
       float kf[8], vf[8];
-      unpack(kq[r], kf);
-      unpack(vq[r], vf);
-      fold(r, live[r], kf, vf);
+      const bool live = take(jt, kf, vf);
+      fold(r, live, kf, vf);
     }
   }
+  if (MXVL_ABL(p.ablate == 3)) return;      // + the beams' own positions
   if (g == 0) {  // the fresh position of every beam
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
@@ -598,6 +651,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       for (int j = 0; j < 8; ++j) wo[(r * NW + wave) * D + sub * 8 + j] = o[r][j];
     }
   }
+  if (MXVL_ABL(p.ablate == 4)) return;      // + the in-wave merge
   __syncthreads();
   for (int i = tid; i < NB * D; i += NT) {
     const int r = i / D, d = i - r * D;
@@ -694,8 +748,7 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(cons
         vf[2 * j] = __builtin_bit_cast(float, vw[j] << 16);
         vf[2 * j + 1] = __builtin_bit_cast(float, vw[j] & 0xffff0000u);
       }
-#pragma unroll
-      for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+      s = group_sum<LPR>(s);
       const float mn = live[u] ? fmaxf(mx, s) : mx;
       const float corr = fast_exp(mx - mn), pr = live[u] ? fast_exp(s - mn) : 0.0f;
       mx = mn;
@@ -838,16 +891,28 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
   a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
   a.q_rope = (uint16_t*)d->q_rope;
+  a.ablate = MXVL_ABL_ENV("MXVL_ATTN_ABLATE");
   hipStream_t s = (hipStream_t)hip_stream;
   if (d->beams > 1) {       // the beams of a sample share a workgroup (and every cache line they have in common)
     if (d->beams > 5 || d->rows % d->beams != 0) return MXVL_ERR_UNSUPPORTED;
+    if ((uint64_t)d->rows * d->n_kv_heads * d->max_len * d->head_dim >= (1ull << 31)) return MXVL_ERR_UNSUPPORTED;   // 32-bit cache offsets
     const int nb = d->beams;
-    const size_t lds = sizeof(float) * ((size_t)3 * nb * a.D + 2 * nb * kBeamAttnWaves + (size_t)nb * kBeamAttnWaves * a.D + (size_t)nb * a.max_len);
-    if (lds > 150 * 1024) return MXVL_ERR_UNSUPPORTED;
-    const dim3 grid(a.H, a.rows / nb), block(kBeamAttnWaves * 64);
+    const int nw = attn_waves_env() ? attn_waves_env() : kBeamAttnWaves;
+    const size_t lds0 = sizeof(float) * ((size_t)3 * nb * a.D + 2 * nb * nw + (size_t)nb * nw * a.D + (size_t)nb * a.max_len);
+    const dim3 grid(a.H, a.rows / nb), block(nw * 64);
+    // ring depth: measured flat from 2 to 8 trips in flight (profiles/r04_attn_ring_probe.txt) -- the kernel is bound by the folds
+    const size_t ring1 = (size_t)nw * 2048;
+    int depth = 4;
+    if (attn_depth_env()) depth = attn_depth_env();
+    while (depth > 2 && lds0 + depth * ring1 > 160 * 1024) depth /= 2;
+    const size_t lds = lds0 + depth * ring1;
+    if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
 #define MXVL_ATTN_BEAMS(DD, NB)                                                                                                    \
   do {                                                                                                                             \
-    auto kern = decode_attn_beams_kernel<DD, NB, kBeamAttnWaves>;                                                                      \
+    void (*kern)(const AttnArgs) = nw == 16     ? (depth >= 4 ? decode_attn_beams_kernel<DD, NB, 16, 4> : decode_attn_beams_kernel<DD, NB, 16, 2>) \
+                                   : depth == 8 ? decode_attn_beams_kernel<DD, NB, 8, 8>                                           \
+                                   : depth == 4 ? decode_attn_beams_kernel<DD, NB, 8, 4>                                           \
+                                                : decode_attn_beams_kernel<DD, NB, 8, 2>;                                          \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return MXVL_ERR_LAUNCH;                                                                                                      \
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                                                              \
@@ -868,16 +933,21 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
 #undef MXVL_ATTN_BEAMS
     return dec_check();
   }
-  const int NG = kAttnWaves * 64 / (a.D / 8);
+  const int nw = attn_waves_env() ? attn_waves_env() : kAttnWaves;
+  const int NG = nw * 64 / (a.D / 8);
   const size_t lds = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
   if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
-  const dim3 grid(a.H, a.rows), block(kAttnWaves * 64);
+  const dim3 grid(a.H, a.rows), block(nw * 64);
+#define MXVL_ATTN_ROW(DD) \
+  if (nw == 16) hipLaunchKernelGGL((decode_attn_kernel<DD, 16>), grid, block, lds, s, a); \
+  else hipLaunchKernelGGL((decode_attn_kernel<DD, 8>), grid, block, lds, s, a)
   switch (a.D) {
-    case 64: hipLaunchKernelGGL(decode_attn_kernel<64>, grid, block, lds, s, a); break;
-    case 128: hipLaunchKernelGGL(decode_attn_kernel<128>, grid, block, lds, s, a); break;
-    case 256: hipLaunchKernelGGL(decode_attn_kernel<256>, grid, block, lds, s, a); break;
+    case 64: MXVL_ATTN_ROW(64); break;
+    case 128: MXVL_ATTN_ROW(128); break;
+    case 256: MXVL_ATTN_ROW(256); break;
     default: return MXVL_ERR_UNSUPPORTED;
   }
+#undef MXVL_ATTN_ROW
   return dec_check();
 }
 

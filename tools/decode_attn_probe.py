@@ -2,6 +2,8 @@
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medical_image_analysis_amd import _abi
+if os.environ.get("MXVL_LIB"):          # the measurement build (python -m medical_image_analysis_amd.build --ablate; MXVL_ATTN_ABLATE=1..4)
+    _abi.LIB_PATH = os.environ["MXVL_LIB"]
 lib = _abi.load()
 dev = "cuda:0"
 bf = dict(dtype=torch.bfloat16, device=dev)
@@ -33,12 +35,13 @@ for rows, nb in ((3, 3), (18, 3), (24, 3), (80, 5)):
     mask = torch.ones(rows, T, dtype=torch.long, device=dev)
     for pos_v in (300, 231):
         pos = torch.tensor([pos_v], device=dev)
-        for share in (False, True):
+        for share, beams in ((False, 0), (True, 0), (True, nb)):
             slot = own.expand(-1, T).contiguous()
             if share:
                 slot[:, :P] = (own // nb) * nb
             a = _abi.DecodeAttnDesc()
             a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len, a.scale = rows, H, H, D, T, D ** -0.5
+            a.beams = beams
             a.qkv, a.cos, a.sin = qkv.data_ptr(), cos.data_ptr(), sin.data_ptr()
             a.slot_table, a.pos, a.mask, a.out = slot.data_ptr(), pos.data_ptr(), mask.data_ptr(), out.data_ptr()
             i = [0]
@@ -47,4 +50,4 @@ for rows, nb in ((3, 3), (18, 3), (24, 3), (80, 5)):
                 a.k_cache, a.v_cache = kcs[j].data_ptr(), vcs[j].data_ptr()
                 _abi.check(lib.mxvl_decode_attn(ctypes.byref(a), _abi.stream_ptr(qkv.device)), "attn")
             us = timeit(fn)
-            print(f"rows={rows:3d} pos={pos_v} share={share!s:5}: {us:7.2f} us  ({2 * rows * H * pos_v * D * 2 / us / 1e3:7.1f} GB/s of logical cache reads)")
+            print(f"rows={rows:3d} pos={pos_v} share={share!s:5} beams={beams}: {us:7.2f} us  ({2 * rows * H * pos_v * D * 2 / us / 1e3:7.1f} GB/s of logical cache reads)")
