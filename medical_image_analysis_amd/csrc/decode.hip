@@ -246,7 +246,7 @@ struct AttnArgs {
   const int64_t* mask;       // (rows, max_len), nonzero = attend
   uint16_t* out;             // (rows, H * D)
   uint16_t* q_rope;          // optional (rows, H * D): the rotated, UNscaled query (what the hybrid layers' image cross-attention reads)
-  int ablate;                // measurement build only (MXVL_ATTN_ABLATE): the beams kernel returns after phase 1 .. 4
+  int ablate;                // measurement build only (MXVL_ATTN_ABLATE): the beams kernel returns after 1 the prologue, 3 the cached positions
 };
 
 struct CrossAttnArgs {
@@ -261,16 +261,11 @@ struct CrossAttnArgs {
   uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
-// measurement knob (tools/decode_attn_probe.py): MXVL_ATTN_DEPTH = 2 / 4 / 8 pins the ring depth of the beams kernel; unset = automatic
-static int attn_depth_env() {
-  static const int v = [] { const char* e = getenv("MXVL_ATTN_DEPTH"); const int d = e ? atoi(e) : 0; return (d == 2 || d == 4 || d == 8) ? d : 0; }();
-  return v;
-}
-static int attn_waves_env() {   // MXVL_ATTN_WAVES = 8 / 16 pins the workgroup size of the self-attention kernels; unset = automatic
+// measurement knob (tools/decode_attn_probe.py)
+static int attn_waves_env() {   // MXVL_ATTN_WAVES = 8 / 16 pins the workgroup size of the per-row kernel (beams kernel: 8 / 4 waves); unset = automatic
   static const int v = [] { const char* e = getenv("MXVL_ATTN_WAVES"); const int d = e ? atoi(e) : 0; return (d == 8 || d == 16) ? d : 0; }();
   return v;
 }
-constexpr int kBeamAttnWaves = 8;    // (16 waves = 128 VGPRs per lane: the nb running softmax states spill; measured 17.8 vs 16.7 us even before that)
 // Sum over the LPR lanes that share a cache row (LPR = head_dim / 8 consecutive lanes), result in every lane.  DPP moves inside a
 // 16-lane row -- quad_perm for the partners at distance 1 and 2, row_half_mirror / row_mirror for the other half of 8 / 16 (every
 // lane of a half already holds the same partial sum, so the mirrored partner is as good as the xor one and the additions are the
@@ -425,21 +420,54 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
 // (whose slots the stepper points at one physical copy) and usually the first generated tokens name the SAME cache lines for every
 // beam -- 230 of ~300 positions at the reference's settings.  With a workgroup per (head, row) those lines were fetched nb times
 // (three workgroups asking for a line at the same moment are three fabric reads: measured, the shared slots alone bought nothing);
-// here positions [0, n_shared) -- the longest prefix on which all beams agree -- are loaded ONCE and folded into nb running
-// softmax states, the rest per beam as before.  18 rows x 32 heads x 300 positions: 88 MB -> 41 MB of cache reads per layer.
-template <int D, int NB, int NW, int DEPTH>
-__global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnArgs p) {
-  constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW, NT = NW * 64;
+// here positions [0, n_shared) -- the longest prefix on which all beams agree -- are loaded ONCE for the nb beams, the rest per
+// beam.  18 rows x 32 heads x 300 positions: 88 MB -> 43 MB of cache reads per layer.
+// History of the arithmetic (docs/DESIGN_HISTORY.md): a VALU version (16 lanes per cache row, one-pass softmax per position, rows in
+// VGPRs, later in an LDS landing ring) went 16.6 -> 14.2 us per layer at 6 x 3 rows and stopped there; the phase ablation
+// (profiles/r04_attn_phase_ablation2.txt) showed it bound by VALU THROUGHPUT, chip-wide: 8 FMA + 4 DPP adds + a dozen softmax
+// instructions + 8 FMA per (position, beam), replicated over the 16 lanes of a cache row, is ~200 VALU instructions per
+// 32-position trip and three beams; 1536 waves x 17 trips of that is ~7 us of all 1024 SIMDs, whatever the memory system does
+// (ring depth 2 .. 8 and 8 vs 16 waves measured flat).  So the two products go to MFMA and the softmax is per 16-position TILE:
+//   S[pos][beam]   = sum_d K[pos][d] Q[beam][d]      v_mfma_f32_16x16x32_bf16: A = K rows straight from the LDS tile (16-byte reads),
+//                                                    B = the nb rotated queries (bf16, rows nb..15 zero), once per kernel
+//   O^T[d][beam]  += sum_pos V[pos][d] P[pos][beam]  v_mfma_f32_16x16x16_bf16: A = V^T through ds_read_b64_tr_b16 (hardware
+//                                                    transpose read of the row-major V tile), B = P straight from the S
+//                                                    accumulator (C layout: lane (beam = l & 15, q = l >> 4) holds positions
+//                                                    4 q .. 4 q + 3 -- exactly the k-slice lane (n, q) of a 16x16x16 B operand owns)
+// so a lane owns ONE beam column: running max / sum / rescale are lane-local, the only cross-lane step per tile is the max over the
+// four q (two ds_bpermute).  P is rounded to bf16 before the second product, as the modules' softmax(...).to(bf16) @ V does.
+// A wave owns whole tiles (tile k -> wave k % NW): ns tiles over the positions every beam shares, then nt per beam over its own
+// positions (only column `beam` of those is kept).  K and V tiles arrive by LDS-DMA into a two-stage ring per wave, XOR-swizzled
+// on the SOURCE address (the DMA writes LDS linearly) so that both the 16-byte fragment reads and the transpose reads spread over
+// the banks; explicit vmcnt waits (the compiler cannot see the DMA).  The fresh position of every beam (its K / V are in LDS, not
+// in the cache yet for the other heads of a KV group) is one more partial in the final merge.
+template <int D> __device__ __forceinline__ int attn_tile_key(int row) {
+  constexpr int UPR = D / 8;
+  return UPR == 8 ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : UPR == 16 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (row & (UPR - 1));
+}
+template <int D> __device__ __forceinline__ int attn_tile_off(int row, int unit) { return row * (D * 2) + ((unit ^ attn_tile_key<D>(row)) << 4); }
+
+template <int D, int NB, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const AttnArgs p) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int UPR = D / 8, RPI = 64 / UPR;     // 16-byte units per cache row; rows per DMA instruction (1 KB)
+  constexpr int TILE = 16, NI = TILE / RPI;      // positions per tile; DMA instructions per K (or V) tile
+  constexpr int TB = TILE * D * 2, STAGE = 2 * TB, NST = 2, OPS = 2 * NI;
+  constexpr int NKK = D / 32, NDT = D / 16, NT = NW * 64, NWP = NW + 1;
+  static_assert(OPS <= 31, "vmcnt immediate");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = p.max_len;
-  char* ring_all = (char*)sm;          // [NW][DEPTH][K 1 KB | V 1 KB]: the landing ring of the cache rows (see below)
-  float* sq = sm + NW * DEPTH * 512;   // [NB][D] rotated, scaled queries
-  float* sk = sq + NB * D;             // [NB][D] rotated new keys
-  float* sv = sk + NB * D;             // [NB][D] new values
-  float* wm = sv + NB * D;             // [NB][NW] per-wave maxima
-  float* wl = wm + NB * NW;            // [NB][NW] per-wave sums
-  float* wo = wl + NB * NW;            // [NB][NW][D] per-wave outputs
-  int* ssl = (int*)(wo + NB * NW * D); // [NB][T] slot of each position, -1 = masked
+  char* ring_all = (char*)sm;                                   // [NW][NST][K tile | V tile]; after the loop: wo [NB][NWP][D] fp32
+  uint16_t* sqb = (uint16_t*)(ring_all + NW * NST * STAGE);     // [16][D] rotated queries, bf16 (rows nb .. 15 zero)
+  float* sq = (float*)(sqb + 16 * D);                           // [NB][D] rotated, scaled queries (fresh position)
+  float* sk = sq + NB * D;                                      // [NB][D] rotated new keys
+  float* sv = sk + NB * D;                                      // [NB][D] new values
+  float* wm = sv + NB * D;                                      // [NB][NWP] partial maxima
+  float* wl = wm + NB * NWP;                                    // [NB][NWP] partial sums
+  int* ssl = (int*)(wl + NB * NWP);                             // [NB][T] slot of each position, -1 = masked
+  float* wo = (float*)ring_all;
   __shared__ int s_nsh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, m0 = blockIdx.y * NB;
@@ -462,6 +490,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
     rope_q[it] = q[d]; rope_qo[it] = q[dp]; rope_k[it] = kn[d]; rope_ko[it] = kn[dp]; rope_v[it] = vn[d];
     rope_c[it] = p.cosv[(size_t)m * D + d]; rope_s[it] = p.sinv[(size_t)m * D + d];
   }
+  for (int i = tid; i < (16 - NB) * D; i += NT) sqb[NB * D + i] = 0;
   __syncthreads();
   for (int t = tid; t <= pos; t += NT) {
     int64_t mk[NB];
@@ -480,12 +509,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       same = same && v == (mk[0] != 0 ? sl[0] : -1);
     }
     // the first position on which the beams differ: t grows with the lane, so the lowest set lane of the ballot has the wave's minimum
-    // (one LDS atomic per wave: with one per differing position the ~70 generated positions serialised on the same LDS word)
     const unsigned long long differ = __ballot(!same && t < pos);
     if (differ != 0 && lane == __ffsll(differ) - 1) atomicMin(&s_nsh, t);
   }
-  // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group.  (The raw operands were
-  // requested BEFORE the slot-table sweep above: one memory round trip for both instead of two in a row.)
+  // RoPE (hybrid_decoder_layer.py:284-322) of the nb rows' q / k, cache append by one head of each KV group
 #pragma unroll
   for (int it = 0; it < RI; ++it) {
     const int i = tid + it * NT;
@@ -497,6 +524,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
       const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * sn))));
       const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * sn))));
       sq[i] = qr * p.scale;
+      sqb[i] = f2bf(qr);
       if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
       sk[i] = kr;
       sv[i] = bf2f(rope_v[it]);
@@ -510,160 +538,152 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_kernel(const AttnAr
   __syncthreads();
   if (MXVL_ABL(p.ablate == 1)) return;      // launch + slot sweep + RoPE + cache append
   const int nsh = s_nsh;
-  const int sub = lane % LPR, g = wave * RPW + lane / LPR;
-  float qv[NB][8], mx[NB], l[NB], o[NB][8];
-#pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    mx[r] = -1e30f;
-    l[r] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { qv[r][j] = sq[r * D + sub * 8 + j]; o[r][j] = 0.0f; }
-  }
-  auto fold = [&](int r, bool live, const float* kf, const float* vf) {
-    float s = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s = fmaf(qv[r][j], kf[j], s);
-    s = group_sum<LPR>(s);
-    const float mn = live ? fmaxf(mx[r], s) : mx[r];
-    const float corr = fast_exp(mx[r] - mn), pr = live ? fast_exp(s - mn) : 0.0f;
-    mx[r] = mn;
-    l[r] = fmaf(l[r], corr, pr);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[r][j] = fmaf(o[r][j], corr, pr * vf[j]);
+  const int l16 = lane & 15, q4 = lane >> 4;
+  const int ns = (nsh + TILE - 1) / TILE, nt = (pos - nsh + TILE - 1) / TILE, ntiles = ns + NB * nt;
+  // tile iterators (wave-uniform): tile k of this wave -> shared (r < 0) tile k, or tile i of beam r
+  struct Tile { int k, r, i; };
+  auto tile_first = [&](Tile& it) {
+    it.k = wave; it.r = -1; it.i = 0;
+    if (it.k >= ns && it.k < ntiles) { it.r = 0; it.i = it.k - ns; while (it.i >= nt) { it.i -= nt; ++it.r; } }
   };
-  auto unpack = [](const uint4 v, float* f) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f[2 * j] = __builtin_bit_cast(float, w[j] << 16);
-      f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+  auto tile_next = [&](Tile& it) {
+    it.k += NW;
+    if (it.k >= ns && it.k < ntiles) {
+      if (it.r < 0) { it.r = 0; it.i = it.k - ns; } else it.i += NW;
+      while (it.i >= nt) { it.i -= nt; ++it.r; }
     }
   };
-  // The cache rows land in LDS, not in registers (round 4): every wave owns a ring of DEPTH trips; a trip = one
-  // global_load_lds_dwordx4 of K and one of V, each lane moving the 16 bytes IT will read back (LDS address = lane * 16: no
-  // swizzle, no cross-lane traffic, no barrier) -- LDS as the register file of the loads in flight, so the depth costs no VGPRs.
-  // Trips are numbered over the whole job: ns trips over the positions every beam shares, then nt per beam over the positions
-  // on which they differ; vmcnt retires in order, so the wait in front of trip j is the constant 2 * (DEPTH - 1) while the
-  // ring is full and 0 on the last DEPTH - 1 trips (all requested long before).
-  // What the phase ablation of this kernel showed (profiles/r04_attn_phase_ablation.txt): it is bound by INSTRUCTION ISSUE, not by
-  // memory -- 0.45 us per one-fold trip, 0.82 us per three-fold trip at two waves per SIMD, the same at every ring depth.  So the
-  // per-trip bookkeeping is kept to a handful of instructions: 32-bit element offsets (sl * c1 + t * D + a per-lane constant; the
-  // launcher checks the cache fits), scalar trip counters instead of a division, liveness carried in a per-lane bit ring instead
-  // of a second LDS lookup, and the cross-lane score sum by DPP (group_sum).
-  static_assert((DEPTH & (DEPTH - 1)) == 0, "ring slots are picked with a mask");
-  const int ns = (nsh + NG - 1) / NG, nt = (pos - nsh + NG - 1) / NG, ntrips = ns + NB * nt;
-  char* ring = ring_all + wave * (DEPTH * 2048);
+  char* ring = ring_all + wave * (NST * STAGE);
   const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
-  const uint32_t c1 = (uint32_t)p.Hkv * (uint32_t)T * D;                    // elements per cache row (slot)
-  const uint32_t lane_off = (uint32_t)hk * (uint32_t)T * D + sub * 8;
-  const uint32_t dummy = (uint32_t)m0 * c1 + lane_off;                       // a masked / out-of-range group re-reads the sample's first line
-  uint32_t livebits = 0;                                                    // bit (j & 31): trip j of this lane group carries an attended position
-  int iss = 0, iss_r = 0, iss_i = 0;                                        // next trip to request; (beam, trip of the beam) once past the shared ones
-  int nx_t = 0, nx_sl = -1;                                                 // its position and slot: looked up one trip EARLY (an LDS round
-  bool nx_in = false;                                                       //  trip in front of every request was a tenth of the loop)
-  auto prep = [&]() {
-    if (iss >= ntrips) return;
-    int lim;
-    const int* sp;
-    if (iss < ns) {
-      nx_t = g + iss * NG; lim = nsh; sp = ssl;
-    } else {
-      nx_t = nsh + g + iss_i * NG; lim = pos; sp = ssl + iss_r * T;
-      if (++iss_i == nt) { iss_i = 0; ++iss_r; }
+  const uint32_t c1 = (uint32_t)p.Hkv * (uint32_t)T * D;                    // elements per cache row (slot); 32-bit offsets: the launcher checks the cache fits
+  const uint32_t hk_off = (uint32_t)hk * (uint32_t)T * D;
+  const uint32_t dummy = (uint32_t)m0 * c1 + hk_off;                        // a masked / out-of-range row re-reads the sample's first line
+  auto issue = [&](const Tile& it, int stage) {
+    if (it.k >= ntiles) return;
+    const int t0 = it.r < 0 ? it.k * TILE : nsh + it.i * TILE, lim = it.r < 0 ? nsh : pos;
+    const int* sp = ssl + (it.r < 0 ? 0 : it.r) * T;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)stage * STAGE);
+#pragma unroll
+    for (int ii = 0; ii < NI; ++ii) {
+      const int row = ii * RPI + lane / UPR, t = t0 + row;
+      const bool in = t < lim;
+      const int sl = sp[in ? t : 0];
+      const bool live = in && sl >= 0;
+      const uint32_t off = (live ? (uint32_t)sl * c1 + (uint32_t)t * D + hk_off : dummy) + (((lane % UPR) ^ attn_tile_key<D>(row)) << 3);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                   "s_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(dst + ii * 1024), "v"(p.kc + off), "v"(p.vc + off), "n"(TB) : "memory", "scc");
     }
-    nx_in = nx_t < lim;
-    nx_sl = sp[nx_in ? nx_t : 0];
   };
-  auto issue = [&]() {
-    if (iss >= ntrips) return;
-    const bool live = nx_in && nx_sl >= 0;
-    const uint32_t off = live ? (uint32_t)nx_sl * c1 + (uint32_t)nx_t * D + lane_off : dummy;
-    const int bit = iss & 31;
-    livebits = (livebits & ~(1u << bit)) | ((uint32_t)live << bit);
-    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(iss & (DEPTH - 1)) * 2048u);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(dst), "v"(p.kc + off), "v"(p.vc + off) : "memory", "scc");
-    ++iss;
-    prep();
-  };
-  auto take = [&](int j, float* kf, float* vf) -> bool {
-    if (j + DEPTH <= ntrips) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");
+  // B operand of the first product: lane (beam = l16, q4) owns Q[beam][32 kk + 8 q4 .. + 8)
+  bf16x8 qb[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) qb[kk] = *(const bf16x8*)(sqb + l16 * D + kk * 32 + q4 * 8);
+  f32x4 oacc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float m_run = -1e30f, l_run = 0.0f;            // this lane's beam column; l_run sums this lane's four rows only until the end
+  Tile ti, tc;
+  tile_first(ti);
+  tc = ti;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the counts below are counts of ring tiles only
+  issue(ti, 0);
+  tile_next(ti);
+  issue(ti, 1);
+  tile_next(ti);
+  int stage = 0;
+  for (; tc.k < ntiles; tile_next(tc), stage ^= 1) {
+    if (tc.k + NW < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* slot = ring + (j & (DEPTH - 1)) * 2048 + lane * 16;
-    const uint4 kq = *(const uint4*)slot, vq = *(const uint4*)(slot + 1024);
-    const bool live = (livebits >> (j & 31)) & 1u;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // both rows are in registers: the slot may be refilled
-    issue();
-    unpack(kq, kf);
-    unpack(vq, vf);
-    return live;
-  };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the counts above are counts of ring trips only
-  prep();
+    const char* kt = ring + stage * STAGE;
+    const char* vt = kt + TB;
+    typedef __attribute__((address_space(3))) s16x4 lds4;
+    bf16x8 kf[NKK];
+    s16x4 vf[NDT];
 #pragma unroll
-  for (int j = 0; j < DEPTH; ++j) issue();
-  // ---- positions every beam shares: one load, nb folds ------------------------------------------------------------------------
-  for (int j = 0; j < ns; ++j) {
-    float kf[8], vf[8];
-    const bool live = take(j, kf, vf);
+    for (int kk = 0; kk < NKK; ++kk) kf[kk] = *(const bf16x8*)(kt + attn_tile_off<D>(l16, kk * 4 + q4));
+    // V^T: within a 16-lane group lane t' supplies the address of row (t' >> 2), columns 4 (t' & 3) .. + 3 of a [4][16] block and
+    // receives column t' of its 4 rows -> lane (d = 16 dt + l16, q4) gets V[4 q4 .. 4 q4 + 3][d]
 #pragma unroll
-    for (int r = 0; r < NB; ++r) fold(r, live, kf, vf);
-  }
-  if (MXVL_ABL(p.ablate == 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }   // + shared positions
-  // ---- positions on which the beams differ: per beam -----------------------------------------------------------------------------
-  int jt = ns;
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int col = dt * 16 + 4 * (l16 & 3);
+      vf[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4*)(vt + attn_tile_off<D>(q4 * 4 + (l16 >> 2), col >> 3) + (col & 7) * 2));
+    }
+    const int t0 = tc.r < 0 ? tc.k * TILE : nsh + tc.i * TILE, lim = tc.r < 0 ? nsh : pos;
+    const int* sp = ssl + (tc.r < 0 ? 0 : tc.r) * T;
+    bool ok[4];
+    const bool colok = l16 < NB && (tc.r < 0 || l16 == tc.r);
 #pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    for (int i = 0; i < nt; ++i, ++jt) {
-      float kf[8], vf[8];
-      const bool live = take(jt, kf, vf);
-      fold(r, live, kf, vf);
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + q4 * 4 + i;
+      ok[i] = colok && t < lim && sp[t < lim ? t : 0] >= 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every fragment of the stage is in registers: it may be refilled
+    issue(ti, stage);
+    tile_next(ti);
+    f32x4 sc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qb[kk], sc, 0, 0, 0);
+    float s[4], tmax = -1e30f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] = sc[i] * p.scale;
+      tmax = ok[i] ? fmaxf(tmax, s[i]) : tmax;
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mn = fmaxf(m_run, tmax), corr = fast_exp(m_run - mn);
+    m_run = mn;
+    float pr[4], psum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pr[i] = ok[i] ? fast_exp(s[i] - mn) : 0.0f;
+      psum += pr[i];
+    }
+    l_run = fmaf(l_run, corr, psum);
+    s16x4 pb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = (short)f2bf(pr[i]);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[dt][i] *= corr;
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[dt], pb, oacc[dt], 0, 0, 0);
     }
   }
-  if (MXVL_ABL(p.ablate == 3)) return;      // + the beams' own positions
-  if (g == 0) {  // the fresh position of every beam
+  if (MXVL_ABL(p.ablate == 3)) return;      // + every cached position
+  // ---- merge: the q-lanes of a column by shuffles, the waves (+ the fresh position as partial NW) through LDS ----------------------
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();                          // every wave is done with its ring: wo reuses the memory
+  if (l16 < NB) {
+    if (q4 == 0) { wm[l16 * NWP + wave] = m_run; wl[l16 * NWP + wave] = l_run; }
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      float kf[8], vf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { kf[j] = sk[r * D + sub * 8 + j]; vf[j] = sv[r * D + sub * 8 + j]; }
-      fold(r, ssl[r * T + pos] >= 0, kf, vf);
-    }
+    for (int dt = 0; dt < NDT; ++dt)
+      *(f32x4*)(wo + (l16 * NWP + wave) * D + dt * 16 + q4 * 4) = oacc[dt];
   }
-  // ---- merge: the position groups of a wave by shuffles, the waves through LDS -------------------------------------------------
+  for (int r = wave; r < NB; r += NW) {     // the fresh position of beam r: score by one wave
+    float part = 0.0f;
+    for (int d = lane; d < D; d += 64) part = fmaf(sq[r * D + d], sk[r * D + d], part);
 #pragma unroll
-  for (int r = 0; r < NB; ++r) {
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {
-      const float m2 = __shfl_xor(mx[r], off, 64), l2 = __shfl_xor(l[r], off, 64);
-      const float mn = fmaxf(mx[r], m2);
-      const float c1 = fast_exp(mx[r] - mn), c2 = fast_exp(m2 - mn);
-      l[r] = l[r] * c1 + l2 * c2;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[r][j] = o[r][j] * c1 + __shfl_xor(o[r][j], off, 64) * c2;
-      mx[r] = mn;
-    }
-    if (lane < LPR) {
-      if (sub == 0) { wm[r * NW + wave] = mx[r]; wl[r * NW + wave] = l[r]; }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wo[(r * NW + wave) * D + sub * 8 + j] = o[r][j];
-    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    const bool live = ssl[r * T + pos] >= 0;
+    if (lane == 0) { wm[r * NWP + NW] = live ? part : -1e30f; wl[r * NWP + NW] = live ? 1.0f : 0.0f; }
+    for (int d = lane; d < D; d += 64) wo[(r * NWP + NW) * D + d] = live ? sv[r * D + d] : 0.0f;
   }
-  if (MXVL_ABL(p.ablate == 4)) return;      // + the in-wave merge
   __syncthreads();
   for (int i = tid; i < NB * D; i += NT) {
     const int r = i / D, d = i - r * D;
     float gmax = -1e30f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) gmax = fmaxf(gmax, wm[r * NW + w]);
+    for (int w = 0; w < NWP; ++w) gmax = fmaxf(gmax, wm[r * NWP + w]);
     float num = 0.0f, den = 0.0f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float c = fast_exp(wm[r * NW + w] - gmax);
-      num = fmaf(c, wo[(r * NW + w) * D + d], num);
-      den = fmaf(c, wl[r * NW + w], den);
+    for (int w = 0; w < NWP; ++w) {
+      const float c = fast_exp(wm[r * NWP + w] - gmax);
+      num = fmaf(c, wo[(r * NWP + w) * D + d], num);
+      den = fmaf(c, wl[r * NWP + w], den);
     }
     p.out[(size_t)(m0 + r) * p.H * D + (size_t)h * D + d] = f2bf(num / den);
   }
@@ -897,22 +917,20 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
     if (d->beams > 5 || d->rows % d->beams != 0) return MXVL_ERR_UNSUPPORTED;
     if ((uint64_t)d->rows * d->n_kv_heads * d->max_len * d->head_dim >= (1ull << 31)) return MXVL_ERR_UNSUPPORTED;   // 32-bit cache offsets
     const int nb = d->beams;
-    const int nw = attn_waves_env() ? attn_waves_env() : kBeamAttnWaves;
-    const size_t lds0 = sizeof(float) * ((size_t)3 * nb * a.D + 2 * nb * nw + (size_t)nb * nw * a.D + (size_t)nb * a.max_len);
-    const dim3 grid(a.H, a.rows / nb), block(nw * 64);
-    // ring depth: measured flat from 2 to 8 trips in flight (profiles/r04_attn_ring_probe.txt) -- the kernel is bound by the folds
-    const size_t ring1 = (size_t)nw * 2048;
-    int depth = 4;
-    if (attn_depth_env()) depth = attn_depth_env();
-    while (depth > 2 && lds0 + depth * ring1 > 160 * 1024) depth /= 2;
-    const size_t lds = lds0 + depth * ring1;
+    // matrix-core kernel: 8 waves (4 when head_dim 256 or a long slot table would not leave room for the ring)
+    const size_t stage = (size_t)2 * 16 * a.D * 2;
+    auto lds_of = [&](int nw) {
+      return (size_t)nw * 2 * stage + (size_t)16 * a.D * 2 + sizeof(float) * ((size_t)3 * nb * a.D + 2 * nb * (nw + 1) + (size_t)nb * a.max_len);
+    };
+    int nw = a.D <= 128 ? 8 : 4;
+    if (attn_waves_env() == 8 || attn_waves_env() == 16) nw = attn_waves_env() == 16 ? 4 : 8;   // (probe knob: 16 = the 4-wave shape)
+    if (nw == 8 && lds_of(8) > 160 * 1024) nw = 4;
+    const size_t lds = lds_of(nw);
     if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
+    const dim3 grid(a.H, a.rows / nb), block(nw * 64);
 #define MXVL_ATTN_BEAMS(DD, NB)                                                                                                    \
   do {                                                                                                                             \
-    void (*kern)(const AttnArgs) = nw == 16     ? (depth >= 4 ? decode_attn_beams_kernel<DD, NB, 16, 4> : decode_attn_beams_kernel<DD, NB, 16, 2>) \
-                                   : depth == 8 ? decode_attn_beams_kernel<DD, NB, 8, 8>                                           \
-                                   : depth == 4 ? decode_attn_beams_kernel<DD, NB, 8, 4>                                           \
-                                                : decode_attn_beams_kernel<DD, NB, 8, 2>;                                          \
+    void (*kern)(const AttnArgs) = nw == 8 ? decode_attn_beams_mfma_kernel<DD, NB, (DD <= 128 ? 8 : 4)> : decode_attn_beams_mfma_kernel<DD, NB, 4>; \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return MXVL_ERR_LAUNCH;                                                                                                      \
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                                                              \
