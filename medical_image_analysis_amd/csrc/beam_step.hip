@@ -22,11 +22,12 @@
 
 namespace mxvl {
 
-constexpr int kBeamThreads = 512, kBeamWaves = kBeamThreads / 64, kMaxKeep = 16, kMaxBeams = 8, kMaxEos = 4, kMaxSurv = 256;   // 8 waves: 256 VGPRs each
+constexpr int kMaxKeep = 16, kMaxBeams = 8, kMaxEos = 4, kMaxSurv = 256;
 // (num_beams 5 of launch_mambaclip_test_iu.sh:27 keeps 2 x 5 = 10 candidates)
 
 struct BeamArgs {
   int batch, nb, V, max_new, min_new, n_eos, early, keep, ablate;   // early: 1 = early_stopping True
+  int vec4;                            // V % 4 == 0 and 16-byte aligned logits: a thread's words come four at a time
   float rep_pen;
   const float* logits;                 // (batch*nb, V)
   long long *run_seq, *fin_seq;        // (batch, nb, max_new)
@@ -42,10 +43,15 @@ struct BeamArgs {
 
 __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
+// kBeamThreads x U logits of a row are in flight per trip: 1024 x 32 covers a 32 000-word vocabulary row in ONE round trip (the
+// 512 x 16 shape of round 3 walked a row in four dependent trips, twice -- statistics and candidates -- for every beam row).
+template <int kBeamThreads, int U>
 __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs p) {
+  constexpr int kBeamWaves = kBeamThreads / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned int smem_u[];
   __shared__ float s_red[16];
   __shared__ int s_redi[16];
+  static_assert(kBeamThreads / 64 <= 16 && U % 4 == 0, "s_red; four words per load");
   __shared__ float s_rowmax[kMaxBeams], s_logz[kMaxBeams];
   __shared__ float s_top_lp[kMaxKeep];
   __shared__ int s_top_ix[kMaxKeep];
@@ -102,17 +108,32 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
         if (v >= 0 && v < V) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
       }
     // ---- (1) log-softmax statistics per beam row: one sweep, U independent loads in flight per thread --------------
-    constexpr int U = 16;
-    for (int r = 0; r < nb; ++r) {
-      const float* row = lg + (size_t)r * V;
-      float m = -INFINITY, s = 0.0f;
-      for (int base = 0; base < V; base += kBeamThreads * U) {
-        float x[U];
+    // word u of a thread's trip: four consecutive words per 16-byte load when the rows allow it (a quarter of the load instructions)
+    auto vof = [&](int base, int u) {
+      return p.vec4 ? base + ((u >> 2) * kBeamThreads + tid) * 4 + (u & 3) : base + u * kBeamThreads + tid;
+    };
+    auto load_trip = [&](const float* row, int base, float (&x)[U]) {
+      if (p.vec4) {
+#pragma unroll
+        for (int q = 0; q < U / 4; ++q) {
+          const int v = base + (q * kBeamThreads + tid) * 4;
+          const float4 t = v < V ? *(const float4*)(row + v) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+          x[4 * q] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        }
+      } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = base + u * kBeamThreads + tid;
           x[u] = v < V ? row[v] : -INFINITY;
         }
+      }
+    };
+    for (int r = 0; r < nb; ++r) {
+      const float* row = lg + (size_t)r * V;
+      float m = -INFINITY, s = 0.0f;
+      for (int base = 0; base < V; base += kBeamThreads * U) {
+        float x[U];
+        load_trip(row, base, x);
         float cm = x[0];
 #pragma unroll
         for (int u = 1; u < U; ++u) cm = fmaxf(cm, x[u]);
@@ -154,7 +175,9 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     // below and repaired by a rescan of that thread's share (practically never taken).
     auto cand_value = [&](int r, int v, float raw, float mx, float lz, float sc, bool mask_eos) -> float {
       float x = (raw - mx) - lz;                                              // log_softmax
-      if ((bitmap[r * words + (v >> 5)] >> (v & 31)) & 1u) x = x < 0.0f ? x * p.rep_pen : x / p.rep_pen;
+      // (the penalty behind a wave-uniform test: as a select, hipcc ran the fp32 division sequence for every word of the vocabulary)
+      const bool hit = (bitmap[r * words + (v >> 5)] >> (v & 31)) & 1u;
+      if (__any(hit)) x = hit ? (x < 0.0f ? x * p.rep_pen : x / p.rep_pen) : x;
       if (mask_eos) {
 #pragma unroll
         for (int e = 0; e < kMaxEos; ++e)
@@ -170,22 +193,20 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
       const bool mask_eos = cur < p.min_new;
       for (int base = 0; base < V; base += kBeamThreads * U) {
         float xs[U];
+        load_trip(row, base, xs);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int v = base + u * kBeamThreads + tid;
-          xs[u] = v < V ? row[v] : -INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int v = base + u * kBeamThreads + tid;
+          const int v = vof(base, u);
           if (v < V) {
             const float x = cand_value(r, v, xs[u], mx, lz, sc, mask_eos);
-            const int idx = r * V + v;
-            const bool b1 = better(x, idx, v1, i1), b2 = better(x, idx, v2, i2);
-            v2 = b1 ? v1 : (b2 ? x : v2);
-            i2 = b1 ? i1 : (b2 ? idx : i2);
-            v1 = b1 ? x : v1;
-            i1 = b1 ? idx : i1;
+            if (x >= v2) {           // below the thread's second entry nothing changes: the insertion is the rare path
+              const int idx = r * V + v;
+              const bool b1 = better(x, idx, v1, i1), b2 = better(x, idx, v2, i2);
+              v2 = b1 ? v1 : (b2 ? x : v2);
+              i2 = b1 ? i1 : (b2 ? idx : i2);
+              v1 = b1 ? x : v1;
+              i1 = b1 ? idx : i1;
+            }
           }
         }
       }
@@ -227,7 +248,9 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
         for (int r = 0; r < nb; ++r) {
           const float* row = lg + (size_t)r * V;
           const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
-          for (int v = tid; v < V; v += kBeamThreads) {
+          for (int k = 0; k < (V + kBeamThreads * U - 1) / (kBeamThreads * U) * U; ++k) {   // this thread's share, word by word
+            const int v = vof(k / U * kBeamThreads * U, k % U);
+            if (v >= V) continue;
             const int idx = r * V + v;
             if (idx == i1 || idx == i2) continue;
             const float x = cand_value(r, v, row[v], mx, lz, sc, cur < p.min_new);
@@ -353,6 +376,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     }
   }
   __syncthreads();
+  if (MXVL_ABL(p.ablate != 0)) return;      // a truncated step must not stop the search it is timed in
   if (tid == 0) {
     bool any_open = s_any_open != 0, all_hits = s_all_hits != 0, all_done = s_all_done != 0, last = true;
     if (gridDim.x > 1) {
@@ -395,10 +419,13 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   a.len_tab = (const float*)d->len_tab; a.hyp_tab = (const float*)d->hyp_tab; a.tok = (long long*)d->tok;
   a.beam_src = (long long*)d->beam_src; a.unfinished = (unsigned char*)d->unfinished;
   a.ticket = (unsigned int*)d->scratch;
+  a.vec4 = (a.V % 4 == 0 && ((uintptr_t)a.logits & 15) == 0) ? 1 : 0;
   const int grid = (a.ticket && d->batch > 1) ? (d->batch < 255 ? d->batch : 255) : 1;
   const size_t words = (size_t)(a.V + 31) / 32;
   const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
   if (lds > 60 * 1024) return MXVL_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(beam_step_kernel, dim3(grid), dim3(kBeamThreads), lds, (hipStream_t)hip_stream, a);
+  static const int shape = MXVL_ABL_ENV("MXVL_BEAM_SHAPE");      // measurement build: 1 = the 512 x 16 shape
+  if (MXVL_ABL(shape == 1)) hipLaunchKernelGGL((beam_step_kernel<512, 16>), dim3(grid), dim3(512), lds, (hipStream_t)hip_stream, a);
+  else hipLaunchKernelGGL((beam_step_kernel<1024, 32>), dim3(grid), dim3(1024), lds, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

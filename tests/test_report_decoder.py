@@ -754,8 +754,8 @@ def test_beam_step_kernel_equals_torch_restatement(cfg):
         logits = 3.0 * torch.randn(B * nb, V, generator=g)
         if steps >= cfg["min_new"]:
             logits[:, 2] += 6.0 * (torch.rand(B * nb, generator=g) < 0.4).float()     # some beams end with EOS
-        if steps % 3 == 1 and V > 2100:   # three+ winners owned by ONE kernel thread (tokens equal mod 512): the repair path
-            logits[0, [5, 517, 1029, 1541]] += torch.tensor([30.0, 29.0, 28.5, 28.0])
+        if steps % 3 == 1 and V > 2100:   # three+ winners owned by ONE kernel thread (four consecutive words of a 16-byte load): the repair path
+            logits[0, [4, 5, 6, 7]] += torch.tensor([30.0, 29.0, 28.5, 28.0])
         logits = logits.to(dev)
         hip.advance(logits.clone())
         ref.advance(logits.clone())
