@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 6
+#define MXVL_ABI_VERSION 7
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -355,6 +355,9 @@ typedef struct mxvl_beam_desc {
   void *unfinished;                /* scalar */
   void *scratch;                   /* ABI v6, optional: (1) uint32, zero before the first call (the kernel leaves it zero): when
                                       given, one workgroup per batch element instead of one workgroup walking the batch */
+  void *unfinished_log;            /* ABI v7, optional: (max_new) bytes the HOST can read (pinned, device-mapped): the step that ran at
+                                      *cur == c also stores its *unfinished at [c], so a token loop that runs ahead of the host
+                                      (report_decoder._search_lookahead) needs no device-to-host copy between the steps */
 } mxvl_beam_desc;
 int mxvl_beam_step(const mxvl_beam_desc *desc, void *hip_stream);
 

@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -200,6 +200,7 @@ class BeamDesc(ctypes.Structure):
         ("logits", c_void_p), ("run_seq", c_void_p), ("fin_seq", c_void_p), ("run_score", c_void_p), ("fin_score", c_void_p),
         ("fin_done", c_void_p), ("heur_open", c_void_p), ("cur", c_void_p), ("eos", c_void_p), ("len_tab", c_void_p),
         ("hyp_tab", c_void_p), ("tok", c_void_p), ("beam_src", c_void_p), ("unfinished", c_void_p), ("scratch", c_void_p),
+        ("unfinished_log", c_void_p),
     ]
 
 

@@ -39,6 +39,7 @@ struct BeamArgs {
   long long *tok, *beam_src;           // (batch*nb)
   unsigned char* unfinished;           // scalar
   unsigned int* ticket;                // optional: arrival word of a multi-workgroup launch (zero between launches)
+  unsigned char* unf_log;              // optional, host-visible (max_new): *unfinished of the step that ran at cur, at [cur]
 };
 
 __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
       bool unf = any_open && !all_hits;
       if (p.early == 1) unf = unf && !all_done;
       *p.unfinished = unf ? 1 : 0;
+      if (p.unf_log && cur < max_new) __hip_atomic_store(p.unf_log + cur, (unsigned char)(unf ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       *p.cur = cur + 1;
     }
   }
@@ -419,6 +421,7 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   a.len_tab = (const float*)d->len_tab; a.hyp_tab = (const float*)d->hyp_tab; a.tok = (long long*)d->tok;
   a.beam_src = (long long*)d->beam_src; a.unfinished = (unsigned char*)d->unfinished;
   a.ticket = (unsigned int*)d->scratch;
+  a.unf_log = (unsigned char*)d->unfinished_log;
   a.vec4 = (a.V % 4 == 0 && ((uintptr_t)a.logits & 15) == 0) ? 1 : 0;
   const int grid = (a.ticket && d->batch > 1) ? (d->batch < 255 ? d->batch : 255) : 1;
   const size_t words = (size_t)(a.V + 31) / 32;

@@ -210,6 +210,10 @@ class _BeamState:
         self.beam_src = torch.zeros(B * nb, dtype=torch.long, device=dev)
         self.unfinished = torch.ones((), dtype=torch.bool, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # arrival word of the multi-workgroup beam kernel
+        # *unfinished of the step that ran at cur = c, at [c], where the HOST can read it (pinned, device-mapped): the look-ahead
+        # token loop polls this instead of enqueueing a device-to-host copy between two replays (a 4 us copy kernel + a 5 us gap
+        # per token in the round-4 timeline)
+        self.unf_log = torch.zeros(max_new, dtype=torch.uint8).pin_memory() if torch.device(dev).type == "cuda" else None
         self.reset()
 
     def reset(self):
@@ -243,6 +247,7 @@ class _BeamState:
         d.len_tab, d.hyp_tab = self.len_tab.data_ptr(), self.hyp_tab.data_ptr()
         d.tok, d.beam_src, d.unfinished = self.tok.data_ptr(), self.beam_src.data_ptr(), self.unfinished.data_ptr()
         d.scratch = self.ticket.data_ptr() if self.B > 1 else None        # one workgroup per sample
+        d.unfinished_log = _abi.ptr(self.unf_log)
         with torch.cuda.device(logits.device):
             _abi.check(lib.mxvl_beam_step(ctypes.byref(d), _abi.stream_ptr(logits.device)), "mxvl_beam_step")
 
@@ -699,25 +704,25 @@ class ReportDecoder(nn.Module):
     @staticmethod
     def _search_lookahead(stepper, state):
         """Token loop without a host round trip per token: replay k + 1 is enqueued BEFORE the host has seen `unfinished` of replay k
-        (copied to pinned memory behind it).  If k was the last token, replay k + 1 is a no-op for the search state -- mxvl_beam_step
+        (the beam kernel leaves it in pinned memory).  If k was the last token, replay k + 1 is a no-op for the search state -- mxvl_beam_step
         returns at once when *unfinished is already 0 -- so the result is what the synchronous loop returns; the ~45 us the
         device idled per token while the host read one byte are gone."""
         if not bool(state.unfinished):
             return
-        if getattr(state, "_look", None) is None:          # pinned flags + events live with the (cached) search state
-            state._look = ([torch.empty(1, dtype=torch.bool).pin_memory() for _ in range(2)], [torch.cuda.Event() for _ in range(2)])
-        flags, events = state._look
-        stepper.step_search(state)                       # (the first call runs eagerly and captures the graph)
+        if getattr(state, "_look", None) is None:          # events live with the (cached) search state
+            state._look = [torch.cuda.Event() for _ in range(2)]
+        events, log = state._look, state.unf_log.numpy()   # the kernel stores the flag of the step at cur = c in log[c] (pinned)
+        c = int(state.cur)                                 # one read per report; from here the host counts the steps itself
+        stepper.step_search(state)                         # (the first call runs eagerly and captures the graph)
         k = 0
-        flags[0].copy_(state.unfinished.view(1), non_blocking=True)
         events[0].record()
         while True:
-            stepper.step_search(state)                   # speculative: a no-op if the previous step finished the search
-            flags[1 - k].copy_(state.unfinished.view(1), non_blocking=True)
+            stepper.step_search(state)                     # speculative: a no-op if the previous step finished the search
             events[1 - k].record()
             events[k].synchronize()
-            if not bool(flags[k][0]):
+            if not log[c]:
                 break
+            c += 1
             k = 1 - k
         torch.cuda.current_stream().synchronize()
 
