@@ -234,10 +234,10 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("decode step = 129 gemv_bf16_kernel + 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)"
-                                if B * beams <= 8 else
-                                "decode step = 129 decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + 65 decode_rmsnorm_kernel "
-                                "+ 32 decode_attn_kernel launches + beam-search update, one hipGraph replay per token (weight streaming)"),
+                     "kernel": ("decode step = 129 decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + 65 decode_rmsnorm_kernel + 32 "
+                                + ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
+                                   "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
+                                + " launches + beam_step_kernel, one hipGraph replay per token; the time per token includes the prompt prefill's share"),
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}
 
 

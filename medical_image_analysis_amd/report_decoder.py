@@ -600,6 +600,8 @@ class _Stack(nn.Module):
 
 
 class ReportDecoder(nn.Module):
+    _tuned_gemms_checked = False
+
     def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads,
                  num_key_value_heads=None, rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096,
                  hybrid_layers: Iterable[int] = (), cross_attn_implementation="vanilla",
@@ -744,6 +746,12 @@ class ReportDecoder(nn.Module):
         if attention_mask is None:
             attention_mask = torch.ones(inputs_embeds.shape[:2], dtype=torch.long, device=dev)
 
+        if inputs_embeds.is_cuda and not ReportDecoder._tuned_gemms_checked:
+            # the prompt prefill is library GEMMs (M = batch x prompt tokens): use the per-shape solutions picked offline on an
+            # MI355X (tuned/tunableop_gfx950.csv, read-only; e.g. gate / up at 6 x 230 tokens run in three tile rounds by default)
+            from .pretrain_engine import enable_tuned_gemms
+            ReportDecoder._tuned_gemms_checked = True
+            enable_tuned_gemms()
         cache = KVCache()
         logits = self.forward(inputs_embeds, attention_mask=attention_mask, past_key_values=cache)[:, -1]   # (B, V)
         if use_graph is None:
