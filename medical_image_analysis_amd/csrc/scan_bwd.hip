@@ -865,11 +865,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int i = lane; i < RPW * N; i += 64) {
+  // (lane / wave re-derived from the work-item id behind an opaque move: as loop-invariant values computed at the top they were
+  //  the two VGPRs the register allocator spilled around the chunk loop -- the kernel's 12 bytes of scratch)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, wave_e = tid_e >> 6;
+  for (int i = lane_e; i < RPW * N; i += 64) {
     const int rr = i / N, n = i - rr * N;
-    const int dd = d0 + wave * RPW + rr;
+    const int dd = d0 + wave_e * RPW + rr;
     // d a / d A = delta * a and A2 = A*log2e only rescales the exponent argument: sdA already holds dA
-    if (dd < d_end) unsafeAtomicAdd(p.dA + (int64_t)dd * N + n, sdA[(wave * RPW + rr) * NP + n]);
+    if (dd < d_end) unsafeAtomicAdd(p.dA + (int64_t)dd * N + n, sdA[(wave_e * RPW + rr) * NP + n]);
   }
 }
 
