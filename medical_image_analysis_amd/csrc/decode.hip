@@ -291,12 +291,14 @@ constexpr int kAttnWaves = 8;    // (16 waves x 8 positions per group -- one tri
 // One workgroup per (head, row).  A cached K or V line of D bf16 is read by LPR = D/8 lanes with one 16-byte load
 // each, so a wave covers 64/LPR positions per load and the workgroup 8 x 64/LPR; K and V of a position are loaded
 // together and folded into a running (max, sum, out[8]) per lane group (one-pass softmax), merged once at the end.
-template <int D, int NW>
+template <int D, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) {
   constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW;
-  extern __shared__ float sm[];
+  static_assert((DEPTH & (DEPTH - 1)) == 0, "ring slots are picked with a mask");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = p.max_len;
-  float* sq = sm;                 // [D] rotated query
+  char* ring_all = (char*)sm;     // [NW][DEPTH][K 1 KB | V 1 KB]: landing ring of the cache rows (see the loop)
+  float* sq = sm + NW * DEPTH * 512;   // [D] rotated query
   float* sk = sq + D;             // [D] rotated new key
   float* sv = sk + D;             // [D] new value
   float* gm = sv + D;             // [NG] group maxima
@@ -314,7 +316,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
   // every request of the prologue goes out before anything is used, none behind a per-lane branch: as `mask ? slot : -1` and
   // `d < half ? -q[d + half] : q[d - half]` the loads sat in exec-masked blocks and hipcc waited for each of them in turn -- eight
   // serialised round trips in front of a kernel whose whole body is a handful of them (8.9 us per launch, 32 launches per token)
-  for (int t = tid; t <= pos; t += NW * 64) {
+  // (the first trip of the slot sweep does not wait for *pos: entries past pos are never looked at, and the table has T of them)
+  {
+    const int t = tid < T ? tid : T - 1;
+    const int64_t mk = p.mask[(size_t)m * T + t];
+    const int sl = p.slot[(size_t)m * T + t];
+    __builtin_amdgcn_sched_barrier(0);
+    ssl[t] = mk != 0 ? sl : -1;
+  }
+  for (int t = tid + NW * 64; t <= pos; t += NW * 64) {
     const int64_t mk = p.mask[(size_t)m * T + t];
     const int sl = p.slot[(size_t)m * T + t];
     ssl[t] = mk != 0 ? sl : -1;
@@ -368,30 +378,48 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
       f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
     }
   };
-  constexpr int U = 4;
-  for (int t0 = g; t0 < pos; t0 += NG * U) {   // cached positions 0 .. pos-1
-    uint4 kq[U], vq[U];
-    bool live[U];
+  // The cache rows land in LDS, not in registers: a wave owns a ring of DEPTH trips; a trip = one global_load_lds_dwordx4 of K and
+  // one of V, each lane moving the 16 bytes IT reads back (LDS address = lane * 16: no swizzle, no cross-lane traffic, no barrier)
+  // -- LDS as the register file of the loads in flight.  At batch 1 x beam 3 this kernel is a chain of memory round trips (96
+  // workgroups, nothing else on the chip): four positions per lane group in VGPRs made a 300-position report three dependent
+  // trips; with DEPTH = 8 trips requested at once it is one and a bit.  vmcnt retires in order: the wait in front of trip j is the
+  // constant 2 * (DEPTH - 1) while the ring is full and 0 on the last DEPTH - 1 trips.
+  const int ntrips = (pos + NG - 1) / NG;
+  char* ring = ring_all + wave * (DEPTH * 2048);
+  const unsigned ring_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+  const size_t c1 = (size_t)p.Hkv * T * D, lane_off = (size_t)hk * T * D + sub * 8;
+  uint32_t livebits = 0;                 // bit (j & 31): trip j of this lane group carries an attended position
+  int iss = 0;
+  auto issue = [&]() {
+    if (iss >= ntrips) return;
+    const int t = g + iss * NG;
+    const int sl = ssl[t < pos ? t : 0];
+    const bool live = t < pos && sl >= 0;    // a masked / out-of-range group re-reads the row's first cache line
+    const size_t off = (live ? (size_t)sl * c1 + (size_t)t * D : (size_t)m * c1) + lane_off;
+    const int bit = iss & 31;
+    livebits = (livebits & ~(1u << bit)) | ((uint32_t)live << bit);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(iss & (DEPTH - 1)) * 2048u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(dst), "v"(p.kc + off), "v"(p.vc + off) : "memory", "scc");
+    ++iss;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the counts below are counts of ring trips only
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 + u * NG;
-      const int sl = t < pos ? ssl[t] : -1;
-      live[u] = sl >= 0;
-      kq[u] = make_uint4(0, 0, 0, 0);
-      vq[u] = kq[u];
-      if (live[u]) {
-        const size_t a = (((size_t)sl * p.Hkv + hk) * T + t) * D + sub * 8;
-        kq[u] = *(const uint4*)(p.kc + a);
-        vq[u] = *(const uint4*)(p.vc + a);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float kf[8], vf[8];
-      unpack(kq[u], kf);
-      unpack(vq[u], vf);
-      fold(live[u], kf, vf);
-    }
+  for (int j = 0; j < DEPTH; ++j) issue();
+  for (int j = 0; j < ntrips; ++j) {                       // cached positions 0 .. pos-1
+    if (j + DEPTH <= ntrips) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* slot = ring + (j & (DEPTH - 1)) * 2048 + lane * 16;
+    const uint4 kq = *(const uint4*)slot, vq = *(const uint4*)(slot + 1024);
+    const bool live = (livebits >> (j & 31)) & 1u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // both rows are in registers: the slot may be refilled
+    issue();
+    float kf[8], vf[8];
+    unpack(kq, kf);
+    unpack(vq, vf);
+    fold(live, kf, vf);
   }
   if (g == 0) {  // the fresh position (always attended: its mask bit was just set)
     float kf[8], vf[8];
@@ -472,8 +500,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x, m0 = blockIdx.y * NB;
   const int group = p.H / p.Hkv, hk = h / group;
-  const int pos = (int)*p.pos;
-  if (tid == 0) s_nsh = pos;
+  const int pos = (int)*p.pos;         // (first USED behind the loads below: the scalar load overlaps them)
   // raw RoPE operands of this thread's (row, dim) items: unconditional loads (clamped index), consumed after the slot sweep
   constexpr int RI = (NB * D + NT - 1) / NT;
   uint16_t rope_q[RI], rope_qo[RI], rope_k[RI], rope_ko[RI], rope_v[RI];
@@ -490,15 +517,33 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
     rope_q[it] = q[d]; rope_qo[it] = q[dp]; rope_k[it] = kn[d]; rope_ko[it] = kn[dp]; rope_v[it] = vn[d];
     rope_c[it] = p.cosv[(size_t)m * D + d]; rope_s[it] = p.sinv[(size_t)m * D + d];
   }
+  // the first trip of the slot sweep is requested here too, before *pos is needed (entries past pos are never looked at)
+  int64_t mk0[NB];
+  int sl0[NB];
+  {
+    const int t = tid < T ? tid : T - 1;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      mk0[r] = p.mask[(size_t)(m0 + r) * T + t];
+      sl0[r] = p.slot[(size_t)(m0 + r) * T + t];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   for (int i = tid; i < (16 - NB) * D; i += NT) sqb[NB * D + i] = 0;
+  if (tid == 0) s_nsh = pos;
   __syncthreads();
   for (int t = tid; t <= pos; t += NT) {
     int64_t mk[NB];
     int sl[NB];
+    if (t == tid) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      mk[r] = p.mask[(size_t)(m0 + r) * T + t];
-      sl[r] = p.slot[(size_t)(m0 + r) * T + t];
+      for (int r = 0; r < NB; ++r) { mk[r] = mk0[r]; sl[r] = sl0[r]; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        mk[r] = p.mask[(size_t)(m0 + r) * T + t];
+        sl[r] = p.slot[(size_t)(m0 + r) * T + t];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);   // all 2 nb loads in flight before the first is looked at (hipcc interleaved them: two round trips)
     bool same = true;
@@ -953,12 +998,23 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   }
   const int nw = attn_waves_env() ? attn_waves_env() : kAttnWaves;
   const int NG = nw * 64 / (a.D / 8);
-  const size_t lds = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
-  if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
+  // ring depth (measured, profiles/r04_attn_row_ring_probe*.txt): 4 trips in flight while one workgroup per CU is all the grid asks
+  // for -- 8 buy nothing at 96 workgroups (the kernel's floor there is launch + three dependent round trips), 2 lose 0.4 us on a
+  // 231-position report -- and 2 beyond, where several workgroups per CU hide each other's round trips (10 % at 18+ rows)
+  const size_t lds0 = sizeof(float) * ((size_t)3 * a.D + 2 * NG + (size_t)NG * a.D + a.max_len);
+  int depth = (size_t)a.H * a.rows <= 256 ? 4 : 2;
+  while (depth > 2 && lds0 + (size_t)nw * depth * 2048 > 160 * 1024) depth /= 2;
+  const size_t lds = lds0 + (size_t)nw * depth * 2048;
+  if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;
   const dim3 grid(a.H, a.rows), block(nw * 64);
 #define MXVL_ATTN_ROW(DD) \
-  if (nw == 16) hipLaunchKernelGGL((decode_attn_kernel<DD, 16>), grid, block, lds, s, a); \
-  else hipLaunchKernelGGL((decode_attn_kernel<DD, 8>), grid, block, lds, s, a)
+  do { \
+    void (*kern)(const AttnArgs) = nw == 16 ? (depth == 8 ? decode_attn_kernel<DD, 16, 4> : depth == 4 ? decode_attn_kernel<DD, 16, 4> : decode_attn_kernel<DD, 16, 2>) \
+                                            : (depth == 8 ? decode_attn_kernel<DD, 8, 8> : depth == 4 ? decode_attn_kernel<DD, 8, 4> : decode_attn_kernel<DD, 8, 2>); \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return MXVL_ERR_LAUNCH; \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a); \
+  } while (0)
   switch (a.D) {
     case 64: MXVL_ATTN_ROW(64); break;
     case 128: MXVL_ATTN_ROW(128); break;
