@@ -193,7 +193,7 @@ class _LinearSwiGLU(torch.autograd.Function):
         if gemm_swiglu_supported(x2, w) and (not needs_grad or x2.shape[1] <= 1024):
             y, ab = gemm_swiglu_fwd_raw(x2, w, bias, want_ab=needs_grad)
         else:
-            ab = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
+            ab = torch.nn.functional.linear(x2, w, None if bias is None else autograd_util.cast_param(bias, cd))
             y = torch.empty((ab.shape[0], H), dtype=ab.dtype, device=ab.device)
             with torch.cuda.device(ab.device):
                 _abi.check(lib.mxvl_swiglu_fwd(ab.data_ptr(), y.data_ptr(), ab.shape[0], H, _abi.dtype_code(ab.dtype),

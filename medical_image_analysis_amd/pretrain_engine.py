@@ -114,7 +114,7 @@ class PretrainEngine:
         skip = model.no_weight_decay() if hasattr(model, "no_weight_decay") else ()
         self.optimizer = torch.optim.AdamW(param_groups_weight_decay(model, weight_decay, skip), lr=lr, betas=(0.9, 0.95),
                                            fused=bool(device is not None and torch.device(device).type == "cuda"))
-        self._cast_params = [p for p in model.parameters() if p.requires_grad and p.ndim >= 2 and p.is_cuda]
+        self._cast_params = [p for p in model.parameters() if p.requires_grad and p.ndim >= 1 and p.is_floating_point() and p.is_cuda]
         self._cast_shadow = None
         if self.world > 1:
             ids = [torch.device(device).index] if (device is not None and torch.device(device).type == "cuda") else None
@@ -125,7 +125,7 @@ class PretrainEngine:
 
     @torch.no_grad()
     def _refresh_casts(self):
-        """Low-precision copies of every >= 2-D parameter (the GEMM weights) in ONE multi-tensor launch, right after the optimizer
+        """Low-precision copies of every parameter (the GEMM weights and the biases added to their outputs) in ONE multi-tensor launch, right after the optimizer
         step; the projections pick them up through autograd_util.cast_param (one cast kernel per weight and forward before)."""
         if self.amp_dtype not in (torch.bfloat16, torch.float16) or not self._cast_params:
             return

@@ -395,7 +395,7 @@ class _LinearSplitK(torch.autograd.Function):
         cd = _compute_dtype(x)
         x2 = x.reshape(-1, x.shape[-1]).to(cd)
         w = autograd_util.cast_param(weight, cd)
-        y = torch.nn.functional.linear(x2, w, None if bias is None else bias.to(cd))
+        y = torch.nn.functional.linear(x2, w, None if bias is None else autograd_util.cast_param(bias, cd))
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y.view(*x.shape[:-1], weight.shape[0])
@@ -426,7 +426,7 @@ class _ProjIn(torch.autograd.Function):
         w = autograd_util.cast_param(weight, cd)
         y2 = torch.matmul(w, x2.t())
         if bias is not None:
-            y2 = y2 + bias.to(cd)[:, None]
+            y2 = y2 + autograd_util.cast_param(bias, cd)[:, None]
         ctx.save_for_backward(x2, w)
         ctx.meta = (Bz, L, K, x.dtype, weight.dtype, bias is not None, None if bias is None else bias.dtype)
         return _from_2d(y2, Bz, L)
@@ -453,7 +453,7 @@ class _ProjOut(torch.autograd.Function):
         w = autograd_util.cast_param(weight, cd)
         o2 = torch.matmul(y2.t(), w.t())
         if bias is not None:
-            o2 = o2 + bias.to(cd)
+            o2 = o2 + autograd_util.cast_param(bias, cd)
         ctx.save_for_backward(y2, w)
         ctx.meta = (Bz, D, L, y.dtype, weight.dtype, bias is not None, None if bias is None else bias.dtype)
         return o2.view(Bz, L, -1)
@@ -540,7 +540,7 @@ class _MambaInnerFn(torch.autograd.Function):
         xc = conv1d_fwd_raw(x, w32, b32, 1)
         io = xc.dtype
         xc2 = _dmajor_2d(xc)
-        wx, wdt = x_proj_w.to(io), dt_proj_w.to(io)
+        wx, wdt = autograd_util.cast_param(x_proj_w, io), autograd_util.cast_param(dt_proj_w, io)
         # the projections run in the io dtype of the conv output whatever the ambient autocast says: under bf16 autocast an
         # fp32 xz would otherwise meet bf16 x_dbl / dt / B / C in the scan ("delta.dtype != u.dtype")
         with torch.autocast(device_type="cuda", enabled=False):
@@ -548,9 +548,9 @@ class _MambaInnerFn(torch.autograd.Function):
             dt = _from_2d(torch.matmul(wdt, x_dbl[:R]), batch, L)
         Bm, Cm = _from_2d(x_dbl[R:R + N], batch, L), _from_2d(x_dbl[R + N:R + 2 * N], batch, L)
         if B_proj_bias is not None:
-            Bm = Bm + B_proj_bias.to(io)[None, :, None]
+            Bm = Bm + autograd_util.cast_param(B_proj_bias, io)[None, :, None]
         if C_proj_bias is not None:
-            Cm = Cm + C_proj_bias.to(io)[None, :, None]
+            Cm = Cm + autograd_util.cast_param(C_proj_bias, io)[None, :, None]
         _, u_, dt_, A_, B_, C_, D_, z_, bias_ = _prep(xc, dt, A, Bm, Cm, D, z, delta_bias)
         needs_grad = autograd_util.wants_grad(ctx, 10)
         out, _, ckpt = scan_fwd_raw(u_, dt_, A_, B_, C_, D_, z_, bias_, delta_softplus, want_ckpt=needs_grad)

@@ -524,8 +524,10 @@ def test_decode_gemm_split_k_folded_by_rmsnorm(K, N, S, rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,H,Hkv,nb,B", [(128, 4, 2, 3, 2), (64, 4, 4, 5, 2), (128, 2, 1, 2, 3), (256, 2, 1, 4, 1), (128, 32, 32, 3, 6)])
-def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B):
+@pytest.mark.parametrize("D,H,Hkv,nb,B,T,P,pos_v", [(128, 4, 2, 3, 2, 96, 37, 71), (64, 4, 4, 5, 2, 96, 37, 71), (128, 2, 1, 2, 3, 96, 37, 71),
+                                                     (256, 2, 1, 4, 1, 96, 37, 71), (128, 32, 32, 3, 6, 96, 37, 71),
+                                                     (128, 2, 2, 5, 1, 2100, 1000, 2050)])   # long table: the 4-wave shape of the beams kernel
+def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P, pos_v):
     """The beams kernel (a workgroup per (head, sample): cache positions the beams share are read once; both products on the matrix
     cores, probabilities rounded to bf16 before the second one as the modules' softmax(...).to(bf16) @ V does) against
     decode_attn_kernel (a workgroup per (head, row), fp32 VALU arithmetic) on the same state: left-padded prompt in shared slots, a
@@ -535,7 +537,7 @@ def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B):
     from medical_image_analysis_amd import _abi
     lib = _abi.load()
     dev = "cuda:0"
-    rows, T, P, pos_v = B * nb, 96, 37, 71
+    rows = B * nb
     g = torch.Generator().manual_seed(D + 7 * nb + B)
     bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(dev)
     qkv = bf(rows, (H + 2 * Hkv) * D)

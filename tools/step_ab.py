@@ -19,6 +19,15 @@ from medical_image_analysis_amd import models_mamba
 if what == "swiglu_pad":
     arms = {"hidden 2730 padded to 2752": lambda: setattr(models_mamba, "_HIDDEN_TILE", 64),
             "hidden 2730 as is": lambda: setattr(models_mamba, "_HIDDEN_TILE", 1)}
+elif what == "cast_cache":       # 1-D parameters (biases) in the refreshed low-precision copies, or cast at every use
+    from medical_image_analysis_amd import autograd_util
+    allp, big = list(eng._cast_params), [p for p in eng._cast_params if p.ndim >= 2]
+    def use(ps):
+        for p in allp:
+            p._mxvl_lp = None
+        eng._cast_params, eng._cast_shadow = ps, None
+        eng._refresh_casts()
+    arms = {"all parameters cached": lambda: use(allp), ">= 2-D parameters only": lambda: use(big)}
 else:
   arms = {"fused GEMM+gate": lambda: setattr(fused_ops, "gemm_swiglu_supported", orig),
           "library GEMM + gate kernel": lambda: setattr(fused_ops, "gemm_swiglu_supported", lambda *a: False)}
