@@ -403,6 +403,13 @@ int mxvl_row_gather(const void *src, const int32_t *idx, const float *fill, cons
                     int rows_out, int dim, int64_t src_bs, int64_t out_bs, int src_dtype, int out_dtype, void *hip_stream);
 int mxvl_patch_loss(const void *img, const void *pred, const void *dloss, void *loss, void *dpred, int batch, int channels, int hw,
                     int patch, int norm_pix, int io_dtype, void *hip_stream);
+/* mxvl_patch_cols (ABI v7): the im2col of a convolution whose kernel equals its stride -- the first projection of a patch embedding
+ * (HD_Xray_Pretrain_MAE/pretrain/patch_embed.py:21-43 SmallPatchEmbed conv1 16x16 / s16; finetune/DP/models/vit.py:186-208) as a GEMM:
+ *   cols[n, i * gw + j, (c * patch + di) * patch + dj] = img[n, c, i * patch + di, j * patch + dj]
+ * img (N, C, H, W) contiguous; cols (N, (H / patch) * (W / patch), C * patch^2) contiguous in out_dtype (== in_dtype, or a 16-bit
+ * dtype for an fp32 image: the autocast cast of the GEMM input).  patch in {4, 8, 16, 32, 64}, 16-byte aligned pointers. */
+int mxvl_patch_cols(const void *img, void *cols, int batch, int channels, int h, int w, int patch, int in_dtype, int out_dtype,
+                    void *hip_stream);
 
 /*
  * mxvl_gemm_swiglu_fwd (ABI v4): the SwiGLU input projection of the block MLP as ONE MFMA GEMM with the gate in its epilogue --

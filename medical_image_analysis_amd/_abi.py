@@ -36,7 +36,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
 ]
@@ -279,6 +279,8 @@ def load() -> ctypes.CDLL:
     lib.mxvl_row_gather.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_int64] * 2 + [c_int] * 2 + [c_void_p]
     lib.mxvl_patch_loss.restype = c_int
     lib.mxvl_patch_loss.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
+    lib.mxvl_patch_cols.restype = c_int
+    lib.mxvl_patch_cols.argtypes = [c_void_p] * 2 + [c_int] * 7 + [c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int
     lib.mxvl_scan_n_chunks.restype = c_int
     lib.mxvl_scan_fold_ok.restype = c_int

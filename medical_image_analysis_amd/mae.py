@@ -44,11 +44,26 @@ def _patch_gemm(x, conv: nn.Conv2d):
     k = conv.kernel_size[0]
     B, C, H, W = x.shape
     gh, gw = H // k, W // k
+    w = conv.weight
     if k == 1:
         cols = x.permute(0, 2, 3, 1).reshape(B, gh * gw, C)
+        w2 = w.reshape(w.shape[0], -1)
+    elif C > 1 and x.permute(0, 2, 3, 1).is_contiguous():
+        # the input is channels-last in memory (it is the previous _patch_gemm's output): sum over (kh, kw, c) instead of (c, kh, kw)
+        # -- the patch rows are then copies of C-element contiguous runs (2 KB at 1024 channels) instead of a gather of single
+        # elements (the generic strided-copy kernel ran at 0.6 TB/s on it: 6.5 ms of a 132 ms MAE step), and the (small) weight
+        # is permuted to match.  Same products, same fp32 accumulation; only the order of the sum differs.
+        cols = x.permute(0, 2, 3, 1).reshape(B, gh, k, gw, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, gh * gw, k * k * C)
+        w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    elif mae_ops.patch_cols_supported(x, k):
+        # an image batch (NCHW): the patch rows by one HIP kernel, already in the dtype the GEMM will run in
+        lp = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled("cuda") and x.dtype == torch.float32) else x.dtype
+        cols = mae_ops.patch_cols(x, k, lp)
+        w2 = w.reshape(w.shape[0], -1)
     else:
         cols = x.reshape(B, C, gh, k, gw, k).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * k * k)
-    y = F.linear(cols, conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+        w2 = w.reshape(w.shape[0], -1)
+    y = F.linear(cols, w2, conv.bias)
     return y.reshape(B, gh, gw, -1).permute(0, 3, 1, 2)
 
 

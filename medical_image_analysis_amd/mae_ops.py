@@ -125,3 +125,39 @@ def patch_loss(imgs, pred, patch, norm_pix_loss):
     if pred.shape != (imgs.shape[0], (imgs.shape[2] // patch) ** 2, patch * patch * imgs.shape[1]):
         raise RuntimeError(f"patch_loss: pred {tuple(pred.shape)} does not match the patch grid of imgs {tuple(imgs.shape)}")
     return _PatchLoss.apply(imgs, pred, int(patch), bool(norm_pix_loss))
+
+
+class _PatchCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, patch, out_dtype):
+        lib = _abi.load()
+        N, C, H, W = img.shape
+        cols = torch.empty((N, (H // patch) * (W // patch), C * patch * patch), dtype=out_dtype, device=img.device)
+        with torch.cuda.device(img.device):
+            _abi.check(lib.mxvl_patch_cols(img.data_ptr(), cols.data_ptr(), N, C, H, W, patch, _abi.dtype_code(img.dtype),
+                                           _abi.dtype_code(out_dtype), _abi.stream_ptr(img.device)), "mxvl_patch_cols")
+        ctx.meta = (img.shape, img.dtype, patch)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        (N, C, H, W), dt, p = ctx.meta        # (an image batch needs no gradient; a feature map that does gets the inverse permutation)
+        d = dcols.reshape(N, H // p, W // p, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(N, C, H, W)
+        return d.to(dt), None, None
+
+
+def patch_cols_supported(img, patch):
+    return (img.is_cuda and img.dim() == 4 and img.is_contiguous() and img.dtype in (torch.float32, torch.float16, torch.bfloat16)
+            and patch % 4 == 0 and 256 % patch == 0 and img.shape[2] % patch == 0 and img.shape[3] % patch == 0
+            and img.shape[0] <= 65535 and img.shape[1] <= 65535 and img.data_ptr() % 16 == 0)
+
+
+def patch_cols(img, patch, out_dtype=None):
+    """(N, C, H, W) -> (N, gh * gw, C * patch^2): `img.reshape(N, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5)` in `out_dtype` (default:
+    img's; a 16-bit dtype for an fp32 image = the autocast cast of the GEMM that consumes the rows)."""
+    _abi.require_gpu(img)
+    out_dtype = out_dtype or img.dtype
+    if out_dtype != img.dtype and img.dtype != torch.float32:
+        raise RuntimeError("patch_cols: the rows are a copy of the image, or the 16-bit cast of an fp32 image")
+    return _PatchCols.apply(img, int(patch), out_dtype)
+

@@ -170,3 +170,29 @@ def test_mae_under_fp16_autocast_and_grad_scaler_like_the_reference_recipe():
     losses = [float(eng.step(x)) for _ in range(3)]
     assert all(l == l and abs(l) < 1e3 for l in losses), losses
     assert eng.scaler.get_scale() > 0 and not torch.equal(before, m.blocks[0].mlp.fc1.weight.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,patch,dt_in,dt_out", [((2, 1, 64, 64), 16, torch.float32, torch.float32),
+                                                      ((2, 1, 320, 1280), 16, torch.float32, torch.float16),
+                                                      ((3, 3, 32, 48), 4, torch.float32, torch.bfloat16),
+                                                      ((1, 2, 64, 576), 64, torch.float16, torch.float16),
+                                                      ((2, 5, 16, 264), 8, torch.bfloat16, torch.bfloat16)])
+def test_patch_cols_is_the_permute_copy(shape, patch, dt_in, dt_out):
+    """mxvl_patch_cols against `img.reshape(N, C, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5)` (+ the cast torch would apply): bit-equal,
+    for widths that are / are not a multiple of the kernel's 256-column chunk; and the patch-embedding GEMM built on it against
+    F.conv2d (HD_Xray_Pretrain_MAE/pretrain/patch_embed.py:25)."""
+    from medical_image_analysis_amd import mae_ops
+    from medical_image_analysis_amd.mae import _patch_gemm
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(sum(shape) + patch)
+    x = torch.randn(*shape, generator=g).to(dev, dt_in)
+    N, C, H, W = shape
+    ref = x.reshape(N, C, H // patch, patch, W // patch, patch).permute(0, 2, 4, 1, 3, 5).reshape(N, -1, C * patch * patch).to(dt_out)
+    got = mae_ops.patch_cols(x, patch, dt_out)
+    assert got.dtype == dt_out and torch.equal(got, ref)
+    if dt_in == torch.float32 and dt_out == torch.float32:
+        conv = torch.nn.Conv2d(C, 24, kernel_size=patch, stride=patch).to(dev)
+        y, r = _patch_gemm(x, conv), torch.nn.functional.conv2d(x, conv.weight, conv.bias, stride=patch)
+        assert float((y - r).abs().max()) <= 1e-4 * float(r.abs().max())
+
