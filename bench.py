@@ -245,8 +245,9 @@ def cpu_baseline_decode(workload):
     """Reported baseline of the decode lines (the HF-generate CPU leg): the SAME decoder arithmetic on the host cores
     -- this package's torch module path (ReportDecoder.forward + the torch restatement of HF beam search), bf16 weights, which is
     what `generate` runs on CPU tensors; HF itself is not on the GPU box, so kind "port".  A Llama-2-7B on the CPU takes minutes to
-    build and seconds per token: the sample is a 2-layer and a 4-layer decoder of the same widths (embedding + lm_head full size),
-    a 16-embedding prompt and 2 vs 10 new tokens; per-token time = fixed part + 32 x per-layer part, both from the four timings."""
+    build and seconds per token: the sample is a 2-layer and a 6-layer decoder of the same widths (embedding + lm_head full size),
+    a 16-embedding prompt and 2 vs 12 new tokens (the less disturbed of two repeats); per-token time = fixed part + 32 x
+    per-layer part, both from those timings."""
     from medical_image_analysis_amd.report_decoder import ReportDecoder
     vocab, hidden, inter, layers, heads, kvh, plen, new, beams, B, desc = DECODE_WORKLOADS[workload]
     cores = min(host_physical_cores(), 64)
@@ -255,24 +256,33 @@ def cpu_baseline_decode(workload):
     emb = (0.02 * torch.randn(B, 16, hidden, generator=g)).to(torch.bfloat16)
     per_tok = {}
     t_begin = time.perf_counter()
-    for nl in (2, 4):
+    lo, hi = 2, 6
+    for nl in (lo, hi):
         torch.manual_seed(0)
         m = ReportDecoder(vocab, hidden, inter, nl, heads, kvh).to(torch.bfloat16).eval()
-        times = {}
-        for n_new in (2, 2, 10):            # (the first call warms the allocator / thread pools up and is overwritten)
+
+        def timed(n_new):
             kw = dict(num_beams=beams, min_new_tokens=n_new, max_new_tokens=n_new, repetition_penalty=2.0, length_penalty=2.0,
                       eos_token_id=2, pad_token_id=0)
             t0 = time.perf_counter()
             m.generate(emb, **kw)
-            times[n_new] = time.perf_counter() - t0
-        per_tok[nl] = (times[10] - times[2]) / 8.0
+            return time.perf_counter() - t0
+
+        timed(2)                              # warms the allocator / thread pools up
+        best, t_model = None, time.perf_counter()
+        for rep in range(2):                  # the difference of two host timings, extrapolated 16x: keep the less disturbed repeat
+            d = (timed(12) - timed(2)) / 10.0
+            best = d if best is None else min(best, d)
+            if time.perf_counter() - t_model > 8.0:
+                break
+        per_tok[nl] = best
         del m
-    per_layer = max((per_tok[4] - per_tok[2]) / 2.0, 0.0)
-    fixed = max(per_tok[2] - 2.0 * per_layer, 0.0)
+    per_layer = max((per_tok[hi] - per_tok[lo]) / (hi - lo), 0.0)
+    fixed = max(per_tok[lo] - lo * per_layer, 0.0)
     step_s = fixed + layers * per_layer
     return {"value": B / step_s, "unit": "tokens/sec", "cores": cores, "kind": "port",
-            "sample": f"torch CPU path of the same decoder (bf16): {B} x beam {beams}, 2- and 4-layer models of the workload's widths, "
-                      f"per-token time {per_tok[2] * 1e3:.0f} / {per_tok[4] * 1e3:.0f} ms -> {fixed * 1e3:.0f} ms + {layers} x {per_layer * 1e3:.1f} ms "
+            "sample": f"torch CPU path of the same decoder (bf16): {B} x beam {beams}, {lo}- and {hi}-layer models of the workload's widths, "
+                      f"per-token time {per_tok[lo] * 1e3:.0f} / {per_tok[hi] * 1e3:.0f} ms -> {fixed * 1e3:.0f} ms + {layers} x {per_layer * 1e3:.1f} ms "
                       f"= {step_s * 1e3:.0f} ms per token for the {layers}-layer model; {time.perf_counter() - t_begin:.0f} s of CPU work"}
 
 
