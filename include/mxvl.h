@@ -358,8 +358,13 @@ typedef struct mxvl_beam_desc {
   void *unfinished_log;            /* ABI v7, optional: (max_new) bytes the HOST can read (pinned, device-mapped): the step that ran at
                                       *cur == c also stores its *unfinished at [c], so a token loop that runs ahead of the host
                                       (report_decoder._search_lookahead) needs no device-to-host copy between the steps */
+  void *workspace;                 /* ABI v7, optional: mxvl_beam_workspace_bytes(batch, beams, keep) bytes of device memory (contents
+                                      irrelevant): when given, the two sweeps over the (beams x vocab) logits of a sample are split over
+                                      slices of the vocabulary (two extra launches in front of the one-workgroup-per-sample kernel) */
+  int64_t workspace_bytes;
 } mxvl_beam_desc;
 int mxvl_beam_step(const mxvl_beam_desc *desc, void *hip_stream);
+int64_t mxvl_beam_workspace_bytes(int batch, int beams, int keep);
 
 /* Residual add + LayerNorm of an ARM / VisionMamba block (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:
  * 110-116 `x + mixer(norm1(x))`, `x + mlp(norm2(x))`; the reference's fused_add_norm path pairs them the same way):

@@ -36,7 +36,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
 ]
@@ -200,7 +200,7 @@ class BeamDesc(ctypes.Structure):
         ("logits", c_void_p), ("run_seq", c_void_p), ("fin_seq", c_void_p), ("run_score", c_void_p), ("fin_score", c_void_p),
         ("fin_done", c_void_p), ("heur_open", c_void_p), ("cur", c_void_p), ("eos", c_void_p), ("len_tab", c_void_p),
         ("hyp_tab", c_void_p), ("tok", c_void_p), ("beam_src", c_void_p), ("unfinished", c_void_p), ("scratch", c_void_p),
-        ("unfinished_log", c_void_p),
+        ("unfinished_log", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -279,6 +279,8 @@ def load() -> ctypes.CDLL:
     lib.mxvl_row_gather.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_int64] * 2 + [c_int] * 2 + [c_void_p]
     lib.mxvl_patch_loss.restype = c_int
     lib.mxvl_patch_loss.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
+    lib.mxvl_beam_workspace_bytes.restype = c_int64
+    lib.mxvl_beam_workspace_bytes.argtypes = [c_int] * 3
     lib.mxvl_patch_cols.restype = c_int
     lib.mxvl_patch_cols.argtypes = [c_void_p] * 2 + [c_int] * 7 + [c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int

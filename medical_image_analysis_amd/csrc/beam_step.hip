@@ -40,9 +40,192 @@ struct BeamArgs {
   unsigned char* unfinished;           // scalar
   unsigned int* ticket;                // optional: arrival word of a multi-workgroup launch (zero between launches)
   unsigned char* unf_log;              // optional, host-visible (max_new): *unfinished of the step that ran at cur, at [cur]
+  // vocabulary split over workgroups (workspace given): slices of VS words; the statistics and the `keep` best candidates of every
+  // (sample, slice) come from beam_stats_kernel / beam_cand_kernel, beam_step_kernel merges them and does the bookkeeping
+  int S, VS;
+  float* ws_stats;                     // (batch*nb, S, 2): max, sum exp(x - max) of a row's slice
+  float* ws_cand_v;                    // (batch, S, keep)
+  int* ws_cand_i;                      // (batch, S, keep): beam * V + token
 };
 
 __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// ---- the vocabulary over workgroups (round 4) ---------------------------------------------------------------------------------------
+// One workgroup per sample reads its nb x V logits twice (statistics, candidates) through ONE CU: 384 KB at the 30-40 GB/s a CU
+// sustains is 2 x 10 us, and the per-word candidate test on 16 waves of one CU another 10 (profiles/r04_beam_phase_ablation2.txt).
+// Split: S slices of the vocabulary, (1) beam_stats_kernel -- max / sum-exp of every (row, slice); (2) beam_cand_kernel -- every
+// (sample, slice) workgroup combines the S partial statistics of its nb rows (the same S values in the same order in every
+// workgroup: identical log Z), sweeps its slice with the thread-local two-entry lists of the one-workgroup kernel and leaves its
+// `keep` best (value, index) pairs -- the global top-keep is a subset of the union of the per-slice top-keeps; (3) beam_step_kernel
+// merges S x keep candidates instead of sweeping, then does the bookkeeping.  Kernel boundaries order the three steps.
+constexpr int kSliceThreads = 256, kSliceWaves = kSliceThreads / 64;
+
+__global__ __launch_bounds__(kSliceThreads) void beam_stats_kernel(const BeamArgs p) {
+  __shared__ float s_red[kSliceWaves];
+  if (*p.unfinished == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, row = blockIdx.y, V = p.V;
+  const int v0 = s * p.VS, v1 = v0 + p.VS < V ? v0 + p.VS : V;
+  const float* x = p.logits + (size_t)row * V;
+  float m = -INFINITY;
+  for (int v = v0 + tid; v < v1; v += kSliceThreads) m = fmaxf(m, x[v]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  float mx = s_red[0];
+#pragma unroll
+  for (int w = 1; w < kSliceWaves; ++w) mx = fmaxf(mx, s_red[w]);
+  __syncthreads();
+  float sum = 0.0f;
+  if (mx > -INFINITY)
+    for (int v = v0 + tid; v < v1; v += kSliceThreads) sum += fast_exp(x[v] - mx);      // (second pass: the slice is in L1 / L2)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) s_red[wave] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float ss = 0.0f;
+    for (int w = 0; w < kSliceWaves; ++w) ss += s_red[w];
+    p.ws_stats[((size_t)row * p.S + s) * 2] = mx;
+    p.ws_stats[((size_t)row * p.S + s) * 2 + 1] = ss;
+  }
+}
+
+__global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int cand_smem[];      // [nb][words of the slice] history membership
+  __shared__ float s_red[kSliceWaves];
+  __shared__ int s_redi[kSliceWaves];
+  __shared__ float s_rowmax[kMaxBeams], s_logz[kMaxBeams], s_rscore[kMaxBeams];
+  __shared__ float s_top_lp[kMaxKeep];
+  __shared__ int s_top_ix[kMaxKeep];
+  __shared__ float s_surv_v[kMaxSurv];
+  __shared__ int s_surv_i[kMaxSurv];
+  __shared__ int s_nsurv;
+  if (*p.unfinished == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, b = blockIdx.y, nb = p.nb, V = p.V, keep = p.keep, S = p.S, max_new = p.max_new;
+  const int v0 = s * p.VS, v1 = v0 + p.VS < V ? v0 + p.VS : V;
+  const int words = (p.VS + 31) / 32;
+  const int cur = (int)*p.cur;
+  unsigned int* bitmap = cand_smem;
+  int eos32[kMaxEos];
+#pragma unroll
+  for (int e = 0; e < kMaxEos; ++e) eos32[e] = e < p.n_eos ? (int)p.eos[e] : -1;
+  for (int i = tid; i < nb * words; i += kSliceThreads) bitmap[i] = 0u;
+  if (tid < nb) {       // log-softmax statistics of row tid: the S partial results, in slice order (the same in every workgroup)
+    const float* st = p.ws_stats + (size_t)(b * nb + tid) * S * 2;
+    float mx = -INFINITY;
+    for (int k = 0; k < S; ++k) mx = fmaxf(mx, st[2 * k]);
+    float ss = 0.0f;
+    for (int k = 0; k < S; ++k) ss += st[2 * k] > -INFINITY ? st[2 * k + 1] * fast_exp(st[2 * k] - mx) : 0.0f;
+    s_rowmax[tid] = mx;
+    s_logz[tid] = logf(ss);
+    s_rscore[tid] = p.run_score[b * nb + tid];
+  }
+  __syncthreads();
+  if (p.rep_pen != 1.0f && cur > 0) {
+    const long long* rs = p.run_seq + (size_t)b * nb * max_new;
+    for (int i = tid; i < nb * cur; i += kSliceThreads) {
+      const int r = i / cur, t = i - r * cur;
+      const int v = (int)rs[r * max_new + t] - v0;
+      if (v >= 0 && v < v1 - v0) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
+    }
+  }
+  __syncthreads();
+  const bool mask_eos = cur < p.min_new;
+  auto cand_value = [&](int r, int v, float raw) -> float {
+    float x = (raw - s_rowmax[r]) - s_logz[r];                              // log_softmax
+    const bool hit = (bitmap[r * words + ((v - v0) >> 5)] >> ((v - v0) & 31)) & 1u;
+    if (__any(hit)) x = hit ? (x < 0.0f ? x * p.rep_pen : x / p.rep_pen) : x;
+    if (mask_eos) {
+#pragma unroll
+      for (int e = 0; e < kMaxEos; ++e)
+        if (eos32[e] == v) x = -INFINITY;
+    }
+    return x + s_rscore[r];
+  };
+  float v1st = -INFINITY, v2nd = -INFINITY;
+  int i1 = 0x7fffffff, i2 = 0x7fffffff;
+  for (int r = 0; r < nb; ++r) {
+    const float* row = p.logits + (size_t)(b * nb + r) * V;
+    for (int v = v0 + tid; v < v1; v += kSliceThreads) {
+      const float x = cand_value(r, v, row[v]);
+      if (x >= v2nd) {
+        const int idx = r * V + v;
+        const bool b1 = better(x, idx, v1st, i1), b2 = better(x, idx, v2nd, i2);
+        v2nd = b1 ? v1st : (b2 ? x : v2nd);
+        i2 = b1 ? i1 : (b2 ? idx : i2);
+        v1st = b1 ? x : v1st;
+        i1 = b1 ? idx : i1;
+      }
+    }
+  }
+  int head = 0;
+  for (int round = 0; round < keep; ++round) {
+    float v = head == 0 ? v1st : head == 1 ? v2nd : -INFINITY;
+    int ix = head == 0 ? i1 : head == 1 ? i2 : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(v, off, 64);
+      const int oi = __shfl_xor(ix, off, 64);
+      if (better(ov, oi, v, ix)) { v = ov; ix = oi; }
+    }
+    if (lane == 0) { s_red[wave] = v; s_redi[wave] = ix; }
+    __syncthreads();
+    if (tid == 0) {
+      float bv = s_red[0];
+      int bi = s_redi[0];
+      for (int w = 1; w < kSliceWaves; ++w)
+        if (better(s_red[w], s_redi[w], bv, bi)) { bv = s_red[w]; bi = s_redi[w]; }
+      s_top_lp[round] = bv;
+      s_top_ix[round] = bi;
+    }
+    __syncthreads();
+    const int win = s_top_ix[round];
+    if ((head == 0 && i1 == win) || (head == 1 && i2 == win)) ++head;
+  }
+  // exactness: a thread with both entries among the winners may hold more candidates above the keep-th value (as in beam_step_kernel)
+  if (tid == 0) s_nsurv = 0;
+  __syncthreads();
+  const bool suspect = head == 2 && keep > 2;
+  if (__syncthreads_or(suspect ? 1 : 0)) {
+    const float tau = s_top_lp[keep - 1];
+    const int tau_ix = s_top_ix[keep - 1];
+    if (suspect) {
+      for (int r = 0; r < nb; ++r) {
+        const float* row = p.logits + (size_t)(b * nb + r) * V;
+        for (int v = v0 + tid; v < v1; v += kSliceThreads) {
+          const int idx = r * V + v;
+          if (idx == i1 || idx == i2) continue;
+          const float x = cand_value(r, v, row[v]);
+          if (better(x, idx, tau, tau_ix)) {
+            const int slot = atomicAdd(&s_nsurv, 1);
+            if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int ns = s_nsurv < kMaxSurv ? s_nsurv : kMaxSurv;
+      for (int q = 0; q < ns; ++q) {
+        float x = s_surv_v[q];
+        int ix = s_surv_i[q];
+        for (int k = 0; k < keep; ++k)
+          if (better(x, ix, s_top_lp[k], s_top_ix[k])) {
+            const float tv = s_top_lp[k]; s_top_lp[k] = x; x = tv;
+            const int ti = s_top_ix[k]; s_top_ix[k] = ix; ix = ti;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < keep) {
+    p.ws_cand_v[((size_t)b * S + s) * keep + tid] = s_top_lp[tid];
+    p.ws_cand_i[((size_t)b * S + s) * keep + tid] = s_top_ix[tid];
+  }
+}
 
 // kBeamThreads x U logits of a row are in flight per trip: 1024 x 32 covers a 32 000-word vocabulary row in ONE round trip (the
 // 512 x 16 shape of round 3 walked a row in four dependent trips, twice -- statistics and candidates -- for every beam row).
@@ -99,10 +282,12 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     } else if (tid == 66) {
       s_tabs[1] = p.hyp_tab[cur];
     }
-    for (int i = tid; i < nb * words; i += kBeamThreads) bitmap[i] = 0u;
+    const bool merged = p.ws_cand_v != nullptr;      // the sweeps were done by beam_stats_kernel / beam_cand_kernel
+    if (!merged)
+      for (int i = tid; i < nb * words; i += kBeamThreads) bitmap[i] = 0u;
     for (int i = tid; i < nb * max_new; i += kBeamThreads) { old_run[i] = rs[i]; old_fin[i] = fs[i]; }
     __syncthreads();
-    if (p.rep_pen != 1.0f && cur > 0)
+    if (!merged && p.rep_pen != 1.0f && cur > 0)
       for (int i = tid; i < nb * cur; i += kBeamThreads) {
         const int r = i / cur, t = i - r * cur;
         const int v = (int)old_run[r * max_new + t];
@@ -129,7 +314,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
         }
       }
     };
-    for (int r = 0; r < nb; ++r) {
+    for (int r = 0; r < (merged ? 0 : nb); ++r) {
       const float* row = lg + (size_t)r * V;
       float m = -INFINITY, s = 0.0f;
       for (int base = 0; base < V; base += kBeamThreads * U) {
@@ -188,7 +373,11 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     };
     float v1 = -INFINITY, v2 = -INFINITY;
     int i1 = 0x7fffffff, i2 = 0x7fffffff;
-    for (int r = 0; r < nb; ++r) {
+    if (merged && tid < p.S * keep) {     // one entry per thread: the `keep` best of every vocabulary slice of this sample
+      v1 = p.ws_cand_v[(size_t)b * p.S * keep + tid];
+      i1 = p.ws_cand_i[(size_t)b * p.S * keep + tid];
+    }
+    for (int r = 0; r < (merged ? 0 : nb); ++r) {
       const float* row = lg + (size_t)r * V;
       const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
       const bool mask_eos = cur < p.min_new;
@@ -241,7 +430,7 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     // exactness: a thread with both entries among the winners may hold more candidates above the keep-th value
     if (tid == 0) s_nsurv = 0;
     __syncthreads();
-    const bool suspect = head == 2 && keep > 2;
+    const bool suspect = !merged && head == 2 && keep > 2;
     if (__syncthreads_or(suspect ? 1 : 0)) {
       const float tau = s_top_lp[keep - 1];
       const int tau_ix = s_top_ix[keep - 1];
@@ -403,6 +592,15 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
 
 using namespace mxvl;
 
+// slices of the vocabulary: enough workgroups to fill the chip at batch 1, S * keep <= 512 candidates to merge
+static int beam_slices(int batch) { return batch <= 4 ? 32 : 16; }
+
+extern "C" int64_t mxvl_beam_workspace_bytes(int batch, int beams, int keep) {
+  if (batch <= 0 || beams <= 0 || keep <= 0) return 0;
+  const int64_t S = beam_slices(batch);
+  return 4 * ((int64_t)batch * beams * S * 2 + 2 * (int64_t)batch * S * keep);
+}
+
 extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   if (!d || !d->logits || !d->run_seq || !d->fin_seq || !d->run_score || !d->fin_score || !d->fin_done || !d->heur_open ||
       !d->cur || !d->len_tab || !d->hyp_tab || !d->tok || !d->beam_src || !d->unfinished)
@@ -427,8 +625,22 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   const size_t words = (size_t)(a.V + 31) / 32;
   const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
   if (lds > 60 * 1024) return MXVL_ERR_UNSUPPORTED;
+  a.S = 0; a.VS = 0; a.ws_stats = nullptr; a.ws_cand_v = nullptr; a.ws_cand_i = nullptr;
+  if (d->workspace && d->workspace_bytes >= mxvl_beam_workspace_bytes(d->batch, d->beams, d->keep) && !MXVL_ABL_ENV("MXVL_BEAM_ONE_WG")) {
+    a.S = beam_slices(d->batch);
+    a.VS = ((a.V + a.S - 1) / a.S + 31) & ~31;
+    a.ws_stats = (float*)d->workspace;
+    a.ws_cand_v = a.ws_stats + (size_t)d->batch * d->beams * a.S * 2;
+    a.ws_cand_i = (int*)(a.ws_cand_v + (size_t)d->batch * a.S * d->keep);
+    hipLaunchKernelGGL(beam_stats_kernel, dim3(a.S, d->batch * d->beams), dim3(kSliceThreads), 0, (hipStream_t)hip_stream, a);
+    const size_t lds_c = 4 * (size_t)a.nb * ((a.VS + 31) / 32);
+    hipLaunchKernelGGL(beam_cand_kernel, dim3(a.S, d->batch), dim3(kSliceThreads), lds_c, (hipStream_t)hip_stream, a);
+  }
   static const int shape = MXVL_ABL_ENV("MXVL_BEAM_SHAPE");      // measurement build: 1 = the 512 x 16 shape
-  if (MXVL_ABL(shape == 1)) hipLaunchKernelGGL((beam_step_kernel<512, 16>), dim3(grid), dim3(512), lds, (hipStream_t)hip_stream, a);
+  if (a.ws_cand_v && a.S * a.keep <= 256)       // merge + bookkeeping only: four waves (barriers and the serial lane are all that is left)
+    hipLaunchKernelGGL((beam_step_kernel<256, 8>), dim3(grid), dim3(256), lds, (hipStream_t)hip_stream, a);
+  else if (MXVL_ABL(shape == 1) || (a.ws_cand_v && a.S * a.keep <= 512))
+    hipLaunchKernelGGL((beam_step_kernel<512, 16>), dim3(grid), dim3(512), lds, (hipStream_t)hip_stream, a);
   else hipLaunchKernelGGL((beam_step_kernel<1024, 32>), dim3(grid), dim3(1024), lds, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

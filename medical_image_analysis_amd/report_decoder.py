@@ -210,6 +210,8 @@ class _BeamState:
         self.beam_src = torch.zeros(B * nb, dtype=torch.long, device=dev)
         self.unfinished = torch.ones((), dtype=torch.bool, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)      # arrival word of the multi-workgroup beam kernel
+        self.workspace = None
+        self.split_vocab = True          # (tests switch it off to run the one-workgroup-per-sample sweeps)
         # *unfinished of the step that ran at cur = c, at [c], where the HOST can read it (pinned, device-mapped): the look-ahead
         # token loop polls this instead of enqueueing a device-to-host copy between two replays (a 4 us copy kernel + a 5 us gap
         # per token in the round-4 timeline)
@@ -248,6 +250,10 @@ class _BeamState:
         d.tok, d.beam_src, d.unfinished = self.tok.data_ptr(), self.beam_src.data_ptr(), self.unfinished.data_ptr()
         d.scratch = self.ticket.data_ptr() if self.B > 1 else None        # one workgroup per sample
         d.unfinished_log = _abi.ptr(self.unf_log)
+        if self.split_vocab:              # the vocabulary sweeps of a sample over 16 / 32 workgroups (csrc/beam_step.hip)
+            if self.workspace is None:
+                self.workspace = torch.empty(max(int(lib.mxvl_beam_workspace_bytes(self.B, self.nb, self.keep)), 4), dtype=torch.uint8, device=logits.device)
+            d.workspace, d.workspace_bytes = self.workspace.data_ptr(), self.workspace.numel()
         with torch.cuda.device(logits.device):
             _abi.check(lib.mxvl_beam_step(ctypes.byref(d), _abi.stream_ptr(logits.device)), "mxvl_beam_step")
 

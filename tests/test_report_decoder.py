@@ -741,7 +741,8 @@ def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning():
 @pytest.mark.parametrize("cfg", [dict(B=1, nb=3, V=32000, max_new=24, min_new=6, rep=2.0, lp=2.0, early=False),
                                  dict(B=2, nb=2, V=997, max_new=12, min_new=0, rep=1.0, lp=1.0, early=True),
                                  dict(B=3, nb=4, V=5000, max_new=16, min_new=3, rep=1.3, lp=0.5, early="never")])
-def test_beam_step_kernel_equals_torch_restatement(cfg):
+@pytest.mark.parametrize("split", [True, False])
+def test_beam_step_kernel_equals_torch_restatement(cfg, split):
     """csrc/beam_step.hip against _BeamState.advance_torch (itself token-exact with HF on the goldens): identical live
     beams, scores, parents, stop flag and finished hypotheses along a whole decode with EOS hits and random logits."""
     from medical_image_analysis_amd.report_decoder import _BeamState
@@ -749,6 +750,7 @@ def test_beam_step_kernel_equals_torch_restatement(cfg):
     B, nb, V = cfg["B"], cfg["nb"], cfg["V"]
     mk = lambda: _BeamState(B, nb, V, cfg["max_new"], 0, [2], cfg["min_new"], cfg["rep"], cfg["lp"], cfg["early"], dev)
     hip, ref = mk(), mk()
+    hip.split_vocab = split           # vocabulary sweeps over 16 / 32 workgroups per sample, or the one-workgroup kernel
     ref.use_hip = False
     g = torch.Generator().manual_seed(V)
     steps = 0
@@ -756,8 +758,11 @@ def test_beam_step_kernel_equals_torch_restatement(cfg):
         logits = 3.0 * torch.randn(B * nb, V, generator=g)
         if steps >= cfg["min_new"]:
             logits[:, 2] += 6.0 * (torch.rand(B * nb, generator=g) < 0.4).float()     # some beams end with EOS
-        if steps % 3 == 1 and V > 2100:   # three+ winners owned by ONE kernel thread (four consecutive words of a 16-byte load): the repair path
+        if steps % 3 == 1 and V > 2100:   # three+ winners owned by ONE kernel thread: the repair path.  One workgroup per sample: four
+            # consecutive words of a 16-byte load; vocabulary slices: words 256 apart in a slice, or the same word of several beam rows
             logits[0, [4, 5, 6, 7]] += torch.tensor([30.0, 29.0, 28.5, 28.0])
+            logits[0, [9, 265, 521, 777]] += torch.tensor([27.5, 27.0, 26.5, 26.0])
+            logits[0:min(nb, 3), 13] += torch.tensor([25.5, 25.0, 24.5])[:min(nb, 3)]
         logits = logits.to(dev)
         hip.advance(logits.clone())
         ref.advance(logits.clone())
