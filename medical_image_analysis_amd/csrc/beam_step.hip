@@ -59,6 +59,8 @@ __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv 
 // `keep` best (value, index) pairs -- the global top-keep is a subset of the union of the per-slice top-keeps; (3) beam_step_kernel
 // merges S x keep candidates instead of sweeping, then does the bookkeeping.  Kernel boundaries order the three steps.
 constexpr int kSliceThreads = 256, kSliceWaves = kSliceThreads / 64;
+constexpr int kCandThreads = 256, kCandWaves = kCandThreads / 64;   // (one wave per (sample, slice) -- no barriers -- measured slower: 47 dependent
+                                                                    //  words per thread, 52 vs 41 us per step at batch 1)
 
 __global__ __launch_bounds__(kSliceThreads) void beam_stats_kernel(const BeamArgs p) {
   __shared__ float s_red[kSliceWaves];
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(kSliceThreads) void beam_stats_kernel(const BeamArg
   }
 }
 
-__global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs p) {
+__global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned int cand_smem[];      // [nb][words of the slice] history membership
-  __shared__ float s_red[kSliceWaves];
-  __shared__ int s_redi[kSliceWaves];
+  __shared__ float s_red[kCandWaves];
+  __shared__ int s_redi[kCandWaves];
   __shared__ float s_rowmax[kMaxBeams], s_logz[kMaxBeams], s_rscore[kMaxBeams];
   __shared__ float s_top_lp[kMaxKeep];
   __shared__ int s_top_ix[kMaxKeep];
@@ -112,21 +114,24 @@ __global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs
   int eos32[kMaxEos];
 #pragma unroll
   for (int e = 0; e < kMaxEos; ++e) eos32[e] = e < p.n_eos ? (int)p.eos[e] : -1;
-  for (int i = tid; i < nb * words; i += kSliceThreads) bitmap[i] = 0u;
-  if (tid < nb) {       // log-softmax statistics of row tid: the S partial results, in slice order (the same in every workgroup)
-    const float* st = p.ws_stats + (size_t)(b * nb + tid) * S * 2;
-    float mx = -INFINITY;
-    for (int k = 0; k < S; ++k) mx = fmaxf(mx, st[2 * k]);
-    float ss = 0.0f;
-    for (int k = 0; k < S; ++k) ss += st[2 * k] > -INFINITY ? st[2 * k + 1] * fast_exp(st[2 * k] - mx) : 0.0f;
-    s_rowmax[tid] = mx;
-    s_logz[tid] = logf(ss);
-    s_rscore[tid] = p.run_score[b * nb + tid];
+  for (int i = tid; i < nb * words; i += kCandThreads) bitmap[i] = 0u;
+  // log-softmax statistics of the nb rows from the S partial results: lane k holds slice k, a shuffle tree combines them (the same
+  // tree in every workgroup of the sample: identical log Z everywhere)
+  for (int r = 0; r < nb; ++r) {
+    const float* st = p.ws_stats + (size_t)(b * nb + r) * S * 2;
+    const float mk = lane < S ? st[2 * lane] : -INFINITY, sk = lane < S ? st[2 * lane + 1] : 0.0f;
+    float mx = mk;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float ss = mk > -INFINITY ? sk * fast_exp(mk - mx) : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (tid == 0) { s_rowmax[r] = mx; s_logz[r] = logf(ss); s_rscore[r] = p.run_score[b * nb + r]; }
   }
   __syncthreads();
   if (p.rep_pen != 1.0f && cur > 0) {
     const long long* rs = p.run_seq + (size_t)b * nb * max_new;
-    for (int i = tid; i < nb * cur; i += kSliceThreads) {
+    for (int i = tid; i < nb * cur; i += kCandThreads) {
       const int r = i / cur, t = i - r * cur;
       const int v = (int)rs[r * max_new + t] - v0;
       if (v >= 0 && v < v1 - v0) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
@@ -149,15 +154,23 @@ __global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs
   int i1 = 0x7fffffff, i2 = 0x7fffffff;
   for (int r = 0; r < nb; ++r) {
     const float* row = p.logits + (size_t)(b * nb + r) * V;
-    for (int v = v0 + tid; v < v1; v += kSliceThreads) {
-      const float x = cand_value(r, v, row[v]);
-      if (x >= v2nd) {
-        const int idx = r * V + v;
-        const bool b1 = better(x, idx, v1st, i1), b2 = better(x, idx, v2nd, i2);
-        v2nd = b1 ? v1st : (b2 ? x : v2nd);
-        i2 = b1 ? i1 : (b2 ? idx : i2);
-        v1st = b1 ? x : v1st;
-        i1 = b1 ? idx : i1;
+    for (int vb = v0 + tid; vb < v1; vb += 4 * kCandThreads) {      // four words of the thread in flight per trip
+      float raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = vb + u * kCandThreads < v1 ? row[vb + u * kCandThreads] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = vb + u * kCandThreads;
+        if (v >= v1) continue;
+        const float x = cand_value(r, v, raw[u]);
+        if (x >= v2nd) {
+          const int idx = r * V + v;
+          const bool b1 = better(x, idx, v1st, i1), b2 = better(x, idx, v2nd, i2);
+          v2nd = b1 ? v1st : (b2 ? x : v2nd);
+          i2 = b1 ? i1 : (b2 ? idx : i2);
+          v1st = b1 ? x : v1st;
+          i1 = b1 ? idx : i1;
+        }
       }
     }
   }
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs
     if (tid == 0) {
       float bv = s_red[0];
       int bi = s_redi[0];
-      for (int w = 1; w < kSliceWaves; ++w)
+      for (int w = 1; w < kCandWaves; ++w)
         if (better(s_red[w], s_redi[w], bv, bi)) { bv = s_red[w]; bi = s_redi[w]; }
       s_top_lp[round] = bv;
       s_top_ix[round] = bi;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(kSliceThreads) void beam_cand_kernel(const BeamArgs
     if (suspect) {
       for (int r = 0; r < nb; ++r) {
         const float* row = p.logits + (size_t)(b * nb + r) * V;
-        for (int v = v0 + tid; v < v1; v += kSliceThreads) {
+        for (int v = v0 + tid; v < v1; v += kCandThreads) {
           const int idx = r * V + v;
           if (idx == i1 || idx == i2) continue;
           const float x = cand_value(r, v, row[v]);
@@ -634,7 +647,7 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
     a.ws_cand_i = (int*)(a.ws_cand_v + (size_t)d->batch * a.S * d->keep);
     hipLaunchKernelGGL(beam_stats_kernel, dim3(a.S, d->batch * d->beams), dim3(kSliceThreads), 0, (hipStream_t)hip_stream, a);
     const size_t lds_c = 4 * (size_t)a.nb * ((a.VS + 31) / 32);
-    hipLaunchKernelGGL(beam_cand_kernel, dim3(a.S, d->batch), dim3(kSliceThreads), lds_c, (hipStream_t)hip_stream, a);
+    hipLaunchKernelGGL(beam_cand_kernel, dim3(a.S, d->batch), dim3(kCandThreads), lds_c, (hipStream_t)hip_stream, a);
   }
   static const int shape = MXVL_ABL_ENV("MXVL_BEAM_SHAPE");      // measurement build: 1 = the 512 x 16 shape
   if (a.ws_cand_v && a.S * a.keep <= 256)       // merge + bookkeeping only: four waves (barriers and the serial lane are all that is left)
