@@ -57,3 +57,26 @@ def test_reference_geometry_still_takes_small_patch_embed():
                              decoder_depth=1, decoder_num_heads=4)
     assert isinstance(b.patch_embed, PatchEmbed) and b.patch_embed.num_patches == 16
     assert tuple(b.decoder_pred.weight.shape) == (256, 64)
+
+
+def test_small_patch_embed_gemms_equal_the_convolutions():
+    """SmallPatchEmbed as three GEMMs (mae._patch_gemm) against the reference's three Conv2d calls
+    (HD_Xray_Pretrain_MAE/pretrain/patch_embed.py:25-43), forward and every gradient: conv1 sums over (c, kh, kw) of the NCHW image,
+    conv2 over (kh, kw, c) of the channels-last feature map conv1 left (the weight is permuted to match), the 1x1 projection over c."""
+    import torch.nn.functional as F
+    from medical_image_analysis_amd.mae import SmallPatchEmbed
+    torch.manual_seed(3)
+    m = SmallPatchEmbed(1, 40, 24)
+    x = torch.randn(2, 1, 128, 192)
+    y = m(x)
+    r = F.relu(F.conv2d(x, m.conv1.weight, m.conv1.bias, stride=16))
+    r = F.relu(F.conv2d(r, m.conv2.weight, m.conv2.bias, stride=4))
+    r = F.conv2d(r, m.proj.weight, m.proj.bias).flatten(2).transpose(1, 2)
+    assert y.shape == r.shape and float((y - r).abs().max()) <= 1e-5 * max(1.0, float(r.abs().max()))
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    got = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    (r * w).sum().backward()
+    for a, p in zip(got, m.parameters()):
+        assert float((a - p.grad).abs().max()) <= 1e-4 * max(1.0, float(p.grad.abs().max()))
