@@ -261,10 +261,11 @@ struct CrossAttnArgs {
   uint16_t* out;               // (rows, H * D) text_state + ctx * gate
 };
 
-// measurement knob (tools/decode_attn_probe.py)
-static int attn_waves_env() {   // MXVL_ATTN_WAVES = 8 / 16 pins the workgroup size of the per-row kernel (beams kernel: 8 / 4 waves); unset = automatic
-  static const int v = [] { const char* e = getenv("MXVL_ATTN_WAVES"); const int d = e ? atoi(e) : 0; return (d == 8 || d == 16) ? d : 0; }();
-  return v;
+// measurement build only (python -m medical_image_analysis_amd.build --ablate; tools/decode_attn_probe.py): MXVL_ATTN_WAVES = 8 / 16
+// pins the workgroup size of the per-row kernel (beams kernel: 8 / 4 waves).  The product library reads no environment: always 0.
+static int attn_waves_env() {
+  static const int v = MXVL_ABL_ENV("MXVL_ATTN_WAVES");
+  return (v == 8 || v == 16) ? v : 0;
 }
 // Sum over the LPR lanes that share a cache row (LPR = head_dim / 8 consecutive lanes), result in every lane.  DPP moves inside a
 // 16-lane row -- quad_perm for the partners at distance 1 and 2, row_half_mirror / row_mirror for the other half of 8 / 16 (every
