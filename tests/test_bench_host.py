@@ -37,3 +37,17 @@ def test_pmc_traffic_record_feeds_the_roofline_object():
 def test_host_core_count_is_sane():
     n = bench.host_physical_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_decode_cpu_baseline_runs_on_a_tiny_workload(monkeypatch):
+    """bench.cpu_baseline_decode: the torch CPU path of the decoder on 2- and 6-layer samples, extrapolated per layer -- here on a
+    toy width so that it takes a second; the record must carry a positive rate, the core count and the description of the sample."""
+    import torch
+    monkeypatch.setitem(bench.DECODE_WORKLOADS, "toy", (128, 64, 96, 8, 4, 4, 16, 8, 2, 2, "toy decoder"))
+    threads = torch.get_num_threads()
+    try:
+        rec = bench.cpu_baseline_decode("toy")
+    finally:
+        torch.set_num_threads(threads)
+    assert rec["unit"] == "tokens/sec" and rec["kind"] == "port" and rec["value"] > 0 and rec["cores"] >= 1
+    assert "2- and 6-layer" in rec["sample"] and "8 x" in rec["sample"]
