@@ -213,7 +213,9 @@ typedef struct mxvl_decode_attn_desc {
                                mxvl_decode_cross_attn for hybrid layers conditioned on image tokens */
   int32_t beams;            /* ABI v6: 0 / 1 = a workgroup per (head, row).  2..5 (rows % beams == 0; rows b * beams .. are the beams of
                                sample b): a workgroup per (head, sample) -- cache positions on which the beams' slot-table entries agree
-                               (the prompt, the common generated prefix) are read once for all of them */
+                               (the prompt, the common generated prefix) are read once for all of them; both products run on the
+                               matrix cores and the probabilities are rounded to bf16 before the second one (softmax(...).to(bf16) @ V
+                               of the modules); needs rows * n_kv_heads * max_len * head_dim < 2^31 (32-bit cache offsets) */
   int32_t reserved0;
 } mxvl_decode_attn_desc;
 
