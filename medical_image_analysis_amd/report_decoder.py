@@ -530,6 +530,14 @@ class _KernelStepper(_SearchFusion):
         d.cos, d.sin, d.pos = self.cos.data_ptr(), self.sin.data_ptr(), self.pos.data_ptr()
         self._abi.check(self.lib.mxvl_decode_prologue(self._ct.byref(d), self._abi.stream_ptr(self.x.device)), "mxvl_decode_prologue")
 
+    def _beams_attn_fits(self):
+        """what mxvl_decode_attn checks before it runs the beams of a sample in one workgroup (csrc/decode.hip): 32-bit cache offsets
+        and the 4-wave shape's LDS (two K / V tile stages per wave + the rotated queries + the nb x max_len slot table) within 160 KB --
+        a long table takes the workgroup-per-row kernel instead of an error"""
+        nb, D, T = self.beams, self.D, self.max_len
+        lds = 4 * 2 * (2 * 16 * D * 2) + 16 * D * 2 + 4 * (3 * nb * D + 2 * nb * 5 + nb * T)
+        return self.rows * self.Hkv * T * D < 2 ** 31 and lds <= 160 * 1024
+
     def _body(self, tok, beam, cur):
         m = self.model
         self._prologue(tok, beam, cur)
@@ -538,7 +546,7 @@ class _KernelStepper(_SearchFusion):
         a.scale = self.D ** -0.5
         # the beams of a sample share a workgroup (and the cache lines they have in common) once head x sample workgroups fill the
         # chip; below that a workgroup per (head, row) keeps more requests in flight (batch 1 x beam 3: 9 vs 15 us per layer)
-        a.beams = self.beams if (2 <= self.beams <= 5 and self.H * (self.rows // self.beams) >= 128) else 0
+        a.beams = self.beams if (2 <= self.beams <= 5 and self.H * (self.rows // self.beams) >= 128 and self._beams_attn_fits()) else 0
         a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
