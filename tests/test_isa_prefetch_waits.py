@@ -86,3 +86,40 @@ def test_dir_merge_tile_loads_are_all_requested_before_the_first_wait():
     first_wait = next(k for k, x in enumerate(ins) if "vmcnt" in x)
     assert sum(1 for x in ins[:first_wait] if x.startswith("global_load_dwordx4")) == 6
     assert sum(1 for x in ins[:first_wait] if x.startswith("global_load_")) >= 20
+
+
+# ---- round 4: properties of the decode kernels and of the scan backward that no numerical test sees --------------------------------
+def _scratch_ops(ins):
+    return [x for x in ins if x.startswith("scratch_") or x.startswith("buffer_store_dword") and "offen" in x]
+
+
+def test_scan_bwd_training_kernels_have_no_scratch():
+    """the 8-wave dstate-16 walks (every training shape): the epilogue's lane / wave indices are re-derived, not kept alive across the
+    chunk loop (they were the two spilled VGPRs of rounds 2-3)"""
+    for name in ("scan_bwd_kernelINS_6bf16_tELi8ELb1ELi16ELb0ELb1E", "scan_bwd_kernelINS_6bf16_tELi8ELb1ELi16ELb1ELb1E",
+                 "scan_bwd_kernelINS_5f16_tELi8ELb1ELi16ELb0ELb1E"):
+        assert not _scratch_ops(_body("scan_bwd.hip", name)), name
+
+
+def test_beams_attention_runs_its_products_on_the_matrix_cores():
+    """decode_attn_beams_mfma_kernel: K Q^T by 16x16x32 MFMA, V^T P by 16x16x16 MFMA with V^T through the transpose read, tiles by
+    LDS-DMA with explicit counted waits, no scratch; the only ds_bpermute left are the per-tile max over the four q-lanes and the
+    final sum (the VALU version ran four dependent ones per (position, beam))."""
+    ins = _body("decode.hip", "decode_attn_beams_mfma_kernelILi128ELi3ELi8E")
+    count = lambda pat: sum(1 for x in ins if re.match(pat, x))
+    assert count(r"v_mfma_f32_16x16x32[_a-z0-9]*bf16") >= 4 and count(r"v_mfma_f32_16x16x16[_a-z0-9]*bf16") >= 8
+    assert count(r"ds_read_b64_tr_b16") >= 8 and count(r"global_load_lds_dwordx4") >= 8
+    assert any(re.match(r"s_waitcnt vmcnt\(8\)", x) for x in ins), "the wait for the older of two tiles in flight"
+    assert not _scratch_ops(ins)
+    assert count(r"ds_bpermute_b32") <= 12      # 2 per tile (max over q) + 2 (final sum) + the fresh position's wave reduction
+
+
+def test_per_row_decode_attention_sums_scores_by_dpp():
+    """decode_attn_kernel: the 16-lane score sum is four DPP adds; ds_bpermute only in the final merge of the lane groups (behind the
+    position loop), and the cache rows arrive through the LDS ring"""
+    ins = _body("decode.hip", "decode_attn_kernelILi128ELi8ELi4E")
+    assert sum(1 for x in ins if x.startswith("v_add_f32_dpp")) >= 4
+    assert sum(1 for x in ins if x.startswith("global_load_lds_dwordx4")) >= 4
+    first_dma = next(k for k, x in enumerate(ins) if x.startswith("global_load_lds_dwordx4"))
+    last_dma = max(k for k, x in enumerate(ins) if x.startswith("global_load_lds_dwordx4"))
+    assert not any(x.startswith("ds_bpermute_b32") for x in ins[first_dma:last_dma]), "a cross-lane LDS round trip inside the position loop"
