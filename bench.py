@@ -122,7 +122,35 @@ DECODE_WORKLOADS = {
                             "configs[3] at the reference's test batch: test_batch_size 8 x beam 3 = 24 rows per decoder step, otherwise as decode_llama7b_b6x3"),
     "decode_llama7b_b16x5": (32000, 4096, 11008, 32, 32, 32, 230, 128, 5, 16,
                              "configs[3] at the reference's IU-Xray test batch: 16 x beam 5 = 80 rows per decoder step, otherwise as decode_llama7b_b6x3"),
+    "decode_llama7b_b16x3": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 16,
+                             "configs[3] at the reference's config default: batch 16 x beam 3 = 48 rows per decoder step (configs/config.py:11-12,50), "
+                             "otherwise as decode_llama7b_b6x3"),
+    # the reference's own LLM dtype: torch_dtype=torch.float16 (MambaXrayVL_DownStream.py:72,85,92) -- the fp16 instantiations of every decode kernel
+    "decode_llama7b_128_fp16": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 1,
+                                "configs[3] in the dtype the reference loads its LLM in: Llama-2-7B-shaped decoder, random-init FP16 weights, "
+                                "230-embedding prompt, beam 3, 128 new tokens (min = max = 128), repetition/length penalty 2.0"),
+    "decode_llama7b_b6x3_fp16": (32000, 4096, 11008, 32, 32, 32, 230, 128, 3, 6,
+                                 "decode_llama7b_b6x3 with fp16 weights / activations (the reference's torch_dtype)"),
+    # the reference's IU-Xray decoder: Qwen1.5-1.8B-Chat in fp16 (MambaXrayVL_DownStream.py:65-77), test_batch_size 16 x beam 5, min 40 / max 100 new
+    # tokens, repetition / length penalty 2.0 (launch/launch_mambaclip_test_iu.sh:26-35)
+    "decode_qwen1p8b_b16x5": (151936, 2048, 5504, 24, 16, 16, 230, 100, 5, 16,
+                              "the reference's IU-Xray report decoder: Qwen1.5-1.8B-shaped (hidden 2048, 16 heads of 128, q/k/v biases, rope_theta 1e6, "
+                              "vocabulary 151 936; random-init FP16 weights), test_batch_size 16 x beam 5 = 80 rows per decoder step, 230-embedding "
+                              "prompts, 100 new tokens (min = max = 100), repetition/length penalty 2.0"),
+    "decode_qwen1p8b_b1x5": (151936, 2048, 5504, 24, 16, 16, 230, 100, 5, 1,
+                             "decode_qwen1p8b_b16x5 at batch 1 (5 rows per decoder step)"),
 }
+# per-workload extras: activation / weight dtype (default bf16) and constructor arguments beyond the widths
+DECODE_EXTRA = {
+    "decode_llama7b_128_fp16": dict(dtype="fp16"), "decode_llama7b_b6x3_fp16": dict(dtype="fp16"),
+    "decode_qwen1p8b_b16x5": dict(dtype="fp16", ctor=dict(rope_theta=1000000.0, rms_norm_eps=1e-6, max_position_embeddings=32768)),
+    "decode_qwen1p8b_b1x5": dict(dtype="fp16", ctor=dict(rope_theta=1000000.0, rms_norm_eps=1e-6, max_position_embeddings=32768)),
+}
+
+
+def _decode_dtype(workload):
+    name = DECODE_EXTRA.get(workload, {}).get("dtype", "bf16")
+    return name, (torch.float16 if name == "fp16" else torch.bfloat16)
 DEFAULT_WORKLOAD = "arm_pretrain_large_1024"
 
 
@@ -191,11 +219,18 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
     Returns the result dict on rank 0 (None elsewhere)."""
     from medical_image_analysis_amd.report_decoder import ReportDecoder
     vocab, hidden, inter, layers, heads, kvh, plen, new, beams, B, desc = DECODE_WORKLOADS[workload]
+    dt_name, dt = _decode_dtype(workload)
+    ctor = DECODE_EXTRA.get(workload, {}).get("ctor", {})
     torch.manual_seed(0)
     with torch.device(dev):
-        m = ReportDecoder(vocab, hidden, inter, layers, heads, kvh).to(torch.bfloat16).eval()
+        m = ReportDecoder(vocab, hidden, inter, layers, heads, kvh, **ctor).to(dt).eval()
+    if ctor:      # Qwen2: the q / k / v biases are real parameters (nn.Linear leaves them at its own init; make them count)
+        with torch.no_grad():
+            for layer in m.model.layers:
+                for proj in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj):
+                    proj.bias.normal_(0.0, 0.1)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    emb = (0.02 * torch.randn(B, plen, hidden, generator=g)).to(dev, torch.bfloat16)
+    emb = (0.02 * torch.randn(B, plen, hidden, generator=g)).to(dev, dt)
     kw = dict(num_beams=beams, min_new_tokens=new, max_new_tokens=new, repetition_penalty=2.0, length_penalty=2.0,
               eos_token_id=2, pad_token_id=0)
     for _ in range(warmup):
@@ -222,19 +257,20 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
     if rank != 0:
         return None
     tokens = B * world * steps * n_out
-    wbytes = 2 * n_params                                   # every decode step streams the bf16 weights once
+    n_params -= vocab * hidden                              # the embedding table is looked up (rows x hidden), not streamed
+    wbytes = 2 * n_params                                   # every decode step streams the 16-bit weights once
     step_s = wall / (steps * n_out)                         # per generated token (beam batch of `beams` rows)
     achieved = wbytes / step_s / 1e9
     return {
         "metric": "report-generation decode tokens/sec (returned tokens; each step advances all beams)",
         "value": tokens / wall, "unit": "tokens/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic prompt embeddings (seed 1000+rank), random-init weights (seed 0)",
-        "config": {"workload": f"{workload}: {desc}", "params": n_params, "batch": B, "num_beams": beams,
+        "dtype": dt_name, "data": "synthetic prompt embeddings (seed 1000+rank), random-init weights (seed 0)",
+        "config": {"workload": f"{workload}: {desc}", "streamed_params": n_params, "batch": B, "num_beams": beams,
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("decode step = 129 decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + 65 decode_rmsnorm_kernel + 32 "
+                     "kernel": (f"decode step = {4 * layers + 1} decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + {2 * layers + 1} decode_rmsnorm_kernel + {layers} "
                                 + ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
                                    "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
                                 + " launches + beam_step_kernel, one hipGraph replay per token; the time per token includes the prompt prefill's share"),
@@ -253,13 +289,16 @@ def cpu_baseline_decode(workload):
     cores = min(host_physical_cores(), 64)
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(1)
-    emb = (0.02 * torch.randn(B, 16, hidden, generator=g)).to(torch.bfloat16)
+    dt_name, dt = _decode_dtype(workload)
+    dt = torch.bfloat16             # (the host's fp16 GEMMs are emulated: the CPU leg runs the same decoder in bf16 whatever the GPU line's dtype)
+    ctor = DECODE_EXTRA.get(workload, {}).get("ctor", {})
+    emb = (0.02 * torch.randn(B, 16, hidden, generator=g)).to(dt)
     per_tok = {}
     t_begin = time.perf_counter()
     lo, hi = 2, 6
     for nl in (lo, hi):
         torch.manual_seed(0)
-        m = ReportDecoder(vocab, hidden, inter, nl, heads, kvh).to(torch.bfloat16).eval()
+        m = ReportDecoder(vocab, hidden, inter, nl, heads, kvh, **ctor).to(dt).eval()
 
         def timed(n_new):
             kw = dict(num_beams=beams, min_new_tokens=n_new, max_new_tokens=n_new, repetition_penalty=2.0, length_penalty=2.0,
@@ -396,7 +435,7 @@ def run_pretrain(args, rank, world, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         cpu_trainable = [n for n, p in model.named_parameters() if p.requires_grad]
-    secondary = None
+    secondary = north = None
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
         # second half of BASELINE.json's metric ("MAE pretrain images/sec + report-gen decode tokens/sec"): the report
         # decoder of configs[3], measured by the same process right after the training steps (replicas on every rank)
@@ -405,6 +444,9 @@ def run_pretrain(args, rank, world, dev, dist):
         secondary = measure_decode("decode_llama7b_128", 5, 1, rank, world, dev, dist)
         if secondary is not None and world == 1 and not args.no_cpu_baseline:
             secondary["cpu_baseline"] = cpu_baseline_decode("decode_llama7b_128")
+        # north_star's one numeric kernel target (BASELINE.json: ">= 40 % of MI355X HBM roofline on the selective-scan kernel at L=4096,
+        # D=1536"): the forward scan alone at B8 x L4096 x D1536 x N16 fp32, ~0.1 s, so that the driver's own line carries it
+        north = measure_scan("scan_fwd_target", 200, 20, rank, world, dev, dist, no_cpu_baseline=True)
     if rank != 0:
         return
     stats = {}
@@ -439,6 +481,8 @@ def run_pretrain(args, rank, world, dev, dist):
     if secondary is not None:
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                       "dtype", "config", "roofline", "cpu_baseline") if k in secondary}
+    if north is not None:
+        out["north_star_kernel"] = {k: north[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
     if cpu_sd is not None:
         out["cpu_baseline"] = cpu_baseline_pretrain(cpu_sd, img, patch, depth, cpu_trainable)
     print(json.dumps(out))
@@ -594,6 +638,75 @@ def run_vmamba(args, rank, world, dev, dist):
                      "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}}}))
 
 
+def measure_scan(workload, steps, warmup, rank, world, dev, dist, no_cpu_baseline=False, one_gpu=False):
+    """One selective-scan micro-benchmark line (the kernel alone, inputs resident in HBM); returns the dict on rank 0."""
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
+    B, D, L, N, dtname, desc = WORKLOADS[workload]
+    dtype = getattr(torch, dtname)
+    x = make_scan_inputs(B, D, L, N, dtype, dev, seed=rank)
+    step = lambda: scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True)
+    backward = workload.startswith("scan_bwd")
+    if backward:
+        from medical_image_analysis_amd.selective_scan_interface import scan_algorithmic_bytes, scan_bwd_raw
+        _, _, ckpt = scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, want_ckpt=True)
+        dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(7 + rank)).to(dev, dtype)
+        step = lambda: scan_bwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, ckpt, dout)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / steps  # mean launch-to-launch duration of the scan kernel
+    if dist is not None:
+        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        images = B * world * steps
+        elt = torch.empty((), dtype=dtype).element_size()
+        nbytes = scan_bytes(B, D, L, N, 1, elt)
+        if backward:
+            nbytes = scan_algorithmic_bytes(B, D, L, N, 1, elt, True, True, ckpt.shape[2])
+        achieved = nbytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "images/sec (one image = one (D x L) patch-token sequence through the selective scan)",
+            "value": images / wall, "unit": "images/sec", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": wall / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtname],
+            "data": "synthetic (reference test distribution, seed = rank), inputs resident in HBM",
+            "config": {"workload": f"{workload}: {desc}", "per_gpu_batch": B, "seq_len": L, "d_inner": D,
+                       "d_state": N, "parallelism": f"dp{world} (independent batch shards, no collective)" + (
+                           " -- DEV CHECK: all ranks on cuda:0, gloo barriers, not a scaling number" if one_gpu and world > 1 else ""),
+                       "kernel": _abi.load().mxvl_last_scan_kernel().decode()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": ("scan_bwd_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
+                                    if backward else "scan_fwd_stream_kernel"),
+                         "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms,
+                         "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
+        }
+        attach_traffic(out["roofline"], workload)
+        if world == 1 and not no_cpu_baseline and not backward:
+            out["cpu_baseline"] = cpu_baseline_scan(B, D, L, N)
+        return out
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -659,67 +772,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    B, D, L, N, dtname, desc = WORKLOADS[args.workload]
-    dtype = getattr(torch, dtname)
-    x = make_scan_inputs(B, D, L, N, dtype, dev, seed=rank)
-    step = lambda: scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True)
-    backward = args.workload.startswith("scan_bwd")
-    if backward:
-        from medical_image_analysis_amd.selective_scan_interface import scan_algorithmic_bytes, scan_bwd_raw
-        _, _, ckpt = scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, want_ckpt=True)
-        dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(7 + rank)).to(dev, dtype)
-        step = lambda: scan_bwd_raw(x["u"], x["delta"], x["A"], x["B"], x["C"], x["D"], x["z"], x["delta_bias"], True, ckpt, dout)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1) / args.steps  # mean launch-to-launch duration of the scan kernel
-    if dist is not None:
-        t = torch.tensor([wall, kern_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kern_ms = float(t[0]), float(t[1])
-
-    if rank == 0:
-        images = B * world * args.steps
-        elt = torch.empty((), dtype=dtype).element_size()
-        nbytes = scan_bytes(B, D, L, N, 1, elt)
-        if backward:
-            nbytes = scan_algorithmic_bytes(B, D, L, N, 1, elt, True, True, ckpt.shape[2])
-        achieved = nbytes / (kern_ms * 1e-3) / 1e9
-        out = {
-            "metric": "images/sec (one image = one (D x L) patch-token sequence through the selective scan)",
-            "value": images / wall, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"float32": "f32", "bfloat16": "bf16"}[dtname],
-            "data": "synthetic (reference test distribution, seed = rank), inputs resident in HBM",
-            "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "seq_len": L, "d_inner": D,
-                       "d_state": N, "parallelism": f"dp{world} (independent batch shards, no collective)" + (
-                           " -- DEV CHECK: all ranks on cuda:0, gloo barriers, not a scaling number" if one_gpu and world > 1 else ""),
-                       "kernel": _abi.load().mxvl_last_scan_kernel().decode()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("scan_bwd_kernel + zero-fill of the fp32 accumulators (one mxvl_scan_bwd call)"
-                                    if backward else "scan_fwd_stream_kernel"),
-                         "algorithmic_bytes_per_launch": nbytes, "kernel_ms": kern_ms,
-                         "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
-        }
-        attach_traffic(out["roofline"], args.workload)
-        if world == 1 and not args.no_cpu_baseline and not backward:
-            out["cpu_baseline"] = cpu_baseline_scan(B, D, L, N)
+    out = measure_scan(args.workload, args.steps, args.warmup, rank, world, dev, dist, args.no_cpu_baseline, one_gpu)
+    if out is not None:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

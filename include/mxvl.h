@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 7
+#define MXVL_ABI_VERSION 8
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -163,8 +163,10 @@ typedef struct mxvl_conv1d_bwd_desc {
 } mxvl_conv1d_bwd_desc;
 
 /*
- * Single-token decoder step of the report generator (bf16 weights and activations, fp32 accumulation), rows =
- * batch * beams <= 80.  Replaces per-token HF `LlamaForCausalLM.forward` + cuBLAS GEMVs
+ * Single-token decoder step of the report generator (16-bit weights and activations, fp32 accumulation), rows =
+ * batch * beams <= 80.  ABI v8: every descriptor of the step carries `dtype` (MXVL_BF16 | MXVL_F16; 0 = bf16, what a v7 caller
+ * leaves there): the reference loads its LLM with torch_dtype=torch.float16 (models/MambaXrayVL_DownStream.py:72,85,92), so every
+ * kernel of the step exists for both element types (csrc/decode_elt.h) -- "bf16" in the field comments below reads "dtype".  Replaces per-token HF `LlamaForCausalLM.forward` + cuBLAS GEMVs
  * (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:292-301; layer arithmetic as restated in
  * EMRRG/models/hybrid_decoder_layer.py:185-199, 266-337, 392-457).
  *
@@ -191,7 +193,7 @@ typedef struct mxvl_gemv_desc {
                                projections with few columns (o_proj, down_proj: N = hidden) that cannot fill the chip otherwise */
   int32_t k_splits;         /* 0: kernel by row count (rows <= 8: GEMV).  != 0: the matrix-core kernels at any row count; 1..16 with
                                split_acc, 1 without */
-  int32_t reserved0;
+  int32_t dtype;            /* ABI v8: mxvl_dtype of x, norm_weight, W, W2, bias, residual, y (0 = MXVL_BF16) */
 } mxvl_gemv_desc;
 
 /*
@@ -216,7 +218,7 @@ typedef struct mxvl_decode_attn_desc {
                                (the prompt, the common generated prefix) are read once for all of them; both products run on the
                                matrix cores and the probabilities are rounded to bf16 before the second one (softmax(...).to(bf16) @ V
                                of the modules); needs rows * n_kv_heads * max_len * head_dim < 2^31 (32-bit cache offsets) */
-  int32_t reserved0;
+  int32_t dtype;            /* ABI v8: mxvl_dtype of qkv, the caches, out, q_rope (0 = MXVL_BF16) */
 } mxvl_decode_attn_desc;
 
 /*
@@ -243,6 +245,8 @@ typedef struct mxvl_decode_cross_attn_desc {
   const void *gate_bias;    /* (1) bf16 */
   const void *warm_up_gate; /* optional (1) bf16 */
   void *out;                /* (rows, n_heads * head_dim) bf16, must not alias text_state */
+  int32_t dtype;            /* ABI v8: mxvl_dtype of every 16-bit tensor above (0 = MXVL_BF16) */
+  int32_t reserved0;
 } mxvl_decode_cross_attn_desc;
 
 /*
@@ -284,6 +288,8 @@ typedef struct mxvl_rmsnorm_desc {
                                normalised is  x_out = bf16(acc) + residual  (the modules' `residual + linear(...)`), acc is zeroed */
   const void *residual;     /* (rows, K) bf16, with acc */
   void *x_out;              /* (rows, K) bf16, with acc; may alias residual */
+  int32_t dtype;            /* ABI v8: mxvl_dtype of x, weight, y, residual, x_out (0 = MXVL_BF16) */
+  int32_t reserved0;
 } mxvl_rmsnorm_desc;
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);

@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -112,13 +112,13 @@ class GemvDesc(ctypes.Structure):
         ("rows", c_int32), ("K", c_int32), ("N", c_int32), ("swiglu", c_int32), ("out_f32", c_int32),
         ("eps", ctypes.c_float),
         ("x", c_void_p), ("norm_weight", c_void_p), ("W", c_void_p), ("W2", c_void_p), ("bias", c_void_p),
-        ("residual", c_void_p), ("y", c_void_p), ("split_acc", c_void_p), ("k_splits", c_int32), ("reserved0", c_int32),
+        ("residual", c_void_p), ("y", c_void_p), ("split_acc", c_void_p), ("k_splits", c_int32), ("dtype", c_int32),
     ]
 
 
 class RmsNormDesc(ctypes.Structure):
     _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p),
-                ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p)]
+                ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p), ("dtype", c_int32), ("reserved0", c_int32)]
 
 
 class DecodeAttnDesc(ctypes.Structure):
@@ -127,7 +127,7 @@ class DecodeAttnDesc(ctypes.Structure):
         ("scale", ctypes.c_float),
         ("qkv", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("k_cache", c_void_p), ("v_cache", c_void_p),
         ("slot_table", c_void_p), ("pos", c_void_p), ("mask", c_void_p), ("out", c_void_p), ("q_rope", c_void_p),
-        ("beams", c_int32), ("reserved0", c_int32),
+        ("beams", c_int32), ("dtype", c_int32),
     ]
 
 
@@ -140,7 +140,7 @@ class DecodeCrossAttnDesc(ctypes.Structure):
         ("kv_rows_div", c_int32), ("gate_flags", c_int32), ("scale", ctypes.c_float),
         ("q_rope", c_void_p), ("k", c_void_p), ("v", c_void_p), ("key_mask", c_void_p), ("row_on", c_void_p),
         ("text_state", c_void_p), ("gate_weight", c_void_p), ("gate_bias", c_void_p), ("warm_up_gate", c_void_p),
-        ("out", c_void_p),
+        ("out", c_void_p), ("dtype", c_int32), ("reserved0", c_int32),
     ]
 
 

@@ -61,6 +61,11 @@ __device__ inline bool better(float v, int i, float bv, int bi) { return v > bv 
 constexpr int kSliceThreads = 256, kSliceWaves = kSliceThreads / 64;
 constexpr int kCandThreads = 256, kCandWaves = kCandThreads / 64;   // (one wave per (sample, slice) -- no barriers -- measured slower: 47 dependent
                                                                     //  words per thread, 52 vs 41 us per step at batch 1)
+// History membership (the repetition penalty) is an LDS bitmap over a TILE of the vocabulary, rebuilt per tile -- round 5: it used
+// to cover the whole vocabulary (beams x vocab / 32 words), which put Qwen1.5's 151 936 tokens at beam 3 / 5 (the reference's
+// IU-Xray decoder, MambaXrayVL_DownStream.py:65-77, launch_mambaclip_test_iu.sh:26-27) past the LDS of a workgroup.  A 32 000-word
+// vocabulary is still one tile in both kernels: nothing changes for Llama.
+constexpr int kCandTile = 8192;
 
 __global__ __launch_bounds__(kSliceThreads) void beam_stats_kernel(const BeamArgs p) {
   __shared__ float s_red[kSliceWaves];
@@ -108,13 +113,13 @@ __global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.x, b = blockIdx.y, nb = p.nb, V = p.V, keep = p.keep, S = p.S, max_new = p.max_new;
   const int v0 = s * p.VS, v1 = v0 + p.VS < V ? v0 + p.VS : V;
-  const int words = (p.VS + 31) / 32;
+  const int tile = p.VS < kCandTile ? p.VS : kCandTile;        // words of the vocabulary per bitmap tile
+  const int words = (tile + 31) / 32;
   const int cur = (int)*p.cur;
   unsigned int* bitmap = cand_smem;
   int eos32[kMaxEos];
 #pragma unroll
   for (int e = 0; e < kMaxEos; ++e) eos32[e] = e < p.n_eos ? (int)p.eos[e] : -1;
-  for (int i = tid; i < nb * words; i += kCandThreads) bitmap[i] = 0u;
   // log-softmax statistics of the nb rows from the S partial results: lane k holds slice k, a shuffle tree combines them (the same
   // tree in every workgroup of the sample: identical log Z everywhere)
   for (int r = 0; r < nb; ++r) {
@@ -128,20 +133,26 @@ __global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs 
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if (tid == 0) { s_rowmax[r] = mx; s_logz[r] = logf(ss); s_rscore[r] = p.run_score[b * nb + r]; }
   }
-  __syncthreads();
-  if (p.rep_pen != 1.0f && cur > 0) {
-    const long long* rs = p.run_seq + (size_t)b * nb * max_new;
-    for (int i = tid; i < nb * cur; i += kCandThreads) {
-      const int r = i / cur, t = i - r * cur;
-      const int v = (int)rs[r * max_new + t] - v0;
-      if (v >= 0 && v < v1 - v0) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
+  // bitmap of the history tokens that fall into [t0, t0 + tile) (workgroup-uniform call: it synchronises)
+  auto build_bitmap = [&](int t0) {
+    __syncthreads();
+    for (int i = tid; i < nb * words; i += kCandThreads) bitmap[i] = 0u;
+    __syncthreads();
+    if (p.rep_pen != 1.0f && cur > 0) {
+      const long long* rs = p.run_seq + (size_t)b * nb * max_new;
+      for (int i = tid; i < nb * cur; i += kCandThreads) {
+        const int r = i / cur, t = i - r * cur;
+        const long long tk = rs[r * max_new + t];
+        const int v = (int)tk - t0;
+        if (tk >= t0 && v < tile && tk < v1) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
+  };
   const bool mask_eos = cur < p.min_new;
-  auto cand_value = [&](int r, int v, float raw) -> float {
+  auto cand_value = [&](int r, int v, float raw, int t0) -> float {
     float x = (raw - s_rowmax[r]) - s_logz[r];                              // log_softmax
-    const bool hit = (bitmap[r * words + ((v - v0) >> 5)] >> ((v - v0) & 31)) & 1u;
+    const bool hit = (bitmap[r * words + ((v - t0) >> 5)] >> ((v - t0) & 31)) & 1u;
     if (__any(hit)) x = hit ? (x < 0.0f ? x * p.rep_pen : x / p.rep_pen) : x;
     if (mask_eos) {
 #pragma unroll
@@ -152,17 +163,20 @@ __global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs 
   };
   float v1st = -INFINITY, v2nd = -INFINITY;
   int i1 = 0x7fffffff, i2 = 0x7fffffff;
+  for (int t0 = v0; t0 < v1; t0 += tile) {
+  build_bitmap(t0);
+  const int t1 = t0 + tile < v1 ? t0 + tile : v1;
   for (int r = 0; r < nb; ++r) {
     const float* row = p.logits + (size_t)(b * nb + r) * V;
-    for (int vb = v0 + tid; vb < v1; vb += 4 * kCandThreads) {      // four words of the thread in flight per trip
+    for (int vb = t0 + tid; vb < t1; vb += 4 * kCandThreads) {      // four words of the thread in flight per trip
       float raw[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) raw[u] = vb + u * kCandThreads < v1 ? row[vb + u * kCandThreads] : -INFINITY;
+      for (int u = 0; u < 4; ++u) raw[u] = vb + u * kCandThreads < t1 ? row[vb + u * kCandThreads] : -INFINITY;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int v = vb + u * kCandThreads;
-        if (v >= v1) continue;
-        const float x = cand_value(r, v, raw[u]);
+        if (v >= t1) continue;
+        const float x = cand_value(r, v, raw[u], t0);
         if (x >= v2nd) {
           const int idx = r * V + v;
           const bool b1 = better(x, idx, v1st, i1), b2 = better(x, idx, v2nd, i2);
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs 
         }
       }
     }
+  }
   }
   int head = 0;
   for (int round = 0; round < keep; ++round) {
@@ -205,16 +220,20 @@ __global__ __launch_bounds__(kCandThreads) void beam_cand_kernel(const BeamArgs 
   if (__syncthreads_or(suspect ? 1 : 0)) {
     const float tau = s_top_lp[keep - 1];
     const int tau_ix = s_top_ix[keep - 1];
-    if (suspect) {
-      for (int r = 0; r < nb; ++r) {
-        const float* row = p.logits + (size_t)(b * nb + r) * V;
-        for (int v = v0 + tid; v < v1; v += kCandThreads) {
-          const int idx = r * V + v;
-          if (idx == i1 || idx == i2) continue;
-          const float x = cand_value(r, v, row[v]);
-          if (better(x, idx, tau, tau_ix)) {
-            const int slot = atomicAdd(&s_nsurv, 1);
-            if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+    for (int t0 = v0; t0 < v1; t0 += tile) {
+      if (v1 - v0 > tile) build_bitmap(t0);          // (a one-tile slice still holds its bitmap)
+      const int t1 = t0 + tile < v1 ? t0 + tile : v1;
+      if (suspect) {
+        for (int r = 0; r < nb; ++r) {
+          const float* row = p.logits + (size_t)(b * nb + r) * V;
+          for (int v = t0 + tid; v < t1; v += kCandThreads) {
+            const int idx = r * V + v;
+            if (idx == i1 || idx == i2) continue;
+            const float x = cand_value(r, v, row[v], t0);
+            if (better(x, idx, tau, tau_ix)) {
+              const int slot = atomicAdd(&s_nsurv, 1);
+              if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+            }
           }
         }
       }
@@ -265,8 +284,10 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
   __shared__ int s_out_fdone[kMaxBeams], s_out_open;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = p.nb, V = p.V, keep = p.keep, max_new = p.max_new;
-  const int words = (V + 31) / 32;
-  unsigned int* bitmap = smem_u;                                   // [nb][words] history membership
+  constexpr int TILE = kBeamThreads * U;                           // one trip of the sweeps = one bitmap tile
+  const bool merged = p.ws_cand_v != nullptr;                      // the sweeps were done by beam_stats_kernel / beam_cand_kernel
+  const int words = merged ? 0 : ((V < TILE ? V : TILE) + 31) / 32;
+  unsigned int* bitmap = smem_u;                                   // [nb][words] history membership of the tile being swept
   long long* old_run = (long long*)(smem_u + ((nb * words + 1) & ~1));   // [nb][max_new]
   long long* old_fin = old_run + nb * max_new;                     // [nb][max_new]
   const int cur = (int)*p.cur;
@@ -295,17 +316,22 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     } else if (tid == 66) {
       s_tabs[1] = p.hyp_tab[cur];
     }
-    const bool merged = p.ws_cand_v != nullptr;      // the sweeps were done by beam_stats_kernel / beam_cand_kernel
-    if (!merged)
-      for (int i = tid; i < nb * words; i += kBeamThreads) bitmap[i] = 0u;
     for (int i = tid; i < nb * max_new; i += kBeamThreads) { old_run[i] = rs[i]; old_fin[i] = fs[i]; }
     __syncthreads();
-    if (!merged && p.rep_pen != 1.0f && cur > 0)
-      for (int i = tid; i < nb * cur; i += kBeamThreads) {
-        const int r = i / cur, t = i - r * cur;
-        const int v = (int)old_run[r * max_new + t];
-        if (v >= 0 && v < V) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
-      }
+    // bitmap of the history tokens in [t0, t0 + TILE) (workgroup-uniform call: it synchronises)
+    auto build_bitmap = [&](int t0) {
+      __syncthreads();
+      for (int i = tid; i < nb * words; i += kBeamThreads) bitmap[i] = 0u;
+      __syncthreads();
+      if (p.rep_pen != 1.0f && cur > 0)
+        for (int i = tid; i < nb * cur; i += kBeamThreads) {
+          const int r = i / cur, t = i - r * cur;
+          const long long tk = old_run[r * max_new + t];
+          const int v = (int)tk - t0;
+          if (tk >= t0 && v < TILE && tk < V) atomicOr(&bitmap[r * words + (v >> 5)], 1u << (v & 31));
+        }
+      __syncthreads();
+    };
     // ---- (1) log-softmax statistics per beam row: one sweep, U independent loads in flight per thread --------------
     // word u of a thread's trip: four consecutive words per 16-byte load when the rows allow it (a quarter of the load instructions)
     auto vof = [&](int base, int u) {
@@ -372,10 +398,10 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     // A sorted `keep`-deep list per thread costs a wave-wide insertion for almost every element (some lane always
     // inserts): 100 us.  Two entries per thread are exact unless one thread owns three of the final `keep` -- detected
     // below and repaired by a rescan of that thread's share (practically never taken).
-    auto cand_value = [&](int r, int v, float raw, float mx, float lz, float sc, bool mask_eos) -> float {
+    auto cand_value = [&](int r, int v, float raw, float mx, float lz, float sc, bool mask_eos, int t0) -> float {
       float x = (raw - mx) - lz;                                              // log_softmax
       // (the penalty behind a wave-uniform test: as a select, hipcc ran the fp32 division sequence for every word of the vocabulary)
-      const bool hit = (bitmap[r * words + (v >> 5)] >> (v & 31)) & 1u;
+      const bool hit = (bitmap[r * words + ((v - t0) >> 5)] >> ((v - t0) & 31)) & 1u;
       if (__any(hit)) x = hit ? (x < 0.0f ? x * p.rep_pen : x / p.rep_pen) : x;
       if (mask_eos) {
 #pragma unroll
@@ -390,18 +416,19 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
       v1 = p.ws_cand_v[(size_t)b * p.S * keep + tid];
       i1 = p.ws_cand_i[(size_t)b * p.S * keep + tid];
     }
-    for (int r = 0; r < (merged ? 0 : nb); ++r) {
-      const float* row = lg + (size_t)r * V;
-      const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
-      const bool mask_eos = cur < p.min_new;
-      for (int base = 0; base < V; base += kBeamThreads * U) {
+    for (int base = 0; base < (merged ? 0 : V); base += TILE) {
+      build_bitmap(base);
+      for (int r = 0; r < nb; ++r) {
+        const float* row = lg + (size_t)r * V;
+        const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
+        const bool mask_eos = cur < p.min_new;
         float xs[U];
         load_trip(row, base, xs);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int v = vof(base, u);
           if (v < V) {
-            const float x = cand_value(r, v, xs[u], mx, lz, sc, mask_eos);
+            const float x = cand_value(r, v, xs[u], mx, lz, sc, mask_eos, base);
             if (x >= v2) {           // below the thread's second entry nothing changes: the insertion is the rare path
               const int idx = r * V + v;
               const bool b1 = better(x, idx, v1, i1), b2 = better(x, idx, v2, i2);
@@ -447,19 +474,22 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
     if (__syncthreads_or(suspect ? 1 : 0)) {
       const float tau = s_top_lp[keep - 1];
       const int tau_ix = s_top_ix[keep - 1];
-      if (suspect) {
-        for (int r = 0; r < nb; ++r) {
-          const float* row = lg + (size_t)r * V;
-          const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
-          for (int k = 0; k < (V + kBeamThreads * U - 1) / (kBeamThreads * U) * U; ++k) {   // this thread's share, word by word
-            const int v = vof(k / U * kBeamThreads * U, k % U);
-            if (v >= V) continue;
-            const int idx = r * V + v;
-            if (idx == i1 || idx == i2) continue;
-            const float x = cand_value(r, v, row[v], mx, lz, sc, cur < p.min_new);
-            if (better(x, idx, tau, tau_ix)) {
-              const int slot = atomicAdd(&s_nsurv, 1);
-              if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+      for (int base = 0; base < (merged ? 0 : V); base += TILE) {
+        if (V > TILE) build_bitmap(base);            // (a one-tile vocabulary still holds its bitmap)
+        if (suspect) {
+          for (int r = 0; r < nb; ++r) {
+            const float* row = lg + (size_t)r * V;
+            const float mx = s_rowmax[r], lz = s_logz[r], sc = s_in_rscore[r];
+            for (int u = 0; u < U; ++u) {            // this thread's share of the tile, word by word
+              const int v = vof(base, u);
+              if (v >= V) continue;
+              const int idx = r * V + v;
+              if (idx == i1 || idx == i2) continue;
+              const float x = cand_value(r, v, row[v], mx, lz, sc, cur < p.min_new, base);
+              if (better(x, idx, tau, tau_ix)) {
+                const int slot = atomicAdd(&s_nsurv, 1);
+                if (slot < kMaxSurv) { s_surv_v[slot] = x; s_surv_i[slot] = idx; }
+              }
             }
           }
         }
@@ -635,9 +665,6 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   a.unf_log = (unsigned char*)d->unfinished_log;
   a.vec4 = (a.V % 4 == 0 && ((uintptr_t)a.logits & 15) == 0) ? 1 : 0;
   const int grid = (a.ticket && d->batch > 1) ? (d->batch < 255 ? d->batch : 255) : 1;
-  const size_t words = (size_t)(a.V + 31) / 32;
-  const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
-  if (lds > 60 * 1024) return MXVL_ERR_UNSUPPORTED;
   a.S = 0; a.VS = 0; a.ws_stats = nullptr; a.ws_cand_v = nullptr; a.ws_cand_i = nullptr;
   if (d->workspace && d->workspace_bytes >= mxvl_beam_workspace_bytes(d->batch, d->beams, d->keep) && !MXVL_ABL_ENV("MXVL_BEAM_ONE_WG")) {
     a.S = beam_slices(d->batch);
@@ -646,14 +673,27 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
     a.ws_cand_v = a.ws_stats + (size_t)d->batch * d->beams * a.S * 2;
     a.ws_cand_i = (int*)(a.ws_cand_v + (size_t)d->batch * a.S * d->keep);
     hipLaunchKernelGGL(beam_stats_kernel, dim3(a.S, d->batch * d->beams), dim3(kSliceThreads), 0, (hipStream_t)hip_stream, a);
-    const size_t lds_c = 4 * (size_t)a.nb * ((a.VS + 31) / 32);
+    const size_t lds_c = 4 * (size_t)a.nb * (((a.VS < kCandTile ? a.VS : kCandTile) + 31) / 32);     // <= 8 KB at 8 beams
     hipLaunchKernelGGL(beam_cand_kernel, dim3(a.S, d->batch), dim3(kCandThreads), lds_c, (hipStream_t)hip_stream, a);
   }
   static const int shape = MXVL_ABL_ENV("MXVL_BEAM_SHAPE");      // measurement build: 1 = the 512 x 16 shape
+  // LDS: the copies of the old sequences (16 bytes x beams x max_new) + the history bitmap of ONE sweep tile (threads x U words of the
+  // vocabulary; none when the sweeps were done by the slice kernels) -- independent of the vocabulary size
+  auto launch = [&](auto kern, int threads, int tile) -> int {
+    const size_t words = a.ws_cand_v ? 0 : (size_t)((a.V < tile ? a.V : tile) + 31) / 32;
+    const size_t lds = 4 * ((a.nb * words + 1) & ~(size_t)1) + 8 * (size_t)2 * a.nb * a.max_new;
+    if (lds > 160 * 1024) return MXVL_ERR_UNSUPPORTED;          // max_new in the thousands
+    if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return MXVL_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, (hipStream_t)hip_stream, a);
+    return MXVL_OK;
+  };
+  int rc;
   if (a.ws_cand_v && a.S * a.keep <= 256)       // merge + bookkeeping only: four waves (barriers and the serial lane are all that is left)
-    hipLaunchKernelGGL((beam_step_kernel<256, 8>), dim3(grid), dim3(256), lds, (hipStream_t)hip_stream, a);
+    rc = launch(beam_step_kernel<256, 8>, 256, 256 * 8);
   else if (MXVL_ABL(shape == 1) || (a.ws_cand_v && a.S * a.keep <= 512))
-    hipLaunchKernelGGL((beam_step_kernel<512, 16>), dim3(grid), dim3(512), lds, (hipStream_t)hip_stream, a);
-  else hipLaunchKernelGGL((beam_step_kernel<1024, 32>), dim3(grid), dim3(1024), lds, (hipStream_t)hip_stream, a);
+    rc = launch(beam_step_kernel<512, 16>, 512, 512 * 16);
+  else rc = launch(beam_step_kernel<1024, 32>, 1024, 1024 * 32);
+  if (rc != MXVL_OK) return rc;
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

@@ -17,7 +17,7 @@
 #include <type_traits>
 #include <cstdlib>
 
-#include "mxvl_common.h"
+#include "decode_elt.h"
 
 namespace mxvl {
 
@@ -30,21 +30,6 @@ struct GemvArgs {
   void* y;
 };
 
-__device__ inline float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
-__device__ inline uint16_t f2bf(float x) {
-  uint32_t u = __builtin_bit_cast(uint32_t, x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-typedef short bf16x2_t __attribute__((ext_vector_type(2)));
-__device__ inline float dot2(uint32_t a, uint32_t b, float c) {
-#if __has_builtin(__builtin_amdgcn_fdot2_f32_bf16)
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
-#else
-  c = fmaf(__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, b << 16), c);
-  return fmaf(__builtin_bit_cast(float, a & 0xffff0000u), __builtin_bit_cast(float, b & 0xffff0000u), c);
-#endif
-}
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -66,8 +51,8 @@ __device__ inline uint4 ldw(const uint16_t* row, int kk, int K) {
 // streams 2*K contiguous bytes with PF 16-byte loads in flight per lane.  The next row's first PF loads are issued
 // before the current row's cross-lane reduction, and the very first row's before the RMSNorm prologue, so the HBM
 // stream never waits for the prologue or an epilogue.
-template <int M>
-__global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
+template <typename E, int M>
+__global__ __launch_bounds__(1024) void gemv_kernel(const GemvArgs p) {
   constexpr int NW = 16;  // waves per workgroup (one workgroup per CU)
   constexpr int PF = 8;   // 16-byte loads in flight per lane
   extern __shared__ __attribute__((aligned(16))) uint16_t sx[];  // [M][K] (normalised) activations, bf16
@@ -104,7 +89,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float a = bf2f((uint16_t)w[j]), b = bf2f((uint16_t)(w[j] >> 16));
+          const float a = E::f((uint16_t)w[j]), b = E::f((uint16_t)(w[j] >> 16));
           s = fmaf(a, a, fmaf(b, b, s));
         }
         s = wave_sum(on ? s : 0.0f);
@@ -122,9 +107,9 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
         uint32_t o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float a = bf2f(f2bf(bf2f((uint16_t)w[j]) * rstd)) * bf2f((uint16_t)gw[j]);
-          const float b = bf2f(f2bf(bf2f((uint16_t)(w[j] >> 16)) * rstd)) * bf2f((uint16_t)(gw[j] >> 16));
-          o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+          const float a = E::rr(E::f((uint16_t)w[j]) * rstd) * E::f((uint16_t)gw[j]);
+          const float b = E::rr(E::f((uint16_t)(w[j] >> 16)) * rstd) * E::f((uint16_t)(gw[j] >> 16));
+          o[j] = (uint32_t)E::r(a) | ((uint32_t)E::r(b) << 16);
         }
         if (on) *(uint4*)(sx + (size_t)m * K + kk) = make_uint4(o[0], o[1], o[2], o[3]);
       }
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
-          acc[m] = dot2(pre[j].x, xv.x, dot2(pre[j].y, xv.y, dot2(pre[j].z, xv.z, dot2(pre[j].w, xv.w, acc[m]))));
+          acc[m] = E::dot2(pre[j].x, xv.x, E::dot2(pre[j].y, xv.y, E::dot2(pre[j].z, xv.z, E::dot2(pre[j].w, xv.w, acc[m]))));
         }
       }
     }
@@ -201,7 +186,7 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
 #pragma unroll
           for (int m = 0; m < M; ++m) {
             const uint4 xv = *(const uint4*)(sx + (size_t)m * K + kk);
-            acc[m] = dot2(pre[j].x, xv.x, dot2(pre[j].y, xv.y, dot2(pre[j].z, xv.z, dot2(pre[j].w, xv.w, acc[m]))));
+            acc[m] = E::dot2(pre[j].x, xv.x, E::dot2(pre[j].y, xv.y, E::dot2(pre[j].z, xv.z, E::dot2(pre[j].w, xv.w, acc[m]))));
           }
         }
       }
@@ -222,13 +207,13 @@ __global__ __launch_bounds__(1024) void gemv_bf16_kernel(const GemvArgs p) {
       if (p.swiglu) {
         if (!(item & 1)) gate[m] = v;
         else if (lane == 0) {  // bf16(bf16(silu(gate)) * up), gate/up rounded to bf16 first (what the torch modules do)
-          const float gte = bf2f(f2bf(gate[m])), up = bf2f(f2bf(v));
-          ((uint16_t*)p.y)[o] = f2bf(bf2f(f2bf(gte * sigmoid(gte))) * up);
+          const float gte = E::rr(gate[m]), up = E::rr(v);
+          ((uint16_t*)p.y)[o] = E::r(E::rr(gte * sigmoid(gte)) * up);
         }
       } else if (lane == 0) {
-        if (p.bias) v += bf2f(p.bias[n]);
-        if (p.res) v = bf2f(f2bf(v)) + bf2f(p.res[o]);  // the linear output rounds to bf16 before the residual add
-        if (p.out_f32) ((float*)p.y)[o] = v; else ((uint16_t*)p.y)[o] = f2bf(v);
+        if (p.bias) v += E::f(p.bias[n]);
+        if (p.res) v = E::rr(v) + E::f(p.res[o]);  // the linear output rounds to bf16 before the residual add
+        if (p.out_f32) ((float*)p.y)[o] = v; else ((uint16_t*)p.y)[o] = E::r(v);
       }
     }
   }
@@ -292,7 +277,7 @@ constexpr int kAttnWaves = 8;    // (16 waves x 8 positions per group -- one tri
 // One workgroup per (head, row).  A cached K or V line of D bf16 is read by LPR = D/8 lanes with one 16-byte load
 // each, so a wave covers 64/LPR positions per load and the workgroup 8 x 64/LPR; K and V of a position are loaded
 // together and folded into a running (max, sum, out[8]) per lane group (one-pass softmax), merged once at the end.
-template <int D, int NW, int DEPTH>
+template <typename E, int D, int NW, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) {
   constexpr int LPR = D / 8, RPW = 64 / LPR, NG = NW * RPW;
   static_assert((DEPTH & (DEPTH - 1)) == 0, "ring slots are picked with a mask");
@@ -336,18 +321,18 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
     const int dp = d < half ? d + half : d - half;
     const uint16_t rq = q[d], rqo = q[dp], rk = kn[d], rko = kn[dp], rv = vn[d];
     const float rc = p.cosv[(size_t)m * D + d], rs = p.sinv[(size_t)m * D + d];
-    const float c = bf2f(f2bf(rc)), s = bf2f(f2bf(rs));
-    const float qd = bf2f(rq), qo = d < half ? -bf2f(rqo) : bf2f(rqo);
-    const float kd = bf2f(rk), ko = d < half ? -bf2f(rko) : bf2f(rko);
-    const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * s))));
-    const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * s))));
+    const float c = E::rr(rc), s = E::rr(rs);
+    const float qd = E::f(rq), qo = d < half ? -E::f(rqo) : E::f(rqo);
+    const float kd = E::f(rk), ko = d < half ? -E::f(rko) : E::f(rko);
+    const float qr = E::rr(E::rr(qd * c) + E::rr(qo * s));
+    const float kr = E::rr(E::rr(kd * c) + E::rr(ko * s));
     sq[d] = qr * p.scale;
-    if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
+    if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = E::r(qr);
     sk[d] = kr;
-    sv[d] = bf2f(rv);
+    sv[d] = E::f(rv);
     if (h % group == 0) {  // one head of the group appends to the cache (slot m owns position pos of beam m)
       const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
-      p.kc[o] = f2bf(kr);
+      p.kc[o] = E::r(kr);
       p.vc[o] = rv;
     }
   }
@@ -370,14 +355,6 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
     l = fmaf(l, corr, pr);
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = fmaf(o[j], corr, pr * vf[j]);
-  };
-  auto unpack = [](const uint4 v, float* f) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f[2 * j] = __builtin_bit_cast(float, w[j] << 16);
-      f[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xffff0000u);
-    }
   };
   // The cache rows land in LDS, not in registers: a wave owns a ring of DEPTH trips; a trip = one global_load_lds_dwordx4 of K and
   // one of V, each lane moving the 16 bytes IT reads back (LDS address = lane * 16: no swizzle, no cross-lane traffic, no barrier)
@@ -418,8 +395,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // both rows are in registers: the slot may be refilled
     issue();
     float kf[8], vf[8];
-    unpack(kq, kf);
-    unpack(vq, vf);
+    elt_unpack8<E>(kq, kf);
+    elt_unpack8<E>(vq, vf);
     fold(live, kf, vf);
   }
   if (g == 0) {  // the fresh position (always attended: its mask bit was just set)
@@ -441,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const AttnArgs p) 
       num = fmaf(w, go[i * D + tid], num);
       den = fmaf(w, gl[i], den);
     }
-    p.out[(size_t)m * p.H * D + (size_t)h * D + tid] = f2bf(num / den);
+    p.out[(size_t)m * p.H * D + (size_t)h * D + tid] = E::r(num / den);
   }
 }
 
@@ -476,10 +453,10 @@ template <int D> __device__ __forceinline__ int attn_tile_key(int row) {
 }
 template <int D> __device__ __forceinline__ int attn_tile_off(int row, int unit) { return row * (D * 2) + ((unit ^ attn_tile_key<D>(row)) << 4); }
 
-template <int D, int NB, int NW>
+template <typename E, int D, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const AttnArgs p) {
   typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef elt_u32x4 bf16x8;      // eight 16-bit elements of a lane (E decides what they mean)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int UPR = D / 8, RPI = 64 / UPR;     // 16-byte units per cache row; rows per DMA instruction (1 KB)
   constexpr int TILE = 16, NI = TILE / RPI;      // positions per tile; DMA instructions per K (or V) tile
@@ -564,19 +541,19 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
     const int i = tid + it * NT;
     if (i < NB * D) {
       const int r = i / D, d = i - r * D, half = D / 2, m = m0 + r;
-      const float c = bf2f(f2bf(rope_c[it])), sn = bf2f(f2bf(rope_s[it]));
-      const float qd = bf2f(rope_q[it]), qo = d < half ? -bf2f(rope_qo[it]) : bf2f(rope_qo[it]);
-      const float kd = bf2f(rope_k[it]), ko = d < half ? -bf2f(rope_ko[it]) : bf2f(rope_ko[it]);
-      const float qr = bf2f(f2bf(bf2f(f2bf(qd * c)) + bf2f(f2bf(qo * sn))));
-      const float kr = bf2f(f2bf(bf2f(f2bf(kd * c)) + bf2f(f2bf(ko * sn))));
+      const float c = E::rr(rope_c[it]), sn = E::rr(rope_s[it]);
+      const float qd = E::f(rope_q[it]), qo = d < half ? -E::f(rope_qo[it]) : E::f(rope_qo[it]);
+      const float kd = E::f(rope_k[it]), ko = d < half ? -E::f(rope_ko[it]) : E::f(rope_ko[it]);
+      const float qr = E::rr(E::rr(qd * c) + E::rr(qo * sn));
+      const float kr = E::rr(E::rr(kd * c) + E::rr(ko * sn));
       sq[i] = qr * p.scale;
-      sqb[i] = f2bf(qr);
-      if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = f2bf(qr);
+      sqb[i] = E::r(qr);
+      if (p.q_rope) p.q_rope[(size_t)m * p.H * D + (size_t)h * D + d] = E::r(qr);
       sk[i] = kr;
-      sv[i] = bf2f(rope_v[it]);
+      sv[i] = E::f(rope_v[it]);
       if (h % group == 0) {
         const size_t o = (((size_t)m * p.Hkv + hk) * T + pos) * D + d;
-        p.kc[o] = f2bf(kr);
+        p.kc[o] = E::r(kr);
         p.vc[o] = rope_v[it];
       }
     }
@@ -670,7 +647,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
     tile_next(ti);
     f32x4 sc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qb[kk], sc, 0, 0, 0);
+    for (int kk = 0; kk < NKK; ++kk) sc = E::mfma32(kf[kk], qb[kk], sc);
     float s[4], tmax = -1e30f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -690,12 +667,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
     l_run = fmaf(l_run, corr, psum);
     s16x4 pb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pb[i] = (short)f2bf(pr[i]);
+    for (int i = 0; i < 4; ++i) pb[i] = (short)E::r(pr[i]);
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) oacc[dt][i] *= corr;
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[dt], pb, oacc[dt], 0, 0, 0);
+      oacc[dt] = E::mfma16(vf[dt], pb, oacc[dt]);
     }
   }
   if (MXVL_ABL(p.ablate == 3)) return;      // + every cached position
@@ -731,7 +708,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
       num = fmaf(c, wo[(r * NWP + w) * D + d], num);
       den = fmaf(c, wl[r * NWP + w], den);
     }
-    p.out[(size_t)(m0 + r) * p.H * D + (size_t)h * D + d] = f2bf(num / den);
+    p.out[(size_t)(m0 + r) * p.H * D + (size_t)h * D + d] = E::r(num / den);
   }
 }
 
@@ -742,7 +719,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_beams_mfma_kernel(const A
 // every product / sum rounded to bf16 where the reference's bf16 tensor ops round.  One workgroup per (head, row), same
 // lane mapping and one-pass softmax as decode_attn_kernel; the gate (a hidden-wide dot product per row) is recomputed by
 // every head's workgroup -- 8 KB from L2 -- instead of costing a launch of its own.
-template <int D>
+template <typename E, int D>
 __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(const CrossAttnArgs p) {
   constexpr int LPR = D / 8, RPW = 64 / LPR, NG = kAttnWaves * RPW, NT = kAttnWaves * 64;
   extern __shared__ float sm[];
@@ -761,21 +738,21 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(cons
   for (int c = tid * 8; c < hidden; c += NT * 8) {
     const uint4 xv = *(const uint4*)(p.text_state + (size_t)m * hidden + c);
     const uint4 wv = *(const uint4*)(p.gate_w + c);
-    part = dot2(xv.x, wv.x, part); part = dot2(xv.y, wv.y, part); part = dot2(xv.z, wv.z, part); part = dot2(xv.w, wv.w, part);
+    part = E::dot2(xv.x, wv.x, part); part = E::dot2(xv.y, wv.y, part); part = E::dot2(xv.z, wv.z, part); part = E::dot2(xv.w, wv.w, part);
   }
   part = wave_sum(part);
   if (lane == 0) sred[wave] = part;
-  if (tid < D) sq[tid] = bf2f(p.q_rope[(size_t)m * hidden + (size_t)h * D + tid]) * p.scale;
+  if (tid < D) sq[tid] = E::f(p.q_rope[(size_t)m * hidden + (size_t)h * D + tid]) * p.scale;
   __syncthreads();
   float gate = 0.0f;
 #pragma unroll
   for (int w = 0; w < kAttnWaves; ++w) gate += sred[w];
-  gate = bf2f(f2bf(gate + bf2f(p.gate_b[0])));                                  // Linear output, bf16
-  if (p.gate_flags & 1) gate = bf2f(f2bf(tanhf(gate)));                          // nn.Tanh in bf16
+  gate = E::rr(gate + E::f(p.gate_b[0]));                                  // Linear output, bf16
+  if (p.gate_flags & 1) gate = E::rr(tanhf(gate));                          // nn.Tanh in bf16
   if (p.warm) {
-    float wu = bf2f(p.warm[0]);
-    if (p.gate_flags & 2) wu = bf2f(f2bf(tanhf(wu)));                            // text-only variant: gate * warm.tanh()
-    gate = bf2f(f2bf(gate * wu));
+    float wu = E::f(p.warm[0]);
+    if (p.gate_flags & 2) wu = E::rr(tanhf(wu));                            // text-only variant: gate * warm.tanh()
+    gate = E::rr(gate * wu);
   }
   // ---- one-query attention over the image tokens ----------------------------------------------------------------------
   const int sub = lane % LPR, g = wave * RPW + lane / LPR;
@@ -805,15 +782,11 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(cons
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t kw[4] = {kq[u].x, kq[u].y, kq[u].z, kq[u].w}, vw[4] = {vq[u].x, vq[u].y, vq[u].z, vq[u].w};
-      float s = 0.0f, vf[8];
+      float s = 0.0f, kf[8], vf[8];
+      elt_unpack8<E>(kq[u], kf);
+      elt_unpack8<E>(vq[u], vf);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s = fmaf(qv[2 * j], __builtin_bit_cast(float, kw[j] << 16), s);
-        s = fmaf(qv[2 * j + 1], __builtin_bit_cast(float, kw[j] & 0xffff0000u), s);
-        vf[2 * j] = __builtin_bit_cast(float, vw[j] << 16);
-        vf[2 * j + 1] = __builtin_bit_cast(float, vw[j] & 0xffff0000u);
-      }
+      for (int j = 0; j < 8; ++j) s = fmaf(qv[j], kf[j], s);
       s = group_sum<LPR>(s);
       const float mn = live[u] ? fmaxf(mx, s) : mx;
       const float corr = fast_exp(mx - mn), pr = live[u] ? fast_exp(s - mn) : 0.0f;
@@ -836,10 +809,10 @@ __global__ __launch_bounds__(kAttnWaves * 64) void decode_cross_attn_kernel(cons
       num = fmaf(w, go[i * D + tid], num);
       den = fmaf(w, gl[i], den);
     }
-    float ctx = den > 0.0f ? bf2f(f2bf(num / den)) : 0.0f;                       // attention output, bf16
+    float ctx = den > 0.0f ? E::rr(num / den) : 0.0f;                       // attention output, bf16
     if (p.row_on && p.row_on[ms] == 0) ctx = 0.0f;
     const size_t o_idx = (size_t)m * hidden + (size_t)h * D + tid;
-    p.out[o_idx] = f2bf(bf2f(p.text_state[o_idx]) + bf2f(f2bf(ctx * gate)));
+    p.out[o_idx] = E::r(E::f(p.text_state[o_idx]) + E::rr(ctx * gate));
   }
 }
 
@@ -898,71 +871,38 @@ static int dec_check() {
   return e == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
 
-template <int M>
+template <typename E, int M>
 static int launch_gemv(const GemvArgs& a, hipStream_t s) {
   const int grid = std::max(1, std::min(256, (a.N + 15) / 16));
   const size_t lds = (size_t)M * a.K * sizeof(uint16_t);
   if (lds > 150 * 1024) return MXVL_ERR_UNSUPPORTED;  // rows * K bf16 must fit one CU's LDS
   // per call: the attribute belongs to the (kernel, device) pair, and a process may drive several devices
-  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)gemv_bf16_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)gemv_kernel<E, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
     return MXVL_ERR_LAUNCH;
-  hipLaunchKernelGGL(gemv_bf16_kernel<M>, dim3(grid), dim3(1024), lds, s, a);
+  hipLaunchKernelGGL((gemv_kernel<E, M>), dim3(grid), dim3(1024), lds, s, a);
   return MXVL_OK;
 }
 
-int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s);   // decode_gemm.hip: 9..80 rows on the matrix cores
-
-}  // namespace mxvl
-
-using namespace mxvl;
-
-extern "C" {
-
-int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
-  if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
-  // k_splits != 0 asks for the matrix-core kernels at any row count (1 = no split); 0 = by row count
-  if (d->rows > kMaxRows || d->k_splits != 0 || d->split_acc) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
-  if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
-  if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
-  if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
-  if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
-  GemvArgs a;
-  a.ablate = MXVL_ABL_ENV("MXVL_GEMV_ABLATE");
-  a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32; a.eps = d->eps;
-  a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->norm_weight; a.W = (const uint16_t*)d->W;
-  a.W2 = (const uint16_t*)d->W2; a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
-  hipStream_t s = (hipStream_t)hip_stream;
-  int rc;
-  switch (d->rows) {
-    case 1: rc = launch_gemv<1>(a, s); break;
-    case 2: rc = launch_gemv<2>(a, s); break;
-    case 3: rc = launch_gemv<3>(a, s); break;
-    case 4: rc = launch_gemv<4>(a, s); break;
-    case 5: rc = launch_gemv<5>(a, s); break;
-    case 6: rc = launch_gemv<6>(a, s); break;
-    case 7: rc = launch_gemv<7>(a, s); break;
-    default: rc = launch_gemv<8>(a, s); break;
+template <typename E>
+static int launch_gemv_rows(const GemvArgs& a, hipStream_t s) {
+  switch (a.rows) {
+    case 1: return launch_gemv<E, 1>(a, s);
+    case 2: return launch_gemv<E, 2>(a, s);
+    case 3: return launch_gemv<E, 3>(a, s);
+    case 4: return launch_gemv<E, 4>(a, s);
+    case 5: return launch_gemv<E, 5>(a, s);
+    case 6: return launch_gemv<E, 6>(a, s);
+    case 7: return launch_gemv<E, 7>(a, s);
+    default: return launch_gemv<E, 8>(a, s);
   }
-  return rc != MXVL_OK ? rc : dec_check();
 }
 
-int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
-  if (!d || !d->qkv || !d->cos || !d->sin || !d->k_cache || !d->v_cache || !d->slot_table || !d->pos || !d->mask || !d->out)
-    return MXVL_ERR_NULL;
-  if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0) return MXVL_ERR_SHAPE;
-  if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;
-  AttnArgs a;
-  a.rows = d->rows; a.H = d->n_heads; a.Hkv = d->n_kv_heads; a.D = d->head_dim; a.max_len = d->max_len;
-  a.scale = d->scale; a.qkv = (const uint16_t*)d->qkv; a.cosv = (const float*)d->cos; a.sinv = (const float*)d->sin;
-  a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
-  a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
-  a.q_rope = (uint16_t*)d->q_rope;
-  a.ablate = MXVL_ABL_ENV("MXVL_ATTN_ABLATE");
-  hipStream_t s = (hipStream_t)hip_stream;
-  if (d->beams > 1) {       // the beams of a sample share a workgroup (and every cache line they have in common)
-    if (d->beams > 5 || d->rows % d->beams != 0) return MXVL_ERR_UNSUPPORTED;
-    if ((uint64_t)d->rows * d->n_kv_heads * d->max_len * d->head_dim >= (1ull << 31)) return MXVL_ERR_UNSUPPORTED;   // 32-bit cache offsets
-    const int nb = d->beams;
+template <typename E>
+static int launch_decode_attn(const AttnArgs& a, int beams, hipStream_t s) {
+  if (beams > 1) {       // the beams of a sample share a workgroup (and every cache line they have in common)
+    if (beams > 5 || a.rows % beams != 0) return MXVL_ERR_UNSUPPORTED;
+    if ((uint64_t)a.rows * a.Hkv * a.max_len * a.D >= (1ull << 31)) return MXVL_ERR_UNSUPPORTED;   // 32-bit cache offsets
+    const int nb = beams;
     // matrix-core kernel: 8 waves (4 when head_dim 256 or a long slot table would not leave room for the ring)
     const size_t stage = (size_t)2 * 16 * a.D * 2;
     auto lds_of = [&](int nw) {
@@ -976,7 +916,7 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
     const dim3 grid(a.H, a.rows / nb), block(nw * 64);
 #define MXVL_ATTN_BEAMS(DD, NB)                                                                                                    \
   do {                                                                                                                             \
-    void (*kern)(const AttnArgs) = nw == 8 ? decode_attn_beams_mfma_kernel<DD, NB, (DD <= 128 ? 8 : 4)> : decode_attn_beams_mfma_kernel<DD, NB, 4>; \
+    void (*kern)(const AttnArgs) = nw == 8 ? decode_attn_beams_mfma_kernel<E, DD, NB, (DD <= 128 ? 8 : 4)> : decode_attn_beams_mfma_kernel<E, DD, NB, 4>; \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return MXVL_ERR_LAUNCH;                                                                                                      \
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);                                                                              \
@@ -1010,8 +950,8 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   const dim3 grid(a.H, a.rows), block(nw * 64);
 #define MXVL_ATTN_ROW(DD) \
   do { \
-    void (*kern)(const AttnArgs) = nw == 16 ? (depth == 8 ? decode_attn_kernel<DD, 16, 4> : depth == 4 ? decode_attn_kernel<DD, 16, 4> : decode_attn_kernel<DD, 16, 2>) \
-                                            : (depth == 8 ? decode_attn_kernel<DD, 8, 8> : depth == 4 ? decode_attn_kernel<DD, 8, 4> : decode_attn_kernel<DD, 8, 2>); \
+    void (*kern)(const AttnArgs) = nw == 16 ? (depth == 8 ? decode_attn_kernel<E, DD, 16, 4> : depth == 4 ? decode_attn_kernel<E, DD, 16, 4> : decode_attn_kernel<E, DD, 16, 2>) \
+                                            : (depth == 8 ? decode_attn_kernel<E, DD, 8, 8> : depth == 4 ? decode_attn_kernel<E, DD, 8, 4> : decode_attn_kernel<E, DD, 8, 2>); \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return MXVL_ERR_LAUNCH; \
     hipLaunchKernelGGL(kern, grid, block, lds, s, a); \
@@ -1024,6 +964,57 @@ int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   }
 #undef MXVL_ATTN_ROW
   return dec_check();
+}
+
+template <typename E>
+static void launch_cross_attn(const CrossAttnArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+  switch (a.D) {
+    case 64: hipLaunchKernelGGL((decode_cross_attn_kernel<E, 64>), grid, block, lds, s, a); break;
+    case 128: hipLaunchKernelGGL((decode_cross_attn_kernel<E, 128>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((decode_cross_attn_kernel<E, 256>), grid, block, lds, s, a); break;
+  }
+}
+
+int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s);   // decode_gemm.hip: 9..80 rows on the matrix cores
+
+}  // namespace mxvl
+
+using namespace mxvl;
+
+extern "C" {
+
+int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
+  if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
+  // k_splits != 0 asks for the matrix-core kernels at any row count (1 = no split); 0 = by row count
+  if (d->rows > kMaxRows || d->k_splits != 0 || d->split_acc) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
+  if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
+  if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;  // 16-byte weight loads
+  if (d->norm_weight && d->K > 8192) return MXVL_ERR_UNSUPPORTED;  // fused RMSNorm keeps a whole row in registers
+  if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
+  GemvArgs a;
+  a.ablate = MXVL_ABL_ENV("MXVL_GEMV_ABLATE");
+  a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32; a.eps = d->eps;
+  a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->norm_weight; a.W = (const uint16_t*)d->W;
+  a.W2 = (const uint16_t*)d->W2; a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int rc = decode_dtype(d->dtype) == MXVL_F16 ? launch_gemv_rows<EltF16>(a, s) : launch_gemv_rows<EltBf16>(a, s);
+  return rc != MXVL_OK ? rc : dec_check();
+}
+
+int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
+  if (!d || !d->qkv || !d->cos || !d->sin || !d->k_cache || !d->v_cache || !d->slot_table || !d->pos || !d->mask || !d->out)
+    return MXVL_ERR_NULL;
+  if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0) return MXVL_ERR_SHAPE;
+  if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;
+  AttnArgs a;
+  a.rows = d->rows; a.H = d->n_heads; a.Hkv = d->n_kv_heads; a.D = d->head_dim; a.max_len = d->max_len;
+  a.scale = d->scale; a.qkv = (const uint16_t*)d->qkv; a.cosv = (const float*)d->cos; a.sinv = (const float*)d->sin;
+  a.kc = (uint16_t*)d->k_cache; a.vc = (uint16_t*)d->v_cache; a.slot = (const int*)d->slot_table;
+  a.pos = (const int64_t*)d->pos; a.mask = (const int64_t*)d->mask; a.out = (uint16_t*)d->out;
+  a.q_rope = (uint16_t*)d->q_rope;
+  a.ablate = MXVL_ABL_ENV("MXVL_ATTN_ABLATE");
+  const hipStream_t s = (hipStream_t)hip_stream;
+  return decode_dtype(d->dtype) == MXVL_F16 ? launch_decode_attn<EltF16>(a, d->beams, s) : launch_decode_attn<EltBf16>(a, d->beams, s);
 }
 
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc* d, void* hip_stream) {
@@ -1066,12 +1057,8 @@ int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc* d, void* hip_strea
   if (lds > 64 * 1024) return MXVL_ERR_UNSUPPORTED;
   const dim3 grid(a.H, a.rows), block(kAttnWaves * 64);
   hipStream_t s = (hipStream_t)hip_stream;
-  switch (a.D) {
-    case 64: hipLaunchKernelGGL(decode_cross_attn_kernel<64>, grid, block, lds, s, a); break;
-    case 128: hipLaunchKernelGGL(decode_cross_attn_kernel<128>, grid, block, lds, s, a); break;
-    case 256: hipLaunchKernelGGL(decode_cross_attn_kernel<256>, grid, block, lds, s, a); break;
-    default: return MXVL_ERR_UNSUPPORTED;
-  }
+  if (decode_dtype(d->dtype) == MXVL_F16) launch_cross_attn<EltF16>(a, grid, block, lds, s);
+  else launch_cross_attn<EltBf16>(a, grid, block, lds, s);
   return dec_check();
 }
 

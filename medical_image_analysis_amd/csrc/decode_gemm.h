@@ -19,11 +19,10 @@
 //     cross-workgroup seam costs 5-13 us (agent-scope fences) on kernels that run 7-40 us.
 //   * activation traffic from L2 per weight byte = MT / R (MT = 16-row activation tiles): R is chosen by the host from N.
 #pragma once
-#include "mxvl_common.h"
+#include "decode_elt.h"
 
 namespace mxvl {
 
-typedef __bf16 dg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float dg_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int dg_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,16 +33,9 @@ struct DecodeGemmArgs {
   float* split_acc;     // K split over gridDim.y workgroups: fp32 (rows, N) sums, added to atomically; the epilogue is the consumer's
 };
 
-__device__ inline float dg_bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
-__device__ inline uint16_t dg_f2bf(float x) {
-  uint32_t u = __builtin_bit_cast(uint32_t, x);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-
 // Reduction over the waves' K split + the epilogue of mxvl_decode_gemv, one round per output tile (SwiGLU: per gate / up pair).
 // acc[r][mt] is lane (col = l%16 -> activation row, 4 * (l/16) + v -> weight row) of the 16x16 tile (weight tile r, row tile mt).
-template <int MT, int R, int NW>
+template <typename E, int MT, int R, int NW>
 __device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, const dg_f32x4 (&acc)[R][MT], float* dg_red, int n0) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N;
@@ -79,13 +71,13 @@ __device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, cons
       if (p.split_acc) {
         atomicAdd(p.split_acc + o, s0);
       } else if (p.swiglu) {   // bf16(bf16(silu(gate)) * up), gate / up rounded to bf16 first (what the torch modules do)
-        const float gte = dg_bf2f(dg_f2bf(s0)), up = dg_bf2f(dg_f2bf(s1));
-        ((uint16_t*)p.y)[o] = dg_f2bf(dg_bf2f(dg_f2bf(gte * sigmoid(gte))) * up);
+        const float gte = E::rr(s0), up = E::rr(s1);
+        ((uint16_t*)p.y)[o] = E::r(E::rr(gte * sigmoid(gte)) * up);
       } else {
         float val = s0;
-        if (p.bias) val += dg_bf2f(p.bias[n]);
-        if (p.res) val = dg_bf2f(dg_f2bf(val)) + dg_bf2f(p.res[o]);   // the linear output rounds to bf16 before the residual add
-        if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = dg_f2bf(val);
+        if (p.bias) val += E::f(p.bias[n]);
+        if (p.res) val = E::rr(val) + E::f(p.res[o]);   // the linear output rounds to bf16 before the residual add
+        if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = E::r(val);
       }
     }
   }
@@ -93,7 +85,7 @@ __device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, cons
 
 // MT: 16-row activation tiles (rows <= 16 * MT), R: 16-column weight tiles per workgroup (with SwiGLU: R/2 gate tiles + the
 // R/2 up tiles of the same columns), NW: waves per workgroup (they split K), PF: k-steps in flight per wave.
-template <int MT, int R, int NW, int PF>
+template <typename E, int MT, int R, int NW, int PF>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dg_red[];   // [NW][TPR][MT][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,8 +143,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmAr
       const dg_u32x4 av = ok ? a[slot][r] : dg_u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
-        acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dg_bf16x8, av), __builtin_bit_cast(dg_bf16x8, b[slot][mt]),
-                                                             acc[r][mt], 0, 0, 0);
+        acc[r][mt] = E::mfma32(av, b[slot][mt], acc[r][mt]);
     }
   };
 #pragma unroll
@@ -172,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmAr
 #pragma unroll
   for (int j = 0; j < PF; ++j) consume(j, s_begin + (iters - 1) * PF + j);
 
-  dg_reduce_epilogue<MT, R, NW>(p, acc, dg_red, n0);
+  dg_reduce_epilogue<E, MT, R, NW>(p, acc, dg_red, n0);
 }
 
 // ---- K % 64 == 0: the weight stream through LDS-DMA -------------------------------------------------------------------------------
@@ -189,7 +180,7 @@ __device__ __forceinline__ int dg_key(int row) { return (((row >> 1) & 1) << 2) 
 
 template <int N> __device__ __forceinline__ void dg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MT, int R, int NW, int PF>
+template <typename E, int MT, int R, int NW, int PF>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dg_smem[];
   constexpr int STAGE = R * 2048, OPS = 2 * R + 2 * MT;          // vector-memory operations per stage
@@ -272,8 +263,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
         const dg_u32x4 av = *(const dg_u32x4*)(ring + slot * STAGE + r * 2048 + l16 * 128 + (unit << 4));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dg_bf16x8, av), __builtin_bit_cast(dg_bf16x8, xb[slot][ks][mt]),
-                                                               acc[r][mt], 0, 0, 0);
+          acc[r][mt] = E::mfma32(av, xb[slot][ks][mt], acc[r][mt]);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's fragment reads have returned: it may be refilled
   };
@@ -297,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
     static_assert(PF <= 4, "tail is written out for PF <= 4");
   }
   __syncthreads();                                            // every wave is done with its ring: the reduction reuses the memory
-  dg_reduce_epilogue<MT, R, NW>(p, acc, (float*)dg_smem, n0);
+  dg_reduce_epilogue<E, MT, R, NW>(p, acc, (float*)dg_smem, n0);
 }
 
 // RMSNorm of the activation rows ahead of a projection (Qwen2RMSNorm / LlamaRMSNorm, EMRRG/models/hybrid_decoder_layer.py:185-199):
@@ -324,6 +314,7 @@ struct RmsNormArgs {
 // residual, the gain -- is requested before anything is stored or reduced; the first version walked the row in 256-thread trips of
 // load -> store -> load, three to four serialised round trips in a kernel that runs 65 times per token (4.9 us each in the
 // step's trace, a tenth of the batch-1 token).
+template <typename E>
 __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs p) {
   constexpr int NT = 1024, MAXV = 2;
   __shared__ float s_part[NT / 64];
@@ -355,9 +346,9 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
       uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float lo = dg_bf2f(dg_f2bf(av[2 * j])) + dg_bf2f((uint16_t)rw[j]);
-        const float hi = dg_bf2f(dg_f2bf(av[2 * j + 1])) + dg_bf2f((uint16_t)(rw[j] >> 16));
-        o[j] = (uint32_t)dg_f2bf(lo) | ((uint32_t)dg_f2bf(hi) << 16);
+        const float lo = E::rr(av[2 * j]) + E::f((uint16_t)rw[j]);
+        const float hi = E::rr(av[2 * j + 1]) + E::f((uint16_t)(rw[j] >> 16));
+        o[j] = (uint32_t)E::r(lo) | ((uint32_t)E::r(hi) << 16);
       }
       xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
       if (on[i]) {
@@ -372,7 +363,7 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
     const uint32_t w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = dg_bf2f((uint16_t)w[j]), b = dg_bf2f((uint16_t)(w[j] >> 16));
+      const float a = E::f((uint16_t)w[j]), b = E::f((uint16_t)(w[j] >> 16));
       s = fmaf(a, a, fmaf(b, b, s));
     }
   }
@@ -392,9 +383,9 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
       uint32_t o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = dg_bf2f(dg_f2bf(dg_bf2f((uint16_t)w[j]) * rstd)) * dg_bf2f((uint16_t)gw[j]);
-        const float b = dg_bf2f(dg_f2bf(dg_bf2f((uint16_t)(w[j] >> 16)) * rstd)) * dg_bf2f((uint16_t)(gw[j] >> 16));
-        o[j] = (uint32_t)dg_f2bf(a) | ((uint32_t)dg_f2bf(b) << 16);
+        const float a = E::rr(E::f((uint16_t)w[j]) * rstd) * E::f((uint16_t)gw[j]);
+        const float b = E::rr(E::f((uint16_t)(w[j] >> 16)) * rstd) * E::f((uint16_t)(gw[j] >> 16));
+        o[j] = (uint32_t)E::r(a) | ((uint32_t)E::r(b) << 16);
       }
       *(uint4*)(p.y + (size_t)m * p.K + k) = make_uint4(o[0], o[1], o[2], o[3]);
     }

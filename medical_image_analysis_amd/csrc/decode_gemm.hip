@@ -7,13 +7,13 @@ namespace mxvl {
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------------
 // K % 64 == 0 (every real decoder: 4096 / 11008 / 3584 / 18944): LDS-DMA weight stream, 4 waves x R tiles, two workgroups per CU.
-template <int MT, int R, int NW, int PF>
+template <typename E, int MT, int R, int NW, int PF>
 static int launch_dma(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   const int cols_per_wg = (a.swiglu ? R / 2 : R) * 16;
   const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
   const size_t ring = (size_t)NW * PF * R * 2048, red = (size_t)NW * 2 * MT * 1024;
   const size_t lds = ring > red ? ring : red;
-  auto kern = decode_gemm_dma_kernel<MT, R, NW, PF>;
+  auto kern = decode_gemm_dma_kernel<E, MT, R, NW, PF>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return MXVL_ERR_LAUNCH;   // per call: the attribute is per device
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
@@ -21,20 +21,20 @@ static int launch_dma(const DecodeGemmArgs& a, int splits, hipStream_t s) {
 }
 
 // any K % 8 == 0: fragments loaded straight into the MFMA operands
-template <int MT, int R>
+template <typename E, int MT, int R>
 static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   constexpr int NW = 8, PF = (R + MT <= 4) ? 4 : ((R + MT <= 6) ? 3 : 2);
   const int cols_per_wg = (a.swiglu ? R / 2 : R) * 16;
   const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
   const size_t lds = (size_t)NW * 2 * MT * 1024;
-  auto kern = decode_gemm_kernel<MT, R, NW, PF>;
+  auto kern = decode_gemm_kernel<E, MT, R, NW, PF>;
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return MXVL_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
   return MXVL_OK;
 }
 
-template <int MT>
+template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   // R = weight tiles per workgroup.  Two effects, both measured (tools/decode_gemm_bench.py A/B at 18 rows, profiles/r04_decode_gemm_r_sweep.txt):
   // (1) a CU streams ~28 GB/s whatever it holds, so the workgroups must fill whole rounds of the 256 CUs -- 344 workgroups (gate / up
@@ -55,16 +55,27 @@ static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s
       if (score(R) > score(best) + 1e-9) best = R;
     }
     switch (best) {
-      case 4: return launch_dma<MT, 4, 4, 2>(a, splits, s);
-      case 3: return launch_dma<MT, 3, 4, 2>(a, splits, s);
-      case 2: return launch_dma<MT, 2, 4, PFN>(a, splits, s);
-      default: return launch_dma<MT, 1, 8, PFN>(a, splits, s);
+      case 4: return launch_dma<E, MT, 4, 4, 2>(a, splits, s);
+      case 3: return launch_dma<E, MT, 3, 4, 2>(a, splits, s);
+      case 2: return launch_dma<E, MT, 2, 4, PFN>(a, splits, s);
+      default: return launch_dma<E, MT, 1, 8, PFN>(a, splits, s);
     }
   }
-  if (a.swiglu) return tiles >= 768 ? launch_direct<MT, 4>(a, splits, s) : launch_direct<MT, 2>(a, splits, s);
-  if (tiles >= 1536) return launch_direct<MT, 4>(a, splits, s);
-  if (tiles >= 512) return launch_direct<MT, 2>(a, splits, s);
-  return launch_direct<MT, 1>(a, splits, s);
+  if (a.swiglu) return tiles >= 768 ? launch_direct<E, MT, 4>(a, splits, s) : launch_direct<E, MT, 2>(a, splits, s);
+  if (tiles >= 1536) return launch_direct<E, MT, 4>(a, splits, s);
+  if (tiles >= 512) return launch_direct<E, MT, 2>(a, splits, s);
+  return launch_direct<E, MT, 1>(a, splits, s);
+}
+
+template <typename E>
+static int launch_decode_gemm_rows(const DecodeGemmArgs& a, int splits, hipStream_t s) {
+  switch ((a.rows + 15) / 16) {
+    case 1: return launch_decode_gemm<E, 1>(a, splits, s);
+    case 2: return launch_decode_gemm<E, 2>(a, splits, s);
+    case 3: return launch_decode_gemm<E, 3>(a, splits, s);
+    case 4: return launch_decode_gemm<E, 4>(a, splits, s);
+    default: return launch_decode_gemm<E, 5>(a, splits, s);
+  }
 }
 
 int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
@@ -84,14 +95,7 @@ int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
     if (d->swiglu || d->bias || d->residual || d->out_f32 || d->k_splits < 1 || d->k_splits > 16) return MXVL_ERR_UNSUPPORTED;
     splits = d->k_splits;
   }
-  int rc;
-  switch ((d->rows + 15) / 16) {
-    case 1: rc = launch_decode_gemm<1>(a, splits, s); break;
-    case 2: rc = launch_decode_gemm<2>(a, splits, s); break;
-    case 3: rc = launch_decode_gemm<3>(a, splits, s); break;
-    case 4: rc = launch_decode_gemm<4>(a, splits, s); break;
-    default: rc = launch_decode_gemm<5>(a, splits, s); break;
-  }
+  const int rc = decode_dtype(d->dtype) == MXVL_F16 ? launch_decode_gemm_rows<EltF16>(a, splits, s) : launch_decode_gemm_rows<EltBf16>(a, splits, s);
   if (rc != MXVL_OK) return rc;
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
@@ -109,6 +113,7 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
   a.rows = d->rows; a.K = d->K; a.eps = d->eps;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->weight; a.y = (uint16_t*)d->y;
   a.acc = (float*)d->acc; a.res = (const uint16_t*)d->residual; a.x_out = (uint16_t*)d->x_out;
-  hipLaunchKernelGGL(decode_rmsnorm_kernel, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
+  if (decode_dtype(d->dtype) == MXVL_F16) hipLaunchKernelGGL(decode_rmsnorm_kernel<EltF16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
+  else hipLaunchKernelGGL(decode_rmsnorm_kernel<EltBf16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }

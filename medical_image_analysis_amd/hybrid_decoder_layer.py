@@ -257,6 +257,12 @@ class Qwen2HybridAttention(nn.Module):
         else:
             cos, sin = position_embeddings
         q, k = apply_rotary_pos_emb(q, k, cos, sin)
+        if q.dtype != v.dtype:
+            # an fp16-loaded LLM under bf16 autocast (the reference's training_step: torch_dtype=torch.float16 weights,
+            # MambaXrayVL_DownStream.py:72-92, under Lightning's bf16-mixed precision, configs/config.py:67): the projections come out
+            # in the autocast dtype, cos / sin in the embeddings' dtype, and torch promotes their product to fp32; HF's SDPA call
+            # casts q / k / v back to the autocast dtype -- the dtype v still has
+            q, k = q.to(v.dtype), k.to(v.dtype)
         if past_key_value is not None:
             k, v = past_key_value.update(k, v, self.layer_idx, {"sin": sin, "cos": cos, "cache_position": cache_position})
         kv_len = k.shape[-2]

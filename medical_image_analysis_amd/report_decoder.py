@@ -187,6 +187,7 @@ class _BeamState:
     def __init__(self, B, nb, vocab, max_new, fill, eos, min_new, rep_pen, len_pen, early_stopping, dev):
         self.B, self.nb, self.V, self.max_new = B, nb, vocab, max_new
         self.use_hip = True      # tests flip this to compare the HIP kernel with the torch restatement
+        self.allow_torch = False  # generate(use_graph="torch" / False) sets it: the torch restatement as an EXPLICIT request only
         self.fill, self.min_new, self.rep_pen, self.early = fill, min_new, rep_pen, early_stopping
         self.eos_t = torch.tensor(eos, device=dev, dtype=torch.long)
         self.keep = max(2, 1 + len(eos)) * nb
@@ -230,10 +231,10 @@ class _BeamState:
         self.unfinished.fill_(True)
 
     def _hip_supported(self, logits):
-        words = (self.V + 31) // 32
-        lds = 4 * ((self.nb * words + 1) & ~1) + 16 * self.nb * self.max_new
-        return (logits.is_cuda and self.nb <= 8 and self.keep <= 16 and self.eos_t.numel() <= 4 and lds <= 60 * 1024 and logits.dtype == torch.float32
-                and logits.is_contiguous())
+        """What csrc/beam_step.hip serves: beams <= 8, keep <= 16, <= 4 EOS ids, beams * vocab < 2^31 -- any vocabulary size (the
+        history bitmap is tiled since round 5: Qwen1.5's 151 936 tokens at beam 5 take the same kernels as Llama's 32 000)."""
+        return (logits.is_cuda and self.nb <= 8 and self.keep <= 16 and self.eos_t.numel() <= 4 and self.nb * self.V < 2 ** 31
+                and 16 * self.nb * self.max_new <= 128 * 1024 and logits.dtype == torch.float32 and logits.is_contiguous())
 
     def _advance_hip(self, logits):
         """csrc/beam_step.hip: the whole update below as one kernel (capturable in the decode step's hipGraph)."""
@@ -264,6 +265,12 @@ class _BeamState:
             lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
             if self._hip_supported(lg):
                 return self._advance_hip(lg)
+            if not self.allow_torch:
+                # ONE search update on a HIP device, as for the decoder step: the kernel, or an error naming what it cannot serve
+                raise RuntimeError(
+                    f"beam-search update on {logits.device}: csrc/beam_step.hip serves num_beams <= 8, <= 4 EOS ids and "
+                    f"num_beams * vocab < 2^31 (got num_beams={self.nb}, eos ids={self.eos_t.numel()}, vocab={self.V}); pass "
+                    f"use_graph=\"torch\" (or False) to generate() for the torch restatement")
         return self.advance_torch(logits)
 
     def advance_torch(self, logits):
@@ -370,7 +377,8 @@ class _KernelStepper(_SearchFusion):
         mfma8 = cfg.hidden_size % 64 == 0 and cfg.intermediate_size % 64 == 0 and cfg.hidden_size <= 16384
         fits = (mfma8 or rows * max(cfg.hidden_size, cfg.intermediate_size) * 2 <= 150 * 1024) if rows <= 8 else \
             (rows <= 80 and min(cfg.hidden_size, cfg.intermediate_size) >= 32 and cfg.hidden_size <= 16384)
-        return (torch.device(device).type == "cuda" and dtype == torch.bfloat16 and D in (64, 128, 256)
+        # bf16, or fp16 -- the dtype the reference loads its LLM in (MambaXrayVL_DownStream.py:72,85,92); csrc/decode_elt.h
+        return (torch.device(device).type == "cuda" and dtype in (torch.bfloat16, torch.float16) and D in (64, 128, 256)
                 and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0 and fits)
 
     def __init__(self, model, rows, prompt_mask, dyn_cache, max_new, dtype):
@@ -387,7 +395,10 @@ class _KernelStepper(_SearchFusion):
         self.P = prompt_mask.shape[1]
         self.max_len = self.P + max_new
         model.fuse_qkv_()
-        bf = dict(dtype=torch.bfloat16, device=dev)
+        if model.lm_head.weight.dtype != dtype:
+            raise RuntimeError(f"decode kernels: weights are {model.lm_head.weight.dtype}, activations {dtype}; cast the decoder first")
+        self.dt = _abi.dtype_code(dtype)
+        bf = dict(dtype=dtype, device=dev)
         L = cfg.num_hidden_layers
         self.kc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
         self.vc = [torch.zeros(rows, self.Hkv, self.max_len, self.D, **bf) for _ in range(L)]
@@ -477,7 +488,7 @@ class _KernelStepper(_SearchFusion):
         c = self.cond[i]
         d = self._abi.DecodeCrossAttnDesc()
         d.rows, d.n_heads, d.n_kv_heads, d.head_dim, d.n_keys = self.rows, self.H, self.Hkv, self.D, c["k"].shape[2]
-        d.kv_rows_div, d.gate_flags, d.scale = c["div"], c["flags"], self.D ** -0.5
+        d.kv_rows_div, d.gate_flags, d.scale, d.dtype = c["div"], c["flags"], self.D ** -0.5, self.dt
         d.q_rope, d.k, d.v = self.q_rope.data_ptr(), c["k"].data_ptr(), c["v"].data_ptr()
         d.key_mask, d.row_on = self._abi.ptr(c["km"]), c["on"].data_ptr()
         d.text_state, d.out = self.att.data_ptr(), self.att2.data_ptr()
@@ -488,7 +499,7 @@ class _KernelStepper(_SearchFusion):
         """rows > 8: RMSNorm ahead of an MFMA projection (the GEMV kernel, rows <= 8, normalises in its own prologue).  With
         fold_res the row is first completed from the split projection's fp32 sums: x_out = bf16(acc) + fold_res; acc is cleared."""
         n = self._abi.RmsNormDesc()
-        n.rows, n.K, n.eps = self.rows, K, eps
+        n.rows, n.K, n.eps, n.dtype = self.rows, K, eps, self.dt
         n.x, n.weight, n.y = self._abi.ptr(x), norm.data_ptr(), self.xn.data_ptr()
         if fold_res is not None:
             n.acc, n.residual, n.x_out = self.acc.data_ptr(), fold_res.data_ptr(), x_out.data_ptr()
@@ -497,7 +508,7 @@ class _KernelStepper(_SearchFusion):
 
     def _gemv(self, x, W, y, K, N, norm=None, eps=0.0, W2=None, bias=None, res=None, out_f32=False, split=0):
         d = self._abi.GemvDesc()
-        d.rows, d.K, d.N = self.rows, K, N
+        d.rows, d.K, d.N, d.dtype = self.rows, K, N, self.dt
         d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), eps
         d.x, d.norm_weight, d.W = x.data_ptr(), self._abi.ptr(norm), W.data_ptr()
         d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), self._abi.ptr(y)
@@ -543,7 +554,7 @@ class _KernelStepper(_SearchFusion):
         self._prologue(tok, beam, cur)
         a = self._abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len = self.rows, self.H, self.Hkv, self.D, self.max_len
-        a.scale = self.D ** -0.5
+        a.scale, a.dtype = self.D ** -0.5, self.dt
         # the beams of a sample share a workgroup (and the cache lines they have in common) once head x sample workgroups fill the
         # chip; below that a workgroup per (head, row) keeps more requests in flight (batch 1 x beam 3: 9 vs 15 us per layer)
         a.beams = self.beams if (2 <= self.beams <= 5 and self.H * (self.rows // self.beams) >= 128 and self._beams_attn_fits()) else 0
@@ -743,11 +754,22 @@ class ReportDecoder(nn.Module):
         torch.cuda.current_stream().synchronize()
 
     @torch.no_grad()
-    def generate(self, inputs_embeds, attention_mask=None, num_beams=1, do_sample=False, min_new_tokens=0,
-                 max_new_tokens=20, repetition_penalty=1.0, length_penalty=1.0, eos_token_id=None, pad_token_id=None,
-                 early_stopping=False, temperature=None, use_graph=None):
+    def generate(self, inputs_embeds, *args, **kwargs):
         """Greedy (num_beams=1) / beam search over a prompt given as embeddings.  Returns (B, <= max_new_tokens) ids.
-        use_graph (default: on for HIP devices): static KV cache + one hipGraph replay per generated token."""
+        use_graph (default: on for HIP devices): static KV cache + one hipGraph replay per generated token.
+        A decoder held in a 16-bit dtype decodes IN that dtype, prompt prefill included: an enclosing autocast context (the
+        reference's validation_step runs under Lightning's bf16-mixed one, configs/config.py:67, around an LLM loaded with
+        torch_dtype=torch.float16, MambaXrayVL_DownStream.py:72-92) is suspended for the call -- the decode kernels never see it,
+        and a prefill that autocast re-cast per nn.Linear would fill the KV cache in another dtype than the steps that extend it."""
+        wdt = self.lm_head.weight.dtype
+        if wdt in (torch.bfloat16, torch.float16):
+            with torch.autocast(device_type=inputs_embeds.device.type, enabled=False):
+                return self._generate(inputs_embeds.to(wdt), *args, **kwargs)
+        return self._generate(inputs_embeds, *args, **kwargs)
+
+    def _generate(self, inputs_embeds, attention_mask=None, num_beams=1, do_sample=False, min_new_tokens=0,
+                  max_new_tokens=20, repetition_penalty=1.0, length_penalty=1.0, eos_token_id=None, pad_token_id=None,
+                  early_stopping=False, temperature=None, use_graph=None):
         if do_sample:
             raise NotImplementedError("the reference decodes with do_sample=False")
         dev = inputs_embeds.device
@@ -792,7 +814,7 @@ class ReportDecoder(nn.Module):
                     # stepper is an explicit request (use_graph="torch": CPU-parity experiments), never a silent substitute
                     if not _KernelStepper.supported(self, B * nb, inputs_embeds.dtype, dev):
                         raise RuntimeError(
-                            f"report decoding on {dev}: the HIP decode kernels serve bf16 models with head_dim 64/128/256 and "
+                            f"report decoding on {dev}: the HIP decode kernels serve bf16 / fp16 models with head_dim 64/128/256 and "
                             f"batch * beams <= 80 (got rows={B * nb}, dtype={inputs_embeds.dtype}, head_dim="
                             f"{self.config.hidden_size // self.config.num_attention_heads}); pass use_graph=\"torch\" for the "
                             f"torch-module stepper or use_graph=False for the eager loop")
@@ -815,6 +837,7 @@ class ReportDecoder(nn.Module):
             self._beam_states[skey] = state
         else:
             state.reset()
+        state.allow_torch = use_graph == "torch" or use_graph is False
         state.advance(logits)                                    # step 0: the prefill logits
         if stepper is None:
             cache.expand(nb)

@@ -928,6 +928,164 @@ def gen_decode_batched():
          **{"cfg_" + k: np.array(v) for k, v in shape.items()}, **out)
 
 
+
+def gen_decode_fp16():
+    """The reference loads its report LLM with torch_dtype=torch.float16 (MambaXrayVL_DownStream.py:72,85,92).  Every decode golden
+    above (HF fp32 on bf16-exact weights, streams robust against bf16 noise) is re-run here with HF ITSELF IN FP16 on the CPU: the
+    token streams must be the stored ones (asserted -- so the stored streams are also the fp16 goldens), and the per-step raw
+    greedy logits of the fp16 runs are stored for the teacher-forced check of the fp16 kernel instantiations."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from keyed_fill import keyed_fill_llama_
+    out = {}
+    gen = dict(do_sample=False, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+    kw_g = dict(num_beams=1, min_new_tokens=4, max_new_tokens=12)
+    kw_b = dict(num_beams=3, min_new_tokens=6, max_new_tokens=12)
+    eq = lambda x, y: x.shape == y.shape and torch.equal(x, y)
+    for name in ("decode_llama_hd64", "decode_llama_hd128", "decode_llama_hd256"):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        if name.endswith("hd64"):
+            cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
+                              num_key_value_heads=1, max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1,
+                              eos_token_id=2, pad_token_id=0, attention_bias=False, tie_word_embeddings=False)
+            m = LlamaForCausalLM(cfg).eval()
+            m.load_state_dict({k[2:]: torch.from_numpy(g[k]).view(torch.bfloat16).float() for k in g.files if k.startswith("p_")})
+        else:
+            shape = {k[4:]: int(g[k]) for k in g.files if k.startswith("cfg_")}
+            cfg = LlamaConfig(max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                              attention_bias=False, tie_word_embeddings=False, **shape)
+            m = keyed_fill_llama_(LlamaForCausalLM(cfg).eval(), int(g["weight_seed"]))
+        mh = m.to(torch.float16)
+        emb, att = torch.from_numpy(g["inputs_embeds"]).to(torch.float16), torch.from_numpy(g["attention_mask"])
+        with torch.no_grad():
+            gr = mh.generate(inputs_embeds=emb, attention_mask=att, output_logits=True, return_dict_in_generate=True, **kw_g, **gen)
+            b3 = mh.generate(inputs_embeds=emb, attention_mask=att, **kw_b, **gen)
+        assert eq(gr.sequences, torch.from_numpy(g["greedy"])) and eq(b3, torch.from_numpy(g["beam3"])), name
+        sl = torch.stack(gr.logits, dim=1).float()
+        ref = torch.from_numpy(g["greedy_step_logits"])
+        print(f"{name}: HF fp16 == stored streams; max |fp16 - fp32| logit {float((sl - ref).abs().max()):.4f} (scale {float(ref.abs().max()):.1f})")
+        out[name + "_greedy_step_logits"] = np_(sl)
+    g = np.load(os.path.join(HERE, "decode_llama_hd128_batched.npz"))
+    shape = {k[4:]: int(g[k]) for k in g.files if k.startswith("cfg_")}
+    cfg = LlamaConfig(max_position_embeddings=128, rms_norm_eps=1e-6, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                      attention_bias=False, tie_word_embeddings=False, **shape)
+    mh = keyed_fill_llama_(LlamaForCausalLM(cfg).eval(), int(g["weight_seed"])).to(torch.float16)
+    emb = torch.from_numpy(g["inputs_embeds_bf16"]).view(torch.bfloat16).to(torch.float16)
+    att = torch.from_numpy(g["attention_mask"])
+    NEW = int(g["max_new_tokens"])
+    for key, nb, B, mn in (("greedy_b16", 1, 16, 4), ("beam3_b6", 3, 6, 6), ("beam5_b16", 5, 16, 6), ("beam3_b16", 3, 16, 6)):
+        with torch.no_grad():
+            seqs = mh.generate(inputs_embeds=emb[:B], attention_mask=att[:B], num_beams=nb, min_new_tokens=mn, max_new_tokens=NEW, **gen)
+        assert eq(seqs, torch.from_numpy(g[key])), key
+        print(f"decode_llama_hd128_batched {key}: HF fp16 == stored stream")
+    save("decode_fp16", checked=np.array(1), **out)
+
+
+DECODE_QWEN = dict(vocab_size=151936, hidden_size=2048, intermediate_size=5504, num_hidden_layers=2, num_attention_heads=16,
+                   num_key_value_heads=16)
+
+
+def gen_decode_qwen():
+    """The reference's IU-Xray decoder is Qwen1.5-1.8B-Chat in fp16 (MambaXrayVL_DownStream.py:65-77), decoded at test_batch_size 16 x
+    beam 5 with repetition / length penalty 2.0 (launch/launch_mambaclip_test_iu.sh:26-35): HF Qwen2ForCausalLM at that model's
+    WIDTHS -- hidden 2048, 16 heads of 128, intermediate 5504, q / k / v biases, rope_theta 1e6, vocabulary 151 936 -- with two
+    layers and keyed weights (not stored).  16 ragged, left-padded prompts, each selected so that greedy and beam-5 streams are
+    identical under HF fp32, HF fp16, HF bf16, this package's fp16 CPU path and injected logit noise; the batched HF fp32 runs
+    (16 x beam 5 = 80 rows, 16 greedy) are the goldens and HF fp16 must reproduce them."""
+    for k in [k for k in sys.modules if k == "timm" or k.startswith("timm.")]:
+        sys.modules.pop(k)
+    from transformers import Qwen2Config, Qwen2ForCausalLM, LogitsProcessor, LogitsProcessorList
+    from keyed_fill import keyed_fill_llama_
+    shape = DECODE_QWEN
+    hid = shape["hidden_size"]
+
+    class Noise(LogitsProcessor):
+        def __init__(self, seed, amp):
+            self.g, self.amp = torch.Generator().manual_seed(seed), amp
+
+        def __call__(self, input_ids, scores):
+            return scores + self.amp * torch.randn(scores.shape, generator=self.g)
+
+    cfg = Qwen2Config(max_position_embeddings=128, rms_norm_eps=1e-6, rope_theta=1000000.0, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                      tie_word_embeddings=False, use_sliding_window=False, **shape)
+    P, NEW = 9, 16
+    kws = {"greedy": dict(num_beams=1, min_new_tokens=4, max_new_tokens=NEW), "beam5": dict(num_beams=5, min_new_tokens=6, max_new_tokens=NEW)}
+    weight_seed = 3
+    fill = dict(std=0.03, lm_std=0.06, bias_std=0.25, hot=192, hot_gain=3.0)
+    m = keyed_fill_llama_(Qwen2ForCausalLM(cfg).eval(), weight_seed, **fill)
+    assert any(float(p.abs().max()) > 0 for n, p in m.named_parameters() if n.endswith("q_proj.bias"))
+    mh = Qwen2ForCausalLM(cfg).eval()
+    mh.load_state_dict(m.state_dict())
+    mh = mh.to(torch.float16)
+    mb = Qwen2ForCausalLM(cfg).eval()
+    mb.load_state_dict(m.state_dict())
+    mb = mb.to(torch.bfloat16)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    rd = ReportDecoder(rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=128, **shape)
+    keyed_fill_llama_(rd, weight_seed, **fill)
+    for (k1, v1), (k2, v2) in zip(sorted(m.state_dict().items()), sorted(rd.state_dict().items())):
+        assert k1 == k2 and torch.equal(v1, v2), (k1, k2)
+    rd = rd.to(torch.float16).eval()
+    eq = lambda x, y: x.shape == y.shape and torch.equal(x, y)
+    gen = dict(do_sample=False, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+    embs, lens, single = [], [], []
+    seed = 0
+    while len(embs) < 16:
+        seed += 1
+        g = torch.Generator().manual_seed(9000 + seed)
+        n_real = 4 + (seed * 5) % 6
+        emb = torch.zeros(1, P, hid)
+        emb[0, P - n_real:] = (0.5 * torch.randn(n_real, hid, generator=g)).to(torch.bfloat16).float()    # fp16- and bf16-exact
+        att = torch.zeros(1, P, dtype=torch.long)
+        att[0, P - n_real:] = 1
+        common = dict(inputs_embeds=emb, attention_mask=att, **gen)
+        ok, outs = True, {}
+        with torch.no_grad():
+            gr = m.generate(output_logits=True, return_dict_in_generate=True, **kws["greedy"], **common)
+            sl = torch.stack(gr.logits, dim=1)
+            scale = float(sl.abs().max())
+            top2 = sl.topk(2, dim=-1).values
+            if float((top2[..., 0] - top2[..., 1]).min()) <= 0.012 * scale:
+                continue
+            outs["greedy"] = gr.sequences
+            outs["beam5"] = m.generate(**kws["beam5"], **common)
+            kw = dict(attention_mask=att, repetition_penalty=2.0, length_penalty=2.0, pad_token_id=0, eos_token_id=2)
+            for name in kws:
+                ok = ok and eq(outs[name], mh.generate(**kws[name], **dict(common, inputs_embeds=emb.to(torch.float16))))
+                ok = ok and eq(outs[name], mb.generate(**kws[name], **dict(common, inputs_embeds=emb.to(torch.bfloat16))))
+                ok = ok and eq(outs[name], rd.generate(emb.to(torch.float16), **kws[name], **kw))
+                for t in range(4):
+                    if not ok:
+                        break
+                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.005 * scale)])
+                    ok = eq(m.generate(logits_processor=lp, **kws[name], **common), outs[name])
+        print(f"decode_qwen prompt seed {seed} ({n_real} real tokens): robust={ok} (scale {scale:.1f})", flush=True)
+        if ok:
+            embs.append(emb)
+            lens.append(n_real)
+            single.append(outs)
+    emb = torch.cat(embs)
+    att = (torch.arange(P)[None, :] >= (P - torch.tensor(lens))[:, None]).long()
+    out = {}
+    with torch.no_grad():
+        for name, nb in (("greedy_b16", "greedy"), ("beam5_b16", "beam5")):
+            seqs = m.generate(inputs_embeds=emb, attention_mask=att, **gen, **kws[nb])
+            for i in range(16):
+                one = single[i][nb][0]
+                assert torch.equal(seqs[i, :one.numel()], one), (name, i)
+            assert eq(seqs, mh.generate(inputs_embeds=emb.to(torch.float16), attention_mask=att, **gen, **kws[nb])), name
+            out[name] = seqs.numpy().copy()
+            print(name, seqs.tolist())
+        logits_prompt = m(inputs_embeds=emb[:2], attention_mask=att[:2]).logits[:, -1]
+    save("decode_qwen_b16", weight_seed=np.array(weight_seed), inputs_embeds_bf16=emb.to(torch.bfloat16).view(torch.int16).numpy().copy(),
+         attention_mask=att.numpy().copy(), max_new_tokens=np.array(NEW), logits_prompt_2=np_(logits_prompt),
+         **{"fill_" + k: np.array(v) for k, v in fill.items()},
+         weight_checksum=np_(sum(v.double().abs().sum() for v in m.state_dict().values()).float()),
+         **{"cfg_" + k: np.array(v) for k, v in shape.items()}, **out)
+
+
 def gen_lr_sched():
     """CXPMRG_Bench_MambaXray_VL/pretrain/utils/lr_sched.py adjust_learning_rate, executed: the learning rates of the stage-1 run
     (pretrain.sh: blr 1.5e-4 x 4096 / 256 -> lr, min_lr 0, warmup 5 / 100 epochs style settings) on a grid of fractional epochs,
@@ -1251,6 +1409,13 @@ if __name__ == "__main__":
         gen_lr_sched()
     elif len(sys.argv) > 1 and sys.argv[1] == "decode_batched":
         gen_decode_batched()
+    elif len(sys.argv) > 1 and sys.argv[1] == "decode_fp16":
+        sys.path.insert(0, HERE)
+        gen_decode_fp16()
+    elif len(sys.argv) > 1 and sys.argv[1] == "decode_qwen":
+        sys.path.insert(0, HERE)
+        torch.set_num_threads(8)
+        gen_decode_qwen()
     elif len(sys.argv) > 1 and sys.argv[1] == "qformer":
         gen_qformer()
     elif len(sys.argv) > 1 and sys.argv[1] == "text":

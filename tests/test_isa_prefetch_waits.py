@@ -101,23 +101,26 @@ def test_scan_bwd_training_kernels_have_no_scratch():
         assert not _scratch_ops(_body("scan_bwd.hip", name)), name
 
 
-def test_beams_attention_runs_its_products_on_the_matrix_cores():
+@pytest.mark.parametrize("elt,suffix", [("EltBf16", "bf16"), ("EltF16", "f16")])
+def test_beams_attention_runs_its_products_on_the_matrix_cores(elt, suffix):
     """decode_attn_beams_mfma_kernel: K Q^T by 16x16x32 MFMA, V^T P by 16x16x16 MFMA with V^T through the transpose read, tiles by
     LDS-DMA with explicit counted waits, no scratch; the only ds_bpermute left are the per-tile max over the four q-lanes and the
-    final sum (the VALU version ran four dependent ones per (position, beam))."""
-    ins = _body("decode.hip", "decode_attn_beams_mfma_kernelILi128ELi3ELi8E")
+    final sum (the VALU version ran four dependent ones per (position, beam)).  Round 5: the same instruction stream for the fp16
+    instantiation (csrc/decode_elt.h), which is the dtype the reference loads its LLM in."""
+    ins = _body("decode.hip", f"decode_attn_beams_mfma_kernelINS_{len(elt)}{elt}ELi128ELi3ELi8E")
     count = lambda pat: sum(1 for x in ins if re.match(pat, x))
-    assert count(r"v_mfma_f32_16x16x32[_a-z0-9]*bf16") >= 4 and count(r"v_mfma_f32_16x16x16[_a-z0-9]*bf16") >= 8
+    assert count(rf"v_mfma_f32_16x16x32[_a-z0-9]*{suffix}") >= 4 and count(rf"v_mfma_f32_16x16x16[_a-z0-9]*{suffix}") >= 8
     assert count(r"ds_read_b64_tr_b16") >= 8 and count(r"global_load_lds_dwordx4") >= 8
     assert any(re.match(r"s_waitcnt vmcnt\(8\)", x) for x in ins), "the wait for the older of two tiles in flight"
     assert not _scratch_ops(ins)
     assert count(r"ds_bpermute_b32") <= 12      # 2 per tile (max over q) + 2 (final sum) + the fresh position's wave reduction
 
 
-def test_per_row_decode_attention_sums_scores_by_dpp():
+@pytest.mark.parametrize("elt", ["EltBf16", "EltF16"])
+def test_per_row_decode_attention_sums_scores_by_dpp(elt):
     """decode_attn_kernel: the 16-lane score sum is four DPP adds; ds_bpermute only in the final merge of the lane groups (behind the
     position loop), and the cache rows arrive through the LDS ring"""
-    ins = _body("decode.hip", "decode_attn_kernelILi128ELi8ELi4E")
+    ins = _body("decode.hip", f"decode_attn_kernelINS_{len(elt)}{elt}ELi128ELi8ELi4E")
     assert sum(1 for x in ins if x.startswith("v_add_f32_dpp")) >= 4
     assert sum(1 for x in ins if x.startswith("global_load_lds_dwordx4")) >= 4
     first_dma = next(k for k, x in enumerate(ins) if x.startswith("global_load_lds_dwordx4"))

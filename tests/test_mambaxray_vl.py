@@ -101,12 +101,18 @@ def _samples(B, views=2):
 
 
 @pytest.mark.gpu
-def test_downstream_loss_generate_and_delta(tmp_path):
+@pytest.mark.parametrize("llm_dtype", [None, torch.bfloat16], ids=["default_fp16", "bf16"])
+def test_downstream_loss_generate_and_delta(tmp_path, llm_dtype):
+    """llm_dtype None = build_report_decoder's default, torch.float16 -- the dtype the reference loads its LLM in
+    (MambaXrayVL_DownStream.py:72,85,92): validation_step must decode it on the HIP kernel stepper (round 4 raised there)."""
     from medical_image_analysis_amd import mambaxray_vl as mx
+    from medical_image_analysis_amd.report_decoder import _KernelStepper
     torch.manual_seed(0)
     args = mx.default_args(vision_model="Base-None", max_length=16, min_new_tokens=4, max_new_tokens=8)
     llm = mx.build_report_decoder(dict(vocab_size=256, hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2,
-                                       num_key_value_heads=2, max_position_embeddings=512), dtype=torch.bfloat16)   # head_dim 64: a width the HIP decode kernels serve
+                                       num_key_value_heads=2, max_position_embeddings=512),
+                                  **({} if llm_dtype is None else dict(dtype=llm_dtype)))   # head_dim 64: a width the HIP decode kernels serve
+    assert llm.lm_head.weight.dtype == (torch.float16 if llm_dtype is None else llm_dtype)
     m = mx.MambaXrayVLDownStream(args, tokenizer=WordTokenizer(), llm=llm).to(DEV)
     assert m.visual_encoder.num_features == 768                       # 'B' in vision_model -> arm_base_pz16
     assert not any(p.requires_grad for p in m.llama_model.parameters()) and not any(p.requires_grad for p in m.visual_encoder.parameters())
@@ -121,6 +127,7 @@ def test_downstream_loss_generate_and_delta(tmp_path):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         hypo, ref = m.validation_step(batch)
     assert len(hypo) == 2 and all(isinstance(h, str) and 4 <= len(h.split()) <= 8 for h in hypo)
+    assert m.llama_model._steppers and all(type(st) is _KernelStepper for st in m.llama_model._steppers.values()), "generate() took the HIP kernels"
     assert ref[0].startswith("w") and "<unk>" not in ref[0]
     scores, ref_d, hyp_d = m.epoch_scores()                            # on_validation_epoch_end's scoring (:329-341)
     assert sorted(ref_d) == sorted(batch["id"]) and all(len(v) == 1 for v in hyp_d.values())

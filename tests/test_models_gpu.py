@@ -128,6 +128,38 @@ def test_pretrain_fused_decoder_path_matches_oracle_and_unfused_path():
             assert_close(fused[k], p.grad, 2e-3 * scale, 2e-3, "grad " + k)
 
 
+def test_pretrain_visionmamba_full_size_1024_matches_oracle():
+    """BASELINE.json configs[2] AT FULL SIZE, once: VisionMamba(1024 x 1024 image, 1024 x 24 encoder, 512 x 4 decoder; 4096 patches, a
+    4080-token scan, 4080-token block-causal attention) on ONE image in fp32 -- the per-token loss vector (4080 values) against the
+    CPU oracle (oracle/models_ref.visionmamba_forward_ref over the C scan / conv oracles, itself pinned to the reference's golden at
+    128 x 128: tests/test_oracle_golden.py), atol 1e-3 (pretrain/models_pretrain.py:510-515).  Then one bf16-autocast training step of
+    the same model (the arithmetic bench.py times): finite loss, finite gradients on every trainable parameter."""
+    from medical_image_analysis_amd.models_pretrain import VisionMamba
+    from oracle import models_ref
+    from oracle import oracle as orc
+    torch.manual_seed(0)
+    m = VisionMamba(img_size=1024, patch_size=16, stride=16, embed_dim=1024, depth=24, dec_embed_dim=512, rms_norm=True,
+                    residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True, bimamba_type="None").to(DEV)
+    img = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(5)).to(DEV)
+    with torch.no_grad():
+        loss = m(img)
+    assert loss.shape == (4080,) and m._decoder_fusable(img)
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    import os
+    cores = max(1, min(64, (os.cpu_count() or 2) // 2))
+    orc.set_threads(cores)
+    torch.set_num_threads(cores)
+    ref_loss, _, _ = models_ref.visionmamba_forward_ref(sd, img.cpu(), patch=16, depth=24)
+    assert_close(loss, ref_loss, 1e-3, 1e-3, "per-token loss of the full-size model vs the CPU oracle")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lb = m(img)
+    assert_close(lb.float(), ref_loss, 0.05 * float(ref_loss.abs().max()), 0.05, "bf16-autocast loss vs the fp32 oracle")
+    lb.mean().backward()
+    bad = [n for n, p in m.named_parameters() if p.requires_grad and (p.grad is None or not bool(torch.isfinite(p.grad).all()))]
+    assert not bad, f"non-finite / missing gradients: {bad[:5]}"
+    assert sum(float(p.grad.abs().sum()) for p in m.parameters() if p.grad is not None) > 0.0
+
+
 def test_reference_style_import_through_dropin():
     """`from mamba_ssm.ops.selective_scan_interface import ...` resolves to the HIP path after dropin.install()."""
     import medical_image_analysis_amd.dropin as dropin

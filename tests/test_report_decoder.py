@@ -7,6 +7,8 @@ import torch
 from conftest import assert_close, load_golden
 
 DEVICES = ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)]
+# one ulp of the 16-bit activation types relative to the top of a binade (bf16: 8 significant bits, fp16: 11)
+ULP = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
 
 
 def _model(g, dev):
@@ -89,7 +91,8 @@ def test_generation_with_conditioned_hybrid_layers_runs_and_depends_on_image():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,nb,inter", [(2, 4, 11008), (6, 3, 1408), (16, 5, 704)])
-def test_hip_decode_step_matches_torch_step_at_wide_and_batched_shapes(B, nb, inter):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_step_matches_torch_step_at_wide_and_batched_shapes(B, nb, inter, dtype):
     """The kernel stepper against the torch-module stepper, teacher-forced with random beam re-ordering, where the HF goldens do not
     reach: 8 rows at the Llama-2-7B intermediate width (11008: the GEMV kernel's LDS bound refused this -- the MFMA kernels have
     none), 18 rows (K-split o_proj / down_proj folded by the norm kernel, beams attention) and 80 rows (beam 5)."""
@@ -97,21 +100,21 @@ def test_hip_decode_step_matches_torch_step_at_wide_and_batched_shapes(B, nb, in
     dev = "cuda:0"
     torch.manual_seed(0)
     m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=inter, num_hidden_layers=2, num_attention_heads=2,
-                      num_key_value_heads=1, max_position_embeddings=256).to(dev).to(torch.bfloat16).eval()
+                      num_key_value_heads=1, max_position_embeddings=256).to(dev).to(dtype).eval()
     with torch.no_grad():
         for p in m.parameters():
             p.mul_(2.0)
     P, new = 9, 5
-    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(dtype)
     mask = torch.ones(B, P, dtype=torch.long, device=dev)
     mask[1, :3] = 0
-    assert _KernelStepper.supported(m, B * nb, torch.bfloat16, dev)
+    assert _KernelStepper.supported(m, B * nb, dtype, dev)
     with torch.no_grad():
         c1, c2 = KVCache(), KVCache()
         m(emb, attention_mask=mask, past_key_values=c1)
         m(emb, attention_mask=mask, past_key_values=c2)
-        ks = _KernelStepper(m, B * nb, mask, c1, new, torch.bfloat16)
-        ts = _GraphStepper(m, B * nb, mask, c2, new, torch.bfloat16)
+        ks = _KernelStepper(m, B * nb, mask, c1, new, dtype)
+        ts = _GraphStepper(m, B * nb, mask, c2, new, dtype)
         assert ks.batched
         g = torch.Generator(device="cpu").manual_seed(1)
         for k in range(new):
@@ -124,7 +127,8 @@ def test_hip_decode_step_matches_torch_step_at_wide_and_batched_shapes(B, nb, in
 
 
 @pytest.mark.gpu
-def test_hip_decode_step_matches_torch_step_bf16():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_step_matches_torch_step_16bit(dtype):
     """csrc/decode.hip (fused RMSNorm+GEMV, RoPE+cache+attention, SwiGLU) against the torch/SDPA decode step on the
     same bf16 weights, teacher-forced over several tokens with RANDOM beam re-ordering at a larger width than the HF
     goldens (which pin the kernels themselves: test_hip_decode_kernels_* below).  Both sides compute in bf16 with fp32
@@ -133,21 +137,21 @@ def test_hip_decode_step_matches_torch_step_bf16():
     dev = "cuda:0"
     torch.manual_seed(0)
     m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
-                      num_key_value_heads=2, max_position_embeddings=256).to(dev).to(torch.bfloat16).eval()
+                      num_key_value_heads=2, max_position_embeddings=256).to(dev).to(dtype).eval()
     with torch.no_grad():
         for p in m.parameters():
             p.mul_(2.0)
     B, nb, P, new = 2, 3, 9, 6
-    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(dtype)
     mask = torch.ones(B, P, dtype=torch.long, device=dev)
     mask[1, :3] = 0
-    assert _KernelStepper.supported(m, B * nb, torch.bfloat16, dev)
+    assert _KernelStepper.supported(m, B * nb, dtype, dev)
     with torch.no_grad():
         c1, c2 = KVCache(), KVCache()
         m(emb, attention_mask=mask, past_key_values=c1)
         m(emb, attention_mask=mask, past_key_values=c2)
-        ks = _KernelStepper(m, B * nb, mask, c1, new, torch.bfloat16)
-        ts = _GraphStepper(m, B * nb, mask, c2, new, torch.bfloat16)
+        ks = _KernelStepper(m, B * nb, mask, c1, new, dtype)
+        ts = _GraphStepper(m, B * nb, mask, c2, new, dtype)
         g = torch.Generator(device="cpu").manual_seed(1)
         for k in range(new):
             tok = torch.randint(3, 512, (B * nb,), generator=g).to(dev)
@@ -160,7 +164,8 @@ def test_hip_decode_step_matches_torch_step_bf16():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("gating", ["whole-dynamic-tanh-warmup", "whole-dynamic"])
-def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_path(gating):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_path(gating, dtype):
     """Hybrid layers conditioned on image tokens (`condition_vis_x`, "vanilla" = every token attends,
     hybrid_decoder_layer.py:653-697): the kernel stepper (mxvl_decode_attn -> mxvl_decode_cross_attn: single-query attention over
     the image K / V, scalar gate, added before o_proj) against the module path (the torch stepper calling the layers' forward,
@@ -171,7 +176,7 @@ def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_pat
     torch.manual_seed(0)
     m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
                       num_key_value_heads=2, max_position_embeddings=256, hybrid_layers=(0, 2), cross_attn_implementation="vanilla",
-                      cross_attn_gating_type=gating).to(dev).to(torch.bfloat16).eval()
+                      cross_attn_gating_type=gating).to(dev).to(dtype).eval()
     with torch.no_grad():
         for p in m.parameters():
             p.mul_(2.0)
@@ -181,10 +186,10 @@ def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_pat
                 at.cross_attn_warm_up_gate.fill_(0.75)
             at.cross_attn_gate_proj[0].bias.fill_(0.5)
     B, P, new, Lv = 3, 9, 5, 37
-    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(dtype)
     mask = torch.ones(B, P, dtype=torch.long, device=dev)
     mask[1, :3] = 0
-    vis = torch.randn(B, Lv, 256, device=dev).to(torch.bfloat16)
+    vis = torch.randn(B, Lv, 256, device=dev).to(dtype)
     cmask = torch.ones(B, Lv, dtype=torch.bool, device=dev)
     cmask[0, 30:] = False
     cmask[2, ::3] = False
@@ -194,14 +199,14 @@ def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_pat
     with torch.no_grad():
         c0 = KVCache()
         m(emb, attention_mask=mask, past_key_values=c0)
-        plain = _KernelStepper(m, B, mask, c0, new, torch.bfloat16)
+        plain = _KernelStepper(m, B, mask, c0, new, dtype)
         m.condition_vis_x(vis, cmask, tt)
-        assert _KernelStepper.supported(m, B, torch.bfloat16, dev)
+        assert _KernelStepper.supported(m, B, dtype, dev)
         c1, c2 = KVCache(), KVCache()
         m(emb, attention_mask=mask, past_key_values=c1)
         m(emb, attention_mask=mask, past_key_values=c2)
-        ks = _KernelStepper(m, B, mask, c1, new, torch.bfloat16)
-        ts = _GraphStepper(m, B, mask, c2, new, torch.bfloat16)
+        ks = _KernelStepper(m, B, mask, c1, new, dtype)
+        ts = _GraphStepper(m, B, mask, c2, new, dtype)
         assert sorted(ks.cond) == [0, 2]
         g = torch.Generator(device="cpu").manual_seed(1)
         beam = torch.arange(B, device=dev)
@@ -227,7 +232,8 @@ def test_hip_decode_step_with_image_conditioned_hybrid_layers_matches_module_pat
 
 
 @pytest.mark.gpu
-def test_hip_decode_conditioned_hybrid_layers_with_beams_matches_module_path():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_conditioned_hybrid_layers_with_beams_matches_module_path(dtype):
     """Image-conditioned hybrid layers under BEAM search (3 beams per sample): the beams of a sample share its image K / V
     (kernel: kv_rows_div = beams; module path: the layer expands vis_x / masks with repeat_interleave, HF's beam expansion of
     per-sample inputs).  Teacher-forced with beam re-orderings that stay inside a sample, kernel stepper vs module path; then
@@ -237,7 +243,7 @@ def test_hip_decode_conditioned_hybrid_layers_with_beams_matches_module_path():
     torch.manual_seed(1)
     m = ReportDecoder(vocab_size=512, hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
                       num_key_value_heads=2, max_position_embeddings=256, hybrid_layers=(0, 2), cross_attn_implementation="vanilla",
-                      cross_attn_gating_type="whole-dynamic-tanh-warmup").to(dev).to(torch.bfloat16).eval()
+                      cross_attn_gating_type="whole-dynamic-tanh-warmup").to(dev).to(dtype).eval()
     with torch.no_grad():
         for p in m.parameters():
             p.mul_(2.0)
@@ -247,22 +253,22 @@ def test_hip_decode_conditioned_hybrid_layers_with_beams_matches_module_path():
             at.cross_attn_gate_proj[0].bias.fill_(0.5)
     B, nb, P, new, Lv = 2, 3, 9, 5, 37
     rows = B * nb
-    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(torch.bfloat16)
+    emb = (0.5 * torch.randn(B, P, 256, device=dev)).to(dtype)
     mask = torch.ones(B, P, dtype=torch.long, device=dev)
     mask[1, :3] = 0
-    vis = torch.randn(B, Lv, 256, device=dev).to(torch.bfloat16)
+    vis = torch.randn(B, Lv, 256, device=dev).to(dtype)
     cmask = torch.ones(B, Lv, dtype=torch.bool, device=dev)
     cmask[0, 30:] = False
     tt = torch.ones(B, P, dtype=torch.long, device=dev)
     tt[:, 1:4] = 3
     with torch.no_grad():
         m.condition_vis_x(vis, cmask, tt)
-        assert _KernelStepper.supported(m, rows, torch.bfloat16, dev)
+        assert _KernelStepper.supported(m, rows, dtype, dev)
         c1, c2 = KVCache(), KVCache()
         m(emb, attention_mask=mask, past_key_values=c1)
         m(emb, attention_mask=mask, past_key_values=c2)
-        ks = _KernelStepper(m, rows, mask, c1, new, torch.bfloat16)
-        ts = _GraphStepper(m, rows, mask, c2, new, torch.bfloat16)
+        ks = _KernelStepper(m, rows, mask, c1, new, dtype)
+        ts = _GraphStepper(m, rows, mask, c2, new, dtype)
         g = torch.Generator(device="cpu").manual_seed(2)
         base = torch.arange(rows) // nb * nb
         for k in range(new):
@@ -315,7 +321,8 @@ def test_hd64_fp32_path_matches_hf(dev):
 
 
 @pytest.mark.gpu
-def test_hip_decode_kernels_match_hf_logits_teacher_forced():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_kernels_match_hf_logits_teacher_forced(dtype):
     """gemv_bf16_kernel (+RMSNorm prologue, +residual, SwiGLU, fp32 logits) and decode_attn_kernel (RoPE, cache append,
     one-query attention) against HF's OWN per-step logits: the HIP stepper is fed HF's greedy tokens and must reproduce
     the raw logits HF recorded for the next position, to bf16 tolerance (weights are bf16-exact in the golden; the
@@ -323,19 +330,19 @@ def test_hip_decode_kernels_match_hf_logits_teacher_forced():
     from medical_image_analysis_amd.report_decoder import KVCache, _KernelStepper
     dev = "cuda:0"
     g = load_golden("decode_llama_hd64")
-    m = _model_hd64(g, dev, torch.bfloat16)
-    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    m = _model_hd64(g, dev, dtype)
+    emb, att = g["inputs_embeds"].to(dev).to(dtype), g["attention_mask"].to(dev)
     want = g["greedy_step_logits"]                      # (B, steps, V): [:, 0] = after the prompt
     toks = g["greedy"].to(dev)
     B, steps, V = want.shape
-    assert _KernelStepper.supported(m, B, torch.bfloat16, dev), "head_dim 64 / bf16 must take the HIP kernels"
+    assert _KernelStepper.supported(m, B, dtype, dev), "head_dim 64 / bf16 must take the HIP kernels"
     scale = float(want.abs().max())
     tol = 0.02 * scale
     with torch.no_grad():
         cache = KVCache()
         pre = m(emb, attention_mask=att, past_key_values=cache)[:, -1].float()
         assert_close(pre, want[:, 0], tol, 0.02, "prefill logits (torch bf16 path)")
-        ks = _KernelStepper(m, B, att, cache, steps, torch.bfloat16)
+        ks = _KernelStepper(m, B, att, cache, steps, dtype)
         ident = torch.arange(B, device=dev)
         worst = 0.0
         for k in range(steps - 1):
@@ -346,18 +353,21 @@ def test_hip_decode_kernels_match_hf_logits_teacher_forced():
             top2 = ref.topk(2, dim=-1)
             clear = (top2.values[:, 0] - top2.values[:, 1]) > 2 * tol
             assert torch.equal(got.argmax(-1)[clear], top2.indices[:, 0][clear]), f"arg-max after token {k}"
-    assert worst > 0.0, "the stepper produced HF's logits bit for bit: it did not run in bf16"
+            if dtype == torch.float16:    # HF itself in fp16 (tests/golden/make_golden.py gen_decode_fp16): two fp16 computations of the same step
+                assert_close(got, load_golden("decode_fp16")["decode_llama_hd64_greedy_step_logits"][:, k + 1], 0.008 * scale, 0.01, f"vs HF fp16 after token {k}")
+    assert worst > 0.0, "the stepper produced HF's logits bit for bit: it did not run in a 16-bit type"
 
 
 @pytest.mark.gpu
-def test_hip_decode_generate_tokens_match_hf():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_generate_tokens_match_hf(dtype):
     """End to end on the HIP path (graph-captured stepper + beam_step kernel + slot-table re-ordering): greedy and beam-3
     token streams equal HF's.  The golden's seed was selected so that no decision sits on a near-tie (make_golden.py
     gen_decode_hd64: identical streams under HF-bf16, this package's bf16 CPU path and injected logit noise)."""
     dev = "cuda:0"
     g = load_golden("decode_llama_hd64")
-    m = _model_hd64(g, dev, torch.bfloat16)
-    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    m = _model_hd64(g, dev, dtype)
+    emb, att = g["inputs_embeds"].to(dev).to(dtype), g["attention_mask"].to(dev)
     for name, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
         out = m.generate(emb, attention_mask=att, use_graph=True, **kw, **HD64_GEN)
         key = [k for k in m._steppers if k[0] == emb.shape[0] * kw["num_beams"]][-1]
@@ -405,26 +415,27 @@ def test_keyed_fp32_path_matches_hf(dev, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", KEYED)
-def test_hip_decode_kernels_match_hf_logits_teacher_forced_hd128_hd256(name):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_kernels_match_hf_logits_teacher_forced_hd128_hd256(name, dtype):
     """decode_attn_kernel<128> / <256> (the Llama-2-7B instantiation bench.py times, and the widest one) + gemv at
     K = 512 / 1408 against HF's per-step logits, teacher-forced with HF's greedy tokens -- same check as the head_dim-64 one."""
     from medical_image_analysis_amd.report_decoder import KVCache, _KernelStepper
     dev = "cuda:0"
     g = load_golden(name)
-    m = _model_keyed(g, dev, torch.bfloat16)
-    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    m = _model_keyed(g, dev, dtype)
+    emb, att = g["inputs_embeds"].to(dev).to(dtype), g["attention_mask"].to(dev)
     want, toks = g["greedy_step_logits"], g["greedy"].to(dev)
     B, steps, V = want.shape
     D = m.config.hidden_size // m.config.num_attention_heads
     assert D == (128 if name.endswith("128") else 256)
-    assert _KernelStepper.supported(m, B, torch.bfloat16, dev), f"head_dim {D} / bf16 must take the HIP kernels"
+    assert _KernelStepper.supported(m, B, dtype, dev), f"head_dim {D} / bf16 must take the HIP kernels"
     scale = float(want.abs().max())
     tol = 0.02 * scale
     with torch.no_grad():
         cache = KVCache()
         pre = m(emb, attention_mask=att, past_key_values=cache)[:, -1].float()
         assert_close(pre, want[:, 0], tol, 0.02, "prefill logits (torch bf16 path)")
-        ks = _KernelStepper(m, B, att, cache, steps, torch.bfloat16)
+        ks = _KernelStepper(m, B, att, cache, steps, dtype)
         ident = torch.arange(B, device=dev)
         worst = 0.0
         for k in range(steps - 1):
@@ -435,17 +446,20 @@ def test_hip_decode_kernels_match_hf_logits_teacher_forced_hd128_hd256(name):
             top2 = ref.topk(2, dim=-1)
             clear = (top2.values[:, 0] - top2.values[:, 1]) > 2 * tol
             assert torch.equal(got.argmax(-1)[clear], top2.indices[:, 0][clear]), f"arg-max after token {k}"
+            if dtype == torch.float16:
+                assert_close(got, load_golden("decode_fp16")[name + "_greedy_step_logits"][:, k + 1], 0.008 * scale, 0.01, f"vs HF fp16 after token {k}")
     assert 0.0 < worst < tol
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", KEYED)
-def test_hip_decode_generate_tokens_match_hf_hd128_hd256(name):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_hip_decode_generate_tokens_match_hf_hd128_hd256(name, dtype):
     """generate() through _KernelStepper (asserted) at head_dim 128 / 256: HF-token-exact greedy and beam-3 streams."""
     dev = "cuda:0"
     g = load_golden(name)
-    m = _model_keyed(g, dev, torch.bfloat16)
-    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    m = _model_keyed(g, dev, dtype)
+    emb, att = g["inputs_embeds"].to(dev).to(dtype), g["attention_mask"].to(dev)
     for key, kw in (("greedy", HD64_GREEDY), ("beam3", HD64_BEAM)):
         out = m.generate(emb, attention_mask=att, use_graph=True, **kw, **HD64_GEN)
         st = [v for k, v in m._steppers.items() if k[0] == emb.shape[0] * kw["num_beams"]][-1]
@@ -462,13 +476,14 @@ BATCHED = [("greedy_b16", 16, dict(num_beams=1, min_new_tokens=4)), ("beam3_b6",
 
 @pytest.mark.parametrize("dev", DEVICES)
 @pytest.mark.parametrize("key,B,kw", BATCHED)
-def test_batched_generate_tokens_match_hf(dev, key, B, kw):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_batched_generate_tokens_match_hf(dev, key, B, kw, dtype):
     """generate() at 16 / 18 / 48 / 80 rows with ragged prompts == HF, token for token.  On the GPU the step is the HIP kernel
     stepper (class asserted): MFMA projections (decode_gemm.h), K-split o_proj / down_proj folded by mxvl_decode_rmsnorm,
     multi-workgroup prologue and beam kernels (beams 5: keep = 10)."""
     g = load_golden("decode_llama_hd128_batched")
-    m = _model_keyed(g, dev, torch.bfloat16)
-    emb = g["inputs_embeds_bf16"].view(torch.bfloat16)[:B].to(dev)
+    m = _model_keyed(g, dev, dtype)
+    emb = g["inputs_embeds_bf16"].view(torch.bfloat16)[:B].to(dtype).to(dev)      # bf16-exact values: exact in fp16 too
     att = g["attention_mask"][:B].to(dev)
     out = m.generate(emb, attention_mask=att, max_new_tokens=int(g["max_new_tokens"]), repetition_penalty=2.0, length_penalty=2.0,
                      pad_token_id=0, eos_token_id=2, **kw)
@@ -482,7 +497,8 @@ def test_batched_generate_tokens_match_hf(dev, key, B, kw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,N,S", [(4096, 4096, 4), (11008, 4096, 4), (4096, 4096, 1), (512, 512, 2), (1408, 520, 3), (72, 24, 2)])
 @pytest.mark.parametrize("rows", [18, 48, 80])
-def test_decode_gemm_split_k_folded_by_rmsnorm(K, N, S, rows):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_gemm_split_k_folded_by_rmsnorm(K, N, S, rows, dtype):
     """o_proj / down_proj at rows > 8: mxvl_decode_gemv with split_acc (K split over S workgroups per column block, fp32 atomics),
     then mxvl_decode_rmsnorm in fold mode: x_out = bf16(acc) + residual, y = RMSNorm(x_out), acc cleared.  Reference: fp32 torch with
     the modules' rounding points (linear output -> bf16, + residual -> bf16, Qwen2RMSNorm)."""
@@ -492,32 +508,32 @@ def test_decode_gemm_split_k_folded_by_rmsnorm(K, N, S, rows):
     lib = _abi.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(K + 3 * N + rows + S)
-    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(torch.bfloat16).to(dev)
+    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dtype).to(dev)
     x, W, res = bf(rows, K), bf(N, K, sc=K ** -0.5), bf(rows, N)
     acc = torch.zeros(rows, N, device=dev)
     d = _abi.GemvDesc()
-    d.rows, d.K, d.N = rows, K, N
+    d.rows, d.K, d.N, d.dtype = rows, K, N, _abi.dtype_code(dtype)
     d.x, d.W, d.split_acc, d.k_splits = x.data_ptr(), W.data_ptr(), acc.data_ptr(), S
     _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv (split)")
     lin = x.float() @ W.float().t()
     assert_close(acc, lin, 3e-5 * float(lin.abs().max()), 1e-5, f"split sums K={K} N={N} S={S} rows={rows}")
-    mod = Qwen2RMSNorm(N, eps=1e-6).to(dev).to(torch.bfloat16)
+    mod = Qwen2RMSNorm(N, eps=1e-6).to(dev).to(dtype)
     with torch.no_grad():
-        mod.weight.copy_((1.0 + 0.1 * torch.randn(N, generator=g)).to(torch.bfloat16))
+        mod.weight.copy_((1.0 + 0.1 * torch.randn(N, generator=g)).to(dtype))
     if N % 8 == 0:
         x_out, y = torch.empty_like(res), torch.empty_like(res)
         n = _abi.RmsNormDesc()
-        n.rows, n.K, n.eps = rows, N, 1e-6
+        n.rows, n.K, n.eps, n.dtype = rows, N, 1e-6, _abi.dtype_code(dtype)
         n.weight, n.y, n.acc, n.residual, n.x_out = mod.weight.data_ptr(), y.data_ptr(), acc.data_ptr(), res.data_ptr(), x_out.data_ptr()
         acc_before = acc.clone()
         _abi.check(lib.mxvl_decode_rmsnorm(ctypes.byref(n), _abi.stream_ptr(x.device)), "mxvl_decode_rmsnorm (fold)")
-        want_x = (acc_before.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
+        want_x = (acc_before.to(dtype).float() + res.float()).to(dtype)
         assert torch.equal(x_out, want_x), "x_out = bf16(bf16(acc) + residual), bit for bit"
         assert float(acc.abs().max()) == 0.0
         with torch.no_grad():
             ref = mod(want_x)
         diff = (y.float() - ref.float()).abs()
-        assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+        assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= ULP[dtype] * float(ref.float().abs().max())
     # an epilogue next to split_acc is refused
     d.residual = res.data_ptr()
     assert lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)) != 0
@@ -527,7 +543,8 @@ def test_decode_gemm_split_k_folded_by_rmsnorm(K, N, S, rows):
 @pytest.mark.parametrize("D,H,Hkv,nb,B,T,P,pos_v", [(128, 4, 2, 3, 2, 96, 37, 71), (64, 4, 4, 5, 2, 96, 37, 71), (128, 2, 1, 2, 3, 96, 37, 71),
                                                      (256, 2, 1, 4, 1, 96, 37, 71), (128, 32, 32, 3, 6, 96, 37, 71),
                                                      (128, 2, 2, 5, 1, 2100, 1000, 2050)])   # long table: the 4-wave shape of the beams kernel
-def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P, pos_v):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P, pos_v, dtype):
     """The beams kernel (a workgroup per (head, sample): cache positions the beams share are read once; both products on the matrix
     cores, probabilities rounded to bf16 before the second one as the modules' softmax(...).to(bf16) @ V does) against
     decode_attn_kernel (a workgroup per (head, row), fp32 VALU arithmetic) on the same state: left-padded prompt in shared slots, a
@@ -539,7 +556,7 @@ def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P,
     dev = "cuda:0"
     rows = B * nb
     g = torch.Generator().manual_seed(D + 7 * nb + B)
-    bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(dev)
+    bf = lambda *s: torch.randn(*s, generator=g).to(dtype).to(dev)
     qkv = bf(rows, (H + 2 * Hkv) * D)
     kc0, vc0 = bf(rows, Hkv, T, D), bf(rows, Hkv, T, D)
     cos, sin = torch.randn(rows, D, generator=g).to(dev), torch.randn(rows, D, generator=g).to(dev)
@@ -557,9 +574,10 @@ def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P,
     outs = []
     for beams in (0, nb):
         kc, vc = kc0.clone(), vc0.clone()
-        out, qr = torch.zeros(rows, H * D, dtype=torch.bfloat16, device=dev), torch.zeros(rows, H * D, dtype=torch.bfloat16, device=dev)
+        out, qr = torch.zeros(rows, H * D, dtype=dtype, device=dev), torch.zeros(rows, H * D, dtype=dtype, device=dev)
         a = _abi.DecodeAttnDesc()
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len, a.scale, a.beams = rows, H, Hkv, D, T, D ** -0.5, beams
+        a.dtype = _abi.dtype_code(dtype)
         a.qkv, a.cos, a.sin, a.k_cache, a.v_cache = qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), kc.data_ptr(), vc.data_ptr()
         a.slot_table, a.pos, a.mask, a.out, a.q_rope = slot.data_ptr(), pos.data_ptr(), mask.data_ptr(), out.data_ptr(), qr.data_ptr()
         _abi.check(lib.mxvl_decode_attn(ctypes.byref(a), _abi.stream_ptr(qkv.device)), "mxvl_decode_attn")
@@ -581,7 +599,7 @@ def test_decode_attn_beams_kernel_matches_per_row_kernel(D, H, Hkv, nb, B, T, P,
             sc = sc.masked_fill(~live, float("-inf"))
             ref[m, h] = torch.softmax(sc, 0) @ V
     ref = ref.reshape(rows, H * D)
-    tol = 2.0 ** -7 * float(ref.abs().max())
+    tol = ULP[dtype] * float(ref.abs().max())
     for name, o in (("per-row", o0), ("beams", o1)):
         err = float((o.double() - ref).abs().max())
         assert err <= tol, (name, err, tol)
@@ -596,7 +614,8 @@ def _KernelStepperFits(rows, K):
                                       (11008, 4096, "residual"), (4096, 32000, "norm_f32"), (11008, 32000, "plain"),
                                       (1408, 512, "residual"), (512, 2048, "norm_f32")])
 @pytest.mark.parametrize("rows", [3, 1, 8])
-def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows, dtype):
     """mxvl_decode_gemv called directly at the Llama-2-7B matrix shapes bench.py's decode line times (K 4096 / 11008,
     N 4096 / 11008 / 12288 / 32000, rows = beams 3) with every prologue / epilogue the stepper uses: RMSNorm prologue,
     bias, residual, SwiGLU pair, fp32 logits.  Reference: fp32 torch on the SAME bf16 inputs, with torch's bf16 rounding
@@ -606,16 +625,16 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
     lib = _abi.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(K * 7 + N + rows)
-    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(torch.bfloat16).to(dev)
+    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dtype).to(dev)
     x, W = bf(rows, K), bf(N, K, sc=K ** -0.5)
-    norm = (1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev) if "norm" in mode else None
+    norm = (1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype).to(dev) if "norm" in mode else None
     W2 = bf(N, K, sc=K ** -0.5) if "swiglu" in mode else None
     bias = bf(N, sc=0.5) if "bias" in mode else None
     res = bf(rows, N) if "residual" in mode else None
     f32 = "f32" in mode
-    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else dtype)
     d = _abi.GemvDesc()
-    d.rows, d.K, d.N = rows, K, N
+    d.rows, d.K, d.N, d.dtype = rows, K, N, _abi.dtype_code(dtype)
     d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(f32), 1e-6
     d.x, d.norm_weight, d.W = x.data_ptr(), _abi.ptr(norm), W.data_ptr()
     d.W2, d.bias, d.residual, d.y = _abi.ptr(W2), _abi.ptr(bias), _abi.ptr(res), y.data_ptr()
@@ -627,9 +646,9 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
     torch.cuda.synchronize()
     xf = x.float()
     if norm is not None:      # Qwen2RMSNorm / LlamaRMSNorm: fp32 statistics, cast to bf16, times the bf16 gain (hybrid_decoder_layer.py:185-199)
-        xf = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16)
+        xf = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype)
         xf = (norm * xf).float()
-    r16 = lambda t: t.to(torch.bfloat16).float()
+    r16 = lambda t: t.to(dtype).float()
     ref = xf @ W.float().t()
     if W2 is not None:        # the modules round gate and up to bf16, then silu, then the product (Qwen2MLP, :326-337)
         ref = r16(torch.nn.functional.silu(r16(ref))) * r16(xf @ W2.float().t())
@@ -640,7 +659,7 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
     scale = float(ref.abs().max())
     # fp32 logits: accumulation-order noise of a K-term dot product; bf16 outputs: one ulp where a rounding boundary flips
     tol = (3e-5 if f32 else 1e-3) * scale
-    assert_close(y.float(), ref, tol, 1e-5 if f32 else 2.0 ** -7, f"gemv K={K} N={N} rows={rows} {mode}")
+    assert_close(y.float(), ref, tol, 1e-5 if f32 else ULP[dtype], f"gemv K={K} N={N} rows={rows} {mode}")
 
 
 @pytest.mark.gpu
@@ -648,7 +667,8 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows):
                                       (11008, 4096, "residual"), (4096, 32000, "f32"), (1408, 520, "residual"),
                                       (512, 2056, "f32"), (72, 24, "swiglu"), (64, 16, "bias")])
 @pytest.mark.parametrize("rows", [18, 9, 16, 24, 33, 48, 80])
-def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows, dtype):
     """mxvl_decode_gemv at the row counts the reference's launch scripts decode with (val 6 x beam 3 = 18, test 8 x 3 = 24,
     config default 16 x 3 = 48, IU test 16 x beam 5 = 80): decode_gemm_kernel (csrc/decode_gemm.h, 16x16x32 MFMA, weight tile
     loaded from HBM into the A operand, K split over the waves of a workgroup).  Every epilogue the stepper uses, Llama-2-7B
@@ -659,22 +679,22 @@ def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows):
     lib = _abi.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(K * 7 + N + rows)
-    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(torch.bfloat16).to(dev)
+    bf = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dtype).to(dev)
     x, W = bf(rows, K), bf(N, K, sc=K ** -0.5)
     W2 = bf(N, K, sc=K ** -0.5) if "swiglu" in mode else None
     bias = bf(N, sc=0.5) if "bias" in mode else None
     res = bf(rows, N) if "residual" in mode else None
     f32 = "f32" in mode
-    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    y = torch.full((rows, N), float("nan"), device=dev, dtype=torch.float32 if f32 else dtype)
     d = _abi.GemvDesc()
-    d.rows, d.K, d.N = rows, K, N
+    d.rows, d.K, d.N, d.dtype = rows, K, N, _abi.dtype_code(dtype)
     d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(f32), 0.0
     d.x, d.norm_weight, d.W = x.data_ptr(), None, W.data_ptr()
     d.W2, d.bias, d.residual, d.y = _abi.ptr(W2), _abi.ptr(bias), _abi.ptr(res), y.data_ptr()
     _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv")
     torch.cuda.synchronize()
     xf = x.float()
-    r16 = lambda t: t.to(torch.bfloat16).float()
+    r16 = lambda t: t.to(dtype).float()
     ref = xf @ W.float().t()
     if W2 is not None:
         ref = r16(torch.nn.functional.silu(r16(ref))) * r16(xf @ W2.float().t())
@@ -685,7 +705,7 @@ def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows):
     scale = float(ref.abs().max())
     tol = (3e-5 if f32 else 1e-3) * scale
     # bf16 outputs: one ulp where a rounding boundary flips; with a residual the linear output is rounded, then the sum (two flips)
-    assert_close(y.float(), ref, tol, 1e-5 if f32 else (2.0 ** -6 if res is not None else 2.0 ** -7), f"gemm K={K} N={N} rows={rows} {mode}")
+    assert_close(y.float(), ref, tol, 1e-5 if f32 else (2 * ULP[dtype] if res is not None else ULP[dtype]), f"gemm K={K} N={N} rows={rows} {mode}")
     # a norm prologue is the GEMV kernel's (rows <= 8): refused here, never silently skipped
     d.norm_weight = x.data_ptr()
     assert lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)) != 0
@@ -693,7 +713,8 @@ def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,K", [(18, 4096), (80, 4096), (3, 11008), (24, 512), (9, 72), (1, 16384)])
-def test_decode_rmsnorm_kernel_matches_module_rounding(rows, K):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_rmsnorm_kernel_matches_module_rounding(rows, K, dtype):
     """mxvl_decode_rmsnorm == Qwen2RMSNorm (hybrid_decoder_layer.py:185-199) bit for bit up to the order of the fp32 sum:
     fp32 statistics, bf16(x * rstd), times the bf16 gain, bf16."""
     import ctypes
@@ -702,36 +723,37 @@ def test_decode_rmsnorm_kernel_matches_module_rounding(rows, K):
     lib = _abi.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(rows * 31 + K)
-    x = (2.0 * torch.randn(rows, K, generator=g)).to(torch.bfloat16).to(dev)
-    mod = Qwen2RMSNorm(K, eps=1e-6).to(dev).to(torch.bfloat16)
+    x = (2.0 * torch.randn(rows, K, generator=g)).to(dtype).to(dev)
+    mod = Qwen2RMSNorm(K, eps=1e-6).to(dev).to(dtype)
     with torch.no_grad():
-        mod.weight.copy_((1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16))
+        mod.weight.copy_((1.0 + 0.1 * torch.randn(K, generator=g)).to(dtype))
     y = torch.empty_like(x)
     d = _abi.RmsNormDesc()
-    d.rows, d.K, d.eps = rows, K, 1e-6
+    d.rows, d.K, d.eps, d.dtype = rows, K, 1e-6, _abi.dtype_code(dtype)
     d.x, d.weight, d.y = x.data_ptr(), mod.weight.data_ptr(), y.data_ptr()
     _abi.check(lib.mxvl_decode_rmsnorm(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_rmsnorm")
     with torch.no_grad():
         ref = mod(x)
     diff = (y.float() - ref.float()).abs()
     # a different summation order can move rstd by an fp32 ulp, which flips at most isolated bf16 roundings
-    assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= 2.0 ** -7 * float(ref.detach().float().abs().max()), float(diff.max())
+    assert float((diff > 0).float().mean()) < 2e-3 and float(diff.max()) <= ULP[dtype] * float(ref.detach().float().abs().max()), float(diff.max())
 
 
 @pytest.mark.gpu
-def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning():
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_captured_stepper_is_not_reused_across_weight_moves_or_conditioning(dtype):
     """A captured decode graph holds weight addresses and the unconditioned layer structure: after the parameters move
     (.to() re-creates their storage) generate() must capture anew -- and still give the same tokens --, and a
     conditioned decoder must not replay the unconditioned kernel path."""
     dev = "cuda:0"
     g = load_golden("decode_llama_hd64")
-    m = _model_hd64(g, dev, torch.bfloat16)
-    emb, att = g["inputs_embeds"].to(dev).to(torch.bfloat16), g["attention_mask"].to(dev)
+    m = _model_hd64(g, dev, dtype)
+    emb, att = g["inputs_embeds"].to(dev).to(dtype), g["attention_mask"].to(dev)
     a = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
     first = list(m._steppers.values())[0]
     b = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
     assert list(m._steppers.values())[0] is first and torch.equal(a, b), "same weights, same shapes: the graph is reused"
-    m = m.to(torch.float32).to(torch.bfloat16)            # new parameter storage
+    m = m.to(torch.float32).to(dtype)            # new parameter storage
     c = m.generate(emb, attention_mask=att, use_graph=True, **HD64_GREEDY, **HD64_GEN)
     assert list(m._steppers.values())[0] is not first, "stale graph over freed weight buffers must not be replayed"
     assert torch.equal(a, c)
@@ -782,7 +804,8 @@ def test_beam_step_kernel_equals_torch_restatement(cfg, split):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,H,Hkv,Lv,div,flags", [(64, 4, 2, 37, 1, 3), (128, 8, 8, 197, 3, 1), (64, 6, 2, 5, 2, 0), (128, 4, 1, 300, 1, 2)])
-def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags, dtype):
     """mxvl_decode_cross_attn alone against a torch restatement of `all2media_cross_attn` for one token per row
     (hybrid_decoder_layer.py:653-697) that rounds to bf16 where the reference's bf16 tensor ops round: grouped-query heads, beams
     sharing a sample's image K / V (kv_rows_div), masked image tokens, a sample without image (row_on = 0), an all-masked
@@ -795,7 +818,7 @@ def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags
     samples = 2
     rows = samples * div
     hidden = H * D
-    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).to(dev)
+    bf = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype).to(dev)
     q, ts = bf(rows, hidden), bf(rows, hidden)
     k, v = bf(samples, Hkv, Lv, D), bf(samples, Hkv, Lv, D)
     km = (torch.rand(samples, Lv, generator=g) > 0.3)
@@ -808,11 +831,12 @@ def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags
     kmd, ond = km.to(torch.uint8).to(dev), row_on.to(dev)
     d = _abi.DecodeCrossAttnDesc()
     d.rows, d.n_heads, d.n_kv_heads, d.head_dim, d.n_keys, d.kv_rows_div, d.gate_flags, d.scale = rows, H, Hkv, D, Lv, div, flags, D ** -0.5
+    d.dtype = _abi.dtype_code(dtype)
     d.q_rope, d.k, d.v, d.key_mask, d.row_on = q.data_ptr(), k.data_ptr(), v.data_ptr(), kmd.data_ptr(), ond.data_ptr()
     d.text_state, d.gate_weight, d.gate_bias, d.warm_up_gate, d.out = ts.data_ptr(), gw.data_ptr(), gb.data_ptr(), warm.data_ptr(), out.data_ptr()
     _abi.check(lib.mxvl_decode_cross_attn(ctypes.byref(d), _abi.stream_ptr(torch.device(dev))), "mxvl_decode_cross_attn")
     torch.cuda.synchronize()
-    r = lambda t: t.to(torch.bfloat16).float()          # one bf16 rounding
+    r = lambda t: t.to(dtype).float()          # one bf16 rounding
     f = lambda t: t.float().cpu()
     gate = r((f(ts) * f(gw)).sum(-1, keepdim=True) + f(gb))
     if flags & 1:
@@ -832,7 +856,122 @@ def test_decode_cross_attn_kernel_vs_torch_restatement(D, H, Hkv, Lv, div, flags
                 ctx[m, h] = torch.softmax(sc, -1) @ f(v)[s_, hk]
     want = r(f(ts) + r(r(ctx.reshape(rows, hidden)) * gate))
     err = (f(out) - want).abs()
-    tol = 2.0 ** -7 * want.abs().clamp(min=1.0)         # one bf16 ulp of the result: the kernel's fp32 softmax vs this one's
+    tol = ULP[dtype] * want.abs().clamp(min=1.0)         # one bf16 ulp of the result: the kernel's fp32 softmax vs this one's
     assert float((err > tol).float().mean()) < 2e-3 and float(err.max()) < 0.06, (float(err.max()), float((err > tol).float().mean()))
     if Lv == 37:
         assert torch.equal(out[div:], ts[div:]), "a sample without image keeps its self-attention output bit for bit"
+
+
+# ---- the reference's IU-Xray decoder: Qwen1.5-1.8B-Chat in fp16, 16 x beam 5 (MambaXrayVL_DownStream.py:65-77, launch_mambaclip_test_iu.sh:26-35) ----
+# golden decode_qwen_b16 (make_golden.py gen_decode_qwen): HF Qwen2ForCausalLM at that model's widths (hidden 2048, 16 heads of 128,
+# q / k / v biases, rope_theta 1e6, vocabulary 151 936), two layers, keyed weights; streams identical under HF fp32 / fp16 / bf16
+def _model_qwen(g, dev, dtype):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from keyed_fill import keyed_fill_llama_
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    shape = {k[4:]: int(v) for k, v in g.items() if k.startswith("cfg_")}
+    fill = {k[5:]: (int(v) if k == "fill_hot" else float(v)) for k, v in g.items() if k.startswith("fill_")}
+    m = ReportDecoder(rms_norm_eps=1e-6, rope_theta=1000000.0, max_position_embeddings=128, **shape)
+    keyed_fill_llama_(m, int(g["weight_seed"]), **fill)
+    chk = sum(v.double().abs().sum() for v in m.state_dict().values()).float()
+    assert abs(float(chk) - float(g["weight_checksum"])) <= 1e-6 * float(chk), "keyed weights differ from the generator's"
+    return m.to(dtype).to(dev).eval()
+
+
+def test_qwen_width_prompt_logits_match_hf_cpu():
+    """fp32 module path at the Qwen1.5-1.8B widths (q / k / v biases, rope_theta 1e6, 151 936-word lm_head) == HF Qwen2ForCausalLM."""
+    g = load_golden("decode_qwen_b16")
+    m = _model_qwen(g, "cpu", torch.float32)
+    emb = g["inputs_embeds_bf16"].view(torch.bfloat16)[:2].float()
+    with torch.no_grad():
+        logits = m(emb, attention_mask=g["attention_mask"][:2])[:, -1]
+    scale = float(g["logits_prompt_2"].abs().max())
+    assert_close(logits, g["logits_prompt_2"], 3e-5 * scale, 1e-4, "prompt logits")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("key,kw", [("beam5_b16", dict(num_beams=5, min_new_tokens=6)), ("greedy_b16", dict(num_beams=1, min_new_tokens=4))])
+def test_qwen_width_generate_tokens_match_hf(key, kw, dtype):
+    """generate() at the reference's IU-Xray decode configuration -- 16 x beam 5 = 80 rows, vocabulary 151 936, fp16 -- through
+    _KernelStepper and csrc/beam_step.hip (asserted: no torch restatement reachable), token for token == HF."""
+    from medical_image_analysis_amd.report_decoder import _BeamState
+    dev = "cuda:0"
+    g = load_golden("decode_qwen_b16")
+    m = _model_qwen(g, dev, dtype)
+    emb = g["inputs_embeds_bf16"].view(torch.bfloat16).to(dtype).to(dev)
+    att = g["attention_mask"].to(dev)
+    called = []
+    orig = _BeamState.advance_torch
+    _BeamState.advance_torch = lambda self, logits: called.append(1) or orig(self, logits)
+    try:
+        out = m.generate(emb, attention_mask=att, max_new_tokens=int(g["max_new_tokens"]), repetition_penalty=2.0, length_penalty=2.0,
+                         pad_token_id=0, eos_token_id=2, **kw)
+    finally:
+        _BeamState.advance_torch = orig
+    assert not called, "the torch restatement of the beam update ran on a HIP device"
+    st = [v for k, v in m._steppers.items() if k[0] == 16 * kw["num_beams"]][-1]
+    assert type(st).__name__ == "_KernelStepper", "generate() must have taken the HIP kernels"
+    assert torch.equal(out.cpu(), g[key]), f"{key}: {out.cpu().tolist()} vs HF {g[key].tolist()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(B=2, nb=5, V=151936, max_new=20, min_new=4, rep=2.0, lp=2.0, early=False),
+                                 dict(B=1, nb=8, V=151936, max_new=12, min_new=2, rep=1.5, lp=1.0, early=False),
+                                 dict(B=16, nb=5, V=151936, max_new=8, min_new=2, rep=2.0, lp=2.0, early=False),
+                                 dict(B=1, nb=3, V=300007, max_new=10, min_new=2, rep=2.0, lp=2.0, early=True)])
+@pytest.mark.parametrize("split", [True, False])
+def test_beam_step_kernel_is_vocabulary_size_independent(cfg, split):
+    """csrc/beam_step.hip at Qwen1.5's 151 936-word vocabulary (beam 5 and 8: the whole-vocabulary LDS bitmap of rounds 3-4 was 95 /
+    152 KB there and the host switched to the torch restatement) and at an odd 300 007 words: history bitmaps are tiled over the
+    vocabulary in both the one-workgroup kernel and the slice kernels.  Repeated tokens are planted across tile boundaries (the
+    repetition penalty reads the bitmap), winners in the first, a middle and the last tile."""
+    from medical_image_analysis_amd.report_decoder import _BeamState
+    dev = "cuda:0"
+    B, nb, V = cfg["B"], cfg["nb"], cfg["V"]
+    mk = lambda: _BeamState(B, nb, V, cfg["max_new"], 0, [2], cfg["min_new"], cfg["rep"], cfg["lp"], cfg["early"], dev)
+    hip, ref = mk(), mk()
+    hip.split_vocab = split
+    ref.use_hip = False
+    g = torch.Generator().manual_seed(V + nb)
+    hot = torch.tensor([5, 8191, 8192, 32767, 32768, 40000, 65535, 65536, 100003, V - 1])
+    steps = 0
+    while bool(ref.unfinished):
+        logits = 3.0 * torch.randn(B * nb, V, generator=g)
+        # a few strong tokens per row, the SAME ids step after step: they enter the history and are penalised the next time
+        pick = hot[torch.randint(0, hot.numel(), (B * nb, 3), generator=g)]
+        logits.scatter_add_(1, pick, 14.0 + 2.0 * torch.rand(B * nb, 3, generator=g))
+        if steps >= cfg["min_new"]:
+            logits[:, 2] += 22.0 * (torch.rand(B * nb, generator=g) < 0.3).float()
+        logits = logits.to(dev)
+        hip.advance(logits.clone())
+        ref.advance(logits.clone())
+        steps += 1
+        c = int(ref.cur)
+        assert int(hip.cur) == c and bool(hip.unfinished) == bool(ref.unfinished), f"step {steps}"
+        if bool(ref.unfinished):
+            assert torch.equal(hip.tok, ref.tok) and torch.equal(hip.beam_src, ref.beam_src), f"step {steps}: next tokens / parents"
+            assert torch.equal(hip.run_seq[:, :, :c], ref.run_seq[:, :, :c]), f"step {steps}: live sequences"
+            assert torch.allclose(hip.run_score, ref.run_score, rtol=2e-6, atol=2e-5), f"step {steps}: live scores"
+        assert torch.equal(hip.fin_done, ref.fin_done) and torch.equal(hip.heur_open, ref.heur_open), f"step {steps}"
+        done = ref.fin_done
+        assert torch.allclose(hip.fin_score[done], ref.fin_score[done], rtol=2e-6, atol=2e-5)
+        assert torch.equal(hip.fin_seq[done], ref.fin_seq[done]), f"step {steps}: finished hypotheses"
+    assert steps >= 3
+    assert int((ref.run_seq[:, :, :2] > 8000).sum()) > 0, "the planted tokens beyond the first bitmap tile were chosen"
+
+
+@pytest.mark.gpu
+def test_beam_update_raises_instead_of_switching_to_torch():
+    """What csrc/beam_step.hip cannot serve (here: five EOS ids) is an error on a HIP device, as for the decoder step; the torch
+    restatement is reachable only as an explicit request (allow_torch: generate(use_graph="torch" / False); use_hip = False in tests)."""
+    from medical_image_analysis_amd.report_decoder import _BeamState
+    dev = "cuda:0"
+    st = _BeamState(1, 3, 1000, 8, 0, [2, 3, 4, 5, 6], 2, 2.0, 2.0, False, dev)
+    logits = torch.randn(3, 1000, device=dev)
+    with pytest.raises(RuntimeError, match="beam_step.hip"):
+        st.advance(logits)
+    st.allow_torch = True
+    st.advance(logits)
+    assert int(st.cur) == 1
