@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def pmc_traffic(workload):
@@ -107,6 +108,18 @@ VMAMBA_WORKLOADS = {
     "vmamba_base_224": (32, "configs[4]: R2GenCSR visual encoder VMamba-base (vssm1_base_0229: dims 128..1024, depths [2,2,15,2], d_state 1, "
                             "SS2D v3noz) at 224x224, encoder training step (forward + backward + AdamW on a synthetic pooled-feature loss), "
                             "bf16 autocast"),
+}
+FINETUNE_WORKLOADS = {
+    # name: (kind, per-GPU batch, description) -- the training steps of the reference's report-generation stages, whole pipeline
+    "finetune_stage3_llama7b": ("mambaxray", 6,
+                                "CXPMRG_Bench stage 3 as launch/launch_mambaclip_chexpert.sh runs it: MambaXray-VL-Large encoder (arm_large_pz16, 4 scan "
+                                "directions, 224x224, TRAINABLE: --freeze_vm False) -> llama_proj -> LayerNorm -> [bos, prompt, 197 image tokens, prompt, "
+                                "report (max_length 100)] -> FROZEN Llama-2-7B-shaped LLM in fp16 (torch_dtype of MambaXrayVL_DownStream.py:85-92) under "
+                                "bf16 autocast, causal-LM loss, backward through the LLM into the encoder, AdamW(lr 1e-4); batch_size 6"),
+    "r2gencsr_step": ("r2gencsr", 36,
+                      "BASELINE configs[4] as R2GenCSR/scripts/mimic.sh trains it: VMamba-base encoder (TRAINABLE) + linear projector + 3 + 3 context "
+                      "studies encoded under no_grad, pooled-feature residuals wrapped in their prompts (R2GenCSR.py:376-474), 49 image tokens, report "
+                      "(max_length 100) -> FROZEN Llama-2-7B-shaped LLM in fp16 under bf16 autocast, loss + backward + AdamW(lr 1e-4); batch_size 36"),
 }
 DECODE_WORKLOADS = {
     # name: (vocab, hidden, inter, layers, heads, kv_heads, prompt_len, new_tokens, beams, batch, description)
@@ -488,6 +501,126 @@ def run_pretrain(args, rank, world, dev, dist):
     print(json.dumps(out))
 
 
+class _SyntheticTokenizer:
+    """Whitespace tokenizer with the HF call surface the models use (ids: 0 pad, 1 bos, 2 eos = '</s>', words hashed into the
+    vocabulary): the reference's tokenizer files are not in this image and no text statistic enters a timed number."""
+    pad_token_id, bos_token_id, eos_token_id, cls_token_id, padding_side = 0, 1, 2, 1, "right"
+
+    class _Toks(dict):
+        __getattr__ = dict.__getitem__
+
+        def to(self, device):
+            return type(self)({k: v.to(device) for k, v in self.items()})
+
+    def __init__(self, vocab=32000):
+        self.vocab = vocab
+
+    def _ids(self, text):
+        return [2 if w == "</s>" else 3 + (sum(map(ord, w)) * 31 + len(w)) % (self.vocab - 3) for w in text.replace("</s>", " </s>").split()]
+
+    def __call__(self, text, return_tensors="pt", padding=False, truncation=False, max_length=None, add_special_tokens=False):
+        rows = [self._ids(t) for t in ([text] if isinstance(text, str) else text)]
+        if truncation and max_length:
+            rows = [r[:max_length] for r in rows]
+        width = max_length if padding == "max_length" else max(len(r) for r in rows)
+        ids = torch.tensor([r + [0] * (width - len(r)) for r in rows])
+        mask = torch.tensor([[1] * len(r) + [0] * (width - len(r)) for r in rows])
+        return self._Toks(input_ids=ids, attention_mask=mask)
+
+
+def run_finetune(args, rank, world, dev, dist):
+    """The training step of the report-generation stages, whole pipeline (encoder forward + backward THROUGH a frozen 7B LLM):
+    CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:195-241 (training_step -> forward -> loss) with
+    configure_optimizers :425-428, and R2GenCSR/models/R2GenCSR.py:309-474 + its training_step.  Data-parallel replicas + DDP on the
+    trainable parameters (the reference: Lightning `--strategy deepspeed` stage 2 / ddp on one device)."""
+    from medical_image_analysis_amd import mambaxray_vl as mx
+    kind, B, desc = FINETUNE_WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(0)
+    tok = _SyntheticTokenizer(32000)
+    with torch.device(dev):
+        llm = mx.build_report_decoder("llama2-7b")                 # fp16, the reference's torch_dtype
+    words = ["heart", "size", "is", "normal", "lungs", "are", "clear", "no", "acute", "cardiopulmonary", "process", "pleural", "effusion",
+             "pneumothorax", "seen", "mild", "opacity", "left", "right", "lower", "lobe", "stable", "unchanged", "since", "prior", "."]
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    texts = [" ".join(words[int(i)] for i in torch.randint(0, len(words), (int(n),), generator=g))
+             for n in torch.randint(40, 99, (B,), generator=g)]
+    if kind == "mambaxray":
+        a = mx.default_args(vision_model="Large-None", type="large", freeze_vm=False, max_length=100)
+        model = mx.MambaXrayVLDownStream(a, tokenizer=tok, llm=llm).to(dev)
+        n_img_tokens = 197
+    else:
+        from medical_image_analysis_amd.r2gencsr import R2GenCSR
+        a = mx.default_args(vision_model="None", freeze_vm=False, max_length=100, context_pair=3, chosen="vmamba", proj="linear", llm="llama2",
+                            positive="Note: <Img><ImageHere></Img> with desease. ", negative="Note: <Img><ImageHere></Img> normal. ",
+                            use_feature_mean=True)
+        model = R2GenCSR(a, tokenizer=tok, llm=llm).to(dev)
+        model.set_context_samples(torch.randn(3, 3, 224, 224, generator=g).to(dev), torch.randn(3, 3, 224, 224, generator=g).to(dev))
+        n_img_tokens = 49
+    model.llama_model.to(torch.float16)                          # (.to(dev) above keeps dtypes; explicit for the record)
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    n_train = sum(p.numel() for p in trainable)
+    n_llm = sum(p.numel() for p in model.llama_model.parameters())
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(model, device_ids=[dev.index], bucket_cap_mb=256, gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(trainable, lr=1e-4, fused=True)
+    batches = [{"id": [f"s{i}" for i in range(B)], "image": [torch.randn(B, 3, 224, 224, generator=g).to(dev)], "input_text": texts} for _ in range(2)]
+
+    def step(batch):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = net(batch)["loss"]
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    steps, warmup = (args.steps if args.steps > 0 else 6), (args.warmup if args.warmup >= 0 else 2)
+    for i in range(warmup):
+        step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t[0])
+    if rank != 0:
+        return
+    with torch.no_grad():
+        seq = model._prefix(batches[0])[0].shape[1] + 100
+    # model flops of a step: the frozen LLM's forward + activation-gradient backward (2 + 2 flops per weight and token, no weight
+    # gradients), the trainable side's forward + both backward products (6 per weight and token; VMamba: 49 tokens is the LAST stage --
+    # its flops are counted from the encoder's own per-image figure instead)
+    T_llm = B * seq
+    enc_params = n_train
+    enc_tokens = B * n_img_tokens
+    flops = 4.0 * (n_llm - 32000 * 4096) * T_llm + (6.0 * enc_params * enc_tokens if kind == "mambaxray" else 15.4e9 * (3 * B + 6))   # VMamba-base: 15.4 GFLOP per 224 x 224 forward (its paper's figure), x 3 training; 6 context images forward only
+    achieved = flops / (wall / steps) / 1e12
+    print(json.dumps({
+        "metric": "report-generation fine-tuning studies/sec (encoder + projector training step through a frozen LLM: forward + backward + AdamW)",
+        "value": B * world * steps / wall, "unit": "studies/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 autocast over fp16 LLM weights",
+        "data": "synthetic N(0,1) images and synthetic report text (seed 1000+rank), random-init weights (seed 0)",
+        "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world, "llm_sequence": seq,
+                   "trainable_params": n_train, "frozen_llm_params": n_llm, "parallelism": _dp_label(world), "final_loss": float(loss)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS,
+                     "traffic": None, "kernel": "whole step (model flops: 4 x frozen-LLM weights x LLM tokens + 6 x trainable weights x image tokens); "
+                     "the LLM's projections are library GEMMs under autocast, its attention csrc/attn.hip, the encoder the scan / conv / add+LN kernels",
+                     "model_flops_per_step": flops}}))
+
+
 def run_mae(args, rank, world, dev, dist):
     """ViT-MAE pre-training step (HD_Xray_Pretrain_MAE/pretrain/main.py:319-323: loss = sum(loss*mask)/sum(mask)).  The
     transformer blocks are library GEMMs + the MFMA flash-attention kernels (csrc/attn.hip); masking gather, mask-token
@@ -713,10 +846,14 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="0 = workload default (20 training steps / 200 kernel launches)")
     ap.add_argument("--warmup", type=int, default=-1, help="-1 = workload default (3 / 20)")
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD,
-                    choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS) + sorted(MAE_WORKLOADS) + sorted(VMAMBA_WORKLOADS))
+                    choices=sorted(WORKLOADS) + sorted(PRETRAIN_WORKLOADS) + sorted(DECODE_WORKLOADS) + sorted(MAE_WORKLOADS) + sorted(VMAMBA_WORKLOADS)
+                    + sorted(FINETUNE_WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
+    ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
+                    help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
+                         "(K-split o_proj / down_proj folded by explicit norm launches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -755,6 +892,14 @@ def main():
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
+    if args.decode_norm:
+        from medical_image_analysis_amd.report_decoder import _KernelStepper
+        _KernelStepper.norm_mode = args.decode_norm
+    if args.workload in FINETUNE_WORKLOADS:
+        run_finetune(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload in DECODE_WORKLOADS:
         run_decode(args, rank, world, dev, dist)
         if dist is not None:

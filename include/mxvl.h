@@ -32,6 +32,25 @@
  * pointers % 16 == 0) -- forward and backward apply the same rule; rows that are only 8-byte aligned (e.g. seqlen % 8 == 4, or a
  * view starting 4 elements into its storage) run on the element-wise kernels (same results, several times slower), and
  * MXVL_SCAN_FOLD_BATCH returns MXVL_ERR_UNSUPPORTED for them.
+ *
+ * Deviations from SURVEY.md section 8-b, recorded here because this header is the boundary:
+ *   * `mxvl_mamba_inner_fwd / mxvl_mamba_inner_bwd` (one fused entry for mamba_inner_fn, CXPMRG_Bench_MambaXray_VL/pretrain/
+ *     mamba_simple.py:388-402) are intentionally NOT exported.  mamba_inner_fn is composed from entries of this header:
+ *     mxvl_conv1d_fwd (conv + SiLU), the x_proj / dt_proj GEMMs (hipBLASLt -- skinny K = 768..1536, N = 80..128 products that are
+ *     0.4 % of the step), mxvl_scan_fwd, and in the backward mxvl_scan_bwd, mxvl_conv1d_bwd and the GEMM gradients; the host-side
+ *     composition is ONE autograd node (medical_image_analysis_amd/selective_scan_interface.py `_MambaInnerFn`).  Fusing the two
+ *     projections into the scan prologue would make every channel tile of the backward re-derive dB / dC contributions of the
+ *     projection (3x the fp32 atomics of mxvl_scan_bwd) for a GEMM share below half a percent.
+ *   * Tolerance of the scan entries against the reference's selective_scan_ref (KSS/test_selective_scan_easy.py:857-922), as the
+ *     parity tests assert it: fp32 io -- |got - ref| <= 1e-4 * max(1, max|ref| / 32) + 1e-5 * |ref|, i.e. north_star's flat
+ *     atol 1e-4 wherever |ref| < 32 and the same bound relative to the output scale beyond (the L = 4097 golden reaches 262:
+ *     the C oracle itself needs that scaling against the reference's fp32 torch loop); bf16 / fp16 io -- the reference test's own
+ *     rtol / atol (test_selective_scan.py: 3e-2 / 5e-2 bf16, 3e-3 / 5e-3 fp16).  Index / ordering entries (mxvl_row_gather,
+ *     mxvl_cross_scan / _merge, mxvl_dir_gather, mxvl_patch_cols, mxvl_image_preprocess, mxvl_beam_step's choices) are bit-exact.
+ *   * mxvl_add_layernorm_fwd / _bwd serve row widths cols = 256 * k, k in {1, 2, 3, 4, 6, 8} (256 .. 2048: every width of the
+ *     reference's ARM / VisionMamba / ViT-MAE factories); the Python mirror (fused_ops.add_layer_norm_supported) routes any other
+ *     width -- e.g. the constructor default embed_dim = 192 -- to torch.nn.functional.layer_norm, which is a library path, not a HIP
+ *     kernel of this library: a documented exception to "no fallback", chosen because no reference configuration reaches it.
  */
 #ifndef MXVL_H_
 #define MXVL_H_
@@ -177,6 +196,10 @@ typedef struct mxvl_conv1d_bwd_desc {
  * rows 9..80 (ABI v6): v_mfma_f32_16x16x32_bf16 with the weight tile as the A operand, loaded from HBM straight into the MFMA
  * registers; K >= 32; norm_weight must be NULL (mxvl_decode_rmsnorm first).  Same epilogues, same rounding points.
  */
+/* ABI v8: rows 1..80 with k_splits == 1 and norm_weight != NULL, K % 64 == 0, K >= 256: the RMSNorm is fused into the matrix-core
+ * projection -- y = rsqrt(mean(x^2) + eps)[m] * sum_k W[n][k] * dtype(norm_weight[k] * x[m][k]): the gain rides on the activation
+ * fragments, the squares are summed beside the MFMAs, the row statistic scales the fp32 sums in the epilogue.  One 16-bit rounding
+ * less than the modules' dtype(dtype(x * rstd) * g) (not bit-equal; within two ulp of the output type). */
 typedef struct mxvl_gemv_desc {
   int32_t rows, K, N;
   int32_t swiglu, out_f32;
@@ -187,10 +210,12 @@ typedef struct mxvl_gemv_desc {
   const void *bias;         /* (N) bf16, optional */
   const void *residual;     /* (rows, N) bf16, optional */
   void *y;                  /* (rows, N) bf16, or fp32 when out_f32 */
-  void *split_acc;          /* ABI v6, rows > 8 only, optional: (rows, N) fp32, ZERO on entry.  K is split over k_splits workgroups per
-                               column block and the partial sums are added here atomically; no epilogue runs (swiglu / bias /
-                               residual / out_f32 must be unset, y is ignored): mxvl_decode_rmsnorm folds the sums (acc).  For the
-                               projections with few columns (o_proj, down_proj: N = hidden) that cannot fill the chip otherwise */
+  void *split_acc;          /* optional: (k_splits, rows, N) fp32 (ABI v8; v6-v7: one (rows, N) plane added to atomically).  K is split
+                               over k_splits workgroups per column block; split s WRITES its partial sums to plane s (contents on
+                               entry irrelevant, every element written); no epilogue runs (swiglu / bias / residual / out_f32 /
+                               norm_weight must be unset, y is ignored): mxvl_decode_rmsnorm adds the planes in a fixed order
+                               (acc, acc_splits) -- a deterministic sum.  For the projections with few columns (o_proj, down_proj:
+                               N = hidden) that cannot fill the chip otherwise */
   int32_t k_splits;         /* 0: kernel by row count (rows <= 8: GEMV).  != 0: the matrix-core kernels at any row count; 1..16 with
                                split_acc, 1 without */
   int32_t dtype;            /* ABI v8: mxvl_dtype of x, norm_weight, W, W2, bias, residual, y (0 = MXVL_BF16) */
@@ -284,12 +309,13 @@ typedef struct mxvl_rmsnorm_desc {
   const void *x;            /* (rows, K) bf16; ignored in fold mode */
   const void *weight;       /* (K) bf16 */
   void *y;                  /* (rows, K) bf16, may alias x */
-  void *acc;                /* optional, fold mode: (rows, K) fp32 sums of a split projection (mxvl_gemv_desc.split_acc).  The row
-                               normalised is  x_out = bf16(acc) + residual  (the modules' `residual + linear(...)`), acc is zeroed */
+  void *acc;                /* optional, fold mode: (acc_splits, rows, K) fp32 partial sums of a split projection
+                               (mxvl_gemv_desc.split_acc).  The row normalised is  x_out = bf16(sum_s acc[s]) + residual  (the modules'
+                               `residual + linear(...)`); acc is left as it is */
   const void *residual;     /* (rows, K) bf16, with acc */
   void *x_out;              /* (rows, K) bf16, with acc; may alias residual */
   int32_t dtype;            /* ABI v8: mxvl_dtype of x, weight, y, residual, x_out (0 = MXVL_BF16) */
-  int32_t reserved0;
+  int32_t acc_splits;       /* ABI v8: planes of acc (0 = 1) */
 } mxvl_rmsnorm_desc;
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);

@@ -118,7 +118,7 @@ class GemvDesc(ctypes.Structure):
 
 class RmsNormDesc(ctypes.Structure):
     _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p),
-                ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p), ("dtype", c_int32), ("reserved0", c_int32)]
+                ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p), ("dtype", c_int32), ("acc_splits", c_int32)]
 
 
 class DecodeAttnDesc(ctypes.Structure):

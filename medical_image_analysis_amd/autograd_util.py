@@ -32,6 +32,9 @@ def cast_param(w, dtype):
     if w.dtype == dtype:
         return w
     lp = getattr(w, "_mxvl_lp", None)
-    if lp is not None and lp[0] == w._version and lp[1].dtype == dtype:
+    # the stamp: autograd version (in-place updates through the parameter), storage address (p.data = ..., .to(device)) and device.
+    # A write THROUGH p.data into the same storage (p.data.copy_, EMA updates) bumps neither: callers that do that must drop the
+    # copies (PretrainEngine.drop_casts; load_state_dict goes through copy_ on the parameter itself and bumps the version)
+    if lp is not None and lp[0] == (w._version, w.data_ptr(), w.device) and lp[1].dtype == dtype:
         return lp[1]
     return w.to(dtype)

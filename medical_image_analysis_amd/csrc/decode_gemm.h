@@ -30,13 +30,20 @@ struct DecodeGemmArgs {
   int rows, K, N, swiglu, out_f32;
   const uint16_t *x, *W, *W2, *bias, *res;
   void* y;
-  float* split_acc;     // K split over gridDim.y workgroups: fp32 (rows, N) sums, added to atomically; the epilogue is the consumer's
+  float* split_acc;     // K split over gridDim.y workgroups: fp32 (gridDim.y, rows, N) PARTIAL sums, slice blockIdx.y fully written by
+                        // plain stores; the consumer (mxvl_decode_rmsnorm) adds the slices in a fixed order -- deterministic, unlike the
+                        // fp32 atomics of round 4 whose order decided the last bit of every residual row
+  const uint16_t* g;    // RMSNorm gain (K) of the activation rows, fused (NORM instantiations of the LDS-DMA kernel); else NULL
+  float eps;
 };
 
 // Reduction over the waves' K split + the epilogue of mxvl_decode_gemv, one round per output tile (SwiGLU: per gate / up pair).
 // acc[r][mt] is lane (col = l%16 -> activation row, 4 * (l/16) + v -> weight row) of the 16x16 tile (weight tile r, row tile mt).
+// s_ss (NORM): [NW][MT * 16] sums of squares of the activation rows over each wave's K slice -- RMSNorm's statistics, gathered
+// from the fragments the MFMAs consumed; the epilogue scales a row's sums by rstd = rsqrt(mean(x^2) + eps).
 template <typename E, int MT, int R, int NW>
-__device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, const dg_f32x4 (&acc)[R][MT], float* dg_red, int n0) {
+__device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, const dg_f32x4 (&acc)[R][MT], float* dg_red, int n0,
+                                                   const float* s_ss = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N;
   constexpr int TPR = 2;                                   // tiles per round (the second one only with SwiGLU)
@@ -67,9 +74,17 @@ __device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, cons
 #pragma unroll
         for (int w = 0; w < NW; ++w) s1 += part[(size_t)(w * TPR + 1) * MT * 256];
       }
+      if (s_ss) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ss += s_ss[w * MT * 16 + m];
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+        s0 *= rstd;
+        s1 *= rstd;
+      }
       const size_t o = (size_t)m * N + n;
       if (p.split_acc) {
-        atomicAdd(p.split_acc + o, s0);
+        p.split_acc[(size_t)blockIdx.y * p.rows * N + o] = s0;
       } else if (p.swiglu) {   // bf16(bf16(silu(gate)) * up), gate / up rounded to bf16 first (what the torch modules do)
         const float gte = E::rr(s0), up = E::rr(s1);
         ((uint16_t*)p.y)[o] = E::r(E::rr(gte * sigmoid(gte)) * up);
@@ -180,10 +195,17 @@ __device__ __forceinline__ int dg_key(int row) { return (((row >> 1) & 1) << 2) 
 
 template <int N> __device__ __forceinline__ void dg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename E, int MT, int R, int NW, int PF>
+// NORM (round 5): RMSNorm of the activation rows fused into the projection that consumes them -- y = rstd[m] * sum_k W[n][k] (g[k] x[m][k]):
+// the gain is applied to the activation fragments on their way into the B operand (two more 16-byte requests per stage: the gain's
+// k-slices), the squares of the RAW fragments are summed beside the MFMAs (the VALU idles in this kernel), and the row's
+// rsqrt(mean(x^2) + eps) scales the sums in the epilogue.  That removes mxvl_decode_rmsnorm's 65 launches per token (4.8 us each:
+// a tenth of the batch-1 token) without the round-4 prologue variant's cost (a memory round trip + two barriers in front of every
+// workgroup's first MFMA while its weight ring is full: rejected, 3.13 -> 3.39 ms).  Rounding: the modules compute
+// bf16(bf16(x * rstd) * g) before the product; here g x is rounded once and rstd stays in fp32 -- one rounding less, not bit-equal.
+template <typename E, int MT, int R, int NW, int PF, bool NORM = false>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dg_smem[];
-  constexpr int STAGE = R * 2048, OPS = 2 * R + 2 * MT;          // vector-memory operations per stage
+  constexpr int STAGE = R * 2048, OPS = 2 * R + 2 * MT + (NORM ? 2 : 0);          // vector-memory operations per stage
   static_assert((PF - 1) * OPS <= 63, "vmcnt is a 6-bit field");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, q = lane >> 4;
@@ -227,6 +249,11 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[r][mt] = dg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   dg_u32x4 xb[PF][2][MT];
+  dg_u32x4 gb[PF][2];                              // NORM: the gain's k-slices of a stage
+  float ss[MT];                                    // NORM: sum of squares of row mt * 16 + l16 over this lane's k-slices
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ss[mt] = 0.0f;
+  const uint16_t* grow = NORM ? p.g + q * 8 : nullptr;
 
   auto issue = [&](int slot, int c) {
     const int cc = c < c_end ? c : 0;              // a chunk past the wave's run re-reads chunk 0; its activations are zeroed
@@ -245,6 +272,11 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xb[slot][ks][mt]) : "v"(xrow[mt] + cc * 64 + ks * 32) : "memory");
+    if constexpr (NORM) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(gb[slot][ks]) : "v"(grow + cc * 64 + ks * 32) : "memory");
+    }
   };
   auto consume = [&](int slot, int c) {
     // (the wait for this stage was issued by the caller: its count depends on how many younger stages are in flight)
@@ -255,6 +287,27 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
         asm volatile("" : "+v"(xb[slot][ks][mt]));           // the fragments are defined HERE, behind the wait
         if (c >= c_end) xb[slot][ks][mt] = dg_u32x4{0u, 0u, 0u, 0u};
       }
+    if constexpr (NORM) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        asm volatile("" : "+v"(gb[slot][ks]));
+        float gf[8];
+        elt_unpack8<E>(make_uint4(gb[slot][ks].x, gb[slot][ks].y, gb[slot][ks].z, gb[slot][ks].w), gf);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float xf[8];
+          const dg_u32x4 raw = xb[slot][ks][mt];
+          elt_unpack8<E>(make_uint4(raw.x, raw.y, raw.z, raw.w), xf);
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ss[mt] = fmaf(xf[2 * j], xf[2 * j], fmaf(xf[2 * j + 1], xf[2 * j + 1], ss[mt]));
+            o[j] = (uint32_t)E::r(xf[2 * j] * gf[2 * j]) | ((uint32_t)E::r(xf[2 * j + 1] * gf[2 * j + 1]) << 16);
+          }
+          xb[slot][ks][mt] = dg_u32x4{o[0], o[1], o[2], o[3]};
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -287,7 +340,19 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
     static_assert(PF <= 4, "tail is written out for PF <= 4");
   }
   __syncthreads();                                            // every wave is done with its ring: the reduction reuses the memory
-  dg_reduce_epilogue<E, MT, R, NW>(p, acc, (float*)dg_smem, n0);
+  if constexpr (NORM) {
+    float* s_ss = (float*)dg_smem + (size_t)NW * 2 * MT * 256;  // behind the reduction tiles
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float v = ss[mt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (q == 0) s_ss[wave * MT * 16 + mt * 16 + l16] = v;
+    }
+    dg_reduce_epilogue<E, MT, R, NW>(p, acc, (float*)dg_smem, n0, s_ss);   // (its first barrier orders the s_ss writes)
+  } else {
+    dg_reduce_epilogue<E, MT, R, NW>(p, acc, (float*)dg_smem, n0);
+  }
 }
 
 // RMSNorm of the activation rows ahead of a projection (Qwen2RMSNorm / LlamaRMSNorm, EMRRG/models/hybrid_decoder_layer.py:185-199):
@@ -298,7 +363,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
 // epilogue of o_proj / down_proj (N = 4096: too few columns to fill 256 CUs without splitting K) in the kernel that has to follow
 // them anyway, instead of a cross-workgroup seam (agent-scope fences, 5-13 us) inside a 7-20 us projection.
 struct RmsNormArgs {
-  int rows, K;
+  int rows, K, splits;
   float eps;
   const uint16_t *x, *g;
   uint16_t* y;
@@ -333,6 +398,13 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
       a0[i] = *(const float4*)ap;
       a1[i] = *(const float4*)(ap + 4);
       rr[i] = *(const uint4*)(p.res + (size_t)m * p.K + kc);
+      const size_t slice = (size_t)p.rows * p.K;
+#pragma unroll 4
+      for (int sp = 1; sp < p.splits; ++sp) {          // the K-split partial sums, always in the order 0, 1, 2, ...
+        const float4 b0 = *(const float4*)(ap + sp * slice), b1 = *(const float4*)(ap + sp * slice + 4);
+        a0[i].x += b0.x; a0[i].y += b0.y; a0[i].z += b0.z; a0[i].w += b0.w;
+        a1[i].x += b1.x; a1[i].y += b1.y; a1[i].z += b1.z; a1[i].w += b1.w;
+      }
     } else {
       xr[i] = *(const uint4*)(p.x + (size_t)m * p.K + kc);
     }
@@ -353,9 +425,6 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
       xr[i] = make_uint4(o[0], o[1], o[2], o[3]);
       if (on[i]) {
         const int k = (i * NT + tid) * 8;
-        float* ap = p.acc + (size_t)m * p.K + k;
-        *(float4*)ap = make_float4(0.f, 0.f, 0.f, 0.f);
-        *(float4*)(ap + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         *(uint4*)(p.x_out + (size_t)m * p.K + k) = xr[i];
       }
     }

@@ -11,9 +11,15 @@ template <typename E, int MT, int R, int NW, int PF>
 static int launch_dma(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   const int cols_per_wg = (a.swiglu ? R / 2 : R) * 16;
   const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
-  const size_t ring = (size_t)NW * PF * R * 2048, red = (size_t)NW * 2 * MT * 1024;
+  const size_t ring = (size_t)NW * PF * R * 2048, red = (size_t)NW * 2 * MT * 1024 + (a.g ? (size_t)NW * MT * 64 : 0);
   const size_t lds = ring > red ? ring : red;
-  auto kern = decode_gemm_dma_kernel<E, MT, R, NW, PF>;
+  // NORM needs (PF - 1) * (OPS + 2) <= 63 outstanding operations: the ring is one stage shallower where it would not fit
+  constexpr bool norm_fits = (PF - 1) * (2 * R + 2 * MT + 2) <= 63;
+  void (*kern)(const DecodeGemmArgs) = decode_gemm_dma_kernel<E, MT, R, NW, PF>;
+  if (a.g) {
+    if constexpr (norm_fits) kern = decode_gemm_dma_kernel<E, MT, R, NW, PF, true>;
+    else kern = decode_gemm_dma_kernel<E, MT, R, NW, (PF > 2 ? PF - 1 : 2), true>;
+  }
   if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return MXVL_ERR_LAUNCH;   // per call: the attribute is per device
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
@@ -82,13 +88,15 @@ int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
   if (d->rows <= 0 || d->rows > 80 || d->K < 32 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;                      // 16-byte fragments
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
-  if (d->norm_weight) return MXVL_ERR_UNSUPPORTED;                      // the matrix-core kernels take rows mxvl_decode_rmsnorm normalised
+  // RMSNorm fused into the projection (ABI v8): the LDS-DMA kernel only (K % 64 == 0); elsewhere rows come from mxvl_decode_rmsnorm
+  if (d->norm_weight && (d->K % 64 != 0 || d->K < 256 || d->split_acc)) return MXVL_ERR_UNSUPPORTED;
   if ((long long)d->N * d->K > 0x7fffffffLL * 16) return MXVL_ERR_SHAPE;
   DecodeGemmArgs a;
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32;
   a.x = (const uint16_t*)d->x; a.W = (const uint16_t*)d->W; a.W2 = (const uint16_t*)d->W2;
   a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
   a.split_acc = (float*)d->split_acc;
+  a.g = (const uint16_t*)d->norm_weight; a.eps = d->eps;
   int splits = 1;
   if (!a.split_acc && d->k_splits > 1) return MXVL_ERR_UNSUPPORTED;    // a split needs the accumulator
   if (a.split_acc) {        // the caller folds the fp32 sums itself (mxvl_decode_rmsnorm): no epilogue here
@@ -111,6 +119,8 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
   if (d->K % 8 != 0 || d->K > 16384) return MXVL_ERR_UNSUPPORTED;
   RmsNormArgs a;
   a.rows = d->rows; a.K = d->K; a.eps = d->eps;
+  a.splits = d->acc_splits > 0 ? d->acc_splits : 1;
+  if (a.splits > 16) return MXVL_ERR_UNSUPPORTED;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->weight; a.y = (uint16_t*)d->y;
   a.acc = (float*)d->acc; a.res = (const uint16_t*)d->residual; a.x_out = (uint16_t*)d->x_out;
   if (decode_dtype(d->dtype) == MXVL_F16) hipLaunchKernelGGL(decode_rmsnorm_kernel<EltF16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);

@@ -100,9 +100,11 @@ class _AddLayerNorm(torch.autograd.Function):
             if dbranch.dtype != br_orig:
                 dbranch = dbranch.to(br_orig)
             else:
-                # the linear layer that produced the branch needs sum_rows(dbranch) for its bias: it rides on the tensor it belongs to
-                # (selective_scan_interface.bias_grad reads it; a tensor autograd had to accumulate into is a new object without it)
-                dbranch._mxvl_colsum = gb[2]
+                # the linear layer that produced the branch needs sum_rows(dbranch) for its bias: it rides on the tensor it belongs to,
+                # stamped with the tensor's version -- when the branch has a second consumer autograd's InputBuffer may accumulate IN
+                # PLACE into this very object (it owns its storage), which keeps the attribute but bumps the version: bias_grad then
+                # ignores the stale sums and reduces the accumulated gradient itself
+                dbranch._mxvl_colsum = (dbranch._version, gb[2])
         return dx_v, dbranch, dgamma, dbeta, None, None
 
 

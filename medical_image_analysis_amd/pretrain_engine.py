@@ -103,6 +103,7 @@ class PretrainEngine:
         if schedule is not None and not iters_per_epoch:
             raise ValueError("a schedule needs iters_per_epoch (the reference evaluates it at data_iter_step / len(data_loader) + epoch)")
         self.data_iter_step = 0
+        self._epoch = 0
         on_gpu = device is not None and torch.device(device).type == "cuda"
         # fp16 autocast trains with dynamic loss scaling (MAE: main.py:317 NativeScaler); bf16 / fp32 never needed one
         self.scaler = torch.amp.GradScaler("cuda" if on_gpu else "cpu") if amp_dtype == torch.float16 else None
@@ -133,7 +134,14 @@ class PretrainEngine:
             self._cast_shadow = [torch.empty_like(p, dtype=self.amp_dtype) for p in self._cast_params]
         torch._foreach_copy_(self._cast_shadow, self._cast_params)
         for p, s_ in zip(self._cast_params, self._cast_shadow):
-            p._mxvl_lp = (p._version, s_)
+            p._mxvl_lp = ((p._version, p.data_ptr(), p.device), s_)
+
+    def drop_casts(self):
+        """Forget the low-precision copies (after writing parameters through `.data`, which no stamp can see; before evaluating the
+        model outside the engine with weights changed that way)."""
+        for p in self._cast_params:
+            if hasattr(p, "_mxvl_lp"):
+                del p._mxvl_lp
 
     def start_epoch(self):
         """engine_pretrain.py:31 `optimizer.zero_grad()` + the iteration counter the schedule and the accumulation window read."""
@@ -144,6 +152,10 @@ class PretrainEngine:
         """One iteration of train_one_epoch (engine_pretrain.py:36-62): a micro-batch forward + backward; on the last micro-batch of
         an accumulation window also clip, optimizer step and zero_grad.  Returns misc.all_reduce_mean(loss) of this micro-batch."""
         dev_type = imgs.device.type
+        if epoch != self._epoch:          # a caller that passes `epoch` without start_epoch(): the per-epoch iteration restarts with it
+            self._epoch = epoch
+            if self.iters_per_epoch and self.data_iter_step >= self.iters_per_epoch:
+                self.data_iter_step = 0
         it, acc = self.data_iter_step, self.accum_iter
         if self.schedule is not None and it % acc == 0:
             adjust_learning_rate(self.optimizer, it / self.iters_per_epoch + epoch, self.lr, **self.schedule)

@@ -407,9 +407,18 @@ class _KernelStepper(_SearchFusion):
         # rows > 8 need the matrix-core projections; below that they are still ~3 % faster per token than the GEMV kernels wherever
         # their LDS-DMA form applies (K % 64 == 0: every real decoder width) -- 5.2-6.2 TB/s against 4.4-5 of the weight stream
         self.batched = rows > 8 or (self.hidden % 64 == 0 and self.inter % 64 == 0 and (self.H * self.D) % 64 == 0)
+        # rows <= 8: RMSNorm fused into the MFMA projection that consumes the rows (csrc/decode_gemm.h NORM, K % 64 == 0): no
+        # mxvl_decode_rmsnorm launches (65 of a token's 229), o_proj / down_proj add their residual in their own epilogue instead of
+        # splitting K.  Measured in one call (profiles/r05_decode_norm_ab.txt): batch 1 x beam 3 332.7 -> 361.1 tok/s, Qwen-1.8B 1 x 5
+        # 755.7 -> 809.6; at 18 / 48 / 80 rows the unsplit o_proj / down_proj (256 workgroups of ONE 16-column tile: activation
+        # re-reads = rows / 16 x the weight bytes) cost more than the launches save (1638 -> 1575, 2894 -> 2656, 2212 -> 1852
+        # tok/s): those keep the K-split sums folded by an explicit norm launch ("split"; norm_mode is the A/B switch of bench.py)
+        self.fused_norm = self.batched and self.norm_mode == "fused" and rows <= 8 and self.hidden % 64 == 0 and self.hidden >= 256 \
+            and self.inter % 64 == 0 and self.inter >= 256 and (self.H * self.D) % 64 == 0 and self.H * self.D >= 256
         self.xn = torch.zeros(rows, self.hidden, **bf) if self.batched else None      # RMSNorm output ahead of an MFMA projection
-        # fp32 sums of the K-split o_proj / down_proj (zero between uses: the folding norm clears what it reads)
-        self.acc = torch.zeros(rows, self.hidden, dtype=torch.float32, device=dev) if self.batched else None
+        # fp32 partial sums of the K-split o_proj / down_proj, one plane per split (written whole by the projection, added in a
+        # fixed order by the folding norm: deterministic -- round 4 added into one plane with fp32 atomics)
+        self.acc = torch.zeros(8, rows, self.hidden, dtype=torch.float32, device=dev) if self.batched else None
         self.qkv = torch.zeros(rows, (self.H + 2 * self.Hkv) * self.D, **bf)
         self.att = torch.zeros(rows, self.H * self.D, **bf)
         self.att2 = torch.zeros(rows, self.H * self.D, **bf)      # self-attention output + gated image context
@@ -495,14 +504,14 @@ class _KernelStepper(_SearchFusion):
         d.gate_weight, d.gate_bias, d.warm_up_gate = c["gate_w"].data_ptr(), c["gate_b"].data_ptr(), self._abi.ptr(c["warm"])
         self._abi.check(self.lib.mxvl_decode_cross_attn(self._ct.byref(d), sp), "mxvl_decode_cross_attn")
 
-    def _rmsnorm(self, x, norm, eps, K, fold_res=None, x_out=None):
+    def _rmsnorm(self, x, norm, eps, K, fold_res=None, x_out=None, splits=1):
         """rows > 8: RMSNorm ahead of an MFMA projection (the GEMV kernel, rows <= 8, normalises in its own prologue).  With
         fold_res the row is first completed from the split projection's fp32 sums: x_out = bf16(acc) + fold_res; acc is cleared."""
         n = self._abi.RmsNormDesc()
         n.rows, n.K, n.eps, n.dtype = self.rows, K, eps, self.dt
         n.x, n.weight, n.y = self._abi.ptr(x), norm.data_ptr(), self.xn.data_ptr()
         if fold_res is not None:
-            n.acc, n.residual, n.x_out = self.acc.data_ptr(), fold_res.data_ptr(), x_out.data_ptr()
+            n.acc, n.residual, n.x_out, n.acc_splits = self.acc.data_ptr(), fold_res.data_ptr(), x_out.data_ptr(), splits
         self._abi.check(self.lib.mxvl_decode_rmsnorm(self._ct.byref(n), self._abi.stream_ptr(self.x.device)), "mxvl_decode_rmsnorm")
         return self.xn
 
@@ -527,6 +536,7 @@ class _KernelStepper(_SearchFusion):
         return s
 
     fused_prologue = True
+    norm_mode = "fused"
 
     def _prologue(self, tok, beam, cur):
         """slot-table re-ordering, new position's slot / mask bit, token embeddings, RoPE rows: ONE launch (mxvl_decode_prologue)
@@ -561,14 +571,14 @@ class _KernelStepper(_SearchFusion):
         a.qkv, a.cos, a.sin = self.qkv.data_ptr(), self.cos.data_ptr(), self.sin.data_ptr()
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
-        batched = self.batched           # MFMA projections: explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
+        batched = self.batched and not self.fused_norm   # MFMA projections with explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
         so, sd = (self._k_splits(self.hidden, self.H * self.D), self._k_splits(self.hidden, self.inter)) if batched else (0, 0)
         for i, layer in enumerate(m.model.layers):
             at = layer.self_attn
             ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
             if batched:
                 xin = self._rmsnorm(self.x, ln1.weight, ln1.variance_epsilon, self.hidden,
-                                    fold_res=self.x2 if i else None, x_out=self.x)      # layer i - 1's down_proj sums + residual
+                                    fold_res=self.x2 if i else None, x_out=self.x, splits=sd)      # layer i - 1's down_proj sums + residual
                 self._gemv(xin, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], bias=at.qkv_bias)
             else:
                 self._gemv(self.x, at.qkv_weight, self.qkv, self.hidden, self.qkv.shape[1], norm=ln1.weight, eps=ln1.variance_epsilon,
@@ -582,7 +592,7 @@ class _KernelStepper(_SearchFusion):
                 att = self.att2
             if batched:
                 self._gemv(att, at.o_proj.weight, None, self.H * self.D, self.hidden, split=so)
-                xin = self._rmsnorm(None, ln2.weight, ln2.variance_epsilon, self.hidden, fold_res=self.x, x_out=self.x2)
+                xin = self._rmsnorm(None, ln2.weight, ln2.variance_epsilon, self.hidden, fold_res=self.x, x_out=self.x2, splits=so)
                 self._gemv(xin, layer.mlp.gate_proj.weight, self.act, self.hidden, self.inter, W2=layer.mlp.up_proj.weight)
                 self._gemv(self.act, layer.mlp.down_proj.weight, None, self.inter, self.hidden, split=sd)
             else:
@@ -591,7 +601,7 @@ class _KernelStepper(_SearchFusion):
                            norm=ln2.weight, eps=ln2.variance_epsilon, W2=layer.mlp.up_proj.weight)
                 self._gemv(self.act, layer.mlp.down_proj.weight, self.x, self.inter, self.hidden, res=self.x2)
         if batched:
-            xin = self._rmsnorm(None, m.model.norm.weight, m.model.norm.variance_epsilon, self.hidden, fold_res=self.x2, x_out=self.x)
+            xin = self._rmsnorm(None, m.model.norm.weight, m.model.norm.variance_epsilon, self.hidden, fold_res=self.x2, x_out=self.x, splits=sd)
             self._gemv(xin, m.lm_head.weight, self.logits, self.hidden, self.V, out_f32=True)
         else:
             self._gemv(self.x, m.lm_head.weight, self.logits, self.hidden, self.V, norm=m.model.norm.weight,

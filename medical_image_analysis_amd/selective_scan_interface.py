@@ -380,10 +380,10 @@ def bias_grad(dy, d2, bdt, dim=0):
     """sum over the token axis of the incoming gradient.  When dy is the branch gradient an add+LayerNorm backward just wrote
     (fused_ops._AddLayerNorm.backward), that kernel has already summed exactly these (rounded) values: no second pass over rows x C."""
     global COLSUM_HITS
-    cs = getattr(dy, "_mxvl_colsum", None)
-    if cs is not None and dim == 0 and cs.numel() == d2.shape[1] and dy.dtype == d2.dtype:
+    stamp = getattr(dy, "_mxvl_colsum", None)
+    if stamp is not None and stamp[0] == dy._version and dim == 0 and stamp[1].numel() == d2.shape[1] and dy.dtype == d2.dtype:
         COLSUM_HITS += 1
-        return cs.to(bdt)
+        return stamp[1].to(bdt)
     return d2.sum(dim, dtype=torch.float32).to(bdt)
 
 

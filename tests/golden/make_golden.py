@@ -1056,10 +1056,12 @@ def gen_decode_qwen():
                 ok = ok and eq(outs[name], mh.generate(**kws[name], **dict(common, inputs_embeds=emb.to(torch.float16))))
                 ok = ok and eq(outs[name], mb.generate(**kws[name], **dict(common, inputs_embeds=emb.to(torch.bfloat16))))
                 ok = ok and eq(outs[name], rd.generate(emb.to(torch.float16), **kws[name], **kw))
-                for t in range(4):
+                for t in range(3):
                     if not ok:
                         break
-                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.005 * scale)])
+                    # sigma 0.3 % of the scale on EVERY logit: HF fp16 sits 0.27 % (max) from HF fp32 on the Llama goldens, the bf16 runs are
+                    # checked directly above
+                    lp = LogitsProcessorList([Noise(1000 * seed + t, 0.003 * scale)])
                     ok = eq(m.generate(logits_processor=lp, **kws[name], **common), outs[name])
         print(f"decode_qwen prompt seed {seed} ({n_real} real tokens): robust={ok} (scale {scale:.1f})", flush=True)
         if ok:
