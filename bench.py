@@ -851,6 +851,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
+    ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
+                    help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
     ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
                     help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
                          "(K-split o_proj / down_proj folded by explicit norm launches)")
@@ -892,6 +894,9 @@ def main():
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
+    if args.mlp_bwd:
+        from medical_image_analysis_amd import fused_ops
+        fused_ops._MlpSwiGLU.FUSED_BWD = args.mlp_bwd == "fused"
     if args.decode_norm:
         from medical_image_analysis_amd.report_decoder import _KernelStepper
         _KernelStepper.norm_mode = args.decode_norm

@@ -467,6 +467,24 @@ typedef struct mxvl_gemm_swiglu_desc {
   void *ab, *h;
 } mxvl_gemm_swiglu_desc;
 int mxvl_gemm_swiglu_fwd(const mxvl_gemm_swiglu_desc *desc, void *hip_stream);
+/* ABI v8: the backward of the same MLP half fused into the dgrad GEMM of its output projection -- `self.w3(self.act(x1) * x2)` of the
+ * reference's SwiGLU (models_mamba.py:59-83), differentiated: with dy (M, K = out_features) the gradient at w3's output and
+ * w3t (H, K) = w3.weight^T (row-major, the hidden axis zero-padded like ab),
+ *     d_h = dy w3t^T ;  dab[:, :H] = d_h * b * silu'(a) ;  dab[:, H:] = d_h * silu(a)      (a | b = ab, the saved pre-activations)
+ * in ONE MFMA kernel: d_h lives only in the accumulators (rounded to the io dtype before use, as the tensor it replaces), ab is read
+ * and dab written in the GEMM's epilogue, and partial (mxvl_gemm_swiglu_bwd_partials(M), 2H) fp32 receives the column sums of the
+ * rounded dab over 128-token slabs (sum over its rows = the bias gradient of [w1; w2]; every element < 2H is written).
+ * K % 64 == 0, H % 8 == 0, 16-byte aligned dy / w3t rows, bf16 / fp16. */
+typedef struct mxvl_gemm_swiglu_bwd_desc {
+  int32_t M, K, H;
+  int32_t io_dtype;
+  int64_t dy_rs, w_rs, ab_rs, dab_rs;  /* row strides in elements */
+  const void *dy, *w3t, *ab;
+  void *dab;
+  void *partial;                       /* optional */
+} mxvl_gemm_swiglu_bwd_desc;
+int mxvl_gemm_swiglu_bwd(const mxvl_gemm_swiglu_bwd_desc *desc, void *hip_stream);
+int mxvl_gemm_swiglu_bwd_partials(int M);
 /* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */
 int mxvl_swiglu_fwd(const void *ab, void *y, int rows, int hidden, int io_dtype, void *hip_stream);

@@ -36,7 +36,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
 ]
@@ -171,6 +171,14 @@ class GemmSwigluDesc(ctypes.Structure):
     ]
 
 
+class GemmSwigluBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int32), ("K", c_int32), ("H", c_int32), ("io_dtype", c_int32),
+        ("dy_rs", c_int64), ("w_rs", c_int64), ("ab_rs", c_int64), ("dab_rs", c_int64),
+        ("dy", c_void_p), ("w3t", c_void_p), ("ab", c_void_p), ("dab", c_void_p), ("partial", c_void_p),
+    ]
+
+
 class AddLnBwdDesc(ctypes.Structure):
     _fields_ = [
         ("rows", c_int32), ("cols", c_int32), ("res_dtype", c_int32), ("branch_dtype", c_int32), ("out_dtype", c_int32),
@@ -232,7 +240,7 @@ def load() -> ctypes.CDLL:
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
     lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
     for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn",
-                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd"):
+                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_conv1d_update.restype = c_int
@@ -252,6 +260,8 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     lib.mxvl_add_layernorm_partials.restype = c_int
     lib.mxvl_add_layernorm_partials.argtypes = [c_int]
+    lib.mxvl_gemm_swiglu_bwd_partials.restype = c_int
+    lib.mxvl_gemm_swiglu_bwd_partials.argtypes = [c_int]
     lib.mxvl_swiglu_fwd.restype = c_int
     lib.mxvl_swiglu_fwd.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.mxvl_swiglu_bwd.restype = c_int

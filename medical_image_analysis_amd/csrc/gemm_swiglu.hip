@@ -44,6 +44,8 @@ struct GemmSwigluArgs {
   int64_t x_rs, w_rs, ab_rs, h_rs;     // row strides in elements
   const void *x, *w, *bias;
   void *ab, *h;
+  // MODE 1 (backward): x = dy (M, K), w = w3^T (H, K); ab is READ, dab (M, 2H; row stride h_rs) and partial (2 ntm, 2H) fp32 are written
+  float* partial;
 };
 
 constexpr int GS_BM = 256, GS_BN = 128, GS_BK = 64, GS_NT = 512, GS_GROUP_M = 4, GS_SLOTS = 2;
@@ -76,7 +78,32 @@ __device__ __forceinline__ void gs_swap32(uint32_t& a, uint32_t& b) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// MODE 0: the forward above.  MODE 1 (round 5): the BACKWARD of the MLP's first half fused into the dgrad GEMM that feeds it --
+//     d_h = dy w3        (M, K = C) x (K, H): the B tile is 256 rows of w3^T, one 256 x 256 output tile of d_h per workgroup
+//     d[a | b] = swiglu'(a, b) d_h    in the epilogue: ab is read and dab written straight from / to the accumulator layout
+//     partial[2 mt + wm][2H] = column sums of the rounded d[a | b] over the workgroup's 128-token halves (the bias gradients)
+// d_h never exists in memory: the round-4 step wrote it (359 MB per ARM-large layer), and mxvl_swiglu_bwd_colsum read it back
+// together with ab and wrote dab -- 4 % of the step in a pass that is now this GEMM's epilogue (same formulas, same roundings:
+// d_h is rounded to the io dtype before it is used, the sums are of the rounded gradients).
+// (MODE 1 epilogue) the same two instructions as gs_swap32 / cvt_pk_bf16 WITHOUT `volatile`: their operands carry every dependency, and
+// as volatile statements they may not be reordered against each other -- the bf16 epilogue then kept 35 more VGPRs alive than the
+// fp16 one (whose packing is plain C) and spilled them
+__device__ __forceinline__ void gs_swap32_nv(uint32_t& a, uint32_t& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 template <typename E>
+__device__ __forceinline__ uint32_t gs_pack2_nv(float a, float b) {
+  if constexpr (__is_same(E, bf16_t)) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, h2{(_Float16)a, (_Float16)b});
+  }
+}
+
+template <typename E, int MODE = 0>
 __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -97,7 +124,7 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
     const int gsz = (p.ntm_x - gm0) < GS_GROUP_M ? (p.ntm_x - gm0) : GS_GROUP_M;
     const int mt = (gm0 + li % gsz) * 8 + xcd;
     m0 = mt * GS_BM;
-    n0 = (li / gsz) * GS_BN;
+    n0 = (li / gsz) * (MODE == 0 ? GS_BN : 2 * GS_BN);
     return mt < p.ntm;
   };
   // the 8th XCD-slice of a ragged grid has holes: skip them (wave-uniform)
@@ -117,10 +144,14 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
         int tk = m0 + row;
         tk = tk < p.M ? tk : p.M - 1;
         src[c] = (const char*)p.x + ((int64_t)tk * p.x_rs + su * 8) * 2;
-      } else {
+      } else if constexpr (MODE == 0) {
         int col = n0 + (row & (GS_BN - 1));
         col = col < p.H ? col : p.H - 1;
         src[c] = (const char*)p.w + ((int64_t)((row >> 7) * p.H + col) * p.w_rs + su * 8) * 2;
+      } else {
+        int col = n0 + row;                      // 256 consecutive rows of w3^T: acc_a = hidden columns n0 .. + 127, acc_b = + 128 .. + 255
+        col = col < p.H ? col : p.H - 1;
+        src[c] = (const char*)p.w + ((int64_t)col * p.w_rs + su * 8) * 2;
       }
     }
   };
@@ -176,7 +207,7 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
         const int c = n0 + wn * 32 + 8 * g + 4 * hi + i;
         col[g][i] = c < p.H ? c : p.H - 1;
       }
-    if (!p.bias) {
+    if (MODE == 1 || !p.bias) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -296,6 +327,7 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
       }
     }
     // ---- epilogue of tile (tm0, tn0): the next tile's bias is requested first, the stores hide its latency ------------------
+    if constexpr (MODE == 0) {
     if (has_next) bias_fetch();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -308,6 +340,116 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
       }
       store_acc((E*)p.h, p.h_rs, tm0, tn0, 0, vh, t);
     }
+    } else {
+      // 8 (column half X, token tile t) units, X outermost (one half's 32 column sums live at a time: with both the bf16
+      // instantiation spilled 70 VGPRs); the pre-activations of unit u + 1 are requested before unit u is computed (two
+      // register sets of 4 x 16 bytes).  A lane loads the 16 contiguous bytes it would store (columns 16 q + 8 hi .. + 7 of its token
+      // row) and the v_permlane32_swap pair of store_acc -- an involution -- turns them into the accumulator layout.
+      const E* abp = (const E*)p.ab;
+      uint32_t wa[2][8], wb[2][8];
+      auto fetch = [&](int u, int set) {
+        const int t = u & 3, X = u >> 2;
+        const int tkn = tm0 + wm * 128 + t * 32 + j;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int col = tn0 + X * 128 + wn * 32 + 16 * q + 8 * hi;
+          const bool ok = tkn < p.M && col < p.H;          // H % 8 == 0: a lane's 8 columns are inside or outside as a whole
+          const E* src_a = abp + (int64_t)(ok ? tkn : 0) * p.ab_rs + (ok ? col : 0);
+          const gs_u4_a4 ra = *(const gs_u4_a4*)src_a, rb = *(const gs_u4_a4*)(src_a + p.H);
+          wa[set][4 * q] = ok ? ra.x : 0u; wa[set][4 * q + 1] = ok ? ra.y : 0u; wa[set][4 * q + 2] = ok ? ra.z : 0u; wa[set][4 * q + 3] = ok ? ra.w : 0u;
+          wb[set][4 * q] = ok ? rb.x : 0u; wb[set][4 * q + 1] = ok ? rb.y : 0u; wb[set][4 * q + 2] = ok ? rb.z : 0u; wb[set][4 * q + 3] = ok ? rb.w : 0u;
+        }
+      };
+      auto unpack2 = [](uint32_t w, float& lo, float& hi_) {
+        if constexpr (__is_same(E, bf16_t)) {
+          lo = __builtin_bit_cast(float, w << 16);
+          hi_ = __builtin_bit_cast(float, w & 0xffff0000u);
+        } else {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 hv = __builtin_bit_cast(h2, w);
+          lo = (float)hv.x;
+          hi_ = (float)hv.y;
+        }
+      };
+      auto rnd = [](float v) -> float {
+        if constexpr (__is_same(E, bf16_t)) {             // round-to-nearest-even in integer arithmetic: schedulable (the v_cvt_pk_bf16_f32
+          uint32_t u = __builtin_bit_cast(uint32_t, v);     // asm statement pinned 37 more VGPRs across the unit: spills)
+          u += 0x7fffu + ((u >> 16) & 1u);
+          return __builtin_bit_cast(float, u & 0xffff0000u);
+        } else return (float)(_Float16)v;
+      };
+      auto red32 = [](float v) -> float {                 // 32 token lanes of each hi half -> lanes 31 / 63
+        v += dpp<DPP_ROW_SHR(1)>(0.0f, v);
+        v += dpp<DPP_ROW_SHR(2)>(0.0f, v);
+        v += dpp<DPP_ROW_SHR(4)>(0.0f, v);
+        v += dpp<DPP_ROW_SHR(8)>(0.0f, v);
+        v += dpp<DPP_ROW_BCAST15, 0xa>(0.0f, v);           // lane 15 of rows 0 / 2 into rows 1 / 3
+        return v;
+      };
+      float csa[16], csb[16];                             // column sums over this wave's 128 tokens of the current half X
+      fetch(0, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = u & 3, X = u >> 2, set = u & 1;
+        if (t == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { csa[r] = 0.0f; csb[r] = 0.0f; }
+        }
+        if (u + 1 < 8) fetch(u + 1, set ^ 1);
+        const int tkn_u = tm0 + wm * 128 + t * 32 + j;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                     // the 8 columns 16 q + 8 hi .. + 7 of this lane's token row, loaded and stored as 16 bytes
+          gs_swap32_nv(wa[set][4 * q], wa[set][4 * q + 2]);
+          gs_swap32_nv(wa[set][4 * q + 1], wa[set][4 * q + 3]);
+          gs_swap32_nv(wb[set][4 * q], wb[set][4 * q + 2]);
+          gs_swap32_nv(wb[set][4 * q + 1], wb[set][4 * q + 3]);
+          uint32_t pda[4], pdb[4];
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg) {                // accumulator groups 2 q and 2 q + 1
+            const int g = 2 * q + gg;
+            float a4[4], b4[4], da4[4], db4[4];
+            unpack2(wa[set][2 * g], a4[0], a4[1]);
+            unpack2(wa[set][2 * g + 1], a4[2], a4[3]);
+            unpack2(wb[set][2 * g], b4[0], b4[1]);
+            unpack2(wb[set][2 * g + 1], b4[2], b4[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int r = 4 * g + i;
+              const float gv = rnd(X ? acc_b[t][r] : acc_a[t][r]);      // d_h as the io-dtype tensor the unfused step materialised
+              const float sg = sigmoid(a4[i]);
+              da4[i] = rnd(gv * b4[i] * (sg * (1.0f + a4[i] * (1.0f - sg))));
+              db4[i] = rnd(gv * (a4[i] * sg));
+              csa[r] += da4[i];
+              csb[r] += db4[i];
+            }
+            pda[2 * gg] = gs_pack2_nv<E>(da4[0], da4[1]); pda[2 * gg + 1] = gs_pack2_nv<E>(da4[2], da4[3]);
+            pdb[2 * gg] = gs_pack2_nv<E>(db4[0], db4[1]); pdb[2 * gg + 1] = gs_pack2_nv<E>(db4[2], db4[3]);
+          }
+          gs_swap32_nv(pda[0], pda[2]); gs_swap32_nv(pda[1], pda[3]);
+          gs_swap32_nv(pdb[0], pdb[2]); gs_swap32_nv(pdb[1], pdb[3]);
+          const int col = tn0 + X * 128 + wn * 32 + 16 * q + 8 * hi;
+          if (tkn_u < p.M && col < p.H) {
+            E* dst = (E*)p.h + (int64_t)tkn_u * p.h_rs + col;
+            *(gs_u4_a4*)dst = gs_u4_a4{pda[0], pda[1], pda[2], pda[3]};
+            *(gs_u4_a4*)(dst + p.H) = gs_u4_a4{pdb[0], pdb[1], pdb[2], pdb[3]};
+          }
+        }
+        if (t == 3 && p.partial) {       // the half's column sums: four row_shr adds + row_bcast15, lanes 31 / 63 write
+          float* prow = p.partial + (int64_t)(2 * (tm0 / GS_BM) + wm) * 2 * p.H;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float sa4[4], sb4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sa4[i] = red32(csa[4 * g + i]); sb4[i] = red32(csb[4 * g + i]); }
+            const int col = tn0 + X * 128 + wn * 32 + 8 * g + 4 * hi;
+            if (j == 31 && col < p.H) {
+              *(float4*)(prow + col) = make_float4(sa4[0], sa4[1], sa4[2], sa4[3]);
+              *(float4*)(prow + p.H + col) = make_float4(sb4[0], sb4[1], sb4[2], sb4[3]);
+            }
+          }
+        }
+      }
+    }
     if (!has_next) break;
     local = nxt;
     acc_init();
@@ -317,9 +459,9 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
 
 static thread_local int g_gs_hip_error = 0;
 
-template <typename E>
+template <typename E, int MODE = 0>
 static int launch_gemm_swiglu(const GemmSwigluArgs& a, hipStream_t s) {
-  auto kern = gemm_swiglu_kernel<E>;
+  auto kern = gemm_swiglu_kernel<E, MODE>;
   const size_t lds = (size_t)GS_SLOTS * GS_STAGE;
   // per call: the attribute belongs to the (kernel, device) pair, and a process may drive several devices
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return MXVL_ERR_LAUNCH;
@@ -347,7 +489,28 @@ extern "C" int mxvl_gemm_swiglu_fwd(const mxvl_gemm_swiglu_desc* d, void* hip_st
   a.M = d->M; a.K = d->K; a.H = d->H; a.bias_f32 = d->bias_dtype == MXVL_F32 ? 1 : 0;
   a.ntm = (d->M + GS_BM - 1) / GS_BM; a.ntn = (d->H + GS_BN - 1) / GS_BN; a.ntm_x = (a.ntm + 7) / 8;
   a.x_rs = d->x_rs; a.w_rs = d->w_rs; a.ab_rs = d->ab_rs; a.h_rs = d->h_rs;
-  a.x = d->x; a.w = d->weight; a.bias = d->bias; a.ab = d->ab; a.h = d->h;
+  a.x = d->x; a.w = d->weight; a.bias = d->bias; a.ab = d->ab; a.h = d->h; a.partial = nullptr;
   hipStream_t s = (hipStream_t)hip_stream;
   return d->io_dtype == MXVL_BF16 ? launch_gemm_swiglu<bf16_t>(a, s) : launch_gemm_swiglu<f16_t>(a, s);
 }
+
+/* see include/mxvl.h: mxvl_gemm_swiglu_bwd */
+extern "C" int mxvl_gemm_swiglu_bwd(const mxvl_gemm_swiglu_bwd_desc* d, void* hip_stream) {
+  if (!d || !d->dy || !d->w3t || !d->ab || !d->dab) return MXVL_ERR_NULL;
+  if (d->io_dtype != MXVL_BF16 && d->io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  if (d->M <= 0 || d->K <= 0 || d->H <= 0) return MXVL_ERR_SHAPE;
+  if (d->K % GS_BK != 0 || d->H % 8 != 0) return MXVL_ERR_UNSUPPORTED;
+  if (d->dy_rs % 8 || d->w_rs % 8 || (uintptr_t)d->dy % 16 || (uintptr_t)d->w3t % 16) return MXVL_ERR_STRIDE;
+  if (d->ab_rs % 2 || d->dab_rs % 2 || (uintptr_t)d->ab % 4 || (uintptr_t)d->dab % 4) return MXVL_ERR_STRIDE;
+  if (d->dy_rs < d->K || d->w_rs < d->K || d->ab_rs < 2 * (int64_t)d->H || d->dab_rs < 2 * (int64_t)d->H) return MXVL_ERR_STRIDE;
+  if (d->partial && ((uintptr_t)d->partial % 16 || d->H % 4)) return MXVL_ERR_STRIDE;
+  GemmSwigluArgs a;
+  a.M = d->M; a.K = d->K; a.H = d->H; a.bias_f32 = 0;
+  a.ntm = (d->M + GS_BM - 1) / GS_BM; a.ntn = (d->H + 2 * GS_BN - 1) / (2 * GS_BN); a.ntm_x = (a.ntm + 7) / 8;
+  a.x_rs = d->dy_rs; a.w_rs = d->w_rs; a.ab_rs = d->ab_rs; a.h_rs = d->dab_rs;
+  a.x = d->dy; a.w = d->w3t; a.bias = nullptr; a.ab = (void*)d->ab; a.h = d->dab; a.partial = (float*)d->partial;
+  hipStream_t s = (hipStream_t)hip_stream;
+  return d->io_dtype == MXVL_BF16 ? launch_gemm_swiglu<bf16_t, 1>(a, s) : launch_gemm_swiglu<f16_t, 1>(a, s);
+}
+
+extern "C" int mxvl_gemm_swiglu_bwd_partials(int M) { return M > 0 ? 2 * ((M + GS_BM - 1) / GS_BM) : 0; }

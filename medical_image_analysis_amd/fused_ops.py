@@ -232,6 +232,95 @@ class _LinearSwiGLU(torch.autograd.Function):
         return dx, dw, db
 
 
+def gemm_swiglu_bwd_raw(dy2, w3t, ab, want_colsum=True):
+    """One mxvl_gemm_swiglu_bwd call: dy2 (M, K), w3t (H, K) = w3.weight^T, ab (M, 2H) -> (dab (M, 2H), column sums (2H) fp32 | None)."""
+    lib = _abi.load()
+    M, K = dy2.shape
+    H = w3t.shape[0]
+    dab = torch.empty_like(ab)
+    n_part = lib.mxvl_gemm_swiglu_bwd_partials(M) if want_colsum else 0
+    partial = torch.empty((n_part, 2 * H), dtype=torch.float32, device=dy2.device) if n_part else None
+    d = _abi.GemmSwigluBwdDesc()
+    d.M, d.K, d.H, d.io_dtype = M, K, H, _abi.dtype_code(dy2.dtype)
+    d.dy_rs, d.w_rs, d.ab_rs, d.dab_rs = dy2.stride(0), w3t.stride(0), ab.stride(0), dab.stride(0)
+    d.dy, d.w3t, d.ab, d.dab, d.partial = dy2.data_ptr(), w3t.data_ptr(), ab.data_ptr(), dab.data_ptr(), _abi.ptr(partial)
+    with torch.cuda.device(dy2.device):
+        _abi.check(lib.mxvl_gemm_swiglu_bwd(ctypes.byref(d), _abi.stream_ptr(dy2.device)), "mxvl_gemm_swiglu_bwd")
+    return dab, (partial.sum(0) if partial is not None else None)
+
+
+class _MlpSwiGLU(torch.autograd.Function):
+    """The whole SwiGLU MLP -- w3(silu(w1 x) * (w2 x)) (models_mamba.py:59-83) -- as ONE autograd node, so that the backward can run
+    the dgrad GEMM of w3 with the SwiGLU backward in its epilogue (csrc/gemm_swiglu.hip MODE 1): d_h = dy w3 never reaches memory.
+    As two nodes (_LinearSwiGLU + _LinearSplitK, rounds 2-4) the step wrote d_h (359 MB per ARM-large layer) and
+    mxvl_swiglu_bwd_colsum read it back with ab to write dab: 4 % of the step.  Forward = the same two kernels as before.
+    MEASURED (profiles/r05_gemm_swiglu_bwd_bench.txt, ARM-large layer 65 280 x 1024 -> 2752): fp16 701 us fused vs 779 us for the two
+    kernels (x1.11); bf16 861 vs 805 us (x0.94: that instantiation spills 35 VGPRs in its epilogue, and a workgroup's epilogue
+    -- 512 KB of ab / dab per 256 x 256 tile with one unit of loads in flight -- is not hidden behind its own K loop); the headline
+    step (bf16) 74.6 fused vs 75.0 images/s unfused in one call.  So the fused backward is the default for fp16 only; bf16 -- the
+    reference's training dtype -- keeps the two-kernel backward until the epilogue keeps >= 2 units of loads in flight."""
+    FUSED_BWD = None          # None: by dtype (fp16 fused, bf16 not); True / False: forced (bench.py --mlp-bwd, tests)
+
+    @staticmethod
+    def forward(ctx, x, w12, b12, w3, b3):
+        from .selective_scan_interface import _compute_dtype
+        cd = _compute_dtype(x)
+        x2 = x.reshape(-1, x.shape[-1]).to(cd)
+        w = autograd_util.cast_param(w12, cd)
+        w3c = autograd_util.cast_param(w3, cd)
+        needs_grad = autograd_util.wants_grad(ctx)
+        h, ab = gemm_swiglu_fwd_raw(x2, w, b12, want_ab=needs_grad)
+        y = torch.nn.functional.linear(h, w3c, None if b3 is None else autograd_util.cast_param(b3, cd))
+        if needs_grad:
+            ctx.save_for_backward(x2, w, ab, h, w3c)
+        ctx.meta = (x.shape, x.dtype, w12.dtype, None if b12 is None else b12.dtype, w3.dtype, None if b3 is None else b3.dtype)
+        return y.view(*x.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .selective_scan_interface import bias_grad, splitk_wgrad
+        x2, w, ab, h, w3c = ctx.saved_tensors
+        shape, xdt, w12dt, b12dt, w3dt, b3dt = ctx.meta
+        lib = _abi.load()
+        rows, H = ab.shape[0], ab.shape[1] // 2
+        d2 = dy.reshape(-1, dy.shape[-1]).to(w3c.dtype)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        db12 = None
+        fused = _MlpSwiGLU.FUSED_BWD if _MlpSwiGLU.FUSED_BWD is not None else ab.dtype == torch.float16
+        if fused:
+            dab, colsum = gemm_swiglu_bwd_raw(d2, w3c.t().contiguous(), ab, want_colsum=b12dt is not None)
+            if colsum is not None:
+                db12 = colsum.to(b12dt)
+        else:
+            dh = torch.matmul(d2, w3c)
+            dab = torch.empty_like(ab)
+            n_part = lib.mxvl_swiglu_partials(rows, H) if b12dt is not None else 0
+            partial = torch.empty((max(n_part, 1), 2 * H), dtype=torch.float32, device=ab.device)
+            with torch.cuda.device(ab.device):
+                _abi.check(lib.mxvl_swiglu_bwd_colsum(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), partial.data_ptr(), n_part, rows, H,
+                                                      _abi.dtype_code(ab.dtype), _abi.stream_ptr(ab.device)), "mxvl_swiglu_bwd_colsum")
+            if b12dt is not None:
+                db12 = partial.sum(0).to(b12dt)
+        dw3 = splitk_wgrad(d2, h, w3dt)
+        db3 = bias_grad(dy, d2, b3dt) if b3dt is not None else None
+        dx = torch.matmul(dab, w).view(shape).to(xdt)
+        dw12 = splitk_wgrad(dab, x2, w12dt)
+        return dx, dw12, db12, dw3, db3
+
+
+def mlp_swiglu_supported(x, w12, w3):
+    """the fused node: 16-bit compute, the MFMA forward's shapes, a hidden axis of whole 8-column groups (the callers pad it to 64)"""
+    H = w12.shape[0] // 2
+    return x.is_cuda and H % 8 == 0 and w12.shape[1] % 64 == 0 and w12.shape[1] <= 1024 and w3.shape[1] == H and w3.shape[0] % 64 == 0
+
+
+def mlp_swiglu(x, w12, b12, w3, b3):
+    """w3(silu(x w1^T + b1) * (x w2^T + b2)) for w12 = [w1; w2] (2H, K), w3 (out, H)."""
+    _abi.require_gpu(x, w12, b12, w3, b3)
+    return autograd_util.apply(_MlpSwiGLU, x, w12, b12, w3, b3)
+
+
 def linear_swiglu(x, weight, bias=None):
     """silu(x w1^T + b1) * (x w2^T + b2) for weight = [w1; w2] (2H, K), bias = [b1 | b2]."""
     _abi.require_gpu(x, weight, bias)

@@ -130,6 +130,9 @@ class SwiGLU(nn.Module):
                 w = torch.cat([self.w1.weight, self.w2.weight], dim=0)
                 b = torch.cat([self.w1.bias, self.w2.bias], dim=0)
                 w3 = self.w3.weight
+            from .selective_scan_interface import _compute_dtype
+            if fused_ops.mlp_swiglu_supported(x, w, w3) and _compute_dtype(x) in (torch.bfloat16, torch.float16):
+                return self.drop(fused_ops.mlp_swiglu(x, w, b, w3, self.w3.bias))      # one node: SwiGLU backward inside w3's dgrad GEMM
             h = fused_ops.linear_swiglu(x, w, b)
             return self.drop(linear_splitk(h, w3, self.w3.bias))
         return self.drop(self.w3(self.ffn_ln(self.act(self.w1(x)) * self.w2(x))))

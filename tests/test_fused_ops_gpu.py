@@ -156,3 +156,74 @@ def test_gemm_swiglu_kernel_vs_fp32_torch(M, K, H, dtype, bias):
     ab2 = fused_ops.gemm_swiglu_fwd_raw(x[:256], w2, b, want_ab=True)[1]
     changed = (ab2.float() - ab[:256].float()).abs().amax(0) > 0
     assert bool(changed[3]) and int(changed.sum()) == 1
+
+
+@pytest.mark.parametrize("M,K,H,dtype", [
+    (300, 128, 328, torch.bfloat16),          # ragged token tile, ragged 256-column tile (328 = 256 + 72)
+    (1000, 256, 512, torch.float16),
+    (513, 64, 8, torch.bfloat16),             # one K step, one 8-column group
+    (4080, 1024, 2752, torch.bfloat16),       # one image of the ARM-large layer: K = 1024, hidden 2730 padded to 2752
+    (2 * 197, 768, 2048, torch.float16)])
+def test_gemm_swiglu_bwd_kernel_vs_torch(M, K, H, dtype):
+    """mxvl_gemm_swiglu_bwd (csrc/gemm_swiglu.hip MODE 1: d_h = dy w3 on MFMA, SwiGLU backward + column sums in the epilogue, d_h never
+    in memory) against the unfused arithmetic it replaces: d_h = io(dy @ w3) by fp32 torch, then the formulas of
+    mxvl_swiglu_bwd_colsum (da = io(d_h b sg (1 + a (1 - sg))), db = io(d_h a sg)), column sums of the rounded values."""
+    from medical_image_analysis_amd.fused_ops import gemm_swiglu_bwd_raw
+    g = torch.Generator().manual_seed(M + K + H)
+    dy = (0.5 * torch.randn(M, K, generator=g)).to(DEV, dtype)
+    w3t = (K ** -0.5 * torch.randn(H, K, generator=g)).to(DEV, dtype)
+    ab = torch.randn(M, 2 * H, generator=g).to(DEV, dtype)
+    dab, colsum = gemm_swiglu_bwd_raw(dy, w3t, ab)
+    torch.cuda.synchronize()
+    rnd = lambda t: t.to(dtype).float()
+    dh = rnd(dy.float() @ w3t.float().t())
+    a, b = ab[:, :H].float(), ab[:, H:].float()
+    sg = torch.sigmoid(a)
+    da = rnd(dh * b * (sg * (1.0 + a * (1.0 - sg))))
+    db = rnd(dh * (a * sg))
+    ref = torch.cat([da, db], dim=1)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    scale = float(ref.abs().max())
+    err = (dab.float() - ref).abs()
+    # d_h is rounded from sums accumulated in a different order: an element of d_h may sit one ulp away, and the product follows it
+    tol = 2 * ulp * ref.abs() + 2 * ulp * ulp * scale + 1e-6
+    assert float((err > tol).float().mean()) < 1e-3 and float(err.max()) <= 4 * ulp * scale, (float(err.max()), float((err > tol).float().mean()))
+    cs_ref = dab.float().sum(0)                          # the sums are of what the kernel wrote
+    assert torch.allclose(colsum, cs_ref, rtol=1e-4, atol=1e-3 * float(cs_ref.abs().max()))
+    assert torch.allclose(colsum, ref.sum(0), rtol=2e-2, atol=2e-2 * float(ref.sum(0).abs().max()))
+
+
+@pytest.mark.parametrize("rows,K,H", [((2, 197), 256, 704), ((3, 340), 1024, 2752), ((1, 33), 64, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mlp_swiglu_node_fused_backward_equals_round4_backward(rows, K, H, dtype):
+    """fused_ops.mlp_swiglu (one autograd node for w3(silu(w1 x) * (w2 x))): the backward with the SwiGLU gradient inside w3's dgrad
+    GEMM against the same node's unfused backward (library dgrad -> mxvl_swiglu_bwd_colsum: the rounds 2-4 arithmetic), and the
+    forward against plain torch in fp32."""
+    from medical_image_analysis_amd import fused_ops
+    g = torch.Generator().manual_seed(K + H)
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(DEV)
+    x0 = mk(*rows, K)
+    w12_0, b12_0 = mk(2 * H, K, sc=K ** -0.5), mk(2 * H, sc=0.1)
+    w3_0, b3_0 = mk(K, H, sc=H ** -0.5), mk(K, sc=0.1)
+    dy = mk(*rows, K)
+    grads = []
+    for fused in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x0, w12_0, b12_0, w3_0, b3_0)]
+        fused_ops._MlpSwiGLU.FUSED_BWD = fused
+        try:
+            with torch.autocast("cuda", dtype=dtype):
+                y = fused_ops.mlp_swiglu(*leaves)
+            y.backward(dy.to(y.dtype))
+        finally:
+            fused_ops._MlpSwiGLU.FUSED_BWD = None
+        grads.append([t.grad.float() for t in leaves])
+        if fused:
+            xf, w12f, w3f = x0.to(dtype).float(), w12_0.to(dtype).float(), w3_0.to(dtype).float()
+            ab = xf @ w12f.t() + b12_0
+            ref = (F.silu(ab[..., :H]) * ab[..., H:]).to(dtype).float() @ w3f.t() + b3_0
+            tol = (2.0 ** -6 if dtype == torch.bfloat16 else 2.0 ** -9) * float(ref.abs().max())
+            assert float((y.float() - ref).abs().max()) <= tol
+    for name, a, b in zip(("dx", "dw12", "db12", "dw3", "db3"), *grads):
+        scale = float(b.abs().max())
+        ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        assert float((a - b).abs().max()) <= 4 * ulp * scale + 1e-6, (name, float((a - b).abs().max()), scale)
