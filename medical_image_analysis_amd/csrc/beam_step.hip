@@ -635,12 +635,14 @@ __global__ __launch_bounds__(kBeamThreads) void beam_step_kernel(const BeamArgs 
 
 using namespace mxvl;
 
-// slices of the vocabulary: enough workgroups to fill the chip at batch 1, S * keep <= 512 candidates to merge
-static int beam_slices(int batch) { return batch <= 4 ? 32 : 16; }
+// slices of the vocabulary: enough workgroups to fill the chip at batch 1, S * keep <= 512 candidates to merge; a vocabulary beyond
+// 64 K words (Qwen1.5: 151 936) is cut into 64 slices -- at 16 x beam 5 the candidate sweep of 16 slices took 124 us of a 2.6 ms token
+// (profiles/r05_decode_timeline_qwen_b16x5_before.txt: 185 dependent words per thread), S <= 64: the statistics are combined by one wave
+static int beam_slices(int batch, int vocab) { return vocab > 65536 ? 64 : (batch <= 4 ? 32 : 16); }
 
 extern "C" int64_t mxvl_beam_workspace_bytes(int batch, int beams, int keep) {
   if (batch <= 0 || beams <= 0 || keep <= 0) return 0;
-  const int64_t S = beam_slices(batch);
+  const int64_t S = 64;                    // the largest slicing (the call does not know the vocabulary)
   return 4 * ((int64_t)batch * beams * S * 2 + 2 * (int64_t)batch * S * keep);
 }
 
@@ -667,7 +669,7 @@ extern "C" int mxvl_beam_step(const mxvl_beam_desc* d, void* hip_stream) {
   const int grid = (a.ticket && d->batch > 1) ? (d->batch < 255 ? d->batch : 255) : 1;
   a.S = 0; a.VS = 0; a.ws_stats = nullptr; a.ws_cand_v = nullptr; a.ws_cand_i = nullptr;
   if (d->workspace && d->workspace_bytes >= mxvl_beam_workspace_bytes(d->batch, d->beams, d->keep) && !MXVL_ABL_ENV("MXVL_BEAM_ONE_WG")) {
-    a.S = beam_slices(d->batch);
+    a.S = beam_slices(d->batch, d->vocab);
     a.VS = ((a.V + a.S - 1) / a.S + 31) & ~31;
     a.ws_stats = (float*)d->workspace;
     a.ws_cand_v = a.ws_stats + (size_t)d->batch * d->beams * a.S * 2;
