@@ -317,6 +317,10 @@ typedef struct mxvl_rmsnorm_desc {
   int32_t dtype;            /* ABI v8: mxvl_dtype of x, weight, y, residual, x_out (0 = MXVL_BF16) */
   int32_t acc_splits;       /* ABI v8: planes of acc (0 = 1) */
 } mxvl_rmsnorm_desc;
+/* Diagnostic / A-B switch of the 33..80-row projections (ABI v8): 1 (default) = the waves of a workgroup split N and share the activation
+ * tile through LDS (csrc/decode_gemm.h decode_gemm_wide_kernel), 0 = the K-split kernels of round 4 at every row count.  Returns the
+ * previous setting.  Same results either way up to the order of the fp32 sums. */
+int mxvl_set_decode_gemm_wide(int on);
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);

@@ -355,6 +355,151 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
   }
 }
 
+// ---- 33..80 rows (MT >= 3): the waves split N, the activations are shared through LDS (round 5) ------------------------------------
+// With the waves of a workgroup splitting K every wave fetches its own activation fragments from L2: MT / R bytes per weight byte,
+// 1.25x the weight stream at 80 rows -- and at MT = 5 only two stages fit the registers.  Measured in round 4
+// (profiles/r04_decode_gemm_bench.txt): 80 rows ran the projections at 1.3-3.2 TB/s where hipBLASLt reaches 2.6-4.2, the 48- and
+// 80-row tokens at 0.30 / 0.23 of the HBM roofline.  Here a workgroup of NW waves owns NW x R column tiles over ITS K range
+// (gridDim.y ranges: o_proj / down_proj write partial planes as before); wave w streams the R tiles of its own columns through a
+// private LDS ring exactly as above, and the activation tile of a 64-column chunk (MT x 16 rows x 128 bytes, same XOR swizzle) is
+// brought in ONCE per workgroup by LDS-DMA (its 2 MT one-kilobyte pieces dealt round-robin to the waves) and read by every wave as
+// the B operand: MT / (NW R) activation bytes per weight byte, no fragment registers, three stages in flight.  One s_barrier per
+// chunk: behind it every wave's pieces of stage i have landed, and every wave is done with the slot of stage i - 1, which is
+// refilled right away.  No cross-wave reduction: a wave owns the whole K range of its columns and runs the epilogue from registers.
+template <typename E, int MT, int R, int NW, int PF>
+__global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char dgw_smem[];
+  constexpr int ACT = MT * 2048, WST = R * 2048, STAGE = ACT + NW * WST;
+  constexpr int AI = (2 * MT + NW - 1) / NW;           // activation DMA instructions per wave and stage (a few waves repeat the last piece)
+  constexpr int OPS = 2 * R + AI;
+  static_assert(PF >= 2 && (PF - 1) * OPS <= 63, "vmcnt is a 6-bit field");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, q = lane >> 4;
+  const int K = p.K, N = p.N;
+  const int cols_per_wave = (p.swiglu ? R / 2 : R) * 16;
+  const int n0 = (blockIdx.x * NW + wave) * cols_per_wave;       // this wave's first output column
+  const int rl = lane >> 3, ul = lane & 7;
+  const char* wsrc[R][2];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int t = p.swiglu ? (r % (R / 2 > 0 ? R / 2 : 1)) : r;
+    const uint16_t* base = (p.swiglu && r >= R / 2) ? p.W2 : p.W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * 8 + rl;
+      int n = n0 + t * 16 + row;
+      n = n < N ? n : N - 1;
+      wsrc[r][h] = (const char*)(base + (size_t)n * K) + ((ul ^ dg_key(row)) << 4);
+    }
+  }
+  const char* asrc[AI];
+  unsigned adst[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int a = wave + NW * i;
+    a = a < 2 * MT ? a : 2 * MT - 1;
+    const int row = a * 8 + rl;                                    // row of the padded MT x 16 tile
+    const int m = row < p.rows ? row : p.rows - 1;
+    asrc[i] = (const char*)(p.x + (size_t)m * K) + ((ul ^ dg_key(row & 15)) << 4);
+    adst[i] = (unsigned)a * 1024u;
+  }
+  const int chunks = K >> 6;
+  const int cpw = (chunks + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int c_begin = blockIdx.y * cpw;
+  const int c_end = c_begin + cpw < chunks ? c_begin + cpw : chunks;
+  const int n_it = c_end - c_begin;
+
+  dg_f32x4 acc[R][MT];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[r][mt] = dg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dgw_smem;
+
+  auto issue = [&](int slot, int c) {
+    int cc = c < c_end ? c : c_begin;                 // past the range: a harmless repeat into a slot nobody reads (the counts stay uniform)
+    cc = cc < chunks ? cc : chunks - 1;
+    const unsigned sbase = lds0 + (unsigned)slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(sbase + adst[i]), "v"(asrc[i] + (size_t)cc * 128) : "memory", "scc");
+    }
+    const unsigned wdst = sbase + ACT + (unsigned)wave * WST;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\t"
+                   "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "s"(wdst + r * 2048), "v"(wsrc[r][0] + (size_t)cc * 128), "v"(wsrc[r][1] + (size_t)cc * 128) : "memory", "scc");
+    }
+  };
+  auto consume = [&](int slot) {
+    const char* act = dgw_smem + slot * STAGE;
+    const char* wt = act + ACT + wave * WST;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int unit = ((ks * 4 + q) ^ dg_key(l16)) << 4;
+      dg_u32x4 bf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt] = *(const dg_u32x4*)(act + (mt * 16 + l16) * 128 + unit);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const dg_u32x4 av = *(const dg_u32x4*)(wt + r * 2048 + l16 * 128 + unit);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[r][mt] = E::mfma32(av, bf[mt], acc[r][mt]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+#pragma unroll
+  for (int j = 0; j < PF - 1; ++j) issue(j, c_begin + j);
+  int slot = 0, fill = PF - 1;
+  for (int i = 0; i < n_it; ++i) {
+    dg_wait_vm<(PF - 2) * OPS>();                      // stage i has landed (this wave's pieces); PF - 2 younger stages stay in flight
+    __builtin_amdgcn_s_barrier();                      // ... and everybody's; every wave is done with the slot of stage i - 1
+    asm volatile("" ::: "memory");
+    issue(fill, c_begin + i + PF - 1);
+    consume(slot);
+    slot = slot + 1 == PF ? 0 : slot + 1;
+    fill = fill + 1 == PF ? 0 : fill + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the repeats issued past the range: nothing may land after the workgroup is gone)
+
+  // ---- epilogue from registers: lane (l16 -> activation row, 4 q + v -> column of the tile) -------------------------------------------
+  const int tiles = p.swiglu ? R / 2 : R;
+#pragma unroll
+  for (int t = 0; t < (R > 1 ? R : 1); ++t) {
+    if (t >= tiles) break;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + l16;
+      if (m >= p.rows) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int n = n0 + t * 16 + 4 * q + v;
+        if (n >= N) continue;
+        const float s0 = acc[t][mt][v];
+        const size_t o = (size_t)m * N + n;
+        if (p.split_acc) {
+          p.split_acc[(size_t)blockIdx.y * p.rows * N + o] = s0;
+        } else if (p.swiglu) {
+          const float s1 = acc[(t + R / 2) < R ? t + R / 2 : t][mt][v];
+          const float gte = E::rr(s0), up = E::rr(s1);
+          ((uint16_t*)p.y)[o] = E::r(E::rr(gte * sigmoid(gte)) * up);
+        } else {
+          float val = s0;
+          if (p.bias) val += E::f(p.bias[n]);
+          if (p.res) val = E::rr(val) + E::f(p.res[o]);
+          if (p.out_f32) ((float*)p.y)[o] = val; else ((uint16_t*)p.y)[o] = E::r(val);
+        }
+      }
+    }
+  }
+}
+
 // RMSNorm of the activation rows ahead of a projection (Qwen2RMSNorm / LlamaRMSNorm, EMRRG/models/hybrid_decoder_layer.py:185-199):
 // y = bf16( bf16(x * rsqrt(mean(x^2) + eps)) * g ), statistics in fp32.  One workgroup per row.  (At <= 8 rows the GEMV kernel
 // does this in its prologue, redundantly per workgroup; at 18..80 rows that redundancy would cost more than the weight stream.)

@@ -40,8 +40,40 @@ static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   return MXVL_OK;
 }
 
+// MT >= 3 (33..80 rows), K % 64 == 0: the waves split N, activations shared through LDS (decode_gemm_wide_kernel)
+template <typename E, int MT, int R>
+static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
+  constexpr int NW = 4, PF = 3;
+  const int cols_per_wg = NW * (a.swiglu ? R / 2 : R) * 16;
+  const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
+  const size_t lds = (size_t)PF * (MT * 2048 + NW * R * 2048);
+  auto kern = decode_gemm_wide_kernel<E, MT, R, NW, PF>;
+  if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return MXVL_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+  return MXVL_OK;
+}
+
+static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B switch of tools / bench (default on)
+
 template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
+  if constexpr (MT >= 3) {
+    if (g_decode_gemm_wide && a.K % 64 == 0 && a.K >= 256 && !a.g) {
+      // 64 R (SwiGLU: 32 R) output columns per workgroup: ~200 workgroups keep every CU streaming (a CU pulls ~28 GB/s whatever it
+      // holds); the K-split projections (N = hidden) bring their own factor
+      // Below ~160 workgroups (Qwen1.5-1.8B's qkv: 96, gate / up: 86) a workgroup's serial walk over the WHOLE K is the kernel's
+      // critical path and the K-split kernels are as fast or faster (profiles/r05_decode_gemm_wide_ab.txt: the Qwen token 2.84 vs 2.80 ms).
+      const long wg64 = (long)((a.swiglu ? 2 * a.N : a.N) + 127) / 128 * splits;      // workgroups at 128 weight rows each
+      if (a.swiglu) {
+        if (wg64 >= 384) return launch_wide<E, MT, 4>(a, splits, s);
+        if (wg64 >= 160) return launch_wide<E, MT, 2>(a, splits, s);
+      } else {
+        if (wg64 >= 192) return launch_wide<E, MT, 2>(a, splits, s);
+        if (2 * wg64 >= 160) return launch_wide<E, MT, 1>(a, splits, s);
+      }
+    }
+  }
   // R = weight tiles per workgroup.  Two effects, both measured (tools/decode_gemm_bench.py A/B at 18 rows, profiles/r04_decode_gemm_r_sweep.txt):
   // (1) a CU streams ~28 GB/s whatever it holds, so the workgroups must fill whole rounds of the 256 CUs -- 344 workgroups (gate / up
   //     at R = 4: 88 CUs with two, 168 with one) run at 4.7 TB/s, 688 (R = 2) at 5.3, 256 (qkv at R = 3) at 5.2 against 4.3 for 384;
@@ -126,4 +158,12 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
   if (decode_dtype(d->dtype) == MXVL_F16) hipLaunchKernelGGL(decode_rmsnorm_kernel<EltF16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
   else hipLaunchKernelGGL(decode_rmsnorm_kernel<EltBf16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+/* diagnostic / A-B switch (tools, bench.py --decode-gemm): 0 = the K-split kernels at every row count (round 4), 1 = waves split N with
+ * LDS-shared activations at 33..80 rows (default) */
+extern "C" int mxvl_set_decode_gemm_wide(int on) {
+  const int was = mxvl::g_decode_gemm_wide;
+  mxvl::g_decode_gemm_wide = on ? 1 : 0;
+  return was;
 }
