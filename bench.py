@@ -853,7 +853,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
     ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
                     help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
-    ap.add_argument("--decode-gemm", choices=["wide", "ksplit"], default=None,
+    ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide2"], default=None,
                     help="A/B switch of the 33..80-row decode projections: waves split N + LDS-shared activations (default) or the round-4 K-split kernels")
     ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
                     help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
@@ -900,7 +900,7 @@ def main():
         from medical_image_analysis_amd import fused_ops
         fused_ops._MlpSwiGLU.FUSED_BWD = args.mlp_bwd == "fused"
     if args.decode_gemm:
-        _abi.load().mxvl_set_decode_gemm_wide(1 if args.decode_gemm == "wide" else 0)
+        _abi.load().mxvl_set_decode_gemm_wide({"wide": 1, "ksplit": 0, "wide2": 2}[args.decode_gemm])
     if args.decode_norm:
         from medical_image_analysis_amd.report_decoder import _KernelStepper
         _KernelStepper.norm_mode = args.decode_norm

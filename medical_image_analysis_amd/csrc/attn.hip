@@ -765,9 +765,13 @@ __global__ __launch_bounds__(256, 2) void attn_dq64_kernel(const AttnArgs p) {
     const E* gv = vb + (int64_t)k0 * p.v_ts;
     unsigned o[4] = {offK[0], offK[1], offV[0], offV[1]};
     if (k0 + KT > p.Lk) {                            // wave-uniform: the ragged last tile re-reads row Lk - 1 for the missing rows
+      int lane_r = threadIdx.x;          // (re-derived behind an opaque move: kept from the top, the lane index of this once-per-kernel
+      asm volatile("" : "+v"(lane_r));   //  branch was a VGPR stored before the key loop and reloaded here -- scratch)
+      lane_r &= 63;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {      // (recomputed here: the row / unit of a lane are not worth two registers each in the loop)
-        const int row = dma_row(i), unit = dma_unit(row);
+        const int row = 16 * wave + 8 * i + (lane_r >> 3);
+        const int unit = ((lane_r & 7) ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) * 8;
         const int r = k0 + row < p.Lk ? row : p.Lk - 1 - k0;
         o[i] = (unsigned)(((int64_t)r * p.k_ts + unit) * 2);
         o[2 + i] = (unsigned)(((int64_t)r * p.v_ts + unit) * 2);
@@ -880,16 +884,23 @@ __global__ __launch_bounds__(256, 2) void attn_dq64_kernel(const AttnArgs p) {
     }
   }
 
+  // (the epilogue's row / half indices are re-derived from the work-item id behind an opaque move: as values computed at the top they were
+  //  the two VGPRs the register allocator stored before the key loop and reloaded here -- the kernel's 12 bytes of scratch, rounds 3-4)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int lane_e = tid_e & 63, j_e = lane_e & 31, hi_e = lane_e >> 5;
+  const int wq0_e = q0 + (tid_e >> 6) * 64;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    if (!qv[qb]) continue;
-    E* dqp = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)h * p.dq_hs + (int64_t)qrow[qb] * p.dq_ts;
+    const int qrow_e = wq0_e + 32 * qb + j_e;
+    if (!(qrow_e < p.Lq)) continue;
+    E* dqp = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)h * p.dq_hs + (int64_t)qrow_e * p.dq_ts;
     const float sc2 = p.scale;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        Pol::st4(dqp + 32 * dt + 8 * g + 4 * hi, acc[qb][dt][4 * g] * sc2, acc[qb][dt][4 * g + 1] * sc2, acc[qb][dt][4 * g + 2] * sc2,
+        Pol::st4(dqp + 32 * dt + 8 * g + 4 * hi_e, acc[qb][dt][4 * g] * sc2, acc[qb][dt][4 * g + 1] * sc2, acc[qb][dt][4 * g + 2] * sc2,
                  acc[qb][dt][4 * g + 3] * sc2);
   }
 }

@@ -524,9 +524,11 @@ struct RmsNormArgs {
 // residual, the gain -- is requested before anything is stored or reduced; the first version walked the row in 256-thread trips of
 // load -> store -> load, three to four serialised round trips in a kernel that runs 65 times per token (4.9 us each in the
 // step's trace, a tenth of the batch-1 token).
-template <typename E>
+// S: planes of the K-split sums as a compile-time constant (1, 2, 4: every load of every plane is requested up front -- as a run-time
+// loop the planes were three more DEPENDENT round trips, +1.9 us on each of the 65 folds of a token); 0: any count, run-time loop
+template <typename E, int S = 1>
 __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs p) {
-  constexpr int NT = 1024, MAXV = 2;
+  constexpr int NT = 1024, MAXV = 2, SU = S > 0 ? S : 1;
   __shared__ float s_part[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = blockIdx.x;
   uint4 xr[MAXV], gr[MAXV], rr[MAXV];
@@ -540,15 +542,27 @@ __global__ __launch_bounds__(1024) void decode_rmsnorm_kernel(const RmsNormArgs 
     gr[i] = *(const uint4*)(p.g + kc);
     if (p.acc) {
       const float* ap = p.acc + (size_t)m * p.K + kc;
-      a0[i] = *(const float4*)ap;
-      a1[i] = *(const float4*)(ap + 4);
-      rr[i] = *(const uint4*)(p.res + (size_t)m * p.K + kc);
       const size_t slice = (size_t)p.rows * p.K;
-#pragma unroll 4
-      for (int sp = 1; sp < p.splits; ++sp) {          // the K-split partial sums, always in the order 0, 1, 2, ...
-        const float4 b0 = *(const float4*)(ap + sp * slice), b1 = *(const float4*)(ap + sp * slice + 4);
-        a0[i].x += b0.x; a0[i].y += b0.y; a0[i].z += b0.z; a0[i].w += b0.w;
-        a1[i].x += b1.x; a1[i].y += b1.y; a1[i].z += b1.z; a1[i].w += b1.w;
+      float4 b0[SU], b1[SU];
+#pragma unroll
+      for (int sp = 0; sp < SU; ++sp) {                // all planes of this thread's columns in flight at once
+        b0[sp] = *(const float4*)(ap + sp * slice);
+        b1[sp] = *(const float4*)(ap + sp * slice + 4);
+      }
+      rr[i] = *(const uint4*)(p.res + (size_t)m * p.K + kc);
+      a0[i] = b0[0];
+      a1[i] = b1[0];
+#pragma unroll
+      for (int sp = 1; sp < SU; ++sp) {                // summed in the order 0, 1, 2, ...: deterministic
+        a0[i].x += b0[sp].x; a0[i].y += b0[sp].y; a0[i].z += b0[sp].z; a0[i].w += b0[sp].w;
+        a1[i].x += b1[sp].x; a1[i].y += b1[sp].y; a1[i].z += b1[sp].z; a1[i].w += b1[sp].w;
+      }
+      if constexpr (S == 0) {
+        for (int sp = 1; sp < p.splits; ++sp) {
+          const float4 c0 = *(const float4*)(ap + sp * slice), c1 = *(const float4*)(ap + sp * slice + 4);
+          a0[i].x += c0.x; a0[i].y += c0.y; a0[i].z += c0.z; a0[i].w += c0.w;
+          a1[i].x += c1.x; a1[i].y += c1.y; a1[i].z += c1.z; a1[i].w += c1.w;
+        }
       }
     } else {
       xr[i] = *(const uint4*)(p.x + (size_t)m * p.K + kc);

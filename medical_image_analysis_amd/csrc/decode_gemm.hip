@@ -54,12 +54,12 @@ static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   return MXVL_OK;
 }
 
-static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B switch of tools / bench (default on)
+static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B switch of tools / bench (default on; 2: also at 17..32 rows)
 
 template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
-  if constexpr (MT >= 3) {
-    if (g_decode_gemm_wide && a.K % 64 == 0 && a.K >= 256 && !a.g) {
+  if constexpr (MT >= 2) {
+    if (g_decode_gemm_wide && (MT >= 3 || g_decode_gemm_wide >= 2) && a.K % 64 == 0 && a.K >= 256 && !a.g) {
       // 64 R (SwiGLU: 32 R) output columns per workgroup: ~200 workgroups keep every CU streaming (a CU pulls ~28 GB/s whatever it
       // holds); the K-split projections (N = hidden) bring their own factor
       // Below ~160 workgroups (Qwen1.5-1.8B's qkv: 96, gate / up: 86) a workgroup's serial walk over the WHOLE K is the kernel's
@@ -155,8 +155,18 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
   if (a.splits > 16) return MXVL_ERR_UNSUPPORTED;
   a.x = (const uint16_t*)d->x; a.g = (const uint16_t*)d->weight; a.y = (uint16_t*)d->y;
   a.acc = (float*)d->acc; a.res = (const uint16_t*)d->residual; a.x_out = (uint16_t*)d->x_out;
-  if (decode_dtype(d->dtype) == MXVL_F16) hipLaunchKernelGGL(decode_rmsnorm_kernel<EltF16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
-  else hipLaunchKernelGGL(decode_rmsnorm_kernel<EltBf16>, dim3(d->rows), dim3(1024), 0, (hipStream_t)hip_stream, a);
+  const bool f16 = decode_dtype(d->dtype) == MXVL_F16;
+  const dim3 grid(d->rows), block(1024);
+  hipStream_t s = (hipStream_t)hip_stream;
+#define MXVL_RMSNORM(SS) do { if (f16) hipLaunchKernelGGL((decode_rmsnorm_kernel<EltF16, SS>), grid, block, 0, s, a); \
+                              else hipLaunchKernelGGL((decode_rmsnorm_kernel<EltBf16, SS>), grid, block, 0, s, a); } while (0)
+  switch (a.acc ? a.splits : 1) {
+    case 1: MXVL_RMSNORM(1); break;
+    case 2: MXVL_RMSNORM(2); break;
+    case 4: MXVL_RMSNORM(4); break;
+    default: MXVL_RMSNORM(0); break;
+  }
+#undef MXVL_RMSNORM
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
 
@@ -164,6 +174,6 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
  * LDS-shared activations at 33..80 rows (default) */
 extern "C" int mxvl_set_decode_gemm_wide(int on) {
   const int was = mxvl::g_decode_gemm_wide;
-  mxvl::g_decode_gemm_wide = on ? 1 : 0;
+  mxvl::g_decode_gemm_wide = on < 0 ? 0 : (on > 2 ? 2 : on);
   return was;
 }

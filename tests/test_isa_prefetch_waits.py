@@ -126,3 +126,11 @@ def test_per_row_decode_attention_sums_scores_by_dpp(elt):
     first_dma = next(k for k, x in enumerate(ins) if x.startswith("global_load_lds_dwordx4"))
     last_dma = max(k for k, x in enumerate(ins) if x.startswith("global_load_lds_dwordx4"))
     assert not any(x.startswith("ds_bpermute_b32") for x in ins[first_dma:last_dma]), "a cross-lane LDS round trip inside the position loop"
+
+
+def test_attention_dq64_kernel_has_no_scratch():
+    """attn_dq64_kernel (the dQ pass of the 4080-token block-causal attention): rounds 3-4 carried 12 bytes of scratch -- the epilogue's row
+    indices and the ragged-tile branch's lane index, stored before the key loop and reloaded behind it; both are re-derived from the
+    work-item id now."""
+    for name in ("attn_dq64_kernelINS_6bf16_tEEE", "attn_dq64_kernelINS_5f16_tEEE"):
+        assert not _scratch_ops(_body("attn.hip", name)), name
