@@ -488,6 +488,18 @@ typedef struct mxvl_gemm_swiglu_bwd_desc {
   void *partial;                       /* optional */
 } mxvl_gemm_swiglu_bwd_desc;
 int mxvl_gemm_swiglu_bwd(const mxvl_gemm_swiglu_bwd_desc *desc, void *hip_stream);
+/* ABI v8: the same MFMA kernel as a plain token-major GEMM, c (M, N) = a (M, K) b^T (+ bias), b (N, K) row-major = an nn.Linear weight
+ * (forward: CXPMRG_Bench_MambaXray_VL/arm/Finetuning/mamba_simple.py:388-402 in_proj / out_proj, models_mamba.py:59-83 w3) or the
+ * transposed weight (the dgrad products).  K % 64 == 0, N % 8 == 0, 16-byte aligned a / b rows, bf16 / fp16, fp32 accumulation. */
+typedef struct mxvl_gemm_nt_desc {
+  int32_t M, K, N;
+  int32_t io_dtype, bias_dtype;
+  int32_t reserved0;
+  int64_t a_rs, b_rs, c_rs;            /* row strides in elements */
+  const void *a, *b, *bias;            /* bias (N) fp32 or io dtype, optional */
+  void *c;
+} mxvl_gemm_nt_desc;
+int mxvl_gemm_nt(const mxvl_gemm_nt_desc *desc, void *hip_stream);
 int mxvl_gemm_swiglu_bwd_partials(int M);
 /* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */

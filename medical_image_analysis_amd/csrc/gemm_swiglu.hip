@@ -148,7 +148,7 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
         int col = n0 + (row & (GS_BN - 1));
         col = col < p.H ? col : p.H - 1;
         src[c] = (const char*)p.w + ((int64_t)((row >> 7) * p.H + col) * p.w_rs + su * 8) * 2;
-      } else {
+      } else {                                   // MODE 1 / 2
         int col = n0 + row;                      // 256 consecutive rows of w3^T: acc_a = hidden columns n0 .. + 127, acc_b = + 128 .. + 255
         col = col < p.H ? col : p.H - 1;
         src[c] = (const char*)p.w + ((int64_t)col * p.w_rs + su * 8) * 2;
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ba[g][i] = bp[col[g][i]]; bb[g][i] = bp[p.H + col[g][i]]; }
+        for (int i = 0; i < 4; ++i) { ba[g][i] = bp[col[g][i]]; bb[g][i] = bp[MODE == 2 ? (col[g][i] + 128 < p.H ? col[g][i] + 128 : p.H - 1) : p.H + col[g][i]]; }
     } else {
       const uint16_t* bp = (const uint16_t*)p.bias;
       uint16_t ra[4][4], rb[4][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[g][i] = bp[col[g][i]]; rb[g][i] = bp[p.H + col[g][i]]; }
+        for (int i = 0; i < 4; ++i) { ra[g][i] = bp[col[g][i]]; rb[g][i] = bp[MODE == 2 ? (col[g][i] + 128 < p.H ? col[g][i] + 128 : p.H - 1) : p.H + col[g][i]]; }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -327,7 +327,18 @@ __global__ __launch_bounds__(GS_NT, 2) void gemm_swiglu_kernel(const GemmSwigluA
       }
     }
     // ---- epilogue of tile (tm0, tn0): the next tile's bias is requested first, the stores hide its latency ------------------
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 2) {
+      // plain GEMM: y (M, N = H) = x w^T (+ bias); acc_a = columns tn0 .. + 127, acc_b = tn0 + 128 .. + 255 of the 256-wide tile
+      if (has_next) bias_fetch();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float va[16], vb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { va[r] = acc_a[t][r]; vb[r] = acc_b[t][r]; }
+        store_acc((E*)p.h, p.h_rs, tm0, tn0, 0, va, t);
+        store_acc((E*)p.h, p.h_rs, tm0, tn0 + 128, 0, vb, t);
+      }
+    } else if constexpr (MODE == 0) {
     if (has_next) bias_fetch();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -514,3 +525,21 @@ extern "C" int mxvl_gemm_swiglu_bwd(const mxvl_gemm_swiglu_bwd_desc* d, void* hi
 }
 
 extern "C" int mxvl_gemm_swiglu_bwd_partials(int M) { return M > 0 ? 2 * ((M + GS_BM - 1) / GS_BM) : 0; }
+
+/* see include/mxvl.h: mxvl_gemm_nt */
+extern "C" int mxvl_gemm_nt(const mxvl_gemm_nt_desc* d, void* hip_stream) {
+  if (!d || !d->a || !d->b || !d->c) return MXVL_ERR_NULL;
+  if (d->io_dtype != MXVL_BF16 && d->io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  if (d->M <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
+  if (d->K % GS_BK != 0 || d->N % 8 != 0) return MXVL_ERR_UNSUPPORTED;
+  if (d->bias && d->bias_dtype != MXVL_F32 && d->bias_dtype != d->io_dtype) return MXVL_ERR_DTYPE;
+  if (d->a_rs % 8 || d->b_rs % 8 || (uintptr_t)d->a % 16 || (uintptr_t)d->b % 16) return MXVL_ERR_STRIDE;
+  if (d->c_rs % 2 || (uintptr_t)d->c % 4 || d->a_rs < d->K || d->b_rs < d->K || d->c_rs < d->N) return MXVL_ERR_STRIDE;
+  GemmSwigluArgs a;
+  a.M = d->M; a.K = d->K; a.H = d->N; a.bias_f32 = d->bias_dtype == MXVL_F32 ? 1 : 0;
+  a.ntm = (d->M + GS_BM - 1) / GS_BM; a.ntn = (d->N + 2 * GS_BN - 1) / (2 * GS_BN); a.ntm_x = (a.ntm + 7) / 8;
+  a.x_rs = d->a_rs; a.w_rs = d->b_rs; a.ab_rs = 0; a.h_rs = d->c_rs;
+  a.x = d->a; a.w = d->b; a.bias = d->bias; a.ab = nullptr; a.h = d->c; a.partial = nullptr;
+  hipStream_t s = (hipStream_t)hip_stream;
+  return d->io_dtype == MXVL_BF16 ? launch_gemm_swiglu<bf16_t, 2>(a, s) : launch_gemm_swiglu<f16_t, 2>(a, s);
+}
