@@ -227,3 +227,31 @@ def test_mlp_swiglu_node_fused_backward_equals_round4_backward(rows, K, H, dtype
         scale = float(b.abs().max())
         ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
         assert float((a - b).abs().max()) <= 4 * ulp * scale + 1e-6, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("M,K,N,dtype,bias", [(300, 128, 328, torch.bfloat16, "f32"), (1000, 256, 512, torch.float16, None),
+                                               (513, 64, 8, torch.bfloat16, "io"), (4080, 1024, 4096, torch.bfloat16, None),
+                                               (2 * 197, 2752, 1024, torch.float16, "f32")])
+def test_gemm_nt_kernel_vs_fp32_torch(M, K, N, dtype, bias):
+    """mxvl_gemm_nt (csrc/gemm_swiglu.hip MODE 2: the persistent 256 x 256 MFMA kernel with a plain store epilogue), c = a b^T + bias,
+    against fp32 torch on the same 16-bit operands: one rounding of the fp32 sums to the io dtype."""
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    lib = _abi.load()
+    g = torch.Generator().manual_seed(M + K + N)
+    a = (0.5 * torch.randn(M, K, generator=g)).to(DEV, dtype)
+    b = (K ** -0.5 * torch.randn(N, K, generator=g)).to(DEV, dtype)
+    bv = None if bias is None else (0.3 * torch.randn(N, generator=g)).to(DEV, torch.float32 if bias == "f32" else dtype)
+    c = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    d = _abi.GemmNtDesc()
+    d.M, d.K, d.N, d.io_dtype = M, K, N, _abi.dtype_code(dtype)
+    d.bias_dtype = _abi.dtype_code(bv.dtype) if bv is not None else 0
+    d.a_rs, d.b_rs, d.c_rs = a.stride(0), b.stride(0), c.stride(0)
+    d.a, d.b, d.bias, d.c = a.data_ptr(), b.data_ptr(), _abi.ptr(bv), c.data_ptr()
+    _abi.check(lib.mxvl_gemm_nt(ctypes.byref(d), _abi.stream_ptr(torch.device(DEV))), "mxvl_gemm_nt")
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float().t() + (bv.float() if bv is not None else 0.0)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    err = (c.float() - ref).abs()
+    assert bool(torch.isfinite(c).all())
+    assert float((err - ulp * ref.abs()).max()) <= 1e-3 * ulp * float(ref.abs().max()) + 1e-6, float(err.max())
