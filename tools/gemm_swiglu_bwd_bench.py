@@ -53,7 +53,7 @@ def main():
         flops = 2.0 * M * K * H
         bytes_epi = 2 * M * 2 * H * ab.element_size()
         print(f"{str(dtype):16s} M={M} K={K} H={H}: library dgrad alone {t_g:7.1f} us ({flops / t_g / 1e6:6.0f} TFLOP/s) | dgrad + swiglu_bwd_colsum "
-              f"{t_u:7.1f} us | fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s, epilogue stream {bytes_epi / t_f / 1e3:5.2f} TB/s)  -> x{t_u / t_f:.2f}")
+              f"{t_u:7.1f} us | fused {t_f:7.1f} us ({flops / t_f / 1e6:6.0f} TFLOP/s, epilogue stream {bytes_epi / t_f / 1e6:5.2f} TB/s)  -> x{t_u / t_f:.2f}")
 
 
 if __name__ == "__main__":
