@@ -853,6 +853,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
     ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
                     help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
+    ap.add_argument("--llm-shadows", choices=["on", "off"], default=None,
+                    help="A/B switch of the fine-tuning steps: cached autocast-dtype copies of the frozen LLM's weights (default) or per-call casts")
     ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide2"], default=None,
                     help="A/B switch of the 33..80-row decode projections: waves split N + LDS-shared activations (default) or the round-4 K-split kernels")
     ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
@@ -899,6 +901,9 @@ def main():
     if args.mlp_bwd:
         from medical_image_analysis_amd import fused_ops
         fused_ops._MlpSwiGLU.FUSED_BWD = args.mlp_bwd == "fused"
+    if args.llm_shadows:
+        from medical_image_analysis_amd.report_decoder import ReportDecoder
+        ReportDecoder.autocast_shadows = args.llm_shadows == "on"
     if args.decode_gemm:
         _abi.load().mxvl_set_decode_gemm_wide({"wide": 1, "ksplit": 0, "wide2": 2}[args.decode_gemm])
     if args.decode_norm:

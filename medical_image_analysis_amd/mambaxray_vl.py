@@ -205,7 +205,8 @@ class MambaXrayVLDownStream(nn.Module):
         llm_dtype = self.embed_tokens.weight.dtype
         inputs = torch.cat([prefix.to(llm_dtype), self.embed_tokens(toks.input_ids)], dim=1)
         mask = torch.cat([atts, toks.attention_mask], dim=1)
-        logits = self.llama_model(inputs, attention_mask=mask)
+        frozen = not any(p.requires_grad for p in self.llama_model.parameters())
+        logits = (self.llama_model.forward_frozen_autocast if frozen else self.llama_model)(inputs, attention_mask=mask)
         # HF causal-LM loss: predict token t+1 from position t, mean over the non-ignored targets
         loss = F.cross_entropy(logits[:, :-1].float().flatten(0, 1), targets[:, 1:].flatten(), ignore_index=-100)
         return {"loss": loss}

@@ -636,6 +636,7 @@ class _Stack(nn.Module):
 
 class ReportDecoder(nn.Module):
     _tuned_gemms_checked = False
+    autocast_shadows = True        # forward_frozen_autocast keeps casted copies (bench.py --llm-shadows off: the A/B switch)
 
     def __init__(self, vocab_size, hidden_size, intermediate_size, num_hidden_layers, num_attention_heads,
                  num_key_value_heads=None, rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=4096,
@@ -707,6 +708,33 @@ class ReportDecoder(nn.Module):
             h = layer(h, attention_mask=attention_mask, position_ids=position_ids, past_key_value=past_key_values,
                       use_cache=past_key_values is not None, position_embeddings=pos_emb)[0]
         return self.lm_head(self.model.norm(h))
+
+    def forward_frozen_autocast(self, inputs_embeds, attention_mask=None, position_ids=None):
+        """forward() for a FROZEN decoder under an autocast context whose dtype is not the weights' -- the reference's stage-3 / R2GenCSR
+        training step: an LLM loaded with torch_dtype=torch.float16 (MambaXrayVL_DownStream.py:72-92, R2GenCSR.py) under Lightning's
+        bf16-mixed precision (configs/config.py:67).  autocast re-casts every nn.Linear weight on every call (13 GB read + 13 GB written
+        per forward of a 7B model; its cast cache only covers parameters that require grad); here ONE casted copy of every projection
+        matrix is kept (refreshed when a weight's storage or version changes) and the call runs on those copies through
+        torch.func.functional_call -- the same values autocast would produce, the same kernels, no per-step cast traffic.  The copies
+        cost the weights' size in HBM once (13.5 GB for Llama-2-7B)."""
+        dev_type = inputs_embeds.device.type
+        if not torch.is_autocast_enabled(dev_type) or not ReportDecoder.autocast_shadows:
+            return self.forward(inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
+        dt = torch.get_autocast_dtype(dev_type)
+        cache = self.__dict__.setdefault("_autocast_shadows", {})
+        shadows = {}
+        for name, w in self.named_parameters():
+            if w.requires_grad or w.dim() != 2 or w.dtype == dt or "embed_tokens" in name or not w.is_floating_point():
+                continue
+            key = (w._version, w.data_ptr(), w.dtype, dt)
+            hit = cache.get(name)
+            if hit is None or hit[0] != key:
+                hit = (key, w.detach().to(dt))
+                cache[name] = hit
+            shadows[name] = hit[1]
+        if not shadows:
+            return self.forward(inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
+        return torch.func.functional_call(self, shadows, (inputs_embeds,), dict(attention_mask=attention_mask, position_ids=position_ids))
 
     # ---- generation ------------------------------------------------------------------------------------------
     def _greedy(self, logits, cache, attn, dtype, eos_t, fill, min_new, max_new, rep_pen, stepper=None):

@@ -1035,3 +1035,39 @@ def test_beam_update_raises_instead_of_switching_to_torch():
     st.allow_torch = True
     st.advance(logits)
     assert int(st.cur) == 1
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_frozen_decoder_autocast_shadows_equal_plain_autocast(dev):
+    """ReportDecoder.forward_frozen_autocast (cached autocast-dtype copies of a frozen decoder's projection matrices, the call through
+    torch.func.functional_call) == the plain forward under the same autocast context -- the reference's stage-3 arithmetic: fp16-loaded
+    LLM under bf16 autocast -- bit for bit, logits and the gradient that flows back into the input embeddings; the copies are reused
+    across calls and refreshed when a weight changes."""
+    from medical_image_analysis_amd.report_decoder import ReportDecoder
+    torch.manual_seed(0)
+    m = ReportDecoder(vocab_size=96, hidden_size=128, intermediate_size=192, num_hidden_layers=2, num_attention_heads=2,
+                      num_key_value_heads=2, max_position_embeddings=64).to(dev).to(torch.float16).eval()
+    for p in m.parameters():
+        p.requires_grad = False
+    x = torch.randn(2, 7, 128, device=dev)
+    att = torch.ones(2, 7, dtype=torch.long, device=dev)
+    att[1, :2] = 0
+    outs = []
+    for fn in (m.forward, m.forward_frozen_autocast, m.forward_frozen_autocast):
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16):
+            y = fn(xi.to(torch.float16), attention_mask=att)
+        y.float().square().mean().backward()
+        outs.append((y.detach().float(), xi.grad.clone()))
+    assert len(m._autocast_shadows) == 2 * 7 + 1                        # q, k, v, o, gate, up, down per layer + lm_head
+    first = {k: v[1].data_ptr() for k, v in m._autocast_shadows.items()}
+    for y, g in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(g, outs[0][1])
+    with torch.no_grad():
+        m.lm_head.weight.mul_(2.0)                                      # a changed weight gets a fresh copy, the others are reused
+    with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16), torch.no_grad():
+        y2 = m.forward_frozen_autocast(x.to(torch.float16), attention_mask=att)
+        y2_ref = m.forward(x.to(torch.float16), attention_mask=att)
+    assert torch.equal(y2.float(), y2_ref.float())
+    now = {k: v[1].data_ptr() for k, v in m._autocast_shadows.items()}
+    assert now["lm_head.weight"] != first["lm_head.weight"] and all(now[k] == first[k] for k in now if k != "lm_head.weight")
