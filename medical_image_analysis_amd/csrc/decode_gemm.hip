@@ -164,6 +164,7 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
     case 1: MXVL_RMSNORM(1); break;
     case 2: MXVL_RMSNORM(2); break;
     case 4: MXVL_RMSNORM(4); break;
+    case 8: MXVL_RMSNORM(8); break;
     default: MXVL_RMSNORM(0); break;
   }
 #undef MXVL_RMSNORM

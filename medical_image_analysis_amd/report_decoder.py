@@ -528,8 +528,10 @@ class _KernelStepper(_SearchFusion):
         self._abi.check(self.lib.mxvl_decode_gemv(self._ct.byref(d), self._abi.stream_ptr(x.device)), "mxvl_decode_gemv")
 
     @staticmethod
-    def _k_splits(N, K):
-        """Workgroups of 64 columns: split K until ~256 of them exist (o_proj / down_proj: N = hidden), a wave keeping >= 4 chunks of 64."""
+    def _k_splits(N, K, rows=0):
+        """Workgroups of 64 columns: split K until ~256 of them exist (o_proj / down_proj: N = hidden), a wave keeping >= 4 chunks of 64.
+        (33..80 rows with 8 splits of 128-column workgroups -- two column tiles per wave on the wide kernel -- measured the same within
+        noise: 2739 / 2719 vs 2756 / 2745 tok/s at 16 x 5, one call; not adopted.)"""
         s = max(1, min(8, 256 // max(1, -(-N // 64))))
         while s > 1 and K // 64 < 4 * 4 * s:
             s //= 2
@@ -572,7 +574,7 @@ class _KernelStepper(_SearchFusion):
         a.slot_table, a.pos, a.mask, a.out = self.slot.data_ptr(), self.pos.data_ptr(), self.mask.data_ptr(), self.att.data_ptr()
         sp = self._abi.stream_ptr(self.x.device)
         batched = self.batched and not self.fused_norm   # MFMA projections with explicit RMSNorm launches; o_proj / down_proj split K and are folded by the next norm
-        so, sd = (self._k_splits(self.hidden, self.H * self.D), self._k_splits(self.hidden, self.inter)) if batched else (0, 0)
+        so, sd = (self._k_splits(self.hidden, self.H * self.D, self.rows), self._k_splits(self.hidden, self.inter, self.rows)) if batched else (0, 0)
         for i, layer in enumerate(m.model.layers):
             at = layer.self_attn
             ln1, ln2 = layer.input_layernorm, layer.post_attention_layernorm
