@@ -274,6 +274,11 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
     wbytes = 2 * n_params                                   # every decode step streams the 16-bit weights once
     step_s = wall / (steps * n_out)                         # per generated token (beam batch of `beams` rows)
     achieved = wbytes / step_s / 1e9
+    # the KV cache a step has to read on top of the weights: the prompt's keys / values once per SAMPLE (the beams share them), the
+    # generated positions once per ROW, averaged over the n_out steps -- 1.6 % of the weight bytes at batch 1 x 3, a third at 16 x 5
+    kv_pos = B * plen + B * beams * (n_out / 2.0)
+    kv_bytes = kv_pos * layers * 2 * kvh * (hidden // heads) * 2
+    achieved_kv = (wbytes + kv_bytes) / step_s / 1e9
     return {
         "metric": "report-generation decode tokens/sec (returned tokens; each step advances all beams)",
         "value": tokens / wall, "unit": "tokens/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -287,7 +292,8 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
                                 + ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
                                    "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
                                 + " launches + beam_step_kernel, one hipGraph replay per token; the time per token includes the prompt prefill's share"),
-                     "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3}}
+                     "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3,
+                     "kv_cache_bytes_per_token": int(kv_bytes), "frac_with_kv_cache": achieved_kv / HBM_PEAK_GBS}}
 
 
 def cpu_baseline_decode(workload):
