@@ -460,7 +460,7 @@ def run_pretrain(args, rank, world, dev, dist):
         # decoder of configs[3], measured by the same process right after the training steps (replicas on every rank)
         del eng, model, batches
         torch.cuda.empty_cache()
-        secondary = measure_decode("decode_llama7b_128", 5, 1, rank, world, dev, dist)
+        secondary = measure_decode("decode_llama7b_128", 5, args.secondary_warmup, rank, world, dev, dist)
         if secondary is not None and world == 1 and not args.no_cpu_baseline:
             secondary["cpu_baseline"] = cpu_baseline_decode("decode_llama7b_128")
         # north_star's one numeric kernel target (BASELINE.json: ">= 40 % of MI355X HBM roofline on the selective-scan kernel at L=4096,
@@ -857,6 +857,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
+    ap.add_argument("--secondary-warmup", type=int, default=8,
+                    help="untimed generate() calls of the decode leg: it starts on a chip the training leg has just driven at its power limit, and "
+                         "the first ~3 s of (memory-bound) decoding run 3 % below the standalone decode line until the clocks recover -- "
+                         "profiles/r05_secondary_warmup.txt: 350.8 tok/s with 1 warm-up call, 354.2 with 3, 361.2 after 3 s idle, 359.3 standalone")
     ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
                     help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
     ap.add_argument("--llm-shadows", choices=["on", "off"], default=None,

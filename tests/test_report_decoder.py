@@ -676,7 +676,9 @@ def test_decode_gemv_kernel_at_llama7b_shapes_vs_fp32_torch(K, N, mode, rows, dt
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,N,mode", [(4096, 4096, "plain"), (4096, 12288, "bias"), (4096, 11008, "swiglu"),
                                       (11008, 4096, "residual"), (4096, 32000, "f32"), (1408, 520, "residual"),
-                                      (512, 2056, "f32"), (72, 24, "swiglu"), (64, 16, "bias")])
+                                      (512, 2056, "f32"), (72, 24, "swiglu"), (64, 16, "bias"),
+                                      # ragged column counts wide enough for decode_gemm_wide_kernel at 33..80 rows (R = 2, R = 1, SwiGLU R = 2)
+                                      (512, 32010, "f32"), (256, 12296, "bias"), (2048, 5512, "swiglu")])
 @pytest.mark.parametrize("rows", [18, 9, 16, 24, 33, 48, 80])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_decode_gemm_kernel_rows_9_to_80_vs_fp32_torch(K, N, mode, rows, dtype):
