@@ -19,6 +19,8 @@
 //     cross-workgroup seam costs 5-13 us (agent-scope fences) on kernels that run 7-40 us.
 //   * activation traffic from L2 per weight byte = MT / R (MT = 16-row activation tiles): R is chosen by the host from N.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "decode_elt.h"
 
 namespace mxvl {
@@ -194,6 +196,13 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_kernel(const DecodeGemmAr
 __device__ __forceinline__ int dg_key(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
 template <int N> __device__ __forceinline__ void dg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loop bodies whose wait counts are immediates
+template <typename F, int... I> __device__ __forceinline__ void dg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void dg_static_for(F&& f) {
+  dg_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // NORM (round 5): RMSNorm of the activation rows fused into the projection that consumes them -- y = rstd[m] * sum_k W[n][k] (g[k] x[m][k]):
 // the gain is applied to the activation fragments on their way into the B operand (two more 16-byte requests per stage: the gain's
@@ -363,9 +372,16 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
 // (gridDim.y ranges: o_proj / down_proj write partial planes as before); wave w streams the R tiles of its own columns through a
 // private LDS ring exactly as above, and the activation tile of a 64-column chunk (MT x 16 rows x 128 bytes, same XOR swizzle) is
 // brought in ONCE per workgroup by LDS-DMA (its 2 MT one-kilobyte pieces dealt round-robin to the waves) and read by every wave as
-// the B operand: MT / (NW R) activation bytes per weight byte, no fragment registers, three stages in flight.  One s_barrier per
-// chunk: behind it every wave's pieces of stage i have landed, and every wave is done with the slot of stage i - 1, which is
-// refilled right away.  No cross-wave reduction: a wave owns the whole K range of its columns and runs the epilogue from registers.
+// the B operand: MT / (NW R) activation bytes per weight byte, no fragment registers, a ring as deep as LDS holds (5..8 stages,
+// decode_gemm.hip wide_pf).  One s_barrier per chunk: behind it every wave's pieces of stage i have landed, and every wave is done
+// with the slot of stage i - 1, which is refilled right away.  No cross-wave reduction: a wave owns the whole K range of its columns
+// and runs the epilogue from registers (a lane's four columns of a row as ONE 16- / 8-byte store).
+// What bounds a launch (tools/cu_stream_probe.hip + the kernel with pieces switched off, profiles/r05_cu_stream_probe.txt,
+// r05_decode_gemm_wide_attribution.txt): ONE CU moves at most ~55 GB/s of full 128-byte lines through its load path, LDS-DMA or
+// registers, hit or miss, weights and activations alike (half-used lines -- the MFMA A layout fetched straight into registers, 64
+// bytes per row and instruction -- halve it), HBM gives ~6.5-7 TB/s to >= 128 streaming CUs.  So the activation bytes a CU has to
+// pull next to its weight share, and the CUs a grid leaves idle, are what the 80-row projections pay for: NW = 3 where that fills
+// the chip (decode_gemm.hip), and the walk over K staggered per workgroup (below).
 template <typename E, int MT, int R, int NW, int PF>
 __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char dgw_smem[];
@@ -417,8 +433,14 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeG
     for (int mt = 0; mt < MT; ++mt) acc[r][mt] = dg_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dgw_smem;
 
+  // Workgroup b starts its walk at chunk (5 b) % n_it of its range and wraps: with everybody at chunk 0 every request in flight on the
+  // chip shares address bits 7..12 (rows are K * 2 bytes apart) and the HBM channels take turns instead of working side by side --
+  // tools/cu_stream_probe.hip, profiles/r05_cu_stream_probe.txt: 192 workgroups streaming 100 MB reach 5.5 TB/s in lock-step, 6.2 staggered.
+  const int stag = n_it > 0 ? (int)((blockIdx.x * 5u) % (unsigned)n_it) : 0;
   auto issue = [&](int slot, int c) {
-    int cc = c < c_end ? c : c_begin;                 // past the range: a harmless repeat into a slot nobody reads (the counts stay uniform)
+    int j = c - c_begin + stag;
+    j = j >= n_it ? j - n_it : j;
+    int cc = c < c_end ? c_begin + j : c_begin;       // past the range: a harmless repeat into a slot nobody reads (the counts stay uniform)
     cc = cc < chunks ? cc : chunks - 1;
     const unsigned sbase = lds0 + (unsigned)slot * STAGE;
 #pragma unroll
@@ -457,7 +479,8 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeG
 #pragma unroll
   for (int j = 0; j < PF - 1; ++j) issue(j, c_begin + j);
   int slot = 0, fill = PF - 1;
-  for (int i = 0; i < n_it; ++i) {
+  const int n_main = n_it - (PF - 1);                  // iterations that still have a stage to ask for
+  for (int i = 0; i < n_main; ++i) {
     dg_wait_vm<(PF - 2) * OPS>();                      // stage i has landed (this wave's pieces); PF - 2 younger stages stay in flight
     __builtin_amdgcn_s_barrier();                      // ... and everybody's; every wave is done with the slot of stage i - 1
     asm volatile("" ::: "memory");
@@ -466,7 +489,20 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeG
     slot = slot + 1 == PF ? 0 : slot + 1;
     fill = fill + 1 == PF ? 0 : fill + 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the repeats issued past the range: nothing may land after the workgroup is gone)
+  // the last PF - 1 stages: nothing left to ask for (the deep rings used to re-request a chunk per iteration here, a tenth of the
+  // launch's LDS-DMA instructions at 64 chunks, a third at 16), the wait counts shrink with the ring
+  const int i_tail = n_main > 0 ? n_main : 0;
+  dg_static_for<PF - 1>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if (i_tail + t < n_it) {                            // (uniform)
+      dg_wait_vm<(PF - 2 - t) * OPS>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      consume(slot);
+      slot = slot + 1 == PF ? 0 : slot + 1;
+    }
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ranges shorter than the ring: the prologue's repeats may not land after the workgroup is gone)
 
   // ---- epilogue from registers: lane (l16 -> activation row, 4 q + v -> column of the tile) -------------------------------------------
   const int tiles = p.swiglu ? R / 2 : R;
@@ -477,6 +513,37 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_wide_kernel(const DecodeG
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + l16;
       if (m >= p.rows) continue;
+      const int nq = n0 + t * 16 + 4 * q;
+      if ((N & 3) == 0 && nq + 3 < N) {             // the lane's four columns as one store (16 bytes of a plane, 8 of a 16-bit row)
+        const size_t o = (size_t)m * N + nq;
+        const dg_f32x4 s0 = acc[t][mt];
+        if (p.split_acc) {
+          *(dg_f32x4*)(p.split_acc + (size_t)blockIdx.y * p.rows * N + o) = s0;
+        } else if (p.swiglu) {
+          const dg_f32x4 s1 = acc[(t + R / 2) < R ? t + R / 2 : t][mt];
+          uint16_t h[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float gte = E::rr(s0[v]), up = E::rr(s1[v]);
+            h[v] = E::r(E::rr(gte * sigmoid(gte)) * up);
+          }
+          *(uint2*)((uint16_t*)p.y + o) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        } else {
+          float val[4] = {s0[0], s0[1], s0[2], s0[3]};
+          if (p.bias) {
+            const uint2 bw = *(const uint2*)(p.bias + nq);
+            val[0] += E::lo(bw.x); val[1] += E::hi(bw.x); val[2] += E::lo(bw.y); val[3] += E::hi(bw.y);
+          }
+          if (p.res) {
+            const uint2 rw = *(const uint2*)(p.res + o);
+            val[0] = E::rr(val[0]) + E::lo(rw.x); val[1] = E::rr(val[1]) + E::hi(rw.x);
+            val[2] = E::rr(val[2]) + E::lo(rw.y); val[3] = E::rr(val[3]) + E::hi(rw.y);
+          }
+          if (p.out_f32) *(dg_f32x4*)((float*)p.y + o) = dg_f32x4{val[0], val[1], val[2], val[3]};
+          else *(uint2*)((uint16_t*)p.y + o) = make_uint2((uint32_t)E::r(val[0]) | ((uint32_t)E::r(val[1]) << 16), (uint32_t)E::r(val[2]) | ((uint32_t)E::r(val[3]) << 16));
+        }
+        continue;
+      }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int n = n0 + t * 16 + 4 * q + v;

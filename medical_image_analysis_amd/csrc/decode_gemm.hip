@@ -41,9 +41,19 @@ static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
 }
 
 // MT >= 3 (33..80 rows), K % 64 == 0: the waves split N, activations shared through LDS (decode_gemm_wide_kernel)
-template <typename E, int MT, int R>
-static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
-  constexpr int NW = 4, PF = 3;
+// ring depth of the wide kernel: as many stages as 150 KB of LDS hold (one workgroup per CU is all these grids ask for), capped by the
+// 6-bit vmcnt field and at 8 -- against the first version's 3 stages: 48-row token +5 %, 80-row +0.7 % (profiles/r05_decode_gemm_ring_ab.txt)
+constexpr int wide_pf(int MT, int R, int NW) {
+  const int stage = MT * 2048 + NW * R * 2048, ops = 2 * R + (2 * MT + NW - 1) / NW;
+  int pf = (150 * 1024) / stage;
+  while (pf > 2 && (pf - 1) * ops > 63) --pf;
+  return pf > 8 ? 8 : (pf < 2 ? 2 : pf);
+}
+static int g_wide_pf3 = 0;     // (A/B: mxvl_set_decode_gemm_wide(3) = the 3-stage ring of the first version)
+static int g_wide_nw4 = 0;     // (A/B: mxvl_set_decode_gemm_wide(4) = four waves per workgroup everywhere)
+
+template <typename E, int MT, int R, int NW, int PF>
+static int launch_wide_pf(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   const int cols_per_wg = NW * (a.swiglu ? R / 2 : R) * 16;
   const dim3 grid((a.N + cols_per_wg - 1) / cols_per_wg, splits);
   const size_t lds = (size_t)PF * (MT * 2048 + NW * R * 2048);
@@ -54,23 +64,46 @@ static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   return MXVL_OK;
 }
 
+template <typename E, int MT, int R, int NW = 4>
+static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
+  if constexpr (NW == 4) { if (g_wide_pf3) return launch_wide_pf<E, MT, R, 4, 3>(a, splits, s); }
+  return launch_wide_pf<E, MT, R, NW, wide_pf(MT, R, NW)>(a, splits, s);
+}
+
 static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B switch of tools / bench (default on; 2: also at 17..32 rows)
 
 template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   if constexpr (MT >= 2) {
     if (g_decode_gemm_wide && (MT >= 3 || g_decode_gemm_wide >= 2) && a.K % 64 == 0 && a.K >= 256 && !a.g) {
-      // 64 R (SwiGLU: 32 R) output columns per workgroup: ~200 workgroups keep every CU streaming (a CU pulls ~28 GB/s whatever it
-      // holds); the K-split projections (N = hidden) bring their own factor
+      // What bounds these launches is what ONE CU can pull through its load path, weights and activations together (~50 GB/s of
+      // full-line LDS-DMA, tools/cu_stream_probe.hip -- HBM needs 27 GB/s from each of 256 CUs): a workgroup of NW waves x R tiles
+      // moves 1 + MT / (NW R) bytes per weight byte, and the launch is as long as its busiest CU.  So: the (NW, R) with the least
+      //   (1 + MT / (NW R)) x rounds / workgroups,      rounds = ceil(workgroups / 256)   (the LDS ring leaves one workgroup per CU)
+      // -- three waves per workgroup when that fills the chip: 230 workgroups for Llama's gate / up (172 with four waves), 256 for qkv (192).
       // Below ~160 workgroups (Qwen1.5-1.8B's qkv: 96, gate / up: 86) a workgroup's serial walk over the WHOLE K is the kernel's
       // critical path and the K-split kernels are as fast or faster (profiles/r05_decode_gemm_wide_ab.txt: the Qwen token 2.84 vs 2.80 ms).
-      const long wg64 = (long)((a.swiglu ? 2 * a.N : a.N) + 127) / 128 * splits;      // workgroups at 128 weight rows each
-      if (a.swiglu) {
-        if (wg64 >= 384) return launch_wide<E, MT, 4>(a, splits, s);
-        if (wg64 >= 160) return launch_wide<E, MT, 2>(a, splits, s);
-      } else {
-        if (wg64 >= 192) return launch_wide<E, MT, 2>(a, splits, s);
-        if (2 * wg64 >= 160) return launch_wide<E, MT, 1>(a, splits, s);
+      int best_nw = 0, best_r = 0;
+      long best_g = 0;
+      double best = 1e30;
+      for (int nw : {4, 3}) {
+        if (nw == 3 && g_wide_nw4) continue;
+        for (int r : {1, 2, 4}) {
+          if (a.swiglu && (r & 1)) continue;
+          if (nw == 3 && r == 4) continue;
+          const int cols = nw * (a.swiglu ? r / 2 : r) * 16;
+          const long g = (long)((a.N + cols - 1) / cols) * splits;
+          const double est = (1.0 + (double)MT / (nw * r)) * (double)((g + 255) / 256) / (double)g;
+          if (est < best - 1e-12) { best = est; best_nw = nw; best_r = r; best_g = g; }
+        }
+      }
+      if (best_g >= 160) {
+        if (best_nw == 3) return best_r == 2 ? launch_wide<E, MT, 2, 3>(a, splits, s) : launch_wide<E, MT, 1, 3>(a, splits, s);
+        switch (best_r) {
+          case 4: return launch_wide<E, MT, 4>(a, splits, s);
+          case 2: return launch_wide<E, MT, 2>(a, splits, s);
+          default: return launch_wide<E, MT, 1>(a, splits, s);
+        }
       }
     }
   }
@@ -172,9 +205,12 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
 }
 
 /* diagnostic / A-B switch (tools, bench.py --decode-gemm): 0 = the K-split kernels at every row count (round 4), 1 = waves split N with
- * LDS-shared activations at 33..80 rows (default) */
+ * LDS-shared activations at 33..80 rows (default), 2 = also at 17..32 rows, 3 = as 1 with the first version's 3-stage ring and four
+ * waves per workgroup, 4 = as 1 with four waves per workgroup everywhere */
 extern "C" int mxvl_set_decode_gemm_wide(int on) {
   const int was = mxvl::g_decode_gemm_wide;
-  mxvl::g_decode_gemm_wide = on < 0 ? 0 : (on > 2 ? 2 : on);
+  mxvl::g_wide_pf3 = on == 3;
+  mxvl::g_wide_nw4 = on == 3 || on == 4;
+  mxvl::g_decode_gemm_wide = on < 0 ? 0 : (on >= 3 ? 1 : on);
   return was;
 }

@@ -3,6 +3,8 @@
 # their section here).   gpurun -- 'bash tools/gpu_r05_ab.sh <section>'
 #   norm       RMSNorm fused into the consuming decode projection vs K-split + explicit fold       -> profiles/r05_decode_norm_ab.txt
 #   wide       33..80-row projections: waves split N + LDS-shared activations vs K-split kernels    -> profiles/r05_decode_gemm_wide_ab.txt
+#   ring       the wide kernel's LDS ring: as deep as 150 KB hold (5..8 stages) vs 3 stages          -> profiles/r05_decode_gemm_ring_ab.txt
+#   probe      what one CU / the chip streams from HBM by load path and pattern (tools/cu_stream_probe.hip) -> profiles/r05_cu_stream_probe.txt
 #   mlp        SwiGLU backward inside w3's dgrad GEMM vs the two-kernel backward (kernel + step)    -> profiles/r05_gemm_swiglu_bwd_bench.txt
 #   gemm       the MFMA kernel as a plain NT GEMM vs hipBLASLt at the step's shapes                 -> profiles/r05_gemm_nt_bench.txt
 #   shadows    cached autocast copies of the frozen LLM's weights vs per-call casts                 -> profiles/r05_llm_shadows_ab.txt
@@ -26,6 +28,14 @@ case "$1" in
     (python tools/decode_gemm_bench.py 48 80 2>&1 | grep -v amdgpu.ids)
     for w in decode_llama7b_b16x3 decode_llama7b_b16x5 decode_qwen1p8b_b16x5 decode_llama7b_b6x3; do
       for m in wide ksplit; do line $w --decode-gemm $m; done; done ;;
+  ring)
+    timeout 600 python -m pytest tests/test_report_decoder.py -q -m gpu -k "wide or decode_gemm or qwen_width" 2>&1 | tail -4
+    for w in decode_llama7b_b16x3 decode_llama7b_b16x5 decode_qwen1p8b_b16x5 decode_llama7b_b6x3; do
+      for m in wide wide_nw4 wide_pf3 wide wide_nw4 wide_pf3; do line $w --decode-gemm $m; done; done ;;
+  probe)
+    hipcc --offload-arch=gfx950 -O3 -o /tmp/cu_stream_probe tools/cu_stream_probe.hip 2>/dev/null || exit 1
+    timeout 200 /tmp/cu_stream_probe
+    for m in ROWS_ONLY SWZ_ONLY VROWS_ONLY SHORT_ONLY; do echo "## $m"; env $m=1 timeout 200 /tmp/cu_stream_probe; done ;;
   mlp)
     (python tools/gemm_swiglu_bwd_bench.py 2>&1 | grep -v amdgpu.ids)
     for m in fused unfused fused unfused; do
@@ -50,5 +60,5 @@ case "$1" in
     done
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $P/mae -o r -- python $R/bench.py --workload mae_vit_large_1280 --steps 3 --warmup 1 --no-cpu-baseline > $P/mae.log 2>&1)
     python tools/rocpd_summary.py $P/mae/r_results.db 2>&1 | head -60 | cut -c1-170 > gpurun_out/ab_mae_stats.txt ;;
-  *) echo "usage: $0 norm|wide|mlp|gemm|shadows|secondary|timelines"; exit 2 ;;
+  *) echo "usage: $0 norm|wide|ring|probe|mlp|gemm|shadows|secondary|timelines"; exit 2 ;;
 esac
