@@ -865,8 +865,10 @@ def main():
                     help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
     ap.add_argument("--llm-shadows", choices=["on", "off"], default=None,
                     help="A/B switch of the fine-tuning steps: cached autocast-dtype copies of the frozen LLM's weights (default) or per-call casts")
-    ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide2", "wide_pf3", "wide_nw4"], default=None,
-                    help="A/B switch of the 33..80-row decode projections: waves split N + LDS-shared activations (default) or the round-4 K-split kernels")
+    ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide_pf3", "wide_nw4", "wide_mt3", "wide1"], default=None,
+                    help="A/B switch of the 17..80-row decode projections: waves split N + LDS-shared activations (wide, default), the round-4 K-split "
+                         "kernels at every row count (ksplit), the wide kernel as first measured (wide_pf3: 33..80 rows, >= 160 workgroups, 3-stage ring, "
+                         "four waves), four waves per workgroup everywhere (wide_nw4), 33..80 rows and >= 160 workgroups only (wide_mt3), from one row on (wide1)")
     ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
                     help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
                          "(K-split o_proj / down_proj folded by explicit norm launches)")
@@ -915,7 +917,7 @@ def main():
         from medical_image_analysis_amd.report_decoder import ReportDecoder
         ReportDecoder.autocast_shadows = args.llm_shadows == "on"
     if args.decode_gemm:
-        _abi.load().mxvl_set_decode_gemm_wide({"wide": 1, "ksplit": 0, "wide2": 2, "wide_pf3": 3, "wide_nw4": 4}[args.decode_gemm])
+        _abi.load().mxvl_set_decode_gemm_wide({"wide": 1, "ksplit": 0, "wide_pf3": 3, "wide_nw4": 4, "wide_mt3": 5, "wide1": 6}[args.decode_gemm])
     if args.decode_norm:
         from medical_image_analysis_amd.report_decoder import _KernelStepper
         _KernelStepper.norm_mode = args.decode_norm

@@ -317,11 +317,12 @@ typedef struct mxvl_rmsnorm_desc {
   int32_t dtype;            /* ABI v8: mxvl_dtype of x, weight, y, residual, x_out (0 = MXVL_BF16) */
   int32_t acc_splits;       /* ABI v8: planes of acc (0 = 1) */
 } mxvl_rmsnorm_desc;
-/* Diagnostic / A-B switch of the 33..80-row projections (ABI v8): 1 (default) = the waves of a workgroup split N and share the activation
- * tile through LDS (csrc/decode_gemm.h decode_gemm_wide_kernel), 0 = the K-split kernels of round 4 at every row count; 2 = wide also at
- * 17..32 rows, 3 = wide as first measured (3-stage ring, four waves per workgroup), 4 = wide with four waves per workgroup everywhere
- * (the default takes three where that fills the 256 CUs).  Returns the previous setting.  Same results in every mode up to the order of
- * the fp32 sums. */
+/* Diagnostic / A-B switch of the 17..80-row projections (ABI v8): 1 (default; 2 = the same) = the waves of a workgroup split N and share
+ * the activation tile through LDS (csrc/decode_gemm.h decode_gemm_wide_kernel) wherever the grid has >= 64 workgroups, 0 = the K-split
+ * kernels of round 4 at every row count; 3 = wide as first measured (33..80 rows, >= 160 workgroups, 3-stage ring, four waves per
+ * workgroup), 4 = wide with four waves per workgroup everywhere (the default takes three where that fills the 256 CUs), 5 = wide at 33..80
+ * rows and >= 160 workgroups only, 6 = wide from one row on.  Returns the previous setting.  Same results in every mode up to the order
+ * of the fp32 sums. */
 int mxvl_set_decode_gemm_wide(int on);
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);

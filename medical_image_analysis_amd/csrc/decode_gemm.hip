@@ -51,6 +51,8 @@ constexpr int wide_pf(int MT, int R, int NW) {
 }
 static int g_wide_pf3 = 0;     // (A/B: mxvl_set_decode_gemm_wide(3) = the 3-stage ring of the first version)
 static int g_wide_nw4 = 0;     // (A/B: mxvl_set_decode_gemm_wide(4) = four waves per workgroup everywhere)
+static int g_wide_min_mt = 2;  // wide from 17 rows on (A/B: mode 5 = from 33 rows on, as first shipped; mode 6 = from 1 row on)
+static int g_wide_min_g = 64;  // ... for grids of at least 64 workgroups (A/B: mode 5 = 160)
 
 template <typename E, int MT, int R, int NW, int PF>
 static int launch_wide_pf(const DecodeGemmArgs& a, int splits, hipStream_t s) {
@@ -74,15 +76,17 @@ static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B 
 
 template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
-  if constexpr (MT >= 2) {
-    if (g_decode_gemm_wide && (MT >= 3 || g_decode_gemm_wide >= 2) && a.K % 64 == 0 && a.K >= 256 && !a.g) {
+  {
+    if (g_decode_gemm_wide && MT >= g_wide_min_mt && a.K % 64 == 0 && a.K >= 256 && !a.g) {
       // What bounds these launches is what ONE CU can pull through its load path, weights and activations together (~50 GB/s of
       // full-line LDS-DMA, tools/cu_stream_probe.hip -- HBM needs 27 GB/s from each of 256 CUs): a workgroup of NW waves x R tiles
       // moves 1 + MT / (NW R) bytes per weight byte, and the launch is as long as its busiest CU.  So: the (NW, R) with the least
       //   (1 + MT / (NW R)) x rounds / workgroups,      rounds = ceil(workgroups / 256)   (the LDS ring leaves one workgroup per CU)
       // -- three waves per workgroup when that fills the chip: 230 workgroups for Llama's gate / up (172 with four waves), 256 for qkv (192).
-      // Below ~160 workgroups (Qwen1.5-1.8B's qkv: 96, gate / up: 86) a workgroup's serial walk over the WHOLE K is the kernel's
-      // critical path and the K-split kernels are as fast or faster (profiles/r05_decode_gemm_wide_ab.txt: the Qwen token 2.84 vs 2.80 ms).
+      // From 17 rows and 64 workgroups on (profiles/r05_decode_gemm_wide_rows_ab.txt: against the K-split kernels the 18-row token
+      // +7 %, the 24-row token +11 %, Qwen1.5-1.8B's 96..128-workgroup projections +4 % at 80 rows; the first version -- 3-stage
+      // ring, aligned walks -- had lost to them below 160 workgroups and at 17..32 rows).  At 1..16 rows the K-split kernel keeps the
+      // launches: it carries the fused RMSNorm, and without it the wide kernel is +2 % (Llama) / 0 % (Qwen) there.
       int best_nw = 0, best_r = 0;
       long best_g = 0;
       double best = 1e30;
@@ -97,7 +101,7 @@ static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s
           if (est < best - 1e-12) { best = est; best_nw = nw; best_r = r; best_g = g; }
         }
       }
-      if (best_g >= 160) {
+      if (best_g >= g_wide_min_g) {
         if (best_nw == 3) return best_r == 2 ? launch_wide<E, MT, 2, 3>(a, splits, s) : launch_wide<E, MT, 1, 3>(a, splits, s);
         switch (best_r) {
           case 4: return launch_wide<E, MT, 4>(a, splits, s);
@@ -205,12 +209,17 @@ extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream)
 }
 
 /* diagnostic / A-B switch (tools, bench.py --decode-gemm): 0 = the K-split kernels at every row count (round 4), 1 = waves split N with
- * LDS-shared activations at 33..80 rows (default), 2 = also at 17..32 rows, 3 = as 1 with the first version's 3-stage ring and four
- * waves per workgroup, 4 = as 1 with four waves per workgroup everywhere */
+ * LDS-shared activations at 17..80 rows for grids of >= 64 workgroups (default; 2 = the same), 3 = the wide kernel as first measured
+ * (33..80 rows, >= 160 workgroups, 3-stage ring, four waves per workgroup), 4 = as 1 with four waves per workgroup everywhere,
+ * 5 = as 1 at 33..80 rows and >= 160 workgroups only, 6 = as 1 from one row on */
 extern "C" int mxvl_set_decode_gemm_wide(int on) {
-  const int was = mxvl::g_decode_gemm_wide;
+  static int mode = 1;
+  const int was = mode;
+  mode = on < 0 ? 0 : on;
   mxvl::g_wide_pf3 = on == 3;
   mxvl::g_wide_nw4 = on == 3 || on == 4;
-  mxvl::g_decode_gemm_wide = on < 0 ? 0 : (on >= 3 ? 1 : on);
+  mxvl::g_wide_min_g = (on == 3 || on == 5) ? 160 : 64;
+  mxvl::g_wide_min_mt = (on == 3 || on == 5) ? 3 : (on == 6 ? 1 : 2);
+  mxvl::g_decode_gemm_wide = on <= 0 ? 0 : 1;
   return was;
 }
