@@ -288,7 +288,11 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": (f"decode step = {4 * layers + 1} decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream; o_proj / down_proj K-split) + {2 * layers + 1} decode_rmsnorm_kernel + {layers} "
+                     "kernel": (f"decode step = {4 * layers + 1} "
+                                + ("decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream, the waves split K; RMSNorm fused into the consuming projection"
+                                   if B * beams <= 8 else "decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream, the waves split K"
+                                   if B * beams <= 16 else "decode_gemm_wide_kernel (16x16x32 MFMA, LDS-DMA weight ring, the waves split N and share the activation tile through LDS")
+                                + f"; o_proj / down_proj K-split into fp32 planes) + {2 * layers + 1} decode_rmsnorm_kernel + {layers} "
                                 + ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
                                    "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
                                 + " launches + beam_step_kernel, one hipGraph replay per token; the time per token includes the prompt prefill's share"),

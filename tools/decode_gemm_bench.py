@@ -1,8 +1,10 @@
-"""Per-kernel timing of the 9..80-row decoder projections (csrc/decode_gemm.h) at Llama-2-7B shapes, next to the library
-GEMM torch would run for the same nn.Linear.  GPU only.   python tools/decode_gemm_bench.py [rows ...]"""
+"""Per-kernel timing of the 1..80-row decoder projections (csrc/decode_gemm.h) at Llama-2-7B shapes, next to the library
+GEMM torch would run for the same nn.Linear; o_proj / down_proj with the K split the stepper gives them (fp32 planes, no epilogue).
+GPU only.   python tools/decode_gemm_bench.py [rows ...]"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medical_image_analysis_amd import _abi
+from medical_image_analysis_amd.report_decoder import _KernelStepper
 
 if os.environ.get('MXVL_LIB'):
     _abi.LIB_PATH = os.environ['MXVL_LIB']
@@ -11,11 +13,13 @@ dev = "cuda:0"
 rows_list = [int(a) for a in sys.argv[1:]] or [18, 24, 48, 80]
 
 
-def gemv(x, W, y, W2=None, res=None, out_f32=False):
+def gemv(x, W, y, W2=None, res=None, out_f32=False, acc=None, splits=1):
     d = _abi.GemvDesc()
     d.rows, d.K, d.N = x.shape[0], W.shape[1], W.shape[0]
     d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), 1e-5
     d.x, d.norm_weight, d.W, d.W2, d.bias, d.residual, d.y = x.data_ptr(), None, W.data_ptr(), _abi.ptr(W2), None, _abi.ptr(res), y.data_ptr()
+    if acc is not None:          # as the stepper launches o_proj / down_proj: fp32 planes, folded (+ residual) by the next norm launch
+        d.residual, d.split_acc, d.k_splits = None, acc.data_ptr(), splits
     _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "gemv")
 
 
@@ -53,10 +57,13 @@ for rows in rows_list:
         res = torch.randn(rows, N, **bf) if "res" in name else None
         f32 = "f32" in name
         y = torch.empty(rows, N, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+        splits = _KernelStepper._k_splits(N, K, rows) if (res is not None and rows > 8) else 1
+        acc = torch.empty(splits, rows, N, dtype=torch.float32, device=dev) if splits > 1 else None
+        if splits > 1: name = f"{name.split('+')[0]} {splits} planes"
         i = [0]
         def fn():
             j = i[0] % NL; i[0] += 1
-            gemv(x, Ws[j], y, W2=W2s[j] if swi else None, res=res, out_f32=f32)
+            gemv(x, Ws[j], y, W2=W2s[j] if swi else None, res=res, out_f32=f32, acc=acc, splits=splits)
         us = timeit(fn, 48)
         byt = N * K * 2 * (2 if swi else 1)
         def fl():
