@@ -134,3 +134,20 @@ def test_attention_dq64_kernel_has_no_scratch():
     work-item id now."""
     for name in ("attn_dq64_kernelINS_6bf16_tEEE", "attn_dq64_kernelINS_5f16_tEEE"):
         assert not _scratch_ops(_body("attn.hip", name)), name
+
+
+@pytest.mark.parametrize("elt", ["EltBf16", "EltF16"])
+@pytest.mark.parametrize("mt,r,nw,pf", [(5, 1, 3, 8), (5, 2, 3, 6), (2, 2, 3, 8)])
+def test_wide_decode_projection_ring_is_asked_for_each_chunk_once(elt, mt, r, nw, pf):
+    """decode_gemm_wide_kernel (the 17..80-row decoder projections; these are the instantiations Llama-2-7B's qkv and gate + up take at
+    80 and 18 rows): a ring of PF stages of OPS = 2 R + ceil(2 MT / NW) LDS-DMA requests.  The prologue asks for PF - 1 stages and the
+    loop body for one -- PF x OPS request instructions in the whole kernel, none in the unrolled tail (the first deep-ring version
+    re-requested a chunk per tail iteration: a tenth of a launch's requests at 64 chunks); the tail's waits shrink with the ring,
+    (PF - 2 - t) x OPS for t = 0 .. PF - 2; the loop body plus the PF - 1 tail copies hold PF x 2 R MT MFMAs; no scratch."""
+    ins = _body("decode_gemm.hip", f"decode_gemm_wide_kernelINS_{len(elt)}{elt}ELi{mt}ELi{r}ELi{nw}ELi{pf}E")
+    ops = 2 * r + (2 * mt + nw - 1) // nw
+    assert sum(1 for x in ins if x.startswith("global_load_lds_dwordx4")) == pf * ops
+    waits = {int(re.search(r"vmcnt\((\d+)\)", x).group(1)) for x in ins if "vmcnt" in x}
+    assert {(pf - 2 - t) * ops for t in range(pf - 1)} <= waits, sorted(waits)
+    assert sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32")) == pf * 2 * r * mt
+    assert not _scratch_ops(ins)
