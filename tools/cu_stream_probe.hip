@@ -168,6 +168,33 @@ int main() {
 #define ROWS(CC) run_rows("rows" #CC, G, W, rowb, [&](int g, int w, int nt, int rb) { \
         (void)hipFuncSetAttribute((const void*)dma_rows_kernel<CC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((dma_rows_kernel<CC, 16>), dim3(g), dim3(w * 64), (size_t)w * 16 * 1024, 0, (const char*)src, out, nt, rb); })
+  if (getenv("MALL_ONLY")) {
+    // a matrix that was read a moment ago (by another kernel, from other XCDs): what the 256 MB memory-side cache gives back.
+    // cold = 8 launches over 8 different regions of the 2 GB buffer, warm = 8 launches over the SAME region (the launch before it warmed it)
+    const int G = 256, W = 4;
+    (void)hipFuncSetAttribute((const void*)dma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (size_t mb : {16, 32, 64, 100, 128, 180, 224, 256}) {
+      const size_t region = mb << 20;
+      const size_t per_wave = region / ((size_t)G * W) / 16;
+      const int iters = (int)(per_wave / (16 * 64));
+      const size_t moved = (size_t)G * W * iters * 16 * 1024;
+      for (int warm = 0; warm < 2; ++warm) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+          hipLaunchKernelGGL(dma_kernel<16>, dim3(G), dim3(W * 64), (size_t)W * 16 * 1024, 0, src, out, per_wave, iters);
+          (void)hipDeviceSynchronize();
+          (void)hipEventRecord(e0);
+          for (int r = 0; r < 8; ++r)
+            hipLaunchKernelGGL(dma_kernel<16>, dim3(G), dim3(W * 64), (size_t)W * 16 * 1024, 0, src + (warm ? 0 : (size_t)(r % 8) * (region / 16)), out, per_wave, iters);
+          (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+          float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+          best = ms < best ? ms : best;
+        }
+        printf("%-5s region %4zu MB: %7.1f us per pass = %7.1f GB/s\n", warm ? "warm" : "cold", mb, best * 1e3 / 8, moved * 8 / best / 1e6);
+      }
+    }
+    return 0;
+  }
   if (getenv("SHORT_ONLY")) {
     const int W = 4;
     for (int rowb : {8192, 22016}) for (int tpw : {1, 2, 4}) for (int G : {48, 96, 192, 256, 512}) {

@@ -35,7 +35,7 @@ case "$1" in
   probe)
     hipcc --offload-arch=gfx950 -O3 -o /tmp/cu_stream_probe tools/cu_stream_probe.hip 2>/dev/null || exit 1
     timeout 200 /tmp/cu_stream_probe
-    for m in ROWS_ONLY SWZ_ONLY VROWS_ONLY SHORT_ONLY; do echo "## $m"; env $m=1 timeout 200 /tmp/cu_stream_probe; done ;;
+    for m in ROWS_ONLY SWZ_ONLY VROWS_ONLY SHORT_ONLY MALL_ONLY; do echo "## $m"; env $m=1 timeout 200 /tmp/cu_stream_probe; done ;;
   mlp)
     (python tools/gemm_swiglu_bwd_bench.py 2>&1 | grep -v amdgpu.ids)
     for m in fused unfused fused unfused; do
