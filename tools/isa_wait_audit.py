@@ -28,7 +28,9 @@ def compile_s(src):
     os.makedirs(TMP, exist_ok=True)
     base = os.path.basename(src)[:-4]
     out = os.path.join(TMP, f"{base}-hip-amdgcn-amd-amdhsa-gfx950.s")
-    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+    import glob
+    newest = max(os.path.getmtime(f) for f in [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:       # (the kernels live in headers as often as in the .hip file)
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
                                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-save-temps=obj", "-c", src,
                                "-o", os.path.join(TMP, base + ".o")], cwd=TMP, stderr=subprocess.DEVNULL)
