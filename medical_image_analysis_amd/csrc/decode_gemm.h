@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
   }
 }
 
-// ---- 33..80 rows (MT >= 3): the waves split N, the activations are shared through LDS (round 5) ------------------------------------
+// ---- 17..80 rows (MT >= 2): the waves split N, the activations are shared through LDS (round 5) ------------------------------------
 // With the waves of a workgroup splitting K every wave fetches its own activation fragments from L2: MT / R bytes per weight byte,
 // 1.25x the weight stream at 80 rows -- and at MT = 5 only two stages fit the registers.  Measured in round 4
 // (profiles/r04_decode_gemm_bench.txt): 80 rows ran the projections at 1.3-3.2 TB/s where hipBLASLt reaches 2.6-4.2, the 48- and

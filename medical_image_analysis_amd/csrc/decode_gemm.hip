@@ -40,7 +40,7 @@ static int launch_direct(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   return MXVL_OK;
 }
 
-// MT >= 3 (33..80 rows), K % 64 == 0: the waves split N, activations shared through LDS (decode_gemm_wide_kernel)
+// MT >= 2 (17..80 rows), K % 64 == 0, >= 64 workgroups: the waves split N, activations shared through LDS (decode_gemm_wide_kernel)
 // ring depth of the wide kernel: as many stages as 150 KB of LDS hold (one workgroup per CU is all these grids ask for), capped by the
 // 6-bit vmcnt field and at 8 -- against the first version's 3 stages: 48-row token +5 %, 80-row +0.7 % (profiles/r05_decode_gemm_ring_ab.txt)
 constexpr int wide_pf(int MT, int R, int NW) {

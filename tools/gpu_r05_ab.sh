@@ -2,7 +2,7 @@
 # The A/B runs of round 5, each as it was run in ONE gpurun call (the results are the profiles/r05_*_ab.txt / *_bench.txt files that name
 # their section here).   gpurun -- 'bash tools/gpu_r05_ab.sh <section>'
 #   norm       RMSNorm fused into the consuming decode projection vs K-split + explicit fold       -> profiles/r05_decode_norm_ab.txt
-#   wide       33..80-row projections: waves split N + LDS-shared activations vs K-split kernels    -> profiles/r05_decode_gemm_wide_ab.txt
+#   wide       17..80-row projections: waves split N + LDS-shared activations vs K-split kernels    -> profiles/r05_decode_gemm_wide_ab.txt (first version, 33..80 rows), r05_decode_gemm_wide_rows_ab.txt
 #   ring       the wide kernel's LDS ring: as deep as 150 KB hold (5..8 stages) vs 3 stages          -> profiles/r05_decode_gemm_ring_ab.txt
 #   probe      what one CU / the chip streams from HBM by load path and pattern (tools/cu_stream_probe.hip) -> profiles/r05_cu_stream_probe.txt
 #   mlp        SwiGLU backward inside w3's dgrad GEMM vs the two-kernel backward (kernel + step)    -> profiles/r05_gemm_swiglu_bwd_bench.txt
