@@ -69,3 +69,36 @@ def test_ops_refuse_cpu_tensors():
     u = torch.randn(1, 4, 8)
     with pytest.raises(RuntimeError, match="no CPU path"):
         selective_scan_fn(u, u, torch.randn(4, 2), torch.randn(1, 2, 8), torch.randn(1, 2, 8))
+
+
+def test_decode_projection_descriptor_validation_and_switch_without_gpu():
+    """mxvl_decode_gemv refuses what the projection kernels cannot serve before anything is launched (no GPU needed: every case
+    returns from the argument checks), and the diagnostic dispatch switch hands back the mode it replaces."""
+    lib = _abi.load()
+    d = _abi.GemvDesc()
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                      # null pointers
+    d.x = d.W = d.y = 64                                                          # fake non-null pointers, never dereferenced
+    d.rows, d.K, d.N = 81, 4096, 4096
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) == -3                      # MXVL_ERR_SHAPE: more than 80 rows
+    d.rows, d.K = 18, 36
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # K % 8 != 0: no 16-byte fragments
+    d.K, d.k_splits = 4096, 4
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # a K split needs the plane buffer
+    d.k_splits, d.split_acc, d.swiglu, d.W2 = 4, 64, 1, 64
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # no SwiGLU epilogue on partial sums
+    d.swiglu, d.W2, d.norm_weight = 0, None, 64
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # no fused norm on partial sums
+    assert lib.mxvl_set_decode_gemm_wide(0) == 1                                  # the default mode is 1
+    assert lib.mxvl_set_decode_gemm_wide(5) == 0
+    assert lib.mxvl_set_decode_gemm_wide(1) == 5
+
+
+def test_k_split_plan_of_the_residual_projections():
+    """_KernelStepper._k_splits: o_proj / down_proj (N = hidden) are cut into fp32 planes until ~256 workgroups of 64 columns exist,
+    a wave keeping >= 4 chunks of 64 -- Llama-2-7B: 4 planes for both; Qwen1.5-1.8B: 2 for o_proj (K = 2048), 4 for down_proj
+    (K = 5504); a projection that already has 256 column groups is not split."""
+    from medical_image_analysis_amd.report_decoder import _KernelStepper
+    ks = _KernelStepper._k_splits
+    assert ks(4096, 4096, 18) == 4 and ks(4096, 11008, 80) == 4
+    assert ks(2048, 2048, 80) == 2 and ks(2048, 5504, 80) == 4
+    assert ks(16384, 4096, 18) == 1 and ks(4096, 256, 18) == 1
