@@ -324,6 +324,11 @@ typedef struct mxvl_rmsnorm_desc {
  * rows and >= 160 workgroups only, 6 = wide from one row on.  Returns the previous setting.  Same results in every mode up to the order
  * of the fp32 sums. */
 int mxvl_set_decode_gemm_wide(int on);
+/* Diagnostic (ABI v8): which kernel mxvl_decode_gemv would launch for a descriptor -- the dispatch as a pure function, nothing is launched
+ * and no GPU is needed.  out[0] = 2 the per-row GEMV kernel (<= 8 rows, k_splits == 0), 1 = decode_gemm_wide_kernel, 0 = the K-split
+ * matrix-core kernels; for 1: out[1] waves per workgroup, out[2] weight tiles per wave, out[3] LDS ring stages, out[4] workgroups.
+ * Same argument checks and error codes as mxvl_decode_gemv. */
+int mxvl_decode_gemm_plan(const mxvl_gemv_desc *desc, int32_t out[5]);
 int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc *desc, void *hip_stream);
 int mxvl_decode_prologue(const mxvl_decode_prologue_desc *desc, void *hip_stream);
 int mxvl_decode_gemv(const mxvl_gemv_desc *desc, void *hip_stream);

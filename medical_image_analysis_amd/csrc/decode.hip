@@ -976,12 +976,25 @@ static void launch_cross_attn(const CrossAttnArgs& a, dim3 grid, dim3 block, siz
 }
 
 int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s);   // decode_gemm.hip: 9..80 rows on the matrix cores
+int decode_gemm_plan(const mxvl_gemv_desc* d, int32_t* out);         // ... and which of its kernels would take a descriptor
 
 }  // namespace mxvl
 
 using namespace mxvl;
 
 extern "C" {
+
+/* The dispatch of mxvl_decode_gemv for a descriptor, nothing launched (no GPU needed): out[0] = 2 the per-row GEMV kernel (<= 8 rows,
+ * k_splits == 0), 1 = decode_gemm_wide_kernel, 0 = the K-split matrix-core kernels; for 1: out[1..4] = waves per workgroup, weight
+ * tiles per wave, ring stages, workgroups.  Same argument checks and error codes as the launch. */
+int mxvl_decode_gemm_plan(const mxvl_gemv_desc* d, int32_t* out) {
+  if (!d || !out || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
+  out[0] = out[1] = out[2] = out[3] = out[4] = 0;
+  if (d->rows > kMaxRows || d->k_splits != 0 || d->split_acc) return decode_gemm_plan(d, out);
+  if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
+  out[0] = 2;
+  return MXVL_OK;
+}
 
 int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;

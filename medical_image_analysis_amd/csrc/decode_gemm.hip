@@ -74,40 +74,46 @@ static int launch_wide(const DecodeGemmArgs& a, int splits, hipStream_t s) {
 
 static int g_decode_gemm_wide = 1;        // mxvl_set_decode_gemm_wide: the A/B switch of tools / bench (default on; 2: also at 17..32 rows)
 
+// The wide kernel's plan for a launch, or false: the K-split kernels keep it.  Shared by the launch below and by mxvl_decode_gemm_plan
+// (the dispatch as a pure function of the descriptor: tests/test_abi.py pins it for the reference's decoder shapes without a GPU).
+// What bounds these launches is what ONE CU can pull through its load path, weights and activations together (~50 GB/s of
+// full-line LDS-DMA, tools/cu_stream_probe.hip -- HBM needs 27 GB/s from each of 256 CUs): a workgroup of NW waves x R tiles
+// moves 1 + MT / (NW R) bytes per weight byte, and the launch is as long as its busiest CU.  So: the (NW, R) with the least
+//   (1 + MT / (NW R)) x rounds / workgroups,      rounds = ceil(workgroups / 256)   (the LDS ring leaves one workgroup per CU)
+// -- three waves per workgroup when that fills the chip: 230 workgroups for Llama's gate / up (172 with four waves), 256 for qkv (192).
+// From 17 rows and 64 workgroups on (profiles/r05_decode_gemm_wide_rows_ab.txt: against the K-split kernels the 18-row token
+// +7 %, the 24-row token +11 %, Qwen1.5-1.8B's 96..128-workgroup projections +4 % at 80 rows; the first version -- 3-stage
+// ring, aligned walks -- had lost to them below 160 workgroups and at 17..32 rows).  At 1..16 rows the K-split kernel keeps the
+// launches: it carries the fused RMSNorm, and without it the wide kernel is +2 % (Llama) / 0 % (Qwen) there.
+struct WidePlan { int nw, r; long g; };
+static bool wide_plan(int MT, const DecodeGemmArgs& a, int splits, WidePlan& pl) {
+  if (!(g_decode_gemm_wide && MT >= g_wide_min_mt && a.K % 64 == 0 && a.K >= 256 && !a.g)) return false;
+  pl = WidePlan{0, 0, 0};
+  double best = 1e30;
+  for (int nw : {4, 3}) {
+    if (nw == 3 && g_wide_nw4) continue;
+    for (int r : {1, 2, 4}) {
+      if (a.swiglu && (r & 1)) continue;
+      if (nw == 3 && r == 4) continue;
+      const int cols = nw * (a.swiglu ? r / 2 : r) * 16;
+      const long g = (long)((a.N + cols - 1) / cols) * splits;
+      const double est = (1.0 + (double)MT / (nw * r)) * (double)((g + 255) / 256) / (double)g;
+      if (est < best - 1e-12) { best = est; pl = WidePlan{nw, r, g}; }
+    }
+  }
+  return pl.g >= g_wide_min_g;
+}
+
 template <typename E, int MT>
 static int launch_decode_gemm(const DecodeGemmArgs& a, int splits, hipStream_t s) {
   {
-    if (g_decode_gemm_wide && MT >= g_wide_min_mt && a.K % 64 == 0 && a.K >= 256 && !a.g) {
-      // What bounds these launches is what ONE CU can pull through its load path, weights and activations together (~50 GB/s of
-      // full-line LDS-DMA, tools/cu_stream_probe.hip -- HBM needs 27 GB/s from each of 256 CUs): a workgroup of NW waves x R tiles
-      // moves 1 + MT / (NW R) bytes per weight byte, and the launch is as long as its busiest CU.  So: the (NW, R) with the least
-      //   (1 + MT / (NW R)) x rounds / workgroups,      rounds = ceil(workgroups / 256)   (the LDS ring leaves one workgroup per CU)
-      // -- three waves per workgroup when that fills the chip: 230 workgroups for Llama's gate / up (172 with four waves), 256 for qkv (192).
-      // From 17 rows and 64 workgroups on (profiles/r05_decode_gemm_wide_rows_ab.txt: against the K-split kernels the 18-row token
-      // +7 %, the 24-row token +11 %, Qwen1.5-1.8B's 96..128-workgroup projections +4 % at 80 rows; the first version -- 3-stage
-      // ring, aligned walks -- had lost to them below 160 workgroups and at 17..32 rows).  At 1..16 rows the K-split kernel keeps the
-      // launches: it carries the fused RMSNorm, and without it the wide kernel is +2 % (Llama) / 0 % (Qwen) there.
-      int best_nw = 0, best_r = 0;
-      long best_g = 0;
-      double best = 1e30;
-      for (int nw : {4, 3}) {
-        if (nw == 3 && g_wide_nw4) continue;
-        for (int r : {1, 2, 4}) {
-          if (a.swiglu && (r & 1)) continue;
-          if (nw == 3 && r == 4) continue;
-          const int cols = nw * (a.swiglu ? r / 2 : r) * 16;
-          const long g = (long)((a.N + cols - 1) / cols) * splits;
-          const double est = (1.0 + (double)MT / (nw * r)) * (double)((g + 255) / 256) / (double)g;
-          if (est < best - 1e-12) { best = est; best_nw = nw; best_r = r; best_g = g; }
-        }
-      }
-      if (best_g >= g_wide_min_g) {
-        if (best_nw == 3) return best_r == 2 ? launch_wide<E, MT, 2, 3>(a, splits, s) : launch_wide<E, MT, 1, 3>(a, splits, s);
-        switch (best_r) {
-          case 4: return launch_wide<E, MT, 4>(a, splits, s);
-          case 2: return launch_wide<E, MT, 2>(a, splits, s);
-          default: return launch_wide<E, MT, 1>(a, splits, s);
-        }
+    WidePlan pl;
+    if (wide_plan(MT, a, splits, pl)) {
+      if (pl.nw == 3) return pl.r == 2 ? launch_wide<E, MT, 2, 3>(a, splits, s) : launch_wide<E, MT, 1, 3>(a, splits, s);
+      switch (pl.r) {
+        case 4: return launch_wide<E, MT, 4>(a, splits, s);
+        case 2: return launch_wide<E, MT, 2>(a, splits, s);
+        default: return launch_wide<E, MT, 1>(a, splits, s);
       }
     }
   }
@@ -153,28 +159,62 @@ static int launch_decode_gemm_rows(const DecodeGemmArgs& a, int splits, hipStrea
   }
 }
 
+static int decode_gemm_args(const mxvl_gemv_desc* d, DecodeGemmArgs& a, int& splits);
+
 int decode_gemm_dispatch(const mxvl_gemv_desc* d, hipStream_t s) {
+  DecodeGemmArgs a;
+  int splits = 1;
+  const int chk = decode_gemm_args(d, a, splits);
+  if (chk != MXVL_OK) return chk;
+  const int rc = decode_dtype(d->dtype) == MXVL_F16 ? launch_decode_gemm_rows<EltF16>(a, splits, s) : launch_decode_gemm_rows<EltBf16>(a, splits, s);
+  if (rc != MXVL_OK) return rc;
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}
+
+// the wide kernel's ring depth for a plan, as launch_wide picks it
+static int wide_plan_pf(int MT, const WidePlan& pl) {
+  if (pl.nw == 4 && g_wide_pf3) return 3;
+  int pf = 2;
+  for (int mt = 1; mt <= 5; ++mt) for (int r : {1, 2, 4}) for (int nw : {3, 4}) if (mt == MT && r == pl.r && nw == pl.nw) pf = wide_pf(mt, r, nw);
+  return pf;
+}
+
+int decode_gemm_plan(const mxvl_gemv_desc* d, int32_t* out) {
+  DecodeGemmArgs a;
+  int splits = 1;
+  const int chk = decode_gemm_args(d, a, splits);
+  if (chk != MXVL_OK) return chk;
+  const int MT = (a.rows + 15) / 16 > 5 ? 5 : (a.rows + 15) / 16;
+  WidePlan pl;
+  const bool wide = wide_plan(MT, a, splits, pl);
+  out[0] = wide ? 1 : 0;
+  out[1] = wide ? pl.nw : 0;
+  out[2] = wide ? pl.r : 0;
+  out[3] = wide ? wide_plan_pf(MT, pl) : 0;
+  out[4] = wide ? (int32_t)pl.g : 0;
+  return MXVL_OK;
+}
+
+// argument checks of mxvl_decode_gemv + the kernel-side argument block (nothing is launched here)
+static int decode_gemm_args(const mxvl_gemv_desc* d, DecodeGemmArgs& a, int& splits) {
   if (d->rows <= 0 || d->rows > 80 || d->K < 32 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;                      // 16-byte fragments
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
   // RMSNorm fused into the projection (ABI v8): the LDS-DMA kernel only (K % 64 == 0); elsewhere rows come from mxvl_decode_rmsnorm
   if (d->norm_weight && (d->K % 64 != 0 || d->K < 256 || d->split_acc)) return MXVL_ERR_UNSUPPORTED;
   if ((long long)d->N * d->K > 0x7fffffffLL * 16) return MXVL_ERR_SHAPE;
-  DecodeGemmArgs a;
   a.rows = d->rows; a.K = d->K; a.N = d->N; a.swiglu = d->swiglu; a.out_f32 = d->out_f32;
   a.x = (const uint16_t*)d->x; a.W = (const uint16_t*)d->W; a.W2 = (const uint16_t*)d->W2;
   a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
   a.split_acc = (float*)d->split_acc;
   a.g = (const uint16_t*)d->norm_weight; a.eps = d->eps;
-  int splits = 1;
+  splits = 1;
   if (!a.split_acc && d->k_splits > 1) return MXVL_ERR_UNSUPPORTED;    // a split needs the accumulator
   if (a.split_acc) {        // the caller folds the fp32 sums itself (mxvl_decode_rmsnorm): no epilogue here
     if (d->swiglu || d->bias || d->residual || d->out_f32 || d->k_splits < 1 || d->k_splits > 16) return MXVL_ERR_UNSUPPORTED;
     splits = d->k_splits;
   }
-  const int rc = decode_dtype(d->dtype) == MXVL_F16 ? launch_decode_gemm_rows<EltF16>(a, splits, s) : launch_decode_gemm_rows<EltBf16>(a, splits, s);
-  if (rc != MXVL_OK) return rc;
-  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+  return MXVL_OK;
 }
 
 }  // namespace mxvl

@@ -102,3 +102,55 @@ def test_k_split_plan_of_the_residual_projections():
     assert ks(4096, 4096, 18) == 4 and ks(4096, 11008, 80) == 4
     assert ks(2048, 2048, 80) == 2 and ks(2048, 5504, 80) == 4
     assert ks(16384, 4096, 18) == 1 and ks(4096, 256, 18) == 1
+
+
+def _plan(rows, K, N, swiglu=False, splits=0, norm=False):
+    lib = _abi.load()
+    d = _abi.GemvDesc()
+    d.x = d.W = d.y = 64                                    # fake non-null pointers, never dereferenced: nothing is launched
+    d.rows, d.K, d.N, d.swiglu = rows, K, N, int(swiglu)
+    if swiglu:
+        d.W2 = 64
+    if splits:
+        d.k_splits = splits
+        if splits > 1:
+            d.split_acc = 64
+    if norm:
+        d.norm_weight = 64
+    out = (ctypes.c_int32 * 5)()
+    assert lib.mxvl_decode_gemm_plan(ctypes.byref(d), out) == 0
+    return tuple(out)
+
+
+def test_decode_projection_dispatch_for_the_reference_decoder_shapes():
+    """mxvl_decode_gemm_plan = the dispatch of mxvl_decode_gemv as a pure function (csrc/decode_gemm.hip wide_plan), at the shapes the
+    reference decodes with: Llama-2-7B (hidden 4096, intermediate 11008, vocabulary 32000) and Qwen1.5-1.8B (2048 / 5504 / 151936) at
+    val 6 x beam 3 = 18, config default 16 x 3 = 48 and IU test 16 x beam 5 = 80 rows.  (kind, waves, tiles per wave, ring stages, workgroups)"""
+    # 80 rows: three waves per workgroup where that fills the 256 CUs
+    assert _plan(80, 4096, 12288, splits=1) == (1, 3, 1, 8, 256)                 # q|k|v: 768 column tiles
+    assert _plan(80, 4096, 11008, swiglu=True, splits=1) == (1, 3, 2, 6, 230)     # gate + up: 688 pairs of tiles
+    assert _plan(80, 4096, 32000, splits=1) == (1, 4, 2, 5, 250)                 # lm_head
+    assert _plan(80, 4096, 4096, splits=4) == (1, 4, 1, 8, 256)                  # o_proj: 4 K planes x 64 column groups
+    assert _plan(80, 11008, 4096, splits=4) == (1, 4, 1, 8, 256)                 # down_proj
+    # 18 and 48 rows take the same kernel since the wide kernel was re-tuned (ring depth by LDS: more stages with fewer row tiles)
+    assert _plan(18, 4096, 12288, splits=1) == (1, 3, 1, 8, 256)
+    assert _plan(18, 4096, 11008, swiglu=True, splits=1) == (1, 3, 2, 8, 230)
+    assert _plan(48, 4096, 11008, swiglu=True, splits=1) == (1, 3, 2, 8, 230)
+    # Qwen1.5-1.8B at 80 rows: 96..128-workgroup grids stay on the wide kernel (>= 64), lm_head's 594 workgroups take four tiles per wave
+    assert _plan(80, 2048, 6144, splits=1)[:3] == (1, 3, 1) and _plan(80, 2048, 6144, splits=1)[4] == 128
+    assert _plan(80, 2048, 151936, splits=1) == (1, 4, 4, 3, 594)
+    # <= 16 rows: the K-split kernels (they carry the fused RMSNorm); <= 8 rows without a request for the matrix cores: the per-row GEMV
+    assert _plan(3, 4096, 12288, splits=1, norm=True)[0] == 0
+    assert _plan(16, 4096, 12288, splits=1)[0] == 0
+    assert _plan(3, 4096, 12288)[0] == 2
+    # grids below 64 workgroups and K that is not a multiple of 64 stay on the K-split kernels
+    assert _plan(80, 2048, 520, splits=1)[0] == 0 and _plan(80, 1408, 12288, splits=1)[0] == 1 and _plan(80, 72, 12288, splits=1)[0] == 0
+    # the A/B modes move the dispatch, the default comes back
+    lib = _abi.load()
+    assert lib.mxvl_set_decode_gemm_wide(0) == 1
+    assert _plan(80, 4096, 12288, splits=1)[0] == 0
+    assert lib.mxvl_set_decode_gemm_wide(4) == 0
+    assert _plan(80, 4096, 12288, splits=1) == (1, 4, 1, 8, 192)
+    assert lib.mxvl_set_decode_gemm_wide(5) == 4
+    assert _plan(18, 4096, 12288, splits=1)[0] == 0
+    assert lib.mxvl_set_decode_gemm_wide(1) == 5
