@@ -88,9 +88,11 @@ def test_decode_projection_descriptor_validation_and_switch_without_gpu():
     assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # no SwiGLU epilogue on partial sums
     d.swiglu, d.W2, d.norm_weight = 0, None, 64
     assert lib.mxvl_decode_gemv(ctypes.byref(d), None) != 0                       # no fused norm on partial sums
-    assert lib.mxvl_set_decode_gemm_wide(0) == 1                                  # the default mode is 1
-    assert lib.mxvl_set_decode_gemm_wide(5) == 0
-    assert lib.mxvl_set_decode_gemm_wide(1) == 5
+    try:
+        assert lib.mxvl_set_decode_gemm_wide(0) == 1                              # the default mode is 1
+        assert lib.mxvl_set_decode_gemm_wide(5) == 0
+    finally:
+        lib.mxvl_set_decode_gemm_wide(1)
 
 
 def test_k_split_plan_of_the_residual_projections():
@@ -147,10 +149,13 @@ def test_decode_projection_dispatch_for_the_reference_decoder_shapes():
     assert _plan(80, 2048, 520, splits=1)[0] == 0 and _plan(80, 1408, 12288, splits=1)[0] == 1 and _plan(80, 72, 12288, splits=1)[0] == 0
     # the A/B modes move the dispatch, the default comes back
     lib = _abi.load()
-    assert lib.mxvl_set_decode_gemm_wide(0) == 1
-    assert _plan(80, 4096, 12288, splits=1)[0] == 0
-    assert lib.mxvl_set_decode_gemm_wide(4) == 0
-    assert _plan(80, 4096, 12288, splits=1) == (1, 4, 1, 8, 192)
-    assert lib.mxvl_set_decode_gemm_wide(5) == 4
-    assert _plan(18, 4096, 12288, splits=1)[0] == 0
-    assert lib.mxvl_set_decode_gemm_wide(1) == 5
+    try:
+        assert lib.mxvl_set_decode_gemm_wide(0) == 1
+        assert _plan(80, 4096, 12288, splits=1)[0] == 0
+        assert lib.mxvl_set_decode_gemm_wide(4) == 0
+        assert _plan(80, 4096, 12288, splits=1) == (1, 4, 1, 8, 192)
+        assert lib.mxvl_set_decode_gemm_wide(5) == 4
+        assert _plan(18, 4096, 12288, splits=1)[0] == 0
+    finally:
+        lib.mxvl_set_decode_gemm_wide(1)
+    assert lib.mxvl_set_decode_gemm_wide(1) == 1
