@@ -863,7 +863,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
     ap.add_argument("--secondary-warmup", type=int, default=8,
                     help="untimed generate() calls of the decode leg: it starts on a chip the training leg has just driven at its power limit, and "
-                         "the first ~3 s of (memory-bound) decoding run 3 % below the standalone decode line until the clocks recover -- "
+                         "the first ~3 s of (memory-bound) decoding run 3 %% below the standalone decode line until the clocks recover -- "
                          "profiles/r05_secondary_warmup.txt: 350.8 tok/s with 1 warm-up call, 354.2 with 3, 361.2 after 3 s idle, 359.3 standalone")
     ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
                     help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")

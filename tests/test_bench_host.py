@@ -2,6 +2,7 @@
 PMC traffic record bench.py reports as roofline.traffic.  No GPU."""
 import json
 import os
+import sys
 
 import bench
 from medical_image_analysis_amd.selective_scan_interface import scan_algorithmic_bytes
@@ -51,3 +52,10 @@ def test_decode_cpu_baseline_runs_on_a_tiny_workload(monkeypatch):
         torch.set_num_threads(threads)
     assert rec["unit"] == "tokens/sec" and rec["kind"] == "port" and rec["value"] > 0 and rec["cores"] >= 1
     assert "2- and 6-layer" in rec["sample"] and "8 x" in rec["sample"]
+
+
+def test_bench_help_renders():
+    """`python bench.py --help` (argparse expands `%` in help strings: an unescaped one made the command raise)"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--workload" in r.stdout and "--decode-gemm" in r.stdout, r.stderr[-500:]
