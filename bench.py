@@ -574,8 +574,8 @@ def run_finetune(args, rank, world, dev, dist):
     n_llm = sum(p.numel() for p in model.llama_model.parameters())
     net = model
     if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(model, device_ids=[dev.index], bucket_cap_mb=256, gradient_as_bucket_view=True)
+        from medical_image_analysis_amd.pretrain_engine import wrap_ddp
+        net = wrap_ddp(model, dev)        # trainable parameters only; find_unused_parameters from the model's own flag
     opt = torch.optim.AdamW(trainable, lr=1e-4, fused=True)
     batches = [{"id": [f"s{i}" for i in range(B)], "image": [torch.randn(B, 3, 224, 224, generator=g).to(dev)], "input_text": texts} for _ in range(2)]
 

@@ -2,11 +2,16 @@
 
     python -m medical_image_analysis_amd.build [--force] [--verbose]
 
-hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot; the objects
+(build/obj/*.o) do not (.gpurunignore).  Staleness is decided by CONTENT, not by mtime: every object carries the sha256 of its
+source + every header + the compile line (build/obj/<name>.o.sha256), the library the sha256 of all of that
+(libmxvl.so.sha256) -- a snapshot copy, a checkout or a touched file neither forces nor hides a rebuild.  `build()` reports what
+it did in `LAST_BUILD` ("up to date" / the objects it recompiled); MXVL_BUILD_FORCE=1 or --force recompiles everything.
 """
 from __future__ import annotations
 
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,11 +27,41 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
+OBJ_DIR = os.path.join(PKG, "build", "obj")
+LAST_BUILD = {"state": "not run", "compiled": []}
+
+
+def headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
+def _digest(paths, extra=()) -> str:
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def source_digest() -> str:
+    """sha256 over every .hip, every header and the compile line: the identity of a libmxvl.so build."""
+    return _digest(sources() + headers(), FLAGS)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    return not os.path.exists(LIB) or _read(LIB + ".sha256") != source_digest()
 
 
 ABLATE_LIB = os.path.join(PKG, "build", "libmxvl_ablate.so")
@@ -37,31 +72,37 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     MXVL_*_ABLATE / MXVL_BWD_WAVES environment switches; the product library has none of that code (mxvl_common.h)."""
     if ablate:
         return _build_ablate(verbose)
+    force = force or os.environ.get("MXVL_BUILD_FORCE") == "1"
     if not force and not _stale():
+        LAST_BUILD.update(state="up to date (content hash matches)", compiled=[])
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = headers()
     for src in sources():
-        obj = os.path.join(PKG, "build", os.path.basename(src).replace(".hip", ".o"))
+        obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                [os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))]
-                + [os.path.getmtime(h) for h in glob.glob(os.path.join(ROOT, "include", "*.h"))]):
+        want = _digest([src] + hdrs, FLAGS)
+        if not force and os.path.exists(obj) and _read(obj + ".sha256") == want:
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, obj, want, subprocess.Popen(cmd)))
+    for src, obj, want, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
+        with open(obj + ".sha256", "w") as f:
+            f.write(want + "\n")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(LIB + ".sha256", "w") as f:
+        f.write(source_digest() + "\n")
+    LAST_BUILD.update(state="forced rebuild" if force else "rebuilt", compiled=[os.path.basename(t[0]) for t in procs])
     return LIB
 
 
@@ -78,13 +119,12 @@ def build_exp(exp: int, files=("scan_fwd.hip", "scan_bwd.hip"), verbose: bool = 
         base = os.path.basename(src)
         if base in files:
             obj = os.path.join(out_dir, base.replace(".hip", ".o"))
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
-                   f"-DMXVL_EXP={exp}", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + [f"-DMXVL_EXP={exp}", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))
         else:
-            obj = os.path.join(PKG, "build", base.replace(".hip", ".o"))
+            obj = os.path.join(OBJ_DIR, base.replace(".hip", ".o"))
         objs.append(obj)
     for src, p in procs:
         if p.wait() != 0:
@@ -97,8 +137,7 @@ def build_exp(exp: int, files=("scan_fwd.hip", "scan_bwd.hip"), verbose: bool = 
 def _build_ablate(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics",
-           "-DMXVL_ABLATE", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-shared", "-o", ABLATE_LIB] + sources()
+    cmd = [hipcc] + FLAGS + ["-DMXVL_ABLATE", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-shared", "-o", ABLATE_LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -110,3 +149,4 @@ if __name__ == "__main__":
         print(build_exp(int(sys.argv[sys.argv.index("--exp") + 1]), verbose="--verbose" in sys.argv))
         sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate="--ablate" in sys.argv))
+    print(LAST_BUILD["state"], LAST_BUILD["compiled"])

@@ -151,6 +151,10 @@ class SmallPatchEmbed(nn.Module):
 
 
 class MaskedAutoencoderViT(nn.Module):
+    # `decoder_image` never receives a gradient: the reference wraps this model with DDP(find_unused_parameters=True,
+    # broadcast_buffers=False) (HD_Xray_Pretrain_MAE/pretrain/main.py:183); PretrainEngine reads this flag for the same wrapping
+    ddp_find_unused_parameters = True
+
     def __init__(self, img_size=1280, patch_size=64, in_chans=1, embed_dim=768, depth=12, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=nn.LayerNorm,
                  norm_pix_loss=False, mask_ratio=0.75, use_learnable_pos_emb=True, new_depth=6):

@@ -6,10 +6,17 @@ Host-side mirror of the reference's hand-rolled loop:
   CXPMRG_Bench_MambaXray_VL/pretrain/engine_pretrain.py:37-62  autocast(bf16) forward -> loss.mean() -> backward ->
                                                                clip_grad_norm_(3.0) -> step -> all_reduce_mean(loss)
   CXPMRG_Bench_MambaXray_VL/pretrain/utils/misc.py:211-233     env:// NCCL(=RCCL) init
-bf16 autocast needs no loss scaling, so the reference's GradScaler (misc.py:236-256) is an identity there and is
-not instantiated; gradients stay fp32 (params are fp32 under autocast) exactly as in the reference.  The ViT-MAE stage
-(HD_Xray_Pretrain_MAE/pretrain/main.py:211-213,317) trains under fp16 autocast WITH the scaler: amp_dtype=torch.float16
-instantiates it (scale -> backward -> unscale_ -> clip -> step -> update, misc.py NativeScalerWithGradNormCount).
+The reference runs its GradScaler (misc.py:236-256 NativeScalerWithGradNormCount: scale -> backward -> unscale_ -> clip ->
+step -> update) on EVERY step, also under bf16 autocast where no scaling is needed (engine_pretrain.py:40,49-50) -- so does
+this engine on a GPU by default (`use_scaler=None`): the same inf / nan skip of the optimizer step, the same scale state in the
+checkpoint (`checkpoint_state()["scaler"]`, misc.py:286-292), the same extra pass over the gradients in the timed step.  With
+finite gradients the scaled step equals the unscaled one up to the power-of-two scaling of the backward (tests/test_engine_cpu.py).
+`use_scaler=False` is the plain bf16 step.  The ViT-MAE stage (HD_Xray_Pretrain_MAE/pretrain/main.py:211-213,317) trains under
+fp16 autocast, where the scaler is needed: amp_dtype=torch.float16 always has one.  Gradients stay fp32 (params are fp32
+under autocast) exactly as in the reference.
+DDP wrapping follows the two call sites: main_pretrain.py:167-169 (plain) and HD_Xray_Pretrain_MAE/pretrain/main.py:183
+(`broadcast_buffers=False, find_unused_parameters=True`: MaskedAutoencoderViT.decoder_image never sees a gradient) -- a model
+says so through `ddp_find_unused_parameters = True` (mae.MaskedAutoencoderViT does) or the caller through the argument.
 Gradient accumulation and the per-iteration schedule of engine_pretrain.py:28-52 / utils/lr_sched.py are part of step():
 accum_iter micro-batches per optimizer update (loss / accum_iter, DDP no_sync() on the micro-steps that do not update),
 half-cycle cosine with linear warm-up evaluated at data_iter_step / iters_per_epoch + epoch on every update boundary.
@@ -64,6 +71,23 @@ def init_distributed(backend: str | None = None):
     return rank, world, local_rank
 
 
+def wrap_ddp(model: nn.Module, device=None, bucket_cap_mb: float = 256, find_unused_parameters: bool | None = None):
+    """DistributedDataParallel the way this package's steps use it (one process per GPU, RCCL over xGMI): 256 MiB buckets,
+    gradients as bucket views, no buffer broadcasts (main.py:183), `find_unused_parameters` from the argument or from any
+    sub-module's `ddp_find_unused_parameters` flag.  Parameters that do not require a gradient (the frozen LLM / encoder of the
+    fine-tuning stages: 13.5 GB for Llama-2-7B) are left out of DDP altogether -- no rank-0 broadcast of them at construction;
+    every rank builds them from the same seed or checkpoint, as the reference's Lightning strategies assume too."""
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    if find_unused_parameters is None:
+        find_unused_parameters = any(getattr(m, "ddp_find_unused_parameters", False) for m in model.modules())
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    if frozen:
+        model._ddp_params_and_buffers_to_ignore = list(getattr(model, "_ddp_params_and_buffers_to_ignore", [])) + frozen
+    return nn.parallel.DistributedDataParallel(model, device_ids=[torch.device(device).index] if on_gpu else None,
+                                               bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, broadcast_buffers=False,
+                                               find_unused_parameters=bool(find_unused_parameters))
+
+
 def param_groups_weight_decay(model: nn.Module, weight_decay: float = 0.05, skip=()):
     """timm.optim.optim_factory.add_weight_decay: 1-D tensors, biases and `skip` names get no decay."""
     decay, no_decay = [], []
@@ -95,9 +119,12 @@ class PretrainEngine:
 
     def __init__(self, model: nn.Module, lr: float = 1.5e-4, weight_decay: float = 0.05, clip_grad: float | None = 3.0,
                  amp_dtype: torch.dtype | None = torch.bfloat16, bucket_cap_mb: int = 256, device=None, accum_iter: int = 1,
-                 schedule: dict | None = None, iters_per_epoch: int | None = None):
+                 schedule: dict | None = None, iters_per_epoch: int | None = None, use_scaler: bool | None = None,
+                 find_unused_parameters: bool | None = None):
         """schedule = dict(min_lr=, warmup_epochs=, epochs=) switches the per-iteration cosine schedule on (peak = lr); it needs
-        iters_per_epoch = len(data_loader).  accum_iter micro-batches feed one optimizer update."""
+        iters_per_epoch = len(data_loader).  accum_iter micro-batches feed one optimizer update.
+        use_scaler: None = the reference's recipe (a GradScaler whenever the step autocasts on a GPU, and for fp16 anywhere).
+        find_unused_parameters: None = any(m.ddp_find_unused_parameters for m in model.modules())."""
         self.device = device
         self.accum_iter, self.lr, self.schedule, self.iters_per_epoch = int(accum_iter), lr, schedule, iters_per_epoch
         if schedule is not None and not iters_per_epoch:
@@ -105,8 +132,11 @@ class PretrainEngine:
         self.data_iter_step = 0
         self._epoch = 0
         on_gpu = device is not None and torch.device(device).type == "cuda"
-        # fp16 autocast trains with dynamic loss scaling (MAE: main.py:317 NativeScaler); bf16 / fp32 never needed one
-        self.scaler = torch.amp.GradScaler("cuda" if on_gpu else "cpu") if amp_dtype == torch.float16 else None
+        # fp16 autocast needs dynamic loss scaling (MAE: main.py:317 NativeScaler); the stage-1 loop runs the same scaler under
+        # bf16 (engine_pretrain.py:49-50): the default follows it on a GPU, the CPU test models stay on the plain step
+        if use_scaler is None:
+            use_scaler = amp_dtype == torch.float16 or (on_gpu and amp_dtype == torch.bfloat16)
+        self.scaler = torch.amp.GradScaler("cuda" if on_gpu else "cpu") if use_scaler else None
         self.tuned_gemms = enable_tuned_gemms() if (device is not None and torch.device(device).type == "cuda") else False
         self.amp_dtype = amp_dtype
         self.clip_grad = clip_grad
@@ -118,9 +148,8 @@ class PretrainEngine:
         self._cast_params = [p for p in model.parameters() if p.requires_grad and p.ndim >= 1 and p.is_floating_point() and p.is_cuda]
         self._cast_shadow = None
         if self.world > 1:
-            ids = [torch.device(device).index] if (device is not None and torch.device(device).type == "cuda") else None
-            self.model = nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
-                                                             gradient_as_bucket_view=True, broadcast_buffers=False)
+            self.model = wrap_ddp(model, device, bucket_cap_mb, find_unused_parameters)
+            self.find_unused_parameters = self.model.find_unused_parameters
         else:
             self.model = model
 
@@ -153,9 +182,8 @@ class PretrainEngine:
         an accumulation window also clip, optimizer step and zero_grad.  Returns misc.all_reduce_mean(loss) of this micro-batch."""
         dev_type = imgs.device.type
         if epoch != self._epoch:          # a caller that passes `epoch` without start_epoch(): the per-epoch iteration restarts with it
-            self._epoch = epoch
-            if self.iters_per_epoch and self.data_iter_step >= self.iters_per_epoch:
-                self.data_iter_step = 0
+            self._epoch = epoch           # (unconditionally: an epoch that ended early -- shorter loader, drop_last -- must not carry its
+            self.data_iter_step = 0       # counter into the next one's schedule and accumulation window)
         it, acc = self.data_iter_step, self.accum_iter
         if self.schedule is not None and it % acc == 0:
             adjust_learning_rate(self.optimizer, it / self.iters_per_epoch + epoch, self.lr, **self.schedule)
@@ -196,6 +224,25 @@ class PretrainEngine:
         self.last_local_loss = loss.detach()
         self.data_iter_step = it + 1
         return reduced
+
+    def checkpoint_state(self, epoch: int | None = None) -> dict:
+        """misc.save_model's dictionary (misc.py:286-292): 'model' (without the DDP prefix), 'optimizer', 'epoch', 'scaler'."""
+        out = {"model": self.raw_model.state_dict(), "optimizer": self.optimizer.state_dict(),
+               "epoch": self._epoch if epoch is None else epoch}
+        if self.scaler is not None:
+            out["scaler"] = self.scaler.state_dict()
+        return out
+
+    def load_checkpoint_state(self, state: dict) -> None:
+        """misc.load_model (misc.py:323-340): model, then optimizer + epoch + scaler when the file has them."""
+        self.raw_model.load_state_dict(state["model"])
+        self.drop_casts()
+        if "optimizer" in state:
+            self.optimizer.load_state_dict(state["optimizer"])
+        if "epoch" in state:
+            self._epoch = int(state["epoch"])
+        if self.scaler is not None and "scaler" in state:
+            self.scaler.load_state_dict(state["scaler"])
 
     def reduced_loss(self, loss: torch.Tensor) -> float:
         """step() already returns misc.all_reduce_mean(loss) (engine_pretrain.py:62); this is the host read of it."""

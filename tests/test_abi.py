@@ -159,3 +159,21 @@ def test_decode_projection_dispatch_for_the_reference_decoder_shapes():
     finally:
         lib.mxvl_set_decode_gemm_wide(1)
     assert lib.mxvl_set_decode_gemm_wide(1) == 1
+
+
+def test_build_staleness_is_a_content_hash_not_an_mtime(tmp_path):
+    """build.py decides by the sha256 of csrc/*.hip + every header + the compile line: touching a file changes
+    nothing, editing one byte of a header does; a built tree reports "up to date" without invoking hipcc."""
+    from medical_image_analysis_amd import build as b
+    a, h = tmp_path / "k.hip", tmp_path / "k.h"
+    a.write_text("__global__ void k() {}\n")
+    h.write_text("#define X 1\n")
+    d0 = b._digest([str(a), str(h)], b.FLAGS)
+    os.utime(a, (1, 1))
+    assert b._digest([str(a), str(h)], b.FLAGS) == d0
+    assert b._digest([str(a), str(h)], b.FLAGS + ["-DY"]) != d0
+    h.write_text("#define X 2\n")
+    assert b._digest([str(a), str(h)], b.FLAGS) != d0
+    _abi.load()                                     # the library exists (conftest / the driver's build())
+    assert not b._stale() and open(b.LIB + ".sha256").read().strip() == b.source_digest()
+    assert b.build() == b.LIB and b.LAST_BUILD["state"].startswith("up to date") and b.LAST_BUILD["compiled"] == []
