@@ -47,6 +47,25 @@ def _digest(paths, extra=()) -> str:
     return h.hexdigest()
 
 
+def local_includes(src: str) -> list:
+    """Transitive `#include "x.h"` closure of one source over csrc/ and include/ (what its object really depends on)."""
+    import re
+    seen, todo = [], [src]
+    while todo:
+        path = todo.pop()
+        with open(path) as f:
+            text = f.read()
+        for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, re.M):
+            for base in (os.path.dirname(path), CSRC, os.path.join(ROOT, "include")):
+                cand = os.path.normpath(os.path.join(base, name))
+                if os.path.exists(cand):
+                    if cand not in seen:
+                        seen.append(cand)
+                        todo.append(cand)
+                    break
+    return sorted(seen)
+
+
 def source_digest() -> str:
     """sha256 over every .hip, every header and the compile line: the identity of a libmxvl.so build."""
     return _digest(sources() + headers(), FLAGS)
@@ -80,11 +99,10 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     objs = []
     procs = []
     os.makedirs(OBJ_DIR, exist_ok=True)
-    hdrs = headers()
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
-        want = _digest([src] + hdrs, FLAGS)
+        want = _digest([src] + local_includes(src), FLAGS)
         if not force and os.path.exists(obj) and _read(obj + ".sha256") == want:
             continue
         cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]

@@ -384,11 +384,13 @@ static int launch_fwd(const ScanArgs& a, hipStream_t stream, const char* name) {
   return MXVL_OK;
 }
 
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T, int NS, bool FOLD = false>
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T, int NS, bool FOLD = false, bool PK = false>
 static int launch_stream1(const ScanArgs& a, hipStream_t stream, const char* name) {
   constexpr int CH = 128, DT = NWAVES * (64 / (CH / T));
-  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + (size_t)2 * (DT + 1) * (a.N + 1) + NWAVES * 64 + 2 * a.N);
-  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T, NS, FOLD>;
+  // PK: sA [DT][18] + sH [DT + 1][18] + a dump pair per thread in the place of the float2 table (scan_fwd_stream.h)
+  const size_t tail = PK ? (size_t)(2 * DT + 1) * 18 + 2 * NWAVES * 64 + a.N : (size_t)2 * (DT + 1) * (a.N + 1) + NWAVES * 64 + 2 * a.N;
+  const size_t lds = sizeof(float) * ((size_t)4 * a.N * CH + (size_t)DT * CH + tail);
+  auto kern = scan_fwd_stream_kernel<io_t, NWAVES, VEC, MINW, T, NS, FOLD, PK>;
   const int dpg = a.dim / a.G;
   dim3 grid(a.G * ((dpg + DT - 1) / DT), FOLD ? (a.batch + a.fold_bpp - 1) / a.fold_bpp : a.batch), block(NWAVES * 64);
   hipLaunchKernelGGL(kern, grid, block, lds, stream, a);
@@ -406,6 +408,9 @@ static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name
 #define MXVL_STREAM_CASE(NW, MW) \
   (a.vec_ok ? launch_stream<io_t, NW, true, MW>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ">") \
             : launch_stream<io_t, NW, false, MW>(a, stream, "scan_fwd_stream<W" #NW ",scalar,occ" #MW ">"))
+// state pairs in packed fp32 (scan_fwd_stream.h, PK): dstate 16, aligned rows
+#define MXVL_STREAM_PK(NW, MW) \
+  launch_stream1<io_t, NW, true, MW, 8, 16, false, true>(a, stream, "scan_fwd_stream<W" #NW ",vec,occ" #MW ",pk>")
 #define MXVL_FWD_CASE(T, LPR, NW, NU) \
   launch_fwd<io_t, T, LPR, NW, NU>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ">")
 #define MXVL_FWD_CASE_OCC(T, LPR, NW, NU, MW) \
@@ -419,6 +424,11 @@ static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
       if (bs >= (1ll << 32)) return MXVL_ERR_UNSUPPORTED;    // seg_off: 32-bit batch strides
     // the same workgroup-shape rule as the plain launch, with (parts of the batch) in the place of (batch elements)
     const int64_t tiles8 = (int64_t)((a.batch + a.fold_bpp - 1) / a.fold_bpp) * a.G * ((a.dim / a.G + 31) / 32);
+    const int fv = g_variant & 0xff;
+    if (fv >= 15 && fv <= 18) {   // packed state pairs (A/B hook)
+      if (tiles8 >= 512) return launch_stream1<io_t, 8, true, 2, 8, 16, true, true>(a, stream, "scan_fwd_stream<W8,vec,occ2,fold,pk>");
+      return launch_stream1<io_t, 4, true, 2, 8, 16, true, true>(a, stream, "scan_fwd_stream<W4,vec,occ2,fold,pk>");
+    }
     if (tiles8 >= 512) return launch_stream1<io_t, 8, true, 3, 8, 16, true>(a, stream, "scan_fwd_stream<W8,vec,occ3,fold>");
     return launch_stream1<io_t, 4, true, 2, 8, 16, true>(a, stream, "scan_fwd_stream<W4,vec,occ2,fold>");
   }
@@ -439,6 +449,15 @@ static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
       }
     } else if (rows >= 1024 || a.L <= 256) v = 3;
     else v = 4;
+  }
+  if (a.N == 16 && a.vec_ok) {
+    switch (v) {
+      case 15: return MXVL_STREAM_PK(4, 2);
+      case 16: return MXVL_STREAM_PK(8, 3);
+      case 17: return MXVL_STREAM_PK(4, 3);
+      case 18: return MXVL_STREAM_PK(8, 2);
+      default: break;
+    }
   }
   if (a.N <= 16) {
     switch (v) {

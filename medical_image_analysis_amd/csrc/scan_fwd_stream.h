@@ -46,9 +46,21 @@ __device__ inline void scan8_x1(float& h0, float& P0, float& x0) {
 // lane product P as well -- which is exactly "state 0 enters the segment" (h = 0 * h_in + b).  L % 8 == 0, so a lane's 8 steps
 // and a staging quarter never straddle two segments; (b, l) of a step come from one multiply-high (fold_magic = 2^32 / L + 1).
 // Checkpoints are indexed by virtual chunk in the same buffer (batch * chunks(L) >= chunks(batch * L) entries per channel).
-template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0, bool FOLD = false>
+//
+// PK (round 6): the state loop walks state PAIRS (n, n + 1) in the two halves of 64-bit register pairs, so every fp32 multiply / FMA of
+// the recurrence -- delta_i * A, delta_i u_i * B_i, both Horner passes, the C_i h_i accumulation -- is ONE v_pk_mul_f32 / v_pk_fma_f32 for
+// two states (measured on this chip at 2 waves per SIMD: 4.5 cycles against 2 x 2.8, profiles/r01_ubench_valu_rates.txt); the v_exp_f32
+// and the DPP steps stay per state (no packed forms exist).  The same IEEE operations per state in the same order: h_t is bit-identical
+// to the unpacked kernel's; y sums the even and the odd states separately and adds the two halves at the end of the chunk.  For that the
+// B / C tile is stored pair-interleaved -- tile row p holds states (2p, 2p + 1): [4 blocks of 2 steps][LPR lanes][step s, state] so that
+// one ds_read_b128 yields (B_n[i], B_n+1[i], B_n[i+1], B_n+1[i+1]) -- and A * log2(e) and the running state live in two separate
+// [rows][N + 2] arrays (an (n, n + 1) pair is one aligned ds_read_b64 / ds_write_b64).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0, bool FOLD = false, bool PK = false>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {
   constexpr int CH = 128, LPR = CH / T, RPW = 64 / LPR, DT = NWAVES * RPW, NT = NWAVES * 64, NMAX = 16;
+  static_assert(!PK || (VEC && T == 8 && NS > 0 && NS % 2 == 0 && (NS * 32) % NT == 0), "PK: aligned rows, 16 lanes per row, even compile-time dstate");
   constexpr int TQ = T / 4;                           // 16-byte quarters per lane
   constexpr int BCV = (NMAX * CH / 4 + NT - 1) / NT;  // float4 per thread per array (VEC)
   constexpr int BCS = (NMAX * CH + NT - 1) / NT;      // floats per thread per array (scalar)
@@ -68,6 +80,11 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   // b32 accesses of the 4 rows of a wave (+ the zero row) were 2-3-way conflicts (half of SQ_LDS_BANK_CONFLICT)
   const int NP = N + 1;
   float* sDump = (float*)(sAC + (DT + 1) * NP);   // [NT + 2 N] write-only words of the lanes that do not own a state entry
+  // PK: the same region as sA [DT][SA] (A * log2 e), sH [DT + 1][SA] (running state; row DT stays zero), sDump2 [2 NT + N]
+  constexpr int SA = NMAX + 2;
+  float* sA = (float*)sAC;
+  float* sH = sA + DT * SA;
+  float* sDump2 = sH + (DT + 1) * SA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane / LPR, j = lane % LPR;
@@ -101,7 +118,13 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
   for (int i = tid; i < (DT + 1) * N; i += NT) {
     const int rr = i / N, n = i - rr * N;
     const int dd = d0 + rr;
-    sAC[rr * NP + n] = make_float2((rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f, 0.0f);
+    const float a2 = (rr < DT && dd < d_end) ? p.A[(int64_t)dd * p.A_ds + (int64_t)n * p.A_ns] * kLog2e : 0.0f;
+    if constexpr (PK) {
+      if (rr < DT) sA[rr * SA + n] = a2;
+      sH[rr * SA + n] = 0.0f;
+    } else {
+      sAC[rr * NP + n] = make_float2(a2, 0.0f);
+    }
   }
   const float bias = p.bias ? p.bias[dr] : 0.0f;
   const float Dv = p.D ? p.D[dc] : 0.0f;
@@ -126,7 +149,59 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     *(uint2*)t = r;
     return make_float4(io::ld(t), io::ld(t + 1), io::ld(t + 2), io::ld(t + 3));
   };
+  // PK: work item = (array B | C, state pair, quarter of 4 steps): two row pieces (states 2p, 2p + 1) per item, NPAIR * 32 items per array
+  constexpr int NPAIR = PK ? NS / 2 : 1, IPT = PK ? (2 * NPAIR * 32) / NT : 1;
+  float4 pl[(PK && !RAWBC) ? IPT : 1], ph[(PK && !RAWBC) ? IPT : 1];
+  uint2 plr[(PK && RAWBC) ? IPT : 1], phr[(PK && RAWBC) ? IPT : 1];
+  auto bc_fetch_pk = [&](int t0) {
+    const bool full = t0 + CH <= L;
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int id = tid + it * NT, arr = id / (NPAIR * 32), pr = (id >> 5) % NPAIR, e4 = (id & 31) * 4;
+      const io_t* q0 = (arr ? Cp : Bp) + (int64_t)(2 * pr) * (arr ? p.C_ns : p.B_ns);
+      const io_t* q1 = q0 + (arr ? p.C_ns : p.B_ns);
+      int64_t off = t0 + e4;
+      if constexpr (FOLD) {        // a quarter past the end reads quarter 0 (see bc_fetch): unconditional loads
+        const int tq = t0 + e4 < L ? t0 + e4 : 0;
+        const int sb = seg_of(tq);
+        off = seg_off(sb, arr ? p.C_bs : p.B_bs, tq - sb * SL);
+      }
+      if (FOLD || full) {
+        if constexpr (RAWBC) { plr[it] = *(const uint2*)(q0 + off); phr[it] = *(const uint2*)(q1 + off); }
+        else { pl[it] = ld4<io_t>(q0 + off); ph[it] = ld4<io_t>(q1 + off); }
+      } else {
+        float tl[4] = {0.f, 0.f, 0.f, 0.f}, th[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (t0 + e4 + q < L) { tl[q] = io::ld(q0 + off + q); th[q] = io::ld(q1 + off + q); }
+        if constexpr (RAWBC) {
+          io_t a[4], b[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { io::st(a + q, tl[q]); io::st(b + q, th[q]); }    // exact: the values came from io_t
+          plr[it] = *(uint2*)a; phr[it] = *(uint2*)b;
+        } else {
+          pl[it] = make_float4(tl[0], tl[1], tl[2], tl[3]); ph[it] = make_float4(th[0], th[1], th[2], th[3]);
+        }
+      }
+    }
+  };
+  // block blk (2 steps: i = 2 blk, 2 blk + 1) of lane jj sits at word (blk * LPR + ((jj + 4 (blk / 2)) % LPR)) * 4: the rotation of the odd
+  // quarter's blocks keeps the 8-lane groups of the staging ds_write_b128 (4 lanes x 2 quarters) on 32 different banks; the reads of a
+  // DPP row stay one 256-byte run per block
+  auto pk_pos = [](int blk, int jj) { return (blk * LPR + ((jj + 4 * (blk >> 1)) & (LPR - 1))) * 4; };
+  auto bc_commit_pk = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int id = tid + it * NT, arr = id / (NPAIR * 32), pr = (id >> 5) % NPAIR, Q = id & 31;
+      float* dst = sBC + buf * 2 * N * CH + arr * N * CH + pr * 2 * CH;
+      float4 lo, hi;
+      if constexpr (RAWBC) { lo = q_unpack(plr[it]); hi = q_unpack(phr[it]); } else { lo = pl[it]; hi = ph[it]; }
+      *(float4*)(dst + pk_pos(2 * (Q & 1), Q >> 1)) = make_float4(lo.x, hi.x, lo.y, hi.y);
+      *(float4*)(dst + pk_pos(2 * (Q & 1) + 1, Q >> 1)) = make_float4(lo.z, hi.z, lo.w, hi.w);
+    }
+  };
   auto bc_fetch = [&](int t0) {
+    if constexpr (PK) { bc_fetch_pk(t0); return; }
     const bool full = t0 + CH <= L;
     if constexpr (VEC) {
       constexpr int CQ = CH / 4, RSTEP = NT / CQ;
@@ -207,6 +282,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     }
   };
   auto bc_commit = [&](int buf) {
+    if constexpr (PK) { bc_commit_pk(buf); return; }
     float* dB = sBC + buf * 2 * N * CH;
     float* dC = dB + N * CH;
     if constexpr (VEC) {
@@ -405,7 +481,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
         if (dd < d_end) {
           // FOLD: (channel, part, virtual chunk); a part owns fold_cpp = chunks(fold_bpp * SL) slots
           const int64_t slot = FOLD ? ((int64_t)dd * gridDim.y + blockIdx.y) * p.fold_cpp + c : ((int64_t)b * p.dim + dd) * p.n_ckpt + c;
-          p.ckpt[slot * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
+          p.ckpt[slot * N + n] = PK ? sH[(wave * RPW + rr) * SA + n] : sAC[(wave * RPW + rr) * NP + n].y;
         }
       }
     }
@@ -481,6 +557,86 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
       }
     };
     const int n_states = MXVL_ABL(p.ablate & 1) ? 0 : MXVL_ABL(p.ablate & 2) ? N / 2 : N;
+    if constexpr (PK) {
+      const float* hin = sH + ((j == 0) ? row : DT) * SA;            // only lane 0 sees the state entering the chunk
+      float* hout = (j == LPR - 1) ? sH + row * SA : sDump2 + 2 * tid;  // the last lane stores the state leaving it; the others a dump pair
+      const float* a2row = sA + row * SA;
+      int rp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rp[k] = pk_pos(k, j);
+      v2f y2[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) y2[i] = v2f{y[i], 0.0f};
+      const v2f rb2 = v2f{rbias, rbias};
+      // one pair per trip = the two states in flight of the unpacked loop's `unroll 2`; two pairs per trip keep 96 registers of
+      // a / b / c live and cost the third workgroup per CU (218 VGPRs: 274.8 vs 252.8 us at the roofline shape)
+#pragma unroll 1
+      for (int n = 0; n < n_states; n += 2) {
+        v2f a[T], bb[T], cv[T];
+        // delta_i and delta_i u_i multiply BOTH halves: left alone, the compiler hoists 16 (x, x) register pairs out of the loop (32
+        // VGPRs -- the kernel lands at 199 and loses the third workgroup per CU); redefined here, the splat is built at the use and
+        // folds into the instruction's op_sel
+        asm volatile("" : "+v"(dl[0]), "+v"(dl[1]), "+v"(dl[2]), "+v"(dl[3]), "+v"(dl[4]), "+v"(dl[5]), "+v"(dl[6]), "+v"(dl[7]),
+                          "+v"(du[0]), "+v"(du[1]), "+v"(du[2]), "+v"(du[3]), "+v"(du[4]), "+v"(du[5]), "+v"(du[6]), "+v"(du[7]));
+        const v2f A2 = *(const v2f*)(a2row + n);
+        const v2f car = *(const v2f*)(hin + n);
+        const float* tB = cB + (n >> 1) * 2 * CH;
+        const float* tC = cC + (n >> 1) * 2 * CH;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 b4 = *(const float4*)(tB + rp[k]);
+          const float4 c4 = *(const float4*)(tC + rp[k]);
+          bb[2 * k] = v2f{b4.x, b4.y}; bb[2 * k + 1] = v2f{b4.z, b4.w};
+          cv[2 * k] = v2f{c4.x, c4.y}; cv[2 * k + 1] = v2f{c4.z, c4.w};
+        }
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          a[i] = A2 * dl[i];
+          bb[i] = bb[i] * du[i];
+        }
+        v2f P = A2 * dsum;
+        if constexpr (FOLD) {
+          a[0] += rb2;
+          P += rb2;
+        }
+        // the 18 v_exp_f32 of a pair back to back (see fold below).  Outputs are NOT tied to the inputs: a tied ("+v") half of a
+        // 64-bit pair made the register allocator copy the other half around it (26 v_mov_b32 per two pairs in the first build)
+        float P0, P1;
+        {
+          float e0, e1, e2, e3, e4, e5, e6, e7, f0, f1, f2, f3, f4, f5, f6, f7;
+          asm volatile(
+              "v_exp_f32 %0, %9\n v_exp_f32 %1, %10\n v_exp_f32 %2, %11\n v_exp_f32 %3, %12\n v_exp_f32 %4, %13\n"
+              "v_exp_f32 %5, %14\n v_exp_f32 %6, %15\n v_exp_f32 %7, %16\n v_exp_f32 %8, %17\n"
+              : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7), "=&v"(P0)
+              : "v"(a[0].x), "v"(a[0].y), "v"(a[1].x), "v"(a[1].y), "v"(a[2].x), "v"(a[2].y), "v"(a[3].x), "v"(a[3].y), "v"(P.x));
+          asm volatile(
+              "v_exp_f32 %0, %9\n v_exp_f32 %1, %10\n v_exp_f32 %2, %11\n v_exp_f32 %3, %12\n v_exp_f32 %4, %13\n"
+              "v_exp_f32 %5, %14\n v_exp_f32 %6, %15\n v_exp_f32 %7, %16\n v_exp_f32 %8, %17\n"
+              : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&v"(f4), "=&v"(f5), "=&v"(f6), "=&v"(f7), "=&v"(P1)
+              : "v"(a[4].x), "v"(a[4].y), "v"(a[5].x), "v"(a[5].y), "v"(a[6].x), "v"(a[6].y), "v"(a[7].x), "v"(a[7].y), "v"(P.y));
+          a[0] = v2f{e0, e1}; a[1] = v2f{e2, e3}; a[2] = v2f{e4, e5}; a[3] = v2f{e6, e7};
+          a[4] = v2f{f0, f1}; a[5] = v2f{f2, f3}; a[6] = v2f{f4, f5}; a[7] = v2f{f6, f7};
+        }
+        v2f h = bb[0];
+#pragma unroll
+        for (int i = 1; i < T; ++i) h = __builtin_elementwise_fma(a[i], h, bb[i]);   // pass 1: lane map h_out = P * h_in + h
+        // from here to the first step of pass 2 the two states are scalars: the DPP block ties its operands, and a pair rebuilt from
+        // tied scalars costs copies
+        float h0 = fmaf(P0, car.x, h.x), h1 = fmaf(P1, car.y, h.y);                     // lane 0 absorbs the incoming state
+        float x0 = car.x, x1 = car.y;
+        scan16_x2(h0, P0, x0, h1, P1, x1);
+        *(v2f*)(hout + n) = v2f{h0, h1};
+        h = v2f{fmaf(a[0].x, x0, bb[0].x), fmaf(a[0].y, x1, bb[0].y)};
+        y2[0] = __builtin_elementwise_fma(cv[0], h, y2[0]);
+#pragma unroll
+        for (int i = 1; i < T; ++i) {
+          h = __builtin_elementwise_fma(a[i], h, bb[i]);
+          y2[i] = __builtin_elementwise_fma(cv[i], h, y2[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < T; ++i) y[i] = y2[i].x + y2[i].y;
+    } else {
 #pragma unroll 2
     for (int n = 0; n < n_states; ++n) {
       float a[T], bb[T], cv[T], P, hl, x;
@@ -494,6 +650,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
         x = (j == 0) ? car : x;
       }
       pass2(n, a, bb, cv, hl, x);
+    }
     }
 
     if (more) bc_commit((c + 1) & 1);
@@ -568,7 +725,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     for (int i = lane; i < RPW * N; i += 64) {
       const int rr = i / N, n = i - rr * N;
       const int dd = d0 + wave * RPW + rr;
-      if (dd < d_end) p.last_state[((int64_t)b * p.dim + dd) * N + n] = sAC[(wave * RPW + rr) * NP + n].y;
+      if (dd < d_end) p.last_state[((int64_t)b * p.dim + dd) * N + n] = PK ? sH[(wave * RPW + rr) * SA + n] : sAC[(wave * RPW + rr) * NP + n].y;
     }
   }
 }

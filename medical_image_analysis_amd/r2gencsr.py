@@ -28,6 +28,11 @@ from .vmamba import vssm1_base_0229
 
 
 class R2GenCSR(MambaXrayVLDownStream):
+    # the step reads VSSM's feature map and its mean (R2GenCSR.py:233-262), never `visual_encoder.classifier.norm`: two trainable
+    # tensors stay without a gradient (tools/unused_params.py).  The reference trains under DeepSpeed stage 2, which tolerates that;
+    # torch DDP needs to be told (pretrain_engine.wrap_ddp reads this flag)
+    ddp_find_unused_parameters = True
+
     def __init__(self, args, tokenizer=None, llm=None, encoder=None):
         nn.Module.__init__(self)
         _reject_unbuilt(args)

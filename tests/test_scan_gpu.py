@@ -616,3 +616,72 @@ def test_scan_batch_folding_half_io_and_fallbacks():
                                      c["delta_bias"], True, want_last_state=last, want_ckpt=True)
         assert ck is None or ck.dim() == 4, (B, L, last)
         assert (ls is not None) == last
+
+
+@pytest.mark.parametrize("variant", [15, 16, 17, 18])
+@pytest.mark.parametrize("case", [(2, 40, 1100, 1, torch.float32), (1, 64, 4096, 2, torch.float32), (3, 24, 132, 1, torch.float32),
+                                  (2, 48, 1096, 1, torch.bfloat16), (2, 32, 520, 1, torch.float16)])
+def test_scan_fwd_packed_state_pairs(case, variant):
+    """scan_fwd_stream_kernel<PK> (round 6): state pairs (n, n + 1) in the halves of 64-bit registers, v_pk_mul_f32 / v_pk_fma_f32 for
+    the recurrence, the B / C tile stored pair-interleaved.  Against the C oracle, and against the unpacked kernel (variant 14): the
+    per-state operations are the same IEEE fmas in the same order, so the states (last_state, every checkpoint) are BIT-identical;
+    out sums even and odd states separately (one reassociation).  Ragged last chunks, channel counts that are not a multiple of the
+    tile, groups, 16-bit rows."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    B, D, L, G, dtype = case
+    cpu = scan_inputs(B, D, L, 16, G, True, True, True, seed=61, dtype=dtype)
+    ref, ref_last = orc.selective_scan_ref(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"], cpu["delta_bias"], True,
+                                           return_last_state=True)
+    x = _to(cpu, _dev())
+    Bm = x["B"] if G > 1 else x["B"].unsqueeze(1)
+    Cm = x["C"] if G > 1 else x["C"].unsqueeze(1)
+    lib = _abi.load()
+    res = {}
+    old = ssi.FOLD_SHORT_ROWS
+    try:
+        ssi.FOLD_SHORT_ROWS = False
+        for v in (14, variant):
+            lib.mxvl_set_scan_variant(v)
+            res[v] = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], x["z"], x["delta_bias"], True, want_last_state=True, want_ckpt=True)
+            torch.cuda.synchronize()
+            res[v] = res[v] + (lib.mxvl_last_scan_kernel().decode(),)
+    finally:
+        lib.mxvl_set_scan_variant(0)
+        ssi.FOLD_SHORT_ROWS = old
+    out, last, ckpt, name = res[variant]
+    assert ",pk>" in name and ",pk>" not in res[14][3], (name, res[14][3])
+    if dtype == torch.float32:
+        assert_close(out, ref, _atol(ref), 1e-5, f"out [{name}]")
+        assert_close(last, ref_last, _atol(ref), 1e-5, "last_state")
+        assert_close(out, res[14][0], 2e-5 * max(1.0, float(ref.abs().max())), 1e-5, "packed vs unpacked out")
+    else:
+        rtol, atol = (3e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 5e-3)
+        assert_close(out, ref, atol * max(1.0, float(ref.abs().max()) / 8), rtol, f"out [{name}]")
+    assert torch.equal(last, res[14][1]), "the states of the packed kernel are the unpacked kernel's, bit for bit"
+    assert torch.equal(ckpt, res[14][2]), "checkpoints bit-identical"
+
+
+def test_scan_fwd_packed_state_pairs_folded_batch():
+    """PK on the batch-folded walk (197-token encoders padded to 200): the segment reset (a_0 = P = 0 by a -inf exponent bias) rides in
+    the packed exponent registers."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    cpu = scan_inputs(6, 48, 200, 16, 1, True, True, True, seed=62)
+    ref = orc.selective_scan_ref(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], cpu["z"], cpu["delta_bias"], True)
+    x = _to(cpu, _dev())
+    lib = _abi.load()
+    res = {}
+    try:
+        for v in (0, 15):
+            lib.mxvl_set_scan_variant(v)
+            res[v] = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], x["B"].unsqueeze(1), x["C"].unsqueeze(1), x["D"], x["z"], x["delta_bias"], True,
+                                      want_ckpt=True) + (lib.mxvl_last_scan_kernel().decode(),)
+            torch.cuda.synchronize()
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    assert "fold,pk>" in res[15][3] and res[15][2].dim() == 3, res[15][3]
+    assert_close(res[15][0], ref, _atol(ref), 1e-5, "folded packed out")
+    assert torch.equal(res[15][2], res[0][2]), "folded checkpoints bit-identical to the unpacked walk"

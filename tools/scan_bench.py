@@ -43,9 +43,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         if os.environ.get("MXVL_LIB"):
             _abi.LIB_PATH = os.environ["MXVL_LIB"]
+        vs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [14]
+        dt = getattr(torch, sys.argv[3]) if len(sys.argv) > 3 else torch.float32
         for ab in (0, 1, 8, 32, 64, 128, 256, 32 | 8, 1 | 32 | 8):
             print("ablate bits", ab, "(1=no n-loop 2=half n-loop 4=no softplus/silu 8=no out store 32=no global loads after chunk 0; one class only: 64=B/C tile 128=z 256=u/delta)")
-            run(8, 1536, 4096, 16, torch.float32, variants=[14 | (ab << 16)], rounds=3)
+            run(8, 1536, 4096, 16, dt, variants=[v | (ab << 16) for v in vs], rounds=3)
     elif len(sys.argv) > 1:
         B, D, L, N = map(int, sys.argv[1:5]); dt = getattr(torch, sys.argv[5]) if len(sys.argv) > 5 else torch.float32
         run(B, D, L, N, dt)

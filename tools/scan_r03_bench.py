@@ -54,7 +54,7 @@ def fwd(rounds):
               (64, 4096, 200, 16, torch.bfloat16, True)]
     for (B, D, L, N, dt, ck) in shapes:
         u, delta, A, Bm, Cm, Dv, z, bias, _ = inputs(B, D, L, N, dt)
-        variants = (0, 10, 14, 12, 20)
+        variants = (0, 10, 14, 12, 20, 15, 16, 17, 18)
         res = {v: [] for v in variants}
         names = {}
         for r in range(rounds + 1):
