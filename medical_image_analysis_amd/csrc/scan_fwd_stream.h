@@ -515,10 +515,16 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
         bb[4 * k] = b4.x; bb[4 * k + 1] = b4.y; bb[4 * k + 2] = b4.z; bb[4 * k + 3] = b4.w;
         cv[4 * k] = c4.x; cv[4 * k + 1] = c4.y; cv[4 * k + 2] = c4.z; cv[4 * k + 3] = c4.w;
       }
+      // steps (i, i + 1) of ONE state in the halves of a register pair: the two element-wise products are v_pk_mul_f32 (delta and
+      // delta u pairs are neighbours already, the B quarter came as a float4) -- 16 packed multiplies in the place of 32 per two
+      // states, the same IEEE products, no layout or register change: 277.8 -> 265.6 us at the roofline shape, one box, alternating
+      // (profiles/r06_scan_fwd_exp_ab.txt)
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        a[i] = dl[i] * A2;
-        bb[i] = du[i] * bb[i];
+      for (int i = 0; i < T; i += 2) {
+        const v2f t = v2f{dl[i], dl[i + 1]} * A2;
+        const v2f w = v2f{du[i], du[i + 1]} * v2f{bb[i], bb[i + 1]};
+        a[i] = t.x; a[i + 1] = t.y;
+        bb[i] = w.x; bb[i + 1] = w.y;
       }
       P = A2 * dsum;
       if constexpr (FOLD) {
@@ -637,6 +643,9 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
 #pragma unroll
       for (int i = 0; i < T; ++i) y[i] = y2[i].x + y2[i].y;
     } else {
+    // (measured and removed, profiles/r06_scan_fwd_exp_ab.txt: two states per trip through ONE interleaved DPP block, scan16_x2, instead of
+    // two scan16_x1 blocks with their s_nops -- 171 VGPRs, the third workgroup per CU is lost: 318.9 vs 259.9 us; with the B / C tile
+    // by LDS-DMA to win the registers back, 167 VGPRs: 275.2 us; the tile by LDS-DMA alone: 271.4 us)
 #pragma unroll 2
     for (int n = 0; n < n_states; ++n) {
       float a[T], bb[T], cv[T], P, hl, x;

@@ -81,7 +81,13 @@ def want(name):
     return not _ONLY or name in _ONLY
 
 
+# MXVL_GOLDEN_FILES=file1,file2 writes only those .npz files (a generator that produces several: add one without touching the others)
+_FILES = {x for x in os.environ.get("MXVL_GOLDEN_FILES", "").split(",") if x}
+
+
 def save(name, **arrs):
+    if _FILES and name not in _FILES:
+        return
     arrs = {k: v for k, v in arrs.items() if v is not None}
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrs)
@@ -1173,6 +1179,22 @@ def gen_vmamba(scan_ref):
         pooled = net(img, global_features=True)
     arrs = {"sd." + k: np_(v) for k, v in net.state_dict().items()}
     save("vmamba_vssm_tiny", img=np_(img), feat=np_(feat), pooled=np_(pooled), **arrs)
+
+    # (4) the same recipe with norm_layer="ln2d" (channel_first): this route has NO hard bf16 cast in front of out_norm
+    # (vmamba.py:411-419 returns before :420), so the whole network is fp32 and pins the mirror below 1e-4 -- forward AND backward
+    torch.manual_seed(13)
+    net = vm.VSSM(depths=[1, 1, 2, 1], dims=8, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
+                  mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0, norm_layer="ln2d").eval()
+    _randomize(net)
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    feat = net(img)
+    cot = torch.randn(feat.shape, generator=g)
+    (feat * cot).sum().backward()
+    with torch.no_grad():
+        pooled = net(img, global_features=True)
+    arrs = {"sd." + k: np_(v) for k, v in net.state_dict().items()}
+    arrs.update({"grad." + k: np_(p.grad) for k, p in net.named_parameters() if p.grad is not None})
+    save("vmamba_vssm_tiny_ln2d", img=np_(img), feat=np_(feat), cot=np_(cot), pooled=np_(pooled), **arrs)
 
 
 def gen_handoff():

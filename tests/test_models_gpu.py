@@ -132,8 +132,9 @@ def test_pretrain_visionmamba_full_size_1024_matches_oracle():
     """BASELINE.json configs[2] AT FULL SIZE, once: VisionMamba(1024 x 1024 image, 1024 x 24 encoder, 512 x 4 decoder; 4096 patches, a
     4080-token scan, 4080-token block-causal attention) on ONE image in fp32 -- the per-token loss vector (4080 values) against the
     CPU oracle (oracle/models_ref.visionmamba_forward_ref over the C scan / conv oracles, itself pinned to the reference's golden at
-    128 x 128: tests/test_oracle_golden.py), atol 1e-3 (pretrain/models_pretrain.py:510-515).  Then one bf16-autocast training step of
-    the same model (the arithmetic bench.py times): finite loss, finite gradients on every trainable parameter."""
+    128 x 128: tests/test_oracle_golden.py), atol 1e-3 (pretrain/models_pretrain.py:510-515), and the fp32 GRADIENTS of eight
+    parameters spread over the model against the oracle's own backward (2e-3 of each tensor's scale).  Then one bf16-autocast training
+    step of the same model (the arithmetic bench.py times): finite loss, finite gradients on every trainable parameter."""
     from medical_image_analysis_amd.models_pretrain import VisionMamba
     from oracle import models_ref
     from oracle import oracle as orc
@@ -149,8 +150,28 @@ def test_pretrain_visionmamba_full_size_1024_matches_oracle():
     cores = max(1, min(64, (os.cpu_count() or 2) // 2))
     orc.set_threads(cores)
     torch.set_num_threads(cores)
-    ref_loss, _, _ = models_ref.visionmamba_forward_ref(sd, img.cpu(), patch=16, depth=24)
-    assert_close(loss, ref_loss, 1e-3, 1e-3, "per-token loss of the full-size model vs the CPU oracle")
+    # the oracle runs WITH autograd on a handful of leaves (oracle.py _ScanRefFn / _ConvRefFn: the C gradient routines): the top, the
+    # bottom and the middle of the 4080-token chain -- scan backward, conv backward, block-causal attention backward, SwiGLU backward
+    grad_names = ["ar_pred.weight", "patch_embed.proj.weight", "layers.12.mixer.in_proj.weight", "layers.0.mixer.A_log",
+                  "layers.23.mixer.dt_proj.bias", "layers.5.mlp.w3.weight", "layers.17.mixer.conv1d.weight", "dec_block.1.attn2.kv.weight"]
+    sd_g = dict(sd)
+    for n in grad_names:
+        sd_g[n] = sd[n].clone().requires_grad_(True)
+    ref_loss, _, _ = models_ref.visionmamba_forward_ref(sd_g, img.cpu(), patch=16, depth=24)
+    assert_close(loss, ref_loss.detach(), 1e-3, 1e-3, "per-token loss of the full-size model vs the CPU oracle")
+    ref_loss.mean().backward()
+    m.zero_grad(set_to_none=True)
+    m(img).mean().backward()                      # fp32 on the HIP kernels
+    params = dict(m.named_parameters())
+    for n in grad_names:
+        want, got = sd_g[n].grad, params[n].grad
+        assert want is not None and got is not None, n
+        scale = float(want.abs().max())
+        assert scale > 0.0, n
+        # fp32 both sides; the sums run over 4080 tokens in different orders (fp32 atomics for dB / dC, split-K wgrads)
+        assert_close(got, want, 2e-3 * scale, 2e-3, f"full-size gradient of {n} vs the CPU oracle's")
+    m.zero_grad(set_to_none=True)
+    ref_loss = ref_loss.detach()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         lb = m(img)
     assert_close(lb.float(), ref_loss, 0.05 * float(ref_loss.abs().max()), 0.05, "bf16-autocast loss vs the fp32 oracle")

@@ -685,3 +685,70 @@ def test_scan_fwd_packed_state_pairs_folded_batch():
     assert "fold,pk>" in res[15][3] and res[15][2].dim() == 3, res[15][3]
     assert_close(res[15][0], ref, _atol(ref), 1e-5, "folded packed out")
     assert torch.equal(res[15][2], res[0][2]), "folded checkpoints bit-identical to the unpacked walk"
+
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's OWN known-answer grid for the oflex kernel (R2GenCSR/VMamba/kernels/selective_scan/test_selective_scan.py:365-517):
+# DSTATE 1, DIM 768, DIM1 24 (delta carries 24 channels for 768 of u), batch 2, seqlen 64 ... 4096 x fp32 / fp16 / bf16 x has_D x
+# has_delta_bias x delta_softplus x varBC_groups 1 | 2, no z, return_last_state -- with the reference's tolerances (:388-395,
+# 474-517): out / last_state (rtol, atol), du (2 x), dA (rtolw, 5 atolw), dB / dC (rtol, atol), dD and ddelta_bias (rtolw, atolw),
+# ddelta as the per-group sums (5 rtol, 10 atol).  The reference compares with its torch loop on the delta expanded to 768
+# channels; here the C oracle (pinned to that loop by tests/test_oracle_golden.py) runs on the same expanded tensors.
+# ---------------------------------------------------------------------------------------------------
+def _allclose(got, ref, rtol, atol, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {bad.numel()} beyond torch.allclose(rtol={rtol}, atol={atol}); max err {float((got - ref).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("seqlen", [64, 128, 256, 512, 1024, 2048, 4096])
+def test_reference_oflex_grid(seqlen, itype):
+    from oracle import oracle as orc
+    from medical_image_analysis_amd.selective_scan_interface import selective_scan_fn
+    dev = _dev()
+    batch, dim, dim1, dstate = 2, 768, 24, 1
+    rtol, atol = (6e-4, 2e-3) if itype == torch.float32 else (3e-3, 5e-3)
+    if itype == torch.bfloat16:
+        rtol, atol = 3e-2, 5e-2
+    rtolw, atolw = 1e-3, 1e-3
+    ratio = dim // dim1
+    case = 0
+    for groups in (1, 2):
+        for has_D in (False, True):
+            for has_bias in (False, True):
+                for softplus in (False, True):
+                    case += 1
+                    g = torch.Generator().manual_seed(1000 * seqlen + case)       # (the reference seeds 0 on the device; any seed of its distribution)
+                    A = -0.5 * torch.rand(dim, dstate, generator=g)
+                    bshape = (batch, dstate, seqlen) if groups == 1 else (batch, groups, dstate, seqlen)
+                    Bm, Cm = torch.randn(*bshape, generator=g).to(itype), torch.randn(*bshape, generator=g).to(itype)
+                    Dv = torch.randn(dim, generator=g) if has_D else None
+                    bias = 0.5 * torch.rand(dim1, generator=g) if has_bias else None
+                    u = torch.randn(batch, dim, seqlen, generator=g).to(itype)
+                    delta = (0.5 * torch.rand(batch, dim1, seqlen, generator=g)).to(itype)
+                    dout = torch.randn(batch, dim, seqlen, generator=g).to(itype)
+                    delta_full = delta.unsqueeze(2).repeat(1, 1, ratio, 1).flatten(1, 2).contiguous()
+                    bias_full = bias.unsqueeze(1).repeat(1, ratio).view(-1) if has_bias else None
+                    f = lambda t: None if t is None else t.float()
+                    ref, ref_state = orc.selective_scan_ref(f(u), f(delta_full), A, f(Bm), f(Cm), Dv, None, bias_full, softplus, return_last_state=True)
+                    rg = orc.selective_scan_ref_bwd(f(u), f(delta_full), A, f(Bm), f(Cm), Dv, None, bias_full, softplus, f(dout))
+                    leaf = lambda t: None if t is None else t.to(dev).requires_grad_(True)
+                    lu, ld, lA, lB, lC, lD, lb = leaf(u), leaf(delta), leaf(A), leaf(Bm), leaf(Cm), leaf(Dv), leaf(bias)
+                    out, state = selective_scan_fn(lu, ld, lA, lB, lC, lD, z=None, delta_bias=lb, delta_softplus=softplus, return_last_state=True)
+                    tag = f"L{seqlen} groups{groups} D{int(has_D)} bias{int(has_bias)} softplus{int(softplus)}: "
+                    assert out.dtype == itype
+                    _allclose(out, ref, rtol, atol, tag + "out")
+                    _allclose(state, ref_state, rtol, atol, tag + "last_state")
+                    out.backward(dout.to(dev))
+                    _allclose(lu.grad, rg["du"].to(itype), rtol * 2, atol * 2, tag + "du")
+                    _allclose(lA.grad, rg["dA"], rtolw, atolw * 5, tag + "dA")
+                    _allclose(lB.grad, rg["dB"], rtol, atol, tag + "dB")
+                    _allclose(lC.grad, rg["dC"], rtol, atol, tag + "dC")
+                    if has_D:
+                        _allclose(lD.grad, rg["dD"], rtolw, atolw, tag + "dD")
+                    dgr = rg["ddelta"].view(batch, dim1, ratio, seqlen).sum(2)
+                    _allclose(ld.grad, dgr.to(itype), rtol * 5, atol * 10, tag + "ddelta (per-group sums)")
+                    if has_bias:
+                        _allclose(lb.grad, rg["ddelta_bias"].view(dim1, ratio).sum(-1), rtolw, atolw, tag + "ddelta_bias")
+                    assert ld.grad.shape == delta.shape and lB.grad.shape == Bm.shape and lB.grad.dtype == itype
