@@ -93,6 +93,39 @@ def test_vssm_tiny_matches_reference():
     assert float((pooled - g["pooled"]).abs().max()) <= 1e-2 * float(g["pooled"].abs().max())
 
 
+def test_vssm_tiny_ln2d_matches_reference_below_1e4_forward_and_backward():
+    """The channel_first route (norm_layer="ln2d") returns in front of the reference's hard bf16 cast (vmamba.py:411-419 vs :420):
+    the whole tiny VSSM is fp32, so the mirror -- CrossScan / CrossMerge order and direction weights, the N = 1 scan forward AND
+    backward, the depth-wise 3x3 convolution, LayerNorm2d, the v3 down-sampling -- is held to 1e-4 of each tensor's scale on the
+    feature map, the pooled feature and EVERY parameter gradient (golden: the reference's own VSSM run by make_golden.py)."""
+    vm = _vm()
+    g = load_golden("vmamba_vssm_tiny_ln2d")
+    net = vm.VSSM(depths=[1, 1, 2, 1], dims=8, ssm_d_state=1, ssm_ratio=2.0, ssm_conv=3, ssm_conv_bias=False, forward_type="v3noz",
+                  mlp_ratio=4.0, downsample_version="v3", patchembed_version="v2", drop_path_rate=0.0, norm_layer="ln2d").eval()
+    net.load_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    net = net.to(DEV)
+    feat = net(g["img"].to(DEV))
+    assert feat.shape == g["feat"].shape
+
+    def close(a, b, what, rel=1e-4):
+        tol = rel * max(float(b.abs().max()), 1e-3)
+        err = float((a.detach().cpu().float() - b).abs().max())
+        assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e}"
+
+    close(feat, g["feat"], "feature map")
+    (feat * g["cot"].to(DEV)).sum().backward()
+    with torch.no_grad():
+        close(net(g["img"].to(DEV), global_features=True), g["pooled"], "pooled feature")
+    checked = 0
+    for n, p in net.named_parameters():
+        if "grad." + n in g:
+            close(p.grad, g["grad." + n], "grad " + n, rel=2e-4)
+            checked += 1
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    assert checked > 40
+
+
 def test_r2gencsr_encoder_runs_bf16():
     """The shipped R2GenCSR encoder (vssm1_base_0229: dims 128..1024, depths [2,2,15,2], d_state 1) at 224x224 under
     bf16 autocast: shapes, finiteness, and a backward pass through every HIP op."""
