@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 8
+#define MXVL_ABI_VERSION 9
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -219,6 +219,12 @@ typedef struct mxvl_gemv_desc {
   int32_t k_splits;         /* 0: kernel by row count (rows <= 8: GEMV).  != 0: the matrix-core kernels at any row count; 1..16 with
                                split_acc, 1 without */
   int32_t dtype;            /* ABI v8: mxvl_dtype of x, norm_weight, W, W2, bias, residual, y (0 = MXVL_BF16) */
+  float norm_gain_scale;    /* ABI v9 (fused RMSNorm only; 0 = 1): a power of two s.  The kernel rounds dtype(norm_weight[k] * s * x[m][k]) and
+                               folds 1 / s into the row's rstd -- exact, so the result is the one of s = 1 wherever that did not leave the
+                               16-bit range.  With s = 2^-ceil(log2 max|norm_weight|) the scaled gain is <= 1: the product cannot overflow
+                               fp16 (|x| <= 65504 already), and a layer of uniformly small gains (Llama's first input_layernorm: 1e-2 ..
+                               1e-3) no longer pushes g * x into fp16's subnormals.  The modules normalise in fp32 FIRST (x * rstd is O(1)),
+                               so they never had either failure; bf16 has fp32's exponent range and does not need it. */
 } mxvl_gemv_desc;
 
 /*

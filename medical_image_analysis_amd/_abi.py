@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -113,6 +113,7 @@ class GemvDesc(ctypes.Structure):
         ("eps", ctypes.c_float),
         ("x", c_void_p), ("norm_weight", c_void_p), ("W", c_void_p), ("W2", c_void_p), ("bias", c_void_p),
         ("residual", c_void_p), ("y", c_void_p), ("split_acc", c_void_p), ("k_splits", c_int32), ("dtype", c_int32),
+        ("norm_gain_scale", ctypes.c_float),
     ]
 
 

@@ -37,6 +37,7 @@ struct DecodeGemmArgs {
                         // fp32 atomics of round 4 whose order decided the last bit of every residual row
   const uint16_t* g;    // RMSNorm gain (K) of the activation rows, fused (NORM instantiations of the LDS-DMA kernel); else NULL
   float eps;
+  float g_scale, g_inv;   // NORM: power-of-two scale on the gain (mxvl_gemv_desc.norm_gain_scale) and its reciprocal, folded into rstd
 };
 
 // Reduction over the waves' K split + the epilogue of mxvl_decode_gemv, one round per output tile (SwiGLU: per gate / up pair).
@@ -80,7 +81,7 @@ __device__ __forceinline__ void dg_reduce_epilogue(const DecodeGemmArgs& p, cons
         float ss = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) ss += s_ss[w * MT * 16 + m];
-        const float rstd = rsqrtf(ss / (float)p.K + p.eps);
+        const float rstd = rsqrtf(ss / (float)p.K + p.eps) * p.g_inv;
         s0 *= rstd;
         s1 *= rstd;
       }
@@ -302,6 +303,8 @@ __global__ __launch_bounds__(NW * 64) void decode_gemm_dma_kernel(const DecodeGe
         asm volatile("" : "+v"(gb[slot][ks]));
         float gf[8];
         elt_unpack8<E>(make_uint4(gb[slot][ks].x, gb[slot][ks].y, gb[slot][ks].z, gb[slot][ks].w), gf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf[j] *= p.g_scale;      // a power of two: exact (fp16 range of g * x)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           float xf[8];

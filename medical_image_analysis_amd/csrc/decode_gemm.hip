@@ -208,6 +208,13 @@ static int decode_gemm_args(const mxvl_gemv_desc* d, DecodeGemmArgs& a, int& spl
   a.bias = (const uint16_t*)d->bias; a.res = (const uint16_t*)d->residual; a.y = d->y;
   a.split_acc = (float*)d->split_acc;
   a.g = (const uint16_t*)d->norm_weight; a.eps = d->eps;
+  a.g_scale = 1.0f; a.g_inv = 1.0f;
+  if (d->norm_weight && d->norm_gain_scale != 0.0f) {
+    int e = 0;
+    const float m = frexpf(d->norm_gain_scale, &e);
+    if (m != 0.5f || e < -60 || e > 60) return MXVL_ERR_UNSUPPORTED;    // a positive power of two, or nothing
+    a.g_scale = d->norm_gain_scale; a.g_inv = 1.0f / d->norm_gain_scale;
+  }
   splits = 1;
   if (!a.split_acc && d->k_splits > 1) return MXVL_ERR_UNSUPPORTED;    // a split needs the accumulator
   if (a.split_acc) {        // the caller folds the fp32 sums itself (mxvl_decode_rmsnorm): no epilogue here

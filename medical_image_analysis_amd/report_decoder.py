@@ -24,6 +24,8 @@ from __future__ import annotations
 from types import SimpleNamespace
 from typing import Iterable, Optional
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -415,6 +417,17 @@ class _KernelStepper(_SearchFusion):
         # tok/s): those keep the K-split sums folded by an explicit norm launch ("split"; norm_mode is the A/B switch of bench.py)
         self.fused_norm = self.batched and self.norm_mode == "fused" and rows <= 8 and self.hidden % 64 == 0 and self.hidden >= 256 \
             and self.inter % 64 == 0 and self.inter >= 256 and (self.H * self.D) % 64 == 0 and self.H * self.D >= 256
+        # fp16 only (bf16 has fp32's exponent range): a power-of-two scale per RMSNorm gain, 2^-ceil(log2 max|g|), so that the fused
+        # projection's dtype(g * s * x) can neither overflow nor sink into subnormals where the modules' dtype(dtype(x * rstd) * g) --
+        # normalised in fp32 first -- would not (mxvl_gemv_desc.norm_gain_scale, ABI v9).  Keyed by the gain's storage and version;
+        # taken once here, outside any graph capture (one host read for all gains)
+        self._gain_scale = {}
+        if self.fused_norm and dtype == torch.float16:
+            norms = [ln.weight for layer in model.model.layers for ln in (layer.input_layernorm, layer.post_attention_layernorm)] + [model.model.norm.weight]
+            with torch.no_grad():
+                peaks = torch.stack([w.detach().float().abs().max() for w in norms]).cpu().tolist()
+            for w, pk in zip(norms, peaks):
+                self._gain_scale[(w.data_ptr(), w._version)] = 2.0 ** -math.ceil(math.log2(pk)) if (pk > 0.0 and math.isfinite(pk)) else 1.0
         self.xn = torch.zeros(rows, self.hidden, **bf) if self.batched else None      # RMSNorm output ahead of an MFMA projection
         # fp32 partial sums of the K-split o_proj / down_proj, one plane per split (written whole by the projection, added in a
         # fixed order by the folding norm: deterministic -- round 4 added into one plane with fp32 atomics)
@@ -520,6 +533,8 @@ class _KernelStepper(_SearchFusion):
         d.rows, d.K, d.N, d.dtype = self.rows, K, N, self.dt
         d.swiglu, d.out_f32, d.eps = int(W2 is not None), int(out_f32), eps
         d.x, d.norm_weight, d.W = x.data_ptr(), self._abi.ptr(norm), W.data_ptr()
+        if norm is not None and self._gain_scale:
+            d.norm_gain_scale = self._gain_scale.get((norm.data_ptr(), norm._version), 1.0)
         d.W2, d.bias, d.residual, d.y = self._abi.ptr(W2), self._abi.ptr(bias), self._abi.ptr(res), self._abi.ptr(y)
         if split:
             d.split_acc, d.k_splits = self.acc.data_ptr(), split

@@ -126,35 +126,42 @@ def test_two_rank_ddp_steps_match_the_mean_of_the_shards(kind):
         assert (g0[k] == g1[k]).all(), f"ranks hold different averaged gradients at {k}"
     # the model's flag says exactly whether trainable parameters stay without a gradient
     assert fu0 == fu1 == bool(idle0), (fu0, idle0[:8])
-    # single process: each shard alone on a fresh replica; DDP's gradient = the mean of the two
-    model, amp, batch, loss_of = _build(kind)
-    shard_grads = []
-    for rank in range(world):
-        model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=amp):
-            loss = loss_of(model, batch(rank, 0))
-        loss.backward()
-        lv = float(loss.detach())
-        assert abs(lv - (l0, l1)[rank][0]) <= 2e-3 * max(1.0, abs(lv)), (rank, lv, (l0, l1)[rank][0])
-        shard_grads.append(_grads(model))
-    assert sorted(shard_grads[0]) == sorted(g0)
-    # bf16 / fp16 autocast + fp32 atomics: a re-run of the same shard moves single activations by a 16-bit rounding, and the small
-    # gradients at the bottom of a 12-layer encoder behind an LLM (cls_token: 5e-3) amplify that -- so the check is in L2, per
-    # tensor (a missing rank or a sum instead of a mean is an error of 0.7 .. 1.0) and over all gradients together
+    # single process: each shard alone on a fresh replica, TWICE; DDP's gradient = the mean of the two shards' gradients.
+    # bf16 / fp16 autocast + fp32 atomics (scan dB / dC) + the library's split-K GEMMs: the same shard does not repeat bit for bit -- the
+    # stage-3 loss itself moves in its 5th digit and the layers that receive almost no gradient through the random-init LLM are pure
+    # rounding noise (tools/grad_noise.py) -- so the second pass measures that floor, per tensor and overall, and the check is "DDP's
+    # gradient is as close to the mean of the shards as a repetition of the shards is to itself" (x4), with 5e-2 as the least
+    # tolerance.  A missing rank or a sum instead of a mean is an error of 0.7 .. 1.0 of the whole gradient.
     import numpy as np
-    worst, num, den = 0.0, 0.0, 0.0
-    wants = {k: 0.5 * (shard_grads[0][k] + shard_grads[1][k]) for k in g0}
-    total = sum(float(np.square(w).sum()) for w in wants.values())
+    model, amp, batch, loss_of = _build(kind)
+    passes = []
+    for rep in range(2):
+        shard_grads = []
+        for rank in range(world):
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=amp):
+                loss = loss_of(model, batch(rank, 0))
+            loss.backward()
+            lv = float(loss.detach())
+            assert abs(lv - (l0, l1)[rank][0]) <= 2e-3 * max(1.0, abs(lv)), (rank, lv, (l0, l1)[rank][0])
+            shard_grads.append(_grads(model))
+        assert sorted(shard_grads[0]) == sorted(g0)
+        passes.append({k: 0.5 * (shard_grads[0][k] + shard_grads[1][k]) for k in g0})
+    wants, again = passes
+    l2 = lambda t: float(np.square(t).sum())
+    total = sum(l2(w) for w in wants.values())
+    floor_all = (sum(l2(again[k] - wants[k]) for k in g0) / total) ** 0.5
+    worst, num = 0.0, 0.0
     for k, got in g0.items():
-        want = wants[k]
-        e2, w2 = float(np.square(got - want).sum()), float(np.square(want).sum())
-        num, den = num + e2, den + w2
-        rel = (e2 / max(w2, 1e-30)) ** 0.5
-        if w2 > 1e-6 * total:       # tensors that carry none of the gradient (A_b_log of layer 0: |g| = 5e-7) are rounding noise
+        e2, w2 = l2(got - wants[k]), l2(wants[k])
+        num += e2
+        if w2 > 1e-6 * total:       # tensors that carry none of the gradient are rounding noise altogether
+            rel, floor = (e2 / w2) ** 0.5, (l2(again[k] - wants[k]) / w2) ** 0.5
             worst = max(worst, rel)
-            assert rel <= 0.35, f"grad {k}: relative L2 difference {rel}"
-    assert (num / den) ** 0.5 <= 5e-2, f"all gradients: relative L2 difference {(num / den) ** 0.5}"
-    print(f"{kind}: DDP(2 ranks) vs mean of shards: worst per-tensor relative L2 difference {worst:.2e}, all gradients {(num / den) ** 0.5:.2e}; idle parameters: {idle0[:6]}")
+            assert rel <= max(5e-2, 4.0 * floor), f"grad {k}: relative L2 difference {rel} (repeatability of the shards themselves: {floor})"
+    den = total
+    assert (num / den) ** 0.5 <= max(5e-2, 4.0 * floor_all), f"all gradients: relative L2 difference {(num / den) ** 0.5} (repeatability {floor_all})"
+    print(f"{kind}: DDP(2 ranks) vs mean of shards: worst per-tensor relative L2 difference {worst:.2e}, all gradients {(num / den) ** 0.5:.2e}; repeatability of the shards {floor_all:.2e}; idle parameters: {idle0[:6]}")
 
 
 @pytest.mark.parametrize("workload,extra", [("mae_vit_large_1280", ["--batch", "4"]), ("finetune_stage3_llama7b", ["--batch", "2"]),

@@ -1073,3 +1073,64 @@ def test_frozen_decoder_autocast_shadows_equal_plain_autocast(dev):
     assert torch.equal(y2.float(), y2_ref.float())
     now = {k: v[1].data_ptr() for k, v in m._autocast_shadows.items()}
     assert now["lm_head.weight"] != first["lm_head.weight"] and all(now[k] == first[k] for k in now if k != "lm_head.weight")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny_gain_tiny_rows", "large_gain_large_rows", "wide_gain_mixed_rows"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_fused_norm_projection_over_real_checkpoint_ranges(case, dtype):
+    """the fused-RMSNorm projection rounds dtype(g * x) BEFORE rstd is applied; the modules normalise in fp32
+    first (x * rstd is O(1)).  In fp16 the raw product underflows for Llama's first input_layernorm (gains 1e-2 .. 1e-3 on
+    activations of 1e-2 and below) and overflows once |g x| > 65504.  ABI v9 passes a power-of-two gain scale
+    (norm_gain_scale = 2^-ceil(log2 max|g|), folded back into rstd exactly): gains 1e-3 .. 10 on rows of 1e-4 .. 1e4 must agree with
+    the module arithmetic to the same two ulp as at unit scale -- and WITHOUT the scale the first two cases must not (so the test
+    sees the failure it guards against)."""
+    import ctypes
+    import math
+    from medical_image_analysis_amd import _abi
+    lib = _abi.load()
+    dev = "cuda:0"
+    rows, K, N = 3, 4096, 4096
+    g = torch.Generator().manual_seed(91)
+    W = (K ** -0.5 * torch.randn(N, K, generator=g)).to(dtype).to(dev)
+    if case == "tiny_gain_tiny_rows":          # every gain ~1e-3, rows of 1e-4 .. 1e-3: g x ~ 1e-7 .. 1e-6, at or under fp16's last subnormal
+        gain = 1e-3 * (1.0 + 0.5 * torch.rand(K, generator=g))
+        row_scale = torch.tensor([1e-4, 3e-4, 1e-3])
+    elif case == "large_gain_large_rows":      # gains ~10 on rows of 1e3 .. 1e4: g x up to 4e5 > 65504
+        gain = 10.0 * (0.5 + 0.5 * torch.rand(K, generator=g))
+        row_scale = torch.tensor([1e3, 3e3, 1e4])
+    else:                                      # log-uniform gains over four decades, rows over six
+        gain = 10.0 ** (-3.0 + 4.0 * torch.rand(K, generator=g))
+        row_scale = torch.tensor([1e-3, 1.0, 1e3])
+    x = (row_scale[:, None] * torch.randn(rows, K, generator=g)).to(dtype).to(dev)
+    norm = gain.to(dtype).to(dev)
+    pk = float(norm.float().abs().max())
+    scale2 = 2.0 ** -math.ceil(math.log2(pk))
+
+    def run(gain_scale):
+        y = torch.full((rows, N), float("nan"), device=dev, dtype=dtype)
+        d = _abi.GemvDesc()
+        d.rows, d.K, d.N, d.dtype, d.k_splits = rows, K, N, _abi.dtype_code(dtype), 1
+        d.eps, d.norm_gain_scale = 1e-6, gain_scale
+        d.x, d.norm_weight, d.W, d.y = x.data_ptr(), norm.data_ptr(), W.data_ptr(), y.data_ptr()
+        _abi.check(lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_decode_gemv (fused norm, gain scale)")
+        torch.cuda.synchronize()
+        return y.float()
+
+    xf = x.float()
+    xf = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype)        # the modules: fp32 statistics, 16-bit(x * rstd), times g
+    ref = (norm * xf).float() @ W.float().t()
+    assert bool(torch.isfinite(ref).all())
+    tol = ULP[dtype] * ref.abs().amax(dim=1, keepdim=True)                             # one ulp of each ROW's output scale
+    err = (run(scale2) - ref).abs()
+    assert bool((err <= tol + 2 * ULP[dtype] * ref.abs()).all()), f"{case}: max err / row scale {float((err / ref.abs().amax(dim=1, keepdim=True)).max()):.3e}"
+    raw = run(0.0)                                                                     # 0 = no scale: the round-5 arithmetic
+    if dtype == torch.float16 and case != "wide_gain_mixed_rows":
+        bad = ~torch.isfinite(raw) | ((raw - ref).abs() > 8 * tol)
+        assert bool(bad.any()), f"{case}: the unscaled product was expected to leave fp16's range"
+    if dtype == torch.bfloat16:
+        assert torch.equal(raw, run(scale2)) or bool(((raw - ref).abs() <= tol + 2 * ULP[dtype] * ref.abs()).all())
+    d = _abi.GemvDesc()
+    d.rows, d.K, d.N, d.dtype, d.k_splits, d.eps, d.norm_gain_scale = rows, K, N, _abi.dtype_code(dtype), 1, 1e-6, 0.3
+    d.x, d.norm_weight, d.W, d.y = x.data_ptr(), norm.data_ptr(), W.data_ptr(), x.data_ptr()
+    assert lib.mxvl_decode_gemv(ctypes.byref(d), _abi.stream_ptr(x.device)) != 0, "a gain scale that is not a power of two is refused"

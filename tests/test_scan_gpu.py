@@ -701,6 +701,29 @@ def _allclose(got, ref, rtol, atol, what):
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {bad.numel()} beyond torch.allclose(rtol={rtol}, atol={atol}); max err {float((got - ref).abs().max()):.3e}"
 
 
+def _dA_float64(u, delta_full, A, Bm, Cm, bias_full, softplus, dout):
+    """dA of the N = 1 grid case in float64 (autograd over the recurrence, vectorised over channels): the arbiter where fp32 summation
+    noise of the ORACLE exceeds the reference's dA tolerance -- channels with A ~ 0 never forget, their 2 x 4096 terms reach 1e5 and
+    cancel to 1e2 .. 1e3 (measured at L 2048: C oracle 1.4 off float64 on a 4.8e5 sum, the HIP kernel 0.37)."""
+    B4 = Bm if Bm.dim() == 4 else Bm.unsqueeze(1)
+    C4 = Cm if Cm.dim() == 4 else Cm.unsqueeze(1)
+    G, dim = B4.shape[1], u.shape[1]
+    rep = dim // G
+    A64 = A.double().clone().requires_grad_(True)
+    dl = delta_full.double() + (bias_full.double()[None, :, None] if bias_full is not None else 0.0)
+    if softplus:
+        dl = torch.nn.functional.softplus(dl)
+    Bx = B4[:, :, 0].double().repeat_interleave(rep, dim=1)          # (batch, dim, L)
+    Cx = C4[:, :, 0].double().repeat_interleave(rep, dim=1)
+    h = torch.zeros(u.shape[0], dim, dtype=torch.float64)
+    acc = 0.0
+    for t in range(u.shape[2]):
+        h = torch.exp(dl[:, :, t] * A64[:, 0]) * h + dl[:, :, t] * Bx[:, :, t] * u[:, :, t].double()
+        acc = acc + (h * Cx[:, :, t] * dout[:, :, t].double()).sum()
+    acc.backward()
+    return A64.grad
+
+
 @pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
 @pytest.mark.parametrize("seqlen", [64, 128, 256, 512, 1024, 2048, 4096])
 def test_reference_oflex_grid(seqlen, itype):
@@ -742,7 +765,12 @@ def test_reference_oflex_grid(seqlen, itype):
                     _allclose(state, ref_state, rtol, atol, tag + "last_state")
                     out.backward(dout.to(dev))
                     _allclose(lu.grad, rg["du"].to(itype), rtol * 2, atol * 2, tag + "du")
-                    _allclose(lA.grad, rg["dA"], rtolw, atolw * 5, tag + "dA")
+                    try:
+                        _allclose(lA.grad, rg["dA"], rtolw, atolw * 5, tag + "dA")
+                    except AssertionError:
+                        # the fp32 oracle is not accurate enough to arbitrate this element (see _dA_float64): float64 does
+                        dA64 = _dA_float64(f(u), f(delta_full), A, f(Bm), f(Cm), bias_full, softplus, f(dout))
+                        _allclose(lA.grad, dA64, rtolw, atolw * 5, tag + "dA vs float64")
                     _allclose(lB.grad, rg["dB"], rtol, atol, tag + "dB")
                     _allclose(lC.grad, rg["dC"], rtol, atol, tag + "dC")
                     if has_D:
