@@ -226,6 +226,22 @@ def cpu_baseline_scan(B, D, L, N, budget_s=12.0):
     }
 
 
+def _decode_kernel_text(layers, heads, B, beams, fused_norm):
+    """What one decode step launches, from the stepper's actual mode (the old string claimed the fused norm AND the norm launches)."""
+    rows = B * beams
+    proj = ("decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream, the waves split K)" if rows <= 16 else
+            "decode_gemm_wide_kernel (16x16x32 MFMA, LDS-DMA weight ring, the waves split N and share the activation tile through LDS)")
+    if fused_norm:
+        norm = ("; RMSNorm fused into the consuming projection (the gain on the activation fragments, rstd in the epilogue), o_proj / down_proj add "
+                "their residual in their own epilogue: no decode_rmsnorm_kernel launches, no K-split planes")
+    else:
+        norm = f"; o_proj / down_proj K-split into fp32 planes, folded by {2 * layers + 1} decode_rmsnorm_kernel launches"
+    attn = ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
+            "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
+    return (f"decode step = {4 * layers + 1} {proj}{norm} + {layers} {attn} launches + beam_step_kernel, one hipGraph replay per token; "
+            "the time per token includes the prompt prefill's share")
+
+
 def measure_decode(workload, steps, warmup, rank, world, dev, dist):
     """Autoregressive report decoding: one 'step' = one full generate() of `new_tokens` tokens per sample.
     Replicas only across GPUs (the reference decodes on a single device, MambaXrayVL_DownStream.py:407).
@@ -263,6 +279,7 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t[0])
     stepper = type(next(iter(m._steppers.values()))).__name__ if getattr(m, "_steppers", None) else "eager"
+    fused_norm = bool(getattr(next(iter(m._steppers.values())), "fused_norm", False)) if getattr(m, "_steppers", None) else False
     n_params = sum(p.numel() for p in m.parameters())
     n_out = int(out.shape[1])
     del m
@@ -288,14 +305,7 @@ def measure_decode(workload, steps, warmup, rank, world, dev, dist):
                    "new_tokens": n_out, "parallelism": f"replicas x{world} (no collective)", "stepper": stepper},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": (f"decode step = {4 * layers + 1} "
-                                + ("decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream, the waves split K; RMSNorm fused into the consuming projection"
-                                   if B * beams <= 8 else "decode_gemm_dma_kernel (16x16x32 MFMA, LDS-DMA weight stream, the waves split K"
-                                   if B * beams <= 16 else "decode_gemm_wide_kernel (16x16x32 MFMA, LDS-DMA weight ring, the waves split N and share the activation tile through LDS")
-                                + f"; o_proj / down_proj K-split into fp32 planes) + {2 * layers + 1} decode_rmsnorm_kernel + {layers} "
-                                + ("decode_attn_kernel (a workgroup per (head, row))" if heads * B < 128 else
-                                   "decode_attn_beams_mfma_kernel (a workgroup per (head, sample), both products on MFMA)")
-                                + " launches + beam_step_kernel, one hipGraph replay per token; the time per token includes the prompt prefill's share"),
+                     "kernel": _decode_kernel_text(layers, heads, B, beams, fused_norm),
                      "algorithmic_bytes_per_launch": wbytes, "kernel_ms": step_s * 1e3,
                      "kv_cache_bytes_per_token": int(kv_bytes), "frac_with_kv_cache": achieved_kv / HBM_PEAK_GBS}}
 
@@ -866,7 +876,8 @@ def main():
                          "the first ~3 s of (memory-bound) decoding run 3 %% below the standalone decode line until the clocks recover -- "
                          "profiles/r05_secondary_warmup.txt: 350.8 tok/s with 1 warm-up call, 354.2 with 3, 361.2 after 3 s idle, 359.3 standalone")
     ap.add_argument("--mlp-bwd", choices=["fused", "unfused"], default=None,
-                    help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (default) or the round-4 two-kernel backward")
+                    help="A/B switch of the training steps: SwiGLU backward inside w3's dgrad GEMM (fused: the default for fp16 autocast) or the round-4 "
+                         "two-kernel backward (unfused: the default for bf16 autocast, the reference's training dtype)")
     ap.add_argument("--llm-shadows", choices=["on", "off"], default=None,
                     help="A/B switch of the fine-tuning steps: cached autocast-dtype copies of the frozen LLM's weights (default) or per-call casts")
     ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide_pf3", "wide_nw4", "wide_mt3", "wide1"], default=None,

@@ -998,6 +998,7 @@ int mxvl_decode_gemm_plan(const mxvl_gemv_desc* d, int32_t* out) {
 
 int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
   if (!d || !d->x || !d->W || (!d->y && !d->split_acc)) return MXVL_ERR_NULL;
+  if (!decode_dtype_ok(d->dtype)) return MXVL_ERR_DTYPE;
   // k_splits != 0 asks for the matrix-core kernels at any row count (1 = no split); 0 = by row count
   if (d->rows > kMaxRows || d->k_splits != 0 || d->split_acc) return decode_gemm_dispatch(d, (hipStream_t)hip_stream);
   if (d->rows <= 0 || d->K <= 0 || d->N <= 0) return MXVL_ERR_SHAPE;
@@ -1017,6 +1018,7 @@ int mxvl_decode_gemv(const mxvl_gemv_desc* d, void* hip_stream) {
 int mxvl_decode_attn(const mxvl_decode_attn_desc* d, void* hip_stream) {
   if (!d || !d->qkv || !d->cos || !d->sin || !d->k_cache || !d->v_cache || !d->slot_table || !d->pos || !d->mask || !d->out)
     return MXVL_ERR_NULL;
+  if (!decode_dtype_ok(d->dtype)) return MXVL_ERR_DTYPE;
   if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0) return MXVL_ERR_SHAPE;
   if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;
   AttnArgs a;
@@ -1054,6 +1056,7 @@ int mxvl_decode_prologue(const mxvl_decode_prologue_desc* d, void* hip_stream) {
 
 int mxvl_decode_cross_attn(const mxvl_decode_cross_attn_desc* d, void* hip_stream) {
   if (!d || !d->q_rope || !d->k || !d->v || !d->text_state || !d->gate_weight || !d->gate_bias || !d->out) return MXVL_ERR_NULL;
+  if (!decode_dtype_ok(d->dtype)) return MXVL_ERR_DTYPE;
   if (d->rows <= 0 || d->n_heads <= 0 || d->n_kv_heads <= 0 || d->n_heads % d->n_kv_heads != 0 || d->n_keys <= 0) return MXVL_ERR_SHAPE;
   if (d->kv_rows_div <= 0 || d->rows % d->kv_rows_div != 0) return MXVL_ERR_SHAPE;
   if (d->head_dim != 64 && d->head_dim != 128 && d->head_dim != 256) return MXVL_ERR_UNSUPPORTED;

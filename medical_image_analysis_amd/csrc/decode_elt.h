@@ -78,5 +78,7 @@ template <typename E> __device__ inline void elt_unpack8(const uint4 v, float* o
 
 // mxvl_dtype of a decode descriptor: 0 (what ABI <= 7 callers leave in the reserved field) means bf16
 inline int decode_dtype(int32_t v) { return v == 0 ? MXVL_BF16 : v; }
+// anything but bf16 / fp16 behind that default is refused (MXVL_ERR_DTYPE), not decoded as bf16
+inline bool decode_dtype_ok(int32_t v) { return v == 0 || v == MXVL_BF16 || v == MXVL_F16; }
 
 }  // namespace mxvl

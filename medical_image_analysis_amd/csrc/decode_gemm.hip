@@ -197,6 +197,7 @@ int decode_gemm_plan(const mxvl_gemv_desc* d, int32_t* out) {
 
 // argument checks of mxvl_decode_gemv + the kernel-side argument block (nothing is launched here)
 static int decode_gemm_args(const mxvl_gemv_desc* d, DecodeGemmArgs& a, int& splits) {
+  if (!decode_dtype_ok(d->dtype)) return MXVL_ERR_DTYPE;
   if (d->rows <= 0 || d->rows > 80 || d->K < 32 || d->N <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0) return MXVL_ERR_UNSUPPORTED;                      // 16-byte fragments
   if (d->swiglu && (!d->W2 || d->out_f32)) return MXVL_ERR_UNSUPPORTED;
@@ -231,6 +232,7 @@ using namespace mxvl;
 extern "C" int mxvl_decode_rmsnorm(const mxvl_rmsnorm_desc* d, void* hip_stream) {
   if (!d || !d->weight || !d->y) return MXVL_ERR_NULL;
   if (d->acc ? (!d->residual || !d->x_out) : !d->x) return MXVL_ERR_NULL;
+  if (!decode_dtype_ok(d->dtype)) return MXVL_ERR_DTYPE;
   if (d->rows <= 0 || d->K <= 0) return MXVL_ERR_SHAPE;
   if (d->K % 8 != 0 || d->K > 16384) return MXVL_ERR_UNSUPPORTED;
   RmsNormArgs a;

@@ -736,22 +736,33 @@ class ReportDecoder(nn.Module):
         cost the weights' size in HBM once (13.5 GB for Llama-2-7B)."""
         dev_type = inputs_embeds.device.type
         if not torch.is_autocast_enabled(dev_type) or not ReportDecoder.autocast_shadows:
+            self.free_autocast_shadows()       # autocast off (or the switch): nothing reads the copies
             return self.forward(inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
         dt = torch.get_autocast_dtype(dev_type)
         cache = self.__dict__.setdefault("_autocast_shadows", {})
         shadows = {}
         for name, w in self.named_parameters():
             if w.requires_grad or w.dim() != 2 or w.dtype == dt or "embed_tokens" in name or not w.is_floating_point():
+                cache.pop(name, None)          # unfrozen / re-typed since the copy was made: the copy (2 bytes per weight) is released
                 continue
-            key = (w._version, w.data_ptr(), w.dtype, dt)
+            key = (w._version, w.data_ptr(), w.dtype, dt, w.device)
             hit = cache.get(name)
             if hit is None or hit[0] != key:
                 hit = (key, w.detach().to(dt))
                 cache[name] = hit
             shadows[name] = hit[1]
+        for name in [n for n in cache if n not in shadows]:
+            del cache[name]
         if not shadows:
             return self.forward(inputs_embeds, attention_mask=attention_mask, position_ids=position_ids)
         return torch.func.functional_call(self, shadows, (inputs_embeds,), dict(attention_mask=attention_mask, position_ids=position_ids))
+
+    def free_autocast_shadows(self) -> int:
+        """Release the casted weight copies of forward_frozen_autocast (13.5 GB for a 7B decoder); the next call under autocast makes
+        them again.  Returns the bytes released.  (The copies are also dropped, per weight, as soon as a call finds the weight
+        unfrozen, re-typed, moved or re-allocated, and all of them when a call runs outside autocast.)"""
+        cache = self.__dict__.pop("_autocast_shadows", None) or {}
+        return sum(t.numel() * t.element_size() for _, t in cache.values())
 
     # ---- generation ------------------------------------------------------------------------------------------
     def _greedy(self, logits, cache, attn, dtype, eos_t, fill, min_new, max_new, rep_pen, stepper=None):

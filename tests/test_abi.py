@@ -177,3 +177,25 @@ def test_build_staleness_is_a_content_hash_not_an_mtime(tmp_path):
     _abi.load()                                     # the library exists (conftest / the driver's build())
     assert not b._stale() and open(b.LIB + ".sha256").read().strip() == b.source_digest()
     assert b.build() == b.LIB and b.LAST_BUILD["state"].startswith("up to date") and b.LAST_BUILD["compiled"] == []
+
+
+def test_decode_descriptors_refuse_dtypes_the_kernels_do_not_have():
+    """dtype 0 is the v7 default (bf16); any other code that is not MXVL_BF16 / MXVL_F16 -- an fp32 request as 3.., garbage --
+    returns MXVL_ERR_DTYPE (-2) from every decode entry instead of silently decoding as bf16.  No launch happens: fake pointers."""
+    lib = _abi.load()
+    for bad in (3, 7, -1, 1 << 20):
+        g = _abi.GemvDesc()
+        g.x = g.W = g.y = 64
+        g.rows, g.K, g.N, g.dtype = 3, 4096, 4096, bad
+        assert lib.mxvl_decode_gemv(ctypes.byref(g), None) == -2
+        g.k_splits = 1                                      # the matrix-core dispatch
+        assert lib.mxvl_decode_gemv(ctypes.byref(g), None) == -2
+        n = _abi.RmsNormDesc()
+        n.x = n.weight = n.y = 64
+        n.rows, n.K, n.eps, n.dtype = 3, 4096, 1e-6, bad
+        assert lib.mxvl_decode_rmsnorm(ctypes.byref(n), None) == -2
+        a = _abi.DecodeAttnDesc()
+        for f in ("qkv", "cos", "sin", "k_cache", "v_cache", "slot_table", "pos", "mask", "out"):
+            setattr(a, f, 64)
+        a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len, a.dtype = 3, 32, 32, 128, 512, bad
+        assert lib.mxvl_decode_attn(ctypes.byref(a), None) == -2

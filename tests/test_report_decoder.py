@@ -1073,6 +1073,20 @@ def test_frozen_decoder_autocast_shadows_equal_plain_autocast(dev):
     assert torch.equal(y2.float(), y2_ref.float())
     now = {k: v[1].data_ptr() for k, v in m._autocast_shadows.items()}
     assert now["lm_head.weight"] != first["lm_head.weight"] and all(now[k] == first[k] for k in now if k != "lm_head.weight")
+    # the copies do not outlive their use -- an unfrozen weight loses its copy at the next call, a call outside autocast
+    # (or free_autocast_shadows()) releases all of them
+    m.lm_head.weight.requires_grad = True
+    with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16):
+        m.forward_frozen_autocast(x.to(torch.float16), attention_mask=att)
+    assert "lm_head.weight" not in m._autocast_shadows and len(m._autocast_shadows) == 2 * 7
+    held = sum(t.numel() * 2 for _, t in m._autocast_shadows.values())
+    assert m.free_autocast_shadows() == held and not m.__dict__.get("_autocast_shadows")
+    with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16):
+        m.forward_frozen_autocast(x.to(torch.float16), attention_mask=att)
+    assert len(m._autocast_shadows) == 2 * 7
+    with torch.no_grad():
+        m.forward_frozen_autocast(x.to(torch.float16), attention_mask=att)      # no autocast: plain forward, copies released
+    assert not m.__dict__.get("_autocast_shadows")
 
 
 @pytest.mark.gpu
