@@ -1,0 +1,69 @@
+"""Dev tool (GPU): the eager-torch launches of one headline training step, by aten op, input shapes and the package source line that
+issued them (torch.profiler with_stack).  usage: python tools/step_eager.py [batch] [workload: pretrain|vmamba|mae]"""
+import os
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+from medical_image_analysis_amd.pretrain_engine import PretrainEngine
+
+dev = "cuda:0"
+torch.manual_seed(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+what = sys.argv[2] if len(sys.argv) > 2 else "pretrain"
+if what == "pretrain":
+    from medical_image_analysis_amd.models_pretrain import VisionMamba
+    model = VisionMamba(img_size=1024, patch_size=16, stride=16, embed_dim=1024, depth=24, dec_embed_dim=512, rms_norm=True,
+                        residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True, bimamba_type="None").to(dev)
+    x = torch.randn(B, 3, 1024, 1024, device=dev)
+    eng = PretrainEngine(model, device=dev)
+elif what == "vmamba":
+    import torch.nn as nn
+    from medical_image_analysis_amd.vmamba import vssm1_base_0229
+
+    class PooledLoss(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, imgs):
+            return self.net(imgs, global_features=True).float().square().mean(-1)
+    model = PooledLoss(vssm1_base_0229(drop_path_rate=0.0)).to(dev)
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    eng = PretrainEngine(model, device=dev)
+else:
+    raise SystemExit("workload")
+for _ in range(2):
+    eng.step(x)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+    eng.step(x)
+    torch.cuda.synchronize()
+PKG = "medical_image_analysis_amd"
+agg = defaultdict(lambda: [0.0, 0])
+tot = 0.0
+n_launch = 0
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
+    t = getattr(e, "self_device_time_total", None)
+    if t is None:
+        t = getattr(e, "self_cuda_time_total", 0)
+    if t <= 0:
+        continue
+    tot += t
+    if not e.key.startswith("aten::") and not e.key.startswith("Optimizer") and "Memcpy" not in e.key and "Memset" not in e.key:
+        continue
+    if e.key in ("aten::mm", "aten::bmm", "aten::addmm", "aten::addmm_", "aten::baddbmm", "aten::matmul", "aten::linear"):
+        continue
+    frame = next((f for f in e.stack if PKG in f or "bench.py" in f or "tools/" in f), (e.stack[0] if e.stack else "?"))
+    frame = frame.replace("/root/repo/", "").split(PKG + "/")[-1][:70]
+    agg[(e.key, str(e.input_shapes)[:60], frame)][0] += t
+    agg[(e.key, str(e.input_shapes)[:60], frame)][1] += e.count
+    n_launch += e.count
+rows = sorted(((v[0], v[1], k) for k, v in agg.items()), reverse=True)
+et = sum(r[0] for r in rows)
+print(f"total device time {tot / 1e3:.1f} ms; eager aten ops (no GEMMs): {et / 1e3:.2f} ms = {100 * et / tot:.1f} %, {n_launch} calls")
+for t, c, (k, sh, fr) in rows[:90]:
+    print(f"{t / 1e3:7.3f} ms x{c:4d}  {k[:26]:26s} {sh:60s} {fr}")
