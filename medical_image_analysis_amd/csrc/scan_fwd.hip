@@ -358,6 +358,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
 
 }  // namespace mxvl
 #include "scan_fwd_stream.h"
+#include "scan_n1.h"
 namespace mxvl {
 
 // ---------------------------------------------------------------------------------------------
@@ -416,8 +417,63 @@ static int launch_stream(const ScanArgs& a, hipStream_t stream, const char* name
 #define MXVL_FWD_CASE_OCC(T, LPR, NW, NU, MW) \
   launch_fwd<io_t, T, LPR, NW, NU, MW>(a, stream, "scan_fwd<T" #T ",LPR" #LPR ",W" #NW ",NU" #NU ",occ" #MW ">")
 
+// dstate 1 without z (VMamba's SS2D): the flat-row kernel of scan_n1.h.  Rows need T-element alignment (T = 8 for 16-bit rows with
+// L % 8 == 0, else 4); a wave's flat range (rw * L elements) and the magic divisions stay inside 32 bits.
+template <typename io_t>
+static int try_n1_fwd(const ScanArgs& a, hipStream_t stream, bool& taken) {
+  taken = false;
+  if (a.N != 1 || a.z || a.fold_magic || (g_variant & 0xff) == 30) return MXVL_OK;      // variant 30: A/B hook, the general kernels
+  const int64_t rows = (int64_t)a.batch * a.dim;
+  const int dpg = a.dim / a.G;
+  if (a.L < 8 || a.L % 4 != 0 || a.L > (1 << 20) || (int64_t)a.dim * dpg >= (1ll << 32)) return MXVL_OK;
+  constexpr int esz = (int)sizeof(io_t);
+  auto aligned = [&](int T) {
+    if (a.L % T != 0) return false;
+    for (int64_t s : {a.u_bs, a.u_ds, a.dl_bs, a.dl_ds, a.B_bs, a.B_gs, a.C_bs, a.C_gs})
+      if (s % T != 0) return false;
+    for (const void* q : {a.u, a.delta, a.B, a.C})
+      if (((uintptr_t)q) % (size_t)(T * esz) != 0) return false;
+    return true;
+  };
+  const int T = (esz == 2 && aligned(8)) ? 8 : (aligned(4) ? 4 : 0);
+  if (T == 0) return MXVL_OK;
+  ScanN1Geom gm;
+  // ~8 waves per SIMD of work items, at least 8 passes per wave where the problem is large enough; rw * L * L < 2^32 (magL exact)
+  int64_t rw = (rows + 8191) / 8192;
+  const int64_t min_rw = (8ll * 64 * T + a.L - 1) / a.L;
+  if (rw < min_rw) rw = min_rw;
+  while (rw > 1 && rw * a.L * (int64_t)a.L >= (1ll << 32)) --rw;
+  if (rw * a.L * (int64_t)a.L >= (1ll << 32) || rw * a.L >= (1ll << 30)) return MXVL_OK;
+  if (rw > rows) rw = rows;
+  gm.rw = (int)rw;
+  gm.n_waves = (int)((rows + rw - 1) / rw);
+  gm.magL = (uint32_t)((1ull << 32) / (uint64_t)a.L + 1ull);
+  gm.magG = (uint32_t)((1ull << 32) / (uint64_t)dpg + 1ull);
+  const int oesz = a.out_f32 ? 4 : esz;
+  gm.out_vec = (a.o_bs % 4 == 0 && a.o_ds % 4 == 0 && ((uintptr_t)a.out) % (size_t)(4 * oesz) == 0) ? 1 : 0;
+  constexpr int NW = 4;
+  const dim3 grid((gm.n_waves + NW - 1) / NW), block(NW * 64);
+  if constexpr (esz == 2) {
+    if (T == 8) hipLaunchKernelGGL((scan_n1_fwd_kernel<io_t, 8, NW>), grid, block, 0, stream, a, gm);
+    else hipLaunchKernelGGL((scan_n1_fwd_kernel<io_t, 4, NW>), grid, block, 0, stream, a, gm);
+    g_last_kernel = T == 8 ? "scan_n1_fwd<T8>" : "scan_n1_fwd<T4>";
+  } else {
+    hipLaunchKernelGGL((scan_n1_fwd_kernel<io_t, 4, NW>), grid, block, 0, stream, a, gm);
+    g_last_kernel = "scan_n1_fwd<T4>";
+  }
+  taken = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_last_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
 template <typename io_t>
 static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
+  {
+    bool taken = false;
+    const int rc = try_n1_fwd<io_t>(a, stream, taken);
+    if (rc != MXVL_OK || taken) return rc;
+  }
   if (a.fold_magic) {   // batch folded into the sequence: aligned rows, dstate 16 (the caller asked with MXVL_SCAN_FOLD_BATCH)
     if (!a.vec_ok || a.N != 16) return MXVL_ERR_UNSUPPORTED;
     for (int64_t bs : {a.u_bs, a.dl_bs, a.z_bs, a.o_bs, a.B_bs, a.C_bs})

@@ -780,3 +780,108 @@ def test_reference_oflex_grid(seqlen, itype):
                     if has_bias:
                         _allclose(lb.grad, rg["ddelta_bias"].view(dim1, ratio).sum(-1), rtolw, atolw, tag + "ddelta_bias")
                     assert ld.grad.shape == delta.shape and lB.grad.shape == Bm.shape and lB.grad.dtype == itype
+
+
+# ---------------------------------------------------------------------------------------------------
+# dstate 1 without z: the flat-row forward kernel (csrc/scan_n1.h) -- VMamba's SS2D scans (vmamba.py:294-312, 406-408)
+# ---------------------------------------------------------------------------------------------------
+N1_CASES = [
+    # B, D,  L,    G, ratio, dtype,          out_f32
+    (2, 96, 196, 4, 1, torch.bfloat16, False),      # the 14 x 14 stage: L % 8 != 0 -> T = 4, rows of 49 lanes
+    (3, 40, 784, 2, 1, torch.bfloat16, True),       # 28 x 28 stage, T = 8, fp32 out (oflex i16o32)
+    (1, 16, 3136, 1, 1, torch.float32, False),      # 56 x 56 stage, fp32 rows (T = 4): 49 passes over one wave's rows
+    (2, 24, 64, 1, 3, torch.float32, False),        # delta carries dim / 3 channels (oflex delta groups)
+    (5, 8, 12, 2, 1, torch.float16, False),         # rows far shorter than a pass: a wave spans several batch elements
+    (2, 768, 256, 1, 32, torch.float16, False),     # the reference test's dim 768 / dim1 24 (test_selective_scan.py:365-371), L % 128 == 0
+]
+
+
+@pytest.mark.parametrize("case", N1_CASES)
+def test_scan_n1_forward_flat_rows(case):
+    """Against the C oracle (fp32: the scan tolerance; 16-bit rows: the reference test's), last_state, and against the general kernels
+    (variant 30) on the same inputs: out within fp32 reassociation (the same io-dtype rounding of one fp32 value up to that), the
+    128-step checkpoints -- same layout, read by mxvl_scan_bwd -- equal to 1e-5 of their scale."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    B, D, L, G, ratio, dtype, of32 = case
+    cpu = scan_inputs(B, D, L, 1, G, False, True, True, seed=71, dtype=dtype)
+    gen = torch.Generator().manual_seed(72)
+    D1 = D // ratio
+    delta1 = (0.5 * torch.rand(B, D1, L, generator=gen)).to(dtype)
+    bias1 = 0.5 * torch.rand(D1, generator=gen)
+    delta_full = delta1.unsqueeze(2).repeat(1, 1, ratio, 1).flatten(1, 2).contiguous()
+    bias_full = bias1.unsqueeze(1).repeat(1, ratio).view(-1)
+    f = lambda t: t.float()
+    ref, ref_last = orc.selective_scan_ref(f(cpu["u"]), f(delta_full), cpu["A"], f(cpu["B"]), f(cpu["C"]), cpu["D"], None, bias_full, True,
+                                           return_last_state=True)
+    dev = _dev()
+    x = _to(dict(cpu, delta=delta1, delta_bias=bias1), dev)
+    Bm = x["B"] if G > 1 else x["B"].unsqueeze(1)
+    Cm = x["C"] if G > 1 else x["C"].unsqueeze(1)
+    lib = _abi.load()
+    res = {}
+    try:
+        for v in (0, 30):
+            lib.mxvl_set_scan_variant(v)
+            res[v] = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], None, x["delta_bias"], True, want_last_state=True,
+                                      want_ckpt=True, out_f32=of32) + (lib.mxvl_last_scan_kernel().decode(),)
+            torch.cuda.synchronize()
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    out, last, ckpt, name = res[0]
+    assert name.startswith("scan_n1_fwd<T"), name
+    assert not res[30][3].startswith("scan_n1"), res[30][3]
+    assert (name == "scan_n1_fwd<T8>") == (dtype != torch.float32 and L % 8 == 0 and (D1 * L) % 8 == 0)
+    assert out.dtype == (torch.float32 if (of32 or dtype == torch.float32) else dtype)
+    if dtype == torch.float32 or of32:
+        assert_close(out, ref, _atol(ref), 1e-5, f"out [{name}]")
+    else:
+        rtol, atol = (3e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 5e-3)
+        assert_close(out, ref, atol, rtol, f"out [{name}]")
+    assert_close(last, ref_last, _atol(ref_last), 1e-5, "last_state")
+    assert_close(last, res[30][1], 1e-5 * max(1.0, float(ref_last.abs().max())), 1e-5, "last_state vs the general kernels")
+    if L > 128:
+        assert ckpt is not None and tuple(ckpt.shape) == (B, D, (L + 127) // 128, 1)
+        assert_close(ckpt, res[30][2], 1e-5 * max(1.0, float(res[30][2].abs().max())), 1e-5, "checkpoints vs the general kernels")
+        assert float(ckpt[:, :, 0].abs().max()) == 0.0
+    else:
+        assert ckpt is None
+
+
+def test_scan_n1_forward_feeds_the_backward():
+    """The flat-row forward's checkpoints are the general backward's input: gradients of a VMamba-shaped call (dstate 1, 4 groups, no z)
+    through the autograd Function against the C oracle."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    B, D, L, G = 2, 64, 392, 4
+    cpu = scan_inputs(B, D, L, 1, G, False, True, True, seed=73)
+    dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(74))
+    ref = orc.selective_scan_ref_bwd(cpu["u"], cpu["delta"], cpu["A"], cpu["B"], cpu["C"], cpu["D"], None, cpu["delta_bias"], True, dout)
+    got = _grads_via_autograd(_to(cpu, _dev()), True, dout.to(_dev()))
+    assert _abi.load().mxvl_last_scan_kernel().decode() != "", "a kernel ran"
+    _check_grads(got, ref, "n1 forward + general backward: ")
+
+
+def test_scan_n1_full_size_vmamba_stage_roundtrip():
+    """Size-independent property at the R2GenCSR encoder's third-stage shape (B 32, K d_inner = 4096, L 196, bf16): the flat-row
+    kernel is linear in u for fixed delta -- out(u1 + 2 u2) == out(u1) + 2 out(u2) up to bf16 rounding -- and agrees with the general
+    kernels on the whole tensor."""
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    dev = _dev()
+    x = _to(scan_inputs(32, 4096, 196, 1, 4, False, False, True, seed=75, dtype=torch.bfloat16), dev)
+    lib = _abi.load()
+    run = lambda u: ssi.scan_fwd_raw(u, x["delta"], x["A"], x["B"], x["C"], None, None, x["delta_bias"], True, out_f32=True)[0]
+    u1 = x["u"]
+    u2 = torch.randn_like(u1)
+    o1, o2, o3 = run(u1), run(u2), run((u1.float() + 2.0 * u2.float()).to(torch.bfloat16))
+    assert lib.mxvl_last_scan_kernel().decode() == "scan_n1_fwd<T4>"
+    lin = o1 + 2.0 * o2
+    assert_close(o3, lin, 3e-2 * float(lin.abs().max()) / 8, 2e-2, "linearity in u (bf16 rounding of the summed input)")
+    try:
+        lib.mxvl_set_scan_variant(30)
+        og = run(u1)
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    assert_close(o1, og, 2e-5 * max(1.0, float(og.abs().max())), 1e-5, "flat-row kernel vs the general kernels, full size")

@@ -27,10 +27,10 @@ def use_lib(path):
     return lib
 
 
-def inputs(B, D, L, N, dt, seed=0):
+def inputs(B, D, L, N, dt, seed=0, G=1):
     g = torch.Generator().manual_seed(seed)
     mk = lambda *s: torch.randn(*s, generator=g).to(dev, dt)
-    u, z, Bm, Cm, dout = mk(B, D, L), mk(B, D, L), mk(B, 1, N, L), mk(B, 1, N, L), mk(B, D, L)
+    u, z, Bm, Cm, dout = mk(B, D, L), mk(B, D, L), mk(B, G, N, L), mk(B, G, N, L), mk(B, D, L)
     delta = (0.5 * torch.rand(B, D, L, generator=g)).to(dev, dt)
     A = (-0.5 * torch.rand(D, N, generator=g)).to(dev)
     Dv = torch.randn(D, generator=g).to(dev)
@@ -136,6 +136,30 @@ def bwd(rounds):
                   f"{nb / med * 1e-6:6.3f} TB/s = {nb / med * 1e-6 / 8 * 100:5.1f} %")
 
 
+def n1(rounds):
+    """dstate 1, 4 direction groups, no z (VMamba's SS2D stages at batch 32): the flat-row kernel (variant 0) vs the general kernels (30)"""
+    for (B, D, L, dt) in [(32, 4096, 196, torch.bfloat16), (32, 2048, 784, torch.bfloat16), (32, 1024, 3136, torch.bfloat16),
+                          (32, 4096, 196, torch.float32)]:
+        u, delta, A, Bm, Cm, Dv, _, bias, _ = inputs(B, D, L, 1, dt, G=4)
+        res, names = {0: [], 30: []}, {}
+        for r in range(rounds + 1):
+            for v in (0, 30):
+                lib.mxvl_set_scan_variant(v)
+                f = lambda: scan_fwd_raw(u, delta, A, Bm, Cm, Dv, None, bias, True, want_ckpt=True)
+                f()
+                torch.cuda.synchronize()
+                t = timed(f, 20)
+                names[v] = lib.mxvl_last_scan_kernel().decode()
+                if r > 0:
+                    res[v].append(t)
+        lib.mxvl_set_scan_variant(0)
+        nb = scan_algorithmic_bytes(B, D, L, 1, 4, u.element_size(), False, False, (L + 127) // 128)
+        print(f"fwd N=1 B={B} D={D} L={L} G=4 {str(dt)[6:]} ckpt=True: algorithmic {nb / 1e6:.1f} MB")
+        for v in (0, 30):
+            med, mn = statistics.median(res[v]), min(res[v])
+            print(f"   v{v:<3d} med {med:8.1f} us  min {mn:8.1f} us   {nb / med * 1e-6:6.3f} TB/s = {nb / med * 1e-6 / 8 * 100:5.1f} %   {names[v]}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -143,6 +167,9 @@ if __name__ == "__main__":
         here = os.path.dirname(PRODUCT)
         libs = [PRODUCT] + [os.path.join(here, "build", f"libmxvl_exp{e}.so") for e in sys.argv[3:]]
         ab(rounds, libs, what[3:])
+        sys.exit(0)
+    if what == "n1":
+        n1(rounds)
         sys.exit(0)
     if what in ("fwd", "all"):
         fwd(rounds)
