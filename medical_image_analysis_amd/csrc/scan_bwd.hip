@@ -881,6 +881,67 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
 static thread_local int g_bwd_hip_error = 0;
 extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxvl_set_scan_variant
 
+}  // namespace mxvl
+#include "scan_n1_bwd.h"
+namespace mxvl {
+
+// dstate 1 without z (VMamba's SS2D): the pass-major kernel of scan_n1_bwd.h.  u / delta / B / C rows need T-element alignment (T = 8
+// for 16-bit rows with L % 8 == 0, else 4), a workgroup's 4 rw channels one B / C group; dout / du / ddelta fall back to element
+// accesses inside the kernel when their rows are not aligned.  Reads the forward's 128-step checkpoints (any forward kernel's).
+template <typename io_t>
+static int try_n1_bwd(const ScanBwdArgs& a, hipStream_t stream, bool& taken) {
+  taken = false;
+  if (a.N != 1 || a.z || a.fold_magic || mxvl_scan_bwd_variant() == 3) return MXVL_OK;     // variant 3: A/B hook, the general kernel
+  const int64_t rows = (int64_t)a.batch * a.dim;
+  const int dpg = a.dim / a.G;
+  if (a.L < 8 || a.L % 4 != 0 || dpg % 4 != 0) return MXVL_OK;
+  constexpr int esz = (int)sizeof(io_t);
+  auto aligned = [&](int T) {
+    if (a.L % T != 0) return false;
+    for (int64_t s : {a.u_bs, a.u_ds, a.dl_bs, a.dl_ds, a.B_bs, a.B_gs, a.C_bs, a.C_gs})
+      if (s % T != 0) return false;
+    for (const void* q : {a.u, a.delta, a.B, a.C})
+      if (((uintptr_t)q) % (size_t)(T * esz) != 0) return false;
+    return true;
+  };
+  const int T = (esz == 2 && aligned(8)) ? 8 : (aligned(4) ? 4 : 0);
+  if (T == 0) return MXVL_OK;
+  if (a.L > 64 * T && !a.ckpt) return MXVL_OK;             // the state entering a later pass comes from the forward's checkpoints
+  constexpr int NW = 4;
+  // ~2048 workgroups where the problem allows, at least 8 rows per wave to amortise the dB / dC flush of a pass
+  int64_t rw = rows / ((int64_t)NW * 2048);
+  if (rw < 8) rw = 8;
+  if (rw > 64) rw = 64;
+  while (rw > 1 && dpg % (NW * rw) != 0) --rw;
+  if (dpg % (NW * rw) != 0) return MXVL_OK;
+  ScanN1BwdGeom gm;
+  gm.rw = (int)rw;
+  const int gesz = a.out_f32 ? 4 : esz;
+  auto vec = [&](const void* q, int64_t bs, int64_t ds, int e, int gran) {
+    return (bs % gran == 0 && ds % gran == 0 && ((uintptr_t)q) % (size_t)(gran * e) == 0) ? 1 : 0;
+  };
+  gm.do_vec = vec(a.dout, a.do_bs, a.do_ds, gesz, a.out_f32 ? 4 : T);
+  gm.du_vec = vec(a.du, a.du_bs, a.du_ds, esz, 4);
+  gm.dd_vec = vec(a.ddelta, a.dd_bs, a.dd_ds, esz, 4);
+  const dim3 grid((unsigned)(rows / (NW * rw))), block(NW * 64);
+  const size_t lds = sizeof(float) * ((size_t)NW * 2 * T * 64 + (size_t)NW * rw);
+  if constexpr (esz == 2) {
+    if (a.out_f32) {
+      if (T == 8) hipLaunchKernelGGL((scan_n1_bwd_kernel<io_t, 8, NW, true>), grid, block, lds, stream, a, gm);
+      else hipLaunchKernelGGL((scan_n1_bwd_kernel<io_t, 4, NW, true>), grid, block, lds, stream, a, gm);
+    } else {
+      if (T == 8) hipLaunchKernelGGL((scan_n1_bwd_kernel<io_t, 8, NW, false>), grid, block, lds, stream, a, gm);
+      else hipLaunchKernelGGL((scan_n1_bwd_kernel<io_t, 4, NW, false>), grid, block, lds, stream, a, gm);
+    }
+  } else {
+    hipLaunchKernelGGL((scan_n1_bwd_kernel<io_t, 4, NW, false>), grid, block, lds, stream, a, gm);
+  }
+  taken = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
 template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false, bool DMAR = false>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
@@ -925,6 +986,11 @@ static bool bwd_wide(int batch, int dim, int G, int /*L*/) {
 
 template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
+  {
+    bool taken = false;
+    const int rc = try_n1_bwd<io_t>(a, stream, taken);
+    if (rc != MXVL_OK || taken) return rc;
+  }
   if (a.fold_magic) {   // batch folded into the sequence (MXVL_SCAN_FOLD_BATCH): aligned rows, dstate 16, io-dtype dout
     if (!a.vec_ok || a.N != 16 || a.out_f32 || a.dB_bs != a.dC_bs) return MXVL_ERR_UNSUPPORTED;
     for (int64_t bs : {a.u_bs, a.dl_bs, a.z_bs, a.do_bs, a.du_bs, a.dd_bs, a.dz_bs, a.B_bs, a.C_bs, a.dB_bs})

@@ -885,3 +885,58 @@ def test_scan_n1_full_size_vmamba_stage_roundtrip():
     finally:
         lib.mxvl_set_scan_variant(0)
     assert_close(o1, og, 2e-5 * max(1.0, float(og.abs().max())), 1e-5, "flat-row kernel vs the general kernels, full size")
+
+
+@pytest.mark.parametrize("case", N1_CASES + [(2, 32, 1100, 4, 1, torch.float32, False), (2, 64, 520, 2, 2, torch.bfloat16, True)])
+def test_scan_n1_backward_pass_major(case):
+    """scan_n1_bwd_kernel (csrc/scan_n1_bwd.h) against the C oracle's gradients (on the delta expanded to all channels) and against
+    the general backward kernel (variant 3) on the same inputs and checkpoints: du / ddelta (io dtype), dA / dB / dC / dD /
+    ddelta_bias (fp32 accumulators).  out_f32 cases pass an fp32 dout (oflex i16o32)."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    B, D, L, G, ratio, dtype, of32 = case
+    cpu = scan_inputs(B, D, L, 1, G, False, True, True, seed=81, dtype=dtype)
+    gen = torch.Generator().manual_seed(82)
+    D1 = D // ratio
+    delta1 = (0.5 * torch.rand(B, D1, L, generator=gen)).to(dtype)
+    bias1 = 0.5 * torch.rand(D1, generator=gen)
+    dout = torch.randn(B, D, L, generator=gen)
+    if not of32:
+        dout = dout.to(dtype)
+    delta_full = delta1.unsqueeze(2).repeat(1, 1, ratio, 1).flatten(1, 2).contiguous()
+    bias_full = bias1.unsqueeze(1).repeat(1, ratio).view(-1)
+    f = lambda t: t.float()
+    ref = orc.selective_scan_ref_bwd(f(cpu["u"]), f(delta_full), cpu["A"], f(cpu["B"]), f(cpu["C"]), cpu["D"], None, bias_full, True, f(dout))
+    dev = _dev()
+    x = _to(dict(cpu, delta=delta1, delta_bias=bias1), dev)
+    Bm = x["B"] if G > 1 else x["B"].unsqueeze(1)
+    Cm = x["C"] if G > 1 else x["C"].unsqueeze(1)
+    lib = _abi.load()
+    _, _, ckpt = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], None, x["delta_bias"], True, want_ckpt=True)
+    res = {}
+    try:
+        for v in (0, 3):
+            lib.mxvl_set_scan_variant(v << 8)
+            res[v] = ssi.scan_bwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], None, x["delta_bias"], True, ckpt, dout.to(dev), dout_f32=of32)
+            torch.cuda.synchronize()
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")
+    got, gen_k = dict(zip(names, res[0])), dict(zip(names, res[3]))
+    want = dict(ref)
+    want["ddelta"] = ref["ddelta"].view(B, D1, ratio, L).sum(2)
+    want["ddelta_bias"] = ref["ddelta_bias"].view(D1, ratio).sum(1)
+    want["dB"], want["dC"] = ref["dB"].reshape(Bm.shape), ref["dC"].reshape(Cm.shape)
+    for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"):
+        r = want[k]
+        scale = max(1.0, float(r.abs().max()))
+        if dtype == torch.float32:
+            assert_close(got[k], r, 2e-5 * scale, 1e-4, f"{k} vs the oracle")
+            assert_close(got[k], gen_k[k], 2e-5 * scale, 1e-4, f"{k} vs the general kernel")
+        else:
+            # 16-bit rows: du / ddelta are rounded once from fp32 (the reference test's tolerances); the fp32 accumulators agree closely
+            rtol, atol = ((3e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 5e-3)) if k in ("du", "ddelta") else (1e-3, 2e-4 * scale)
+            assert_close(got[k].float(), r, atol * (scale if k in ("du", "ddelta") else 1.0), rtol, f"{k} vs the oracle")
+            assert_close(got[k].float(), gen_k[k].float(), atol * (scale if k in ("du", "ddelta") else 1.0), rtol, f"{k} vs the general kernel")
+    assert got["ddelta"].shape == delta1.shape and got["du"].dtype == dtype and got["dB"].dtype == torch.float32

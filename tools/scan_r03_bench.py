@@ -158,6 +158,27 @@ def n1(rounds):
         for v in (0, 30):
             med, mn = statistics.median(res[v]), min(res[v])
             print(f"   v{v:<3d} med {med:8.1f} us  min {mn:8.1f} us   {nb / med * 1e-6:6.3f} TB/s = {nb / med * 1e-6 / 8 * 100:5.1f} %   {names[v]}")
+        # backward: the pass-major kernel (variant 0) vs the general kernel (3); the times include the zero fill of dA | dD | dbias
+        _, _, ckpt = scan_fwd_raw(u, delta, A, Bm, Cm, Dv, None, bias, True, want_ckpt=True)
+        dout = torch.randn(B, D, L, generator=torch.Generator().manual_seed(5)).to(dev, dt)
+        dB = torch.zeros(Bm.shape, dtype=torch.float32, device=dev)
+        dC = torch.zeros_like(dB)
+        resb = {0: [], 3: []}
+        for r in range(rounds + 1):
+            for v in (0, 3):
+                lib.mxvl_set_scan_variant(v << 8)
+                f = lambda: scan_bwd_raw(u, delta, A, Bm, Cm, Dv, None, bias, True, ckpt, dout, dB=dB, dC=dC)
+                f()
+                torch.cuda.synchronize()
+                t = timed(f, 10)
+                if r > 0:
+                    resb[v].append(t)
+        lib.mxvl_set_scan_variant(0)
+        nbb = scan_algorithmic_bytes(B, D, L, 1, 4, u.element_size(), False, True, ckpt.shape[2])
+        print(f"bwd N=1 B={B} D={D} L={L} G=4 {str(dt)[6:]}: algorithmic {nbb / 1e6:.1f} MB")
+        for v in (0, 3):
+            med, mn = statistics.median(resb[v]), min(resb[v])
+            print(f"   variant {v} ({'scan_n1_bwd' if v == 0 else 'general kernel'}): med {med:8.1f} us  min {mn:8.1f} us   {nbb / med * 1e-6:6.3f} TB/s = {nbb / med * 1e-6 / 8 * 100:5.1f} %")
 
 
 if __name__ == "__main__":
