@@ -426,6 +426,63 @@ def cpu_baseline_pretrain(sd, img, patch, depth, trainable, budget_s=20.0):
                       f"{cores}); {elapsed:.1f} s of CPU work, of which forward {fwd_s:.1f} s"}
 
 
+def _cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_mae(budget_s=15.0):
+    """BASELINE configs[0]'s route -- "HD_Xray_Pretrain_MAE ... on CPU reference path": the MAE mirror's own torch-CPU arithmetic (the
+    restatement of pretrain/models/mae.py over finetune/DP/models/vit.py's Block that tests/test_mae_vitb_cfg1.py pins to the
+    reference's golden), the same mae_vit_large_patch16 on one 1280 x 1280 image: forward + backward + AdamW in fp32, host cores."""
+    from medical_image_analysis_amd.mae import mae_vit_large_patch16
+    cores = min(host_physical_cores(), 64)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = mae_vit_large_patch16()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0.05)
+    x = torch.randn(1, 1, 1280, 1280, generator=torch.Generator().manual_seed(0))
+    n, elapsed = 0, 0.0
+    while elapsed < budget_s and n < 16:
+        t0 = time.perf_counter()
+        loss, mask = net(x, 1, 0.85, 0.95)
+        opt.zero_grad(set_to_none=True)
+        ((loss * mask).sum() / mask.sum()).backward()
+        opt.step()
+        elapsed += time.perf_counter() - t0
+        n += 1
+    return {"value": n / elapsed, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": _cpu_model_name(),
+            "sample": f"{n} x (forward + backward + AdamW) of the same mae_vit_large_patch16 on one 1280x1280 image, fp32, the mirror's "
+                      f"torch-CPU arithmetic (no GradScaler: fp32), torch intra-op threads = {cores}; {elapsed:.1f} s of CPU work"}
+
+
+def cpu_baseline_vssm(sd, depths, budget_s=15.0):
+    """VMamba-base forward on the host: oracle/models_ref.vssm_forward_ref over the C scan oracle, one 224 x 224 image, fp32.
+    FORWARD ONLY (the model-level oracle has no SS2D backward): the unit is images/sec of the encoder forward, said so in `sample`."""
+    from oracle import models_ref
+    from oracle import oracle as orc
+    cores = min(host_physical_cores(), 64)
+    orc.set_threads(cores)
+    torch.set_num_threads(cores)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    n, elapsed = 0, 0.0
+    with torch.no_grad():
+        while elapsed < budget_s and n < 16:
+            t0 = time.perf_counter()
+            models_ref.vssm_forward_ref(sd, x, depths, "v3noz", global_features=True)
+            elapsed += time.perf_counter() - t0
+            n += 1
+    return {"value": n / elapsed, "unit": "images/sec (forward only)", "cores": cores, "kind": "port", "cpu": _cpu_model_name(),
+            "sample": f"{n} x FORWARD of the same vssm1_base_0229 on one 224x224 image, fp32 (oracle/models_ref.vssm_forward_ref over "
+                      f"oracle/mxvl_oracle.c; the GPU value is a training step: forward + backward + AdamW), threads = {cores}; {elapsed:.1f} s of CPU work"}
+
+
 def run_pretrain(args, rank, world, dev, dist):
     """Stage-1 pre-training step: VisionMamba forward+backward+clip+AdamW, bf16 autocast, DDP gradient all-reduce."""
     import medical_image_analysis_amd.selective_scan_interface as ssi
@@ -697,7 +754,13 @@ def run_mae(args, rank, world, dev, dist):
     kept, L = model.kept + 1, 401
     flops = 6.0 * B * (enc * kept + dec * L) + 12.0 * B * (24 * kept * kept * 1024 + 8 * L * L * 512)   # GEMMs + attention, fwd+bwd
     step_s = wall / steps
+    cpu_b = None
+    if world == 1 and not args.no_cpu_baseline:
+        del eng, batches
+        torch.cuda.empty_cache()
+        cpu_b = cpu_baseline_mae()
     print(json.dumps({
+        **({"cpu_baseline": cpu_b} if cpu_b is not None else {}),
         "metric": "pre-training images/sec (forward + backward + grad-clip + AdamW)", "value": B * world * steps / wall,
         "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16",
@@ -777,7 +840,12 @@ def run_vmamba(args, rank, world, dev, dist):
     kind = max(stats, key=lambda k: stats[k][0])
     tot_ms, calls, tot_bytes = stats[kind]
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+    cpu_b = None
+    if world == 1 and not args.no_cpu_baseline and args.workload == "vmamba_base_224":
+        sd = {k: v.detach().float().cpu() for k, v in model.net.state_dict().items()}
+        cpu_b = cpu_baseline_vssm(sd, [2, 2, 15, 2])
     print(json.dumps({
+        **({"cpu_baseline": cpu_b} if cpu_b is not None else {}),
         "metric": "encoder training images/sec (forward + backward + grad-clip + AdamW)", "value": B * world * steps / wall,
         "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
