@@ -216,7 +216,14 @@ def cross_selective_scan(x, x_proj_weight, x_proj_bias, dt_projs_weight, dt_proj
     if out_norm_shape == "v1":
         y = out_norm(y.view(B, -1, H, W)).permute(0, 2, 3, 1)
     else:
-        y = out_norm(y.transpose(1, 2).contiguous()).view(B, H, W, -1)
+        yt = y.transpose(1, 2).contiguous()
+        if (type(out_norm) is nn.LayerNorm and yt.is_cuda and yt.dtype in (torch.float32, torch.bfloat16)
+                and fused_ops.add_layer_norm_supported(yt, yt.shape[-1])):
+            # the package's LayerNorm kernels (csrc/fused_norm_act.hip; branch = None: a plain LayerNorm, fp32 statistics) in the
+            # place of aten::native_layer_norm + its eager backward (2 ms of the 54 ms VMamba-base step, tools/step_eager.py)
+            y = fused_ops.add_layer_norm(yt, None, out_norm.weight, out_norm.bias, out_norm.eps, out_dtype=yt.dtype)[1].view(B, H, W, -1)
+        else:
+            y = out_norm(yt).view(B, H, W, -1)
     return y.to(x.dtype) if to_dtype else y
 
 
