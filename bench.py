@@ -952,6 +952,8 @@ def main():
                     help="A/B switch of the 17..80-row decode projections: waves split N + LDS-shared activations (wide, default), the round-4 K-split "
                          "kernels at every row count (ksplit), the wide kernel as first measured (wide_pf3: 33..80 rows, >= 160 workgroups, 3-stage ring, "
                          "four waves), four waves per workgroup everywhere (wide_nw4), 33..80 rows and >= 160 workgroups only (wide_mt3), from one row on (wide1)")
+    ap.add_argument("--scan-variant", type=int, default=0,
+                    help="A/B switch: mxvl_set_scan_variant (forward kernel choice in bits 0..7, backward in bits 8..15; 0 = automatic)")
     ap.add_argument("--decode-norm", choices=["fused", "split"], default=None,
                     help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
                          "(K-split o_proj / down_proj folded by explicit norm launches)")
@@ -993,6 +995,8 @@ def main():
     from medical_image_analysis_amd import _abi
     from medical_image_analysis_amd.selective_scan_interface import scan_fwd_raw
 
+    if args.scan_variant:
+        _abi.load().mxvl_set_scan_variant(args.scan_variant)
     if args.mlp_bwd:
         from medical_image_analysis_amd import fused_ops
         fused_ops._MlpSwiGLU.FUSED_BWD = args.mlp_bwd == "fused"

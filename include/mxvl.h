@@ -32,6 +32,12 @@
  * pointers % 16 == 0) -- forward and backward apply the same rule; rows that are only 8-byte aligned (e.g. seqlen % 8 == 4, or a
  * view starting 4 elements into its storage) run on the element-wise kernels (same results, several times slower), and
  * MXVL_SCAN_FOLD_BATCH returns MXVL_ERR_UNSUPPORTED for them.
+ * dstate 1 without z (VMamba / R2GenCSR SS2D, vmamba.py:294-312; the vendored oflex kernels' own test configuration): forward and
+ * backward have kernels of their own (csrc/scan_n1.h, scan_n1_bwd.h) -- rows of the whole launch walked as one flat sequence
+ * (forward) / pass-major per wave (backward), wave-wide DPP scans, no LDS tiles.  Taken when seqlen % 4 == 0 and the rows of u,
+ * delta, B, C start on 4-element boundaries (8 elements for 16-bit rows with seqlen % 8 == 0: 16-byte accesses); the backward also
+ * needs dim / n_groups % 4 == 0.  Same descriptors, same checkpoint layout (the state entering every 128-step chunk), same
+ * tolerances: nothing about the call changes, and either direction may run on the general kernels while the other does not.
  *
  * Deviations from SURVEY.md section 8-b, recorded here because this header is the boundary:
  *   * `mxvl_mamba_inner_fwd / mxvl_mamba_inner_bwd` (one fused entry for mamba_inner_fn, CXPMRG_Bench_MambaXray_VL/pretrain/

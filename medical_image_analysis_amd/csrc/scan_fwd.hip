@@ -481,7 +481,10 @@ static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
     // the same workgroup-shape rule as the plain launch, with (parts of the batch) in the place of (batch elements)
     const int64_t tiles8 = (int64_t)((a.batch + a.fold_bpp - 1) / a.fold_bpp) * a.G * ((a.dim / a.G + 31) / 32);
     const int fv = g_variant & 0xff;
-    if (fv >= 15 && fv <= 18) {   // packed state pairs (A/B hook)
+    // packed state pairs (scan_fwd_stream.h PK): the automatic pick for 16-bit rows -- B64 x D4096 x L200 bf16 (the 4-direction encoder):
+    // 279 -> 247 us (profiles/r06_scan_fwd_exp_ab.txt), arm_encoder_large_224 823-826 -> 828-832 images/s, stage-3 step 54.2-54.9 ->
+    // 55.0-55.1 studies/s (profiles/r06_fold_pk_step_ab.txt); variant 14 forces the unpacked walk
+    if ((fv >= 15 && fv <= 18) || (fv == 0 && sizeof(io_t) == 2)) {
       if (tiles8 >= 512) return launch_stream1<io_t, 8, true, 2, 8, 16, true, true>(a, stream, "scan_fwd_stream<W8,vec,occ2,fold,pk>");
       return launch_stream1<io_t, 4, true, 2, 8, 16, true, true>(a, stream, "scan_fwd_stream<W4,vec,occ2,fold,pk>");
     }
