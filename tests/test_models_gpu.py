@@ -288,8 +288,15 @@ def test_bias_gradient_from_add_ln_column_sums_and_cached_weight_casts():
     # (dB / dC of the scan backward leave as fp32 atomics: two runs of the same step differ in the last bits, cache or no cache)
     for a, b in zip(outs[0][0], outs[1][0]):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (outs[0][0], outs[1][0])
+    # ... and AdamW turns a gradient element that is ~0 with either sign into +-lr per step: isolated elements may sit up to 2 lr x 3 steps
+    # apart (1 of 174 592 did, at 4.3e-4, once the reference's GradScaler kept the tiniest bf16 gradients from flushing): the bound is
+    # the tight one for all but 1e-4 of a tensor's elements and 2 lr x steps for every element
     for n in outs[0][1]:
-        assert_close(outs[0][1][n], outs[1][1][n], 2e-3 * float(outs[1][1][n].abs().max()) + 1e-6, 1e-2, n)
+        a, b = outs[0][1][n].float(), outs[1][1][n].float()
+        err = (a - b).abs()
+        tight = err <= 2e-3 * float(b.abs().max()) + 1e-6 + 1e-2 * b.abs()
+        assert float((~tight).float().mean()) <= 1e-4, f"{n}: {int((~tight).sum())} / {tight.numel()} elements beyond the tight bound"
+        assert float(err.max()) <= 2 * 1e-3 * 3 + 1e-6, f"{n}: max |difference| {float(err.max()):.3e} exceeds 2 lr x steps"
 
 
 def test_bias_column_sums_are_dropped_when_the_branch_has_a_second_consumer():

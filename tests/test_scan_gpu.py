@@ -701,27 +701,44 @@ def _allclose(got, ref, rtol, atol, what):
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} / {bad.numel()} beyond torch.allclose(rtol={rtol}, atol={atol}); max err {float((got - ref).abs().max()):.3e}"
 
 
-def _dA_float64(u, delta_full, A, Bm, Cm, bias_full, softplus, dout):
-    """dA of the N = 1 grid case in float64 (autograd over the recurrence, vectorised over channels): the arbiter where fp32 summation
-    noise of the ORACLE exceeds the reference's dA tolerance -- channels with A ~ 0 never forget, their 2 x 4096 terms reach 1e5 and
-    cancel to 1e2 .. 1e3 (measured at L 2048: C oracle 1.4 off float64 on a 4.8e5 sum, the HIP kernel 0.37)."""
+def _reductions_float64(u, delta_full, A, Bm, Cm, bias_full, softplus, dout):
+    """dA, dB, dC of the N = 1 grid case in float64, by the explicit forward / adjoint recurrences, each with S = the sum of the
+    absolute values of what is summed (dA: |g_t a_t h_{t-1} delta_t| over batch and time; dB / dC: the channels' shares of a step):
+    the arbiter where fp32 noise exceeds the reference's tolerance.  Channels with A ~ 0
+    never forget -- at L 4096 one has A = -4.3e-4, dA = -4.8e3 out of S = 6.4e6 (terms up to 3.8e3 that cancel): a state carried in
+    fp32 over 4096 non-decaying steps is off by ~sqrt(L) eps relative, i.e. ~25 on that sum, for ANY fp32 kernel (the C oracle:
+    1.4 off float64 on a 4.8e5 sum at L 2048; the general HIP kernel 0.37; the dstate-1 kernel 30 at L 4096)."""
     B4 = Bm if Bm.dim() == 4 else Bm.unsqueeze(1)
     C4 = Cm if Cm.dim() == 4 else Cm.unsqueeze(1)
-    G, dim = B4.shape[1], u.shape[1]
+    G, dim, L = B4.shape[1], u.shape[1], u.shape[2]
     rep = dim // G
-    A64 = A.double().clone().requires_grad_(True)
     dl = delta_full.double() + (bias_full.double()[None, :, None] if bias_full is not None else 0.0)
     if softplus:
         dl = torch.nn.functional.softplus(dl)
     Bx = B4[:, :, 0].double().repeat_interleave(rep, dim=1)          # (batch, dim, L)
     Cx = C4[:, :, 0].double().repeat_interleave(rep, dim=1)
+    a = torch.exp(dl * A.double()[:, 0][None, :, None])
+    b = dl * Bx * u.double()
+    cd = Cx * dout.double()
+    hprev = torch.zeros(u.shape[0], dim, L, dtype=torch.float64)     # h_{t-1}
     h = torch.zeros(u.shape[0], dim, dtype=torch.float64)
-    acc = 0.0
-    for t in range(u.shape[2]):
-        h = torch.exp(dl[:, :, t] * A64[:, 0]) * h + dl[:, :, t] * Bx[:, :, t] * u[:, :, t].double()
-        acc = acc + (h * Cx[:, :, t] * dout[:, :, t].double()).sum()
-    acc.backward()
-    return A64.grad
+    for t in range(L):
+        hprev[:, :, t] = h
+        h = a[:, :, t] * h + b[:, :, t]
+    terms = torch.empty_like(hprev)
+    gs = torch.empty_like(hprev)
+    g = torch.zeros_like(h)
+    for t in range(L - 1, -1, -1):
+        g = cd[:, :, t] + (a[:, :, t + 1] * g if t + 1 < L else 0.0)
+        gs[:, :, t] = g
+        terms[:, :, t] = g * a[:, :, t] * hprev[:, :, t] * dl[:, :, t]
+    hs = a * hprev + b                                               # h_t
+    vB = (gs * dl * u.double()).view(u.shape[0], G, rep, L)          # shares of dB[b, g, t] / dC[b, g, t] per channel
+    vC = (dout.double() * hs).view(u.shape[0], G, rep, L)
+    shape = tuple(Bm.shape)
+    return {"dA": (terms.sum((0, 2)).unsqueeze(1), terms.abs().sum((0, 2)).unsqueeze(1)),
+            "dB": (vB.sum(2).reshape(shape), vB.abs().sum(2).reshape(shape)),
+            "dC": (vC.sum(2).reshape(shape), vC.abs().sum(2).reshape(shape))}
 
 
 @pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16], ids=["fp32", "fp16", "bf16"])
@@ -765,14 +782,21 @@ def test_reference_oflex_grid(seqlen, itype):
                     _allclose(state, ref_state, rtol, atol, tag + "last_state")
                     out.backward(dout.to(dev))
                     _allclose(lu.grad, rg["du"].to(itype), rtol * 2, atol * 2, tag + "du")
-                    try:
-                        _allclose(lA.grad, rg["dA"], rtolw, atolw * 5, tag + "dA")
-                    except AssertionError:
-                        # the fp32 oracle is not accurate enough to arbitrate this element (see _dA_float64): float64 does
-                        dA64 = _dA_float64(f(u), f(delta_full), A, f(Bm), f(Cm), bias_full, softplus, f(dout))
-                        _allclose(lA.grad, dA64, rtolw, atolw * 5, tag + "dA vs float64")
-                    _allclose(lB.grad, rg["dB"], rtol, atol, tag + "dB")
-                    _allclose(lC.grad, rg["dC"], rtol, atol, tag + "dC")
+                    f64 = None
+                    for key, got_t, rt, at in (("dA", lA.grad, rtolw, atolw * 5), ("dB", lB.grad, rtol, atol), ("dC", lC.grad, rtol, atol)):
+                        try:
+                            _allclose(got_t, rg[key], rt, at, tag + key)
+                        except AssertionError:
+                            # the fp32 oracle cannot arbitrate an ill-conditioned sum (see _reductions_float64): the reference's tolerance
+                            # against float64, plus what an fp32 state recurrence of L steps must be allowed on a sum of size S
+                            if f64 is None:
+                                f64 = _reductions_float64(f(u), f(delta_full), A, f(Bm), f(Cm), bias_full, softplus, f(dout))
+                            val, S = f64[key]
+                            err = (got_t.detach().double().cpu() - val).abs()
+                            bound = at + rt * val.abs() + 4.0 * (seqlen ** 0.5) * 2.0 ** -24 * S
+                            assert bool((err <= bound).all()), tag + f"{key} vs float64: max err {float(err.max()):.3e}, max excess over the bound {float((err - bound).max()):.3e}"
+                            oerr = (rg[key].double() - val).abs()
+                            assert bool((oerr <= bound).all()), tag + key + ": the C oracle itself is outside the conditioning-aware bound"
                     if has_D:
                         _allclose(lD.grad, rg["dD"], rtolw, atolw, tag + "dD")
                     dgr = rg["ddelta"].view(batch, dim1, ratio, seqlen).sum(2)
