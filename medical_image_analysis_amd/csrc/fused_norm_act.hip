@@ -32,9 +32,16 @@ struct NormBwdArgs {
                                // linear that produced the branch: its backward no longer re-reads rows x C to sum it)
 };
 
-__device__ inline float wsum(float v) {
+// sum over the LPR lanes that own one row (LPR = 64: the wave; 32 / 16: two / four rows per wave)
+template <int LPR = 64> __device__ inline float wsum(float v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// sum over the 64 / LPR rows of a wave that share a column (lanes l, l + LPR, ...)
+template <int LPR> __device__ inline float rsum(float v) {
+#pragma unroll
+  for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
@@ -44,31 +51,38 @@ template <typename T> __device__ inline void ld4v(const T* p, float (&v)[4]) {
 }
 template <typename T> __device__ inline void st4v(T* p, const float (&v)[4]) { st4<T>(p, make_float4(v[0], v[1], v[2], v[3])); }
 
-// K = C / 256: every lane owns K groups of 4 consecutive columns: column (k*64 + lane)*4
-template <typename res_t, typename br_t, typename out_t, int K>
+// C = 4 K LPR: a row is owned by LPR lanes (64: one row per wave; 32 / 16 -- rows of 128 / 64 columns and their odd multiples: VMamba's
+// first stage and patch embedding, the constructors' default embed_dim 192 -- two / four rows per wave), every lane owns K groups of 4
+// consecutive columns: column (k * LPR + lane % LPR) * 4
+template <typename res_t, typename br_t, typename out_t, int K, int LPR = 64>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const NormArgs p) {
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = lane % LPR, sub = lane / LPR;
   const int C = p.C;
   float g[K][4], bta[K][4];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int c = (k * 64 + lane) * 4;
+    const int c = (k * LPR + sl) * 4;
     ld4v<float>(p.gamma + c, g[k]);
     if (p.beta) ld4v<float>(p.beta + c, bta[k]);
     else { bta[k][0] = bta[k][1] = bta[k][2] = bta[k][3] = 0.0f; }
   }
-  for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < p.rows; row0 += gridDim.x * 4 * RPW) {
+    const int row_i = row0 + sub;
+    const bool live = row_i < p.rows;                  // the last wave of a narrow-row launch may own fewer than RPW rows
+    const int row = live ? row_i : p.rows - 1;         // (its idle lanes re-read the last row and store nothing)
     float v[K][4];
     const res_t* xr = (const res_t*)p.x + (size_t)row * C;
 #pragma unroll
-    for (int k = 0; k < K; ++k) ld4v<res_t>(xr + (k * 64 + lane) * 4, v[k]);
+    for (int k = 0; k < K; ++k) ld4v<res_t>(xr + (k * LPR + sl) * 4, v[k]);
     if (p.br) {
       const br_t* br = (const br_t*)p.br + (size_t)row * C;
       res_t* hr = (res_t*)p.h + (size_t)row * C;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         float b[4];
-        ld4v<br_t>(br + (k * 64 + lane) * 4, b);
+        ld4v<br_t>(br + (k * LPR + sl) * 4, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[k][j] += b[j];
@@ -76,28 +90,28 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const NormArgs p) {
             res_t t; Io<res_t>::st(&t, v[k][j]); v[k][j] = Io<res_t>::ld(&t);
           }
         }
-        st4v<res_t>(hr + (k * 64 + lane) * 4, v[k]);
+        if (live) st4v<res_t>(hr + (k * LPR + sl) * 4, v[k]);
       }
     }
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
-    const float mean = wsum(s) / (float)C;
+    const float mean = wsum<LPR>(s) / (float)C;
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(wsum(q) / (float)C + p.eps);
+    const float rstd = rsqrtf(wsum<LPR>(q) / (float)C + p.eps);
     out_t* nr = (out_t*)p.n + (size_t)row * C;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float o[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = fmaf((v[k][j] - mean) * rstd, g[k][j], bta[k][j]);
-      st4v<out_t>(nr + (k * 64 + lane) * 4, o);
+      if (live) st4v<out_t>(nr + (k * LPR + sl) * 4, o);
     }
-    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+    if (sl == 0 && live) { p.mean[row] = mean; p.rstd[row] = rstd; }
   }
 }
 
@@ -107,19 +121,24 @@ template <typename T> __device__ inline float ln_round_trip(float v) {   // valu
   else return (float)(_Float16)v;
 }
 
-template <typename res_t, typename br_t, typename out_t, int K>
+template <typename res_t, typename br_t, typename out_t, int K, int LPR = 64>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
-  __shared__ float sred[2][4][K * 256];   // [gamma|beta][wave][column]; re-used for the branch-gradient sums
+  constexpr int RPW = 64 / LPR;
+  __shared__ float sred[2][4][K * LPR * 4];   // [gamma|beta][wave][column]; re-used for the branch-gradient sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = lane % LPR, sub = lane / LPR;
   const int C = p.C;
   float g[K][4], ag[K][4], ab[K][4], ad[K][4];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    ld4v<float>(p.gamma + (k * 64 + lane) * 4, g[k]);
+    ld4v<float>(p.gamma + (k * LPR + sl) * 4, g[k]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ag[k][j] = 0.0f; ab[k][j] = 0.0f; ad[k][j] = 0.0f; }
   }
-  for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < p.rows; row0 += gridDim.x * 4 * RPW) {
+    const int row_i = row0 + sub;
+    const bool live = row_i < p.rows;
+    const int row = live ? row_i : p.rows - 1;
     const float mean = p.mean[row], rstd = p.rstd[row];
     float xh[K][4], dy[K][4];
     const res_t* hr = (const res_t*)p.h + (size_t)row * C;
@@ -127,10 +146,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      ld4v<res_t>(hr + (k * 64 + lane) * 4, xh[k]);
-      ld4v<out_t>(dr + (k * 64 + lane) * 4, dy[k]);
+      ld4v<res_t>(hr + (k * LPR + sl) * 4, xh[k]);
+      ld4v<out_t>(dr + (k * LPR + sl) * 4, dy[k]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (!live) dy[k][j] = 0.0f;                    // an idle sub-row adds nothing to the column sums
         xh[k][j] = (xh[k][j] - mean) * rstd;
         ag[k][j] = fmaf(dy[k][j], xh[k][j], ag[k][j]);
         ab[k][j] += dy[k][j];
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
         s2 = fmaf(dy[k][j], xh[k][j], s2);
       }
     }
-    const float m1 = wsum(s1) / (float)C, m2 = wsum(s2) / (float)C;
+    const float m1 = wsum<LPR>(s1) / (float)C, m2 = wsum<LPR>(s2) / (float)C;
     res_t* dxr = (res_t*)p.dx + (size_t)row * C;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -148,22 +168,32 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
       for (int j = 0; j < 4; ++j) o[j] = rstd * (dy[k][j] - m1 - xh[k][j] * m2);
       if (p.dh) {
         float r[4];
-        ld4v<res_t>((const res_t*)p.dh + (size_t)row * C + (k * 64 + lane) * 4, r);
+        ld4v<res_t>((const res_t*)p.dh + (size_t)row * C + (k * LPR + sl) * 4, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += r[j];
       }
-      st4v<res_t>(dxr + (k * 64 + lane) * 4, o);
-      if (p.dbr) st4v<br_t>((br_t*)p.dbr + (size_t)row * C + (k * 64 + lane) * 4, o);
-      if (p.pdbr) {      // uniform: the sum of the values the consumer will read (the branch dtype's rounding of dx)
+      if (live) {
+        st4v<res_t>(dxr + (k * LPR + sl) * 4, o);
+        if (p.dbr) st4v<br_t>((br_t*)p.dbr + (size_t)row * C + (k * LPR + sl) * 4, o);
+      }
+      if (p.pdbr && live) {      // the sum of the values the consumer will read (the branch dtype's rounding of dx)
 #pragma unroll
         for (int j = 0; j < 4; ++j) ad[k][j] += p.dbr ? ln_round_trip<br_t>(o[j]) : ln_round_trip<res_t>(o[j]);
       }
     }
   }
+  if constexpr (RPW > 1) {       // the rows of a wave that share a column: one sum per column before the cross-wave tree
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    *(float4*)&sred[0][wave][(k * 64 + lane) * 4] = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
-    *(float4*)&sred[1][wave][(k * 64 + lane) * 4] = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ag[k][j] = rsum<LPR>(ag[k][j]); ab[k][j] = rsum<LPR>(ab[k][j]); ad[k][j] = rsum<LPR>(ad[k][j]); }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      *(float4*)&sred[0][wave][(k * LPR + sl) * 4] = make_float4(ag[k][0], ag[k][1], ag[k][2], ag[k][3]);
+      *(float4*)&sred[1][wave][(k * LPR + sl) * 4] = make_float4(ab[k][0], ab[k][1], ab[k][2], ab[k][3]);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -172,8 +202,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
   }
   if (p.pdbr) {
     __syncthreads();
+    if (sub == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) *(float4*)&sred[0][wave][(k * 64 + lane) * 4] = make_float4(ad[k][0], ad[k][1], ad[k][2], ad[k][3]);
+      for (int k = 0; k < K; ++k) *(float4*)&sred[0][wave][(k * LPR + sl) * 4] = make_float4(ad[k][0], ad[k][1], ad[k][2], ad[k][3]);
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256)
       p.pdbr[(size_t)blockIdx.x * C + c] = (sred[0][0][c] + sred[0][1][c]) + (sred[0][2][c] + sred[0][3][c]);
@@ -450,14 +482,26 @@ static int dispatch_swiglu(const void* ab, const void* dy, void* out, int rows, 
 // ARM-large step) on top of a kernel that is bandwidth-bound either way.
 constexpr int kLnBwdPartials = 1024;
 
-template <typename R, typename B, typename O, int K>
+template <typename R, typename B, typename O, int K, int LPR = 64>
 static void launch_ln(bool bwd, const void* args, int rows, hipStream_t s) {
+  // (the backward's grid IS the caller's n_partials = mxvl_add_layernorm_partials(rows), whatever the row width: workgroups that
+  // get no row of a narrow-row launch write zero partials)
   const int wgs = std::min((rows + 3) / 4, bwd ? kLnBwdPartials : 2048);
-  if (bwd) hipLaunchKernelGGL((add_ln_bwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormBwdArgs*)args);
-  else hipLaunchKernelGGL((add_ln_fwd_kernel<R, B, O, K>), dim3(wgs), dim3(256), 0, s, *(const NormArgs*)args);
+  if (bwd) hipLaunchKernelGGL((add_ln_bwd_kernel<R, B, O, K, LPR>), dim3(wgs), dim3(256), 0, s, *(const NormBwdArgs*)args);
+  else hipLaunchKernelGGL((add_ln_fwd_kernel<R, B, O, K, LPR>), dim3(wgs), dim3(256), 0, s, *(const NormArgs*)args);
 }
 template <typename R, typename B, typename O>
 static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s) {
+  if (C % 256 != 0) {       // narrow rows: 128 k (two rows per wave) or 64 k (four rows per wave), k in {1, 3}
+    switch (C) {
+      case 128: launch_ln<R, B, O, 1, 32>(bwd, args, rows, s); break;
+      case 384: launch_ln<R, B, O, 3, 32>(bwd, args, rows, s); break;
+      case 64: launch_ln<R, B, O, 1, 16>(bwd, args, rows, s); break;
+      case 192: launch_ln<R, B, O, 3, 16>(bwd, args, rows, s); break;
+      default: return MXVL_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+  }
   switch (C / 256) {
     case 1: launch_ln<R, B, O, 1>(bwd, args, rows, s); break;
     case 2: launch_ln<R, B, O, 2>(bwd, args, rows, s); break;
@@ -470,7 +514,7 @@ static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
 static int dispatch_ln(bool bwd, const void* args, int rows, int C, int res_dt, int br_dt, int out_dt, hipStream_t s) {
-  if (C % 256 != 0) return MXVL_ERR_UNSUPPORTED;
+  if (C % 64 != 0) return MXVL_ERR_UNSUPPORTED;
   if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_F32) return dispatch_k<float, float, float>(bwd, args, rows, C, s);
   if (res_dt == MXVL_F32 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<float, bf16_t, bf16_t>(bwd, args, rows, C, s);
   if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_BF16) return dispatch_k<float, float, bf16_t>(bwd, args, rows, C, s);

@@ -20,7 +20,9 @@ _LN_DTYPES = {(torch.float32, torch.float32, torch.float32), (torch.float32, tor
 
 
 def add_layer_norm_supported(x, cols):
-    return x.is_cuda and cols % 256 == 0 and cols // 256 in (1, 2, 3, 4, 6, 8)
+    """Row widths csrc/fused_norm_act.hip has kernels for: 256 k (k in 1, 2, 3, 4, 6, 8: one row per wave) and the narrow rows 64, 128,
+    192, 384 (four / two rows per wave: VMamba's first stage and patch embedding, the constructors' default embed_dim 192)."""
+    return x.is_cuda and ((cols % 256 == 0 and cols // 256 in (1, 2, 3, 4, 6, 8)) or cols in (64, 128, 192, 384))
 
 
 def _autocast_dtype(x):

@@ -249,6 +249,20 @@ class Linear2d(nn.Linear):
         return super()._load_from_state_dict(state_dict, prefix, *args)
 
 
+class LayerNormHip(nn.LayerNorm):
+    """nn.LayerNorm (same parameters, same state_dict keys) whose forward and backward run on the package's LayerNorm kernels
+    (csrc/fused_norm_act.hip through fused_ops.add_layer_norm with no branch) wherever they have the row width: VSSM's patch-embedding,
+    down-sampling and classifier norms -- with the blocks' own norms fused into add+LayerNorm (VSSBlock.forward_fused) no
+    aten::native_layer_norm / native_layer_norm_backward is left in the R2GenCSR encoder's step (4.5 ms of 54 in round 5,
+    tools/step_eager.py).  fp32 statistics; the output takes the autocast dtype where autocast would have cast it for the next layer."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.elementwise_affine and len(self.normalized_shape) == 1
+                and fused_ops.add_layer_norm_supported(x, x.shape[-1])):
+            return fused_ops.add_layer_norm(x, None, self.weight, self.bias, self.eps)[1]
+        return super().forward(x)
+
+
 class LayerNorm2d(nn.LayerNorm):
     def forward(self, x):
         return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
@@ -508,7 +522,7 @@ class VSSBlock(nn.Module):
     def fusable(self, x):
         """Pre-norm, channel-last LayerNorms of a width the add+LayerNorm kernel takes (256 / 512 / 1024 of VSSM-base)."""
         return (self.ssm_branch and self.mlp_branch and not self.post_norm and not self.use_checkpoint
-                and type(self.norm) is nn.LayerNorm and type(self.norm2) is nn.LayerNorm
+                and type(self.norm) in (nn.LayerNorm, LayerNormHip) and type(self.norm2) in (nn.LayerNorm, LayerNormHip)
                 and x.dtype in (torch.float32, torch.bfloat16) and fused_ops.add_layer_norm_supported(x, x.shape[-1]))
 
     def forward_fused(self, h, pending, inference_params=None):
@@ -518,7 +532,7 @@ class VSSBlock(nn.Module):
         return h, self.drop_path(self.mlp(n))
 
 
-_NORMS = dict(ln=nn.LayerNorm, ln2d=LayerNorm2d, bn=nn.BatchNorm2d)
+_NORMS = dict(ln=LayerNormHip, ln2d=LayerNorm2d, bn=nn.BatchNorm2d)
 _ACTS = dict(silu=nn.SiLU, gelu=nn.GELU, relu=nn.ReLU, sigmoid=nn.Sigmoid)
 
 

@@ -181,3 +181,32 @@ def test_dwconv3x3_act_forward_backward_vs_torch(shape, dtype, bias, silu):
     close(convd.weight.grad, ref_dw, "dweight", tol * 4)
     if bias:
         close(convd.bias.grad, ref_db, "dbias", tol * 4)
+
+
+@pytest.mark.parametrize("C,shape", [(64, (2, 28, 28)), (128, (3, 14, 14)), (256, (2, 7, 9)), (1024, (2, 5, 5))])
+def test_layer_norm_hip_equals_nn_layer_norm(C, shape):
+    """vmamba.LayerNormHip -- the norm VSSM builds for norm_layer="ln": the package's LayerNorm kernels (narrow rows 64 / 128 since
+    round 6) against torch's nn.LayerNorm with the same parameters, forward and backward, on a contiguous tensor and on the permuted
+    view the patch embedding feeds it (Permute(0, 2, 3, 1) of a convolution's output)."""
+    vm = _vm()
+    torch.manual_seed(C)
+    ln = vm.LayerNormHip(C).to(DEV)
+    ref = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, device=DEV))
+        ln.bias.copy_(0.1 * torch.randn(C, device=DEV))
+    ref.load_state_dict(ln.state_dict())
+    for permuted in (False, True):
+        base = torch.randn(shape[0], C, *shape[1:], device=DEV) if permuted else torch.randn(*shape, C, device=DEV)
+        xa = base.clone().requires_grad_(True)
+        xb = base.clone().requires_grad_(True)
+        ya = ln(xa.permute(0, 2, 3, 1) if permuted else xa)
+        yb = ref(xb.permute(0, 2, 3, 1) if permuted else xb)
+        cot = torch.randn_like(yb)
+        (ya * cot).sum().backward()
+        (yb * cot).sum().backward()
+        assert float((ya - yb).abs().max()) <= 2e-5 * max(1.0, float(yb.abs().max()))
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-4 * max(1.0, float(xb.grad.abs().max()))
+        assert float((ln.weight.grad - ref.weight.grad).abs().max()) <= 1e-4 * max(1.0, float(ref.weight.grad.abs().max()))
+        assert float((ln.bias.grad - ref.bias.grad).abs().max()) <= 1e-4 * max(1.0, float(ref.bias.grad.abs().max()))
+        ln.zero_grad(); ref.zero_grad()
