@@ -491,6 +491,14 @@ def run_pretrain(args, rank, world, dev, dist):
     img, patch, embed, depth, dec, B, desc = PRETRAIN_WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    north = None
+    if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
+        # north_star's one numeric kernel target (BASELINE.json: ">= 40 % of MI355X HBM roofline on the selective-scan kernel at L=4096,
+        # D=1536"): the forward scan alone at B8 x L4096 x D1536 x N16 fp32, ~0.1 s, so that the driver's own line carries it.  Measured
+        # FIRST, before the training leg has driven the chip to its power limit (a memory-bound kernel right behind it runs ~3 % below
+        # its standalone rate until the clocks recover: profiles/r05_secondary_warmup.txt) -- the standalone `--workload scan_fwd_target`
+        # line is the same measurement
+        north = measure_scan("scan_fwd_target", 200, 20, rank, world, dev, dist, no_cpu_baseline=True)
     torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcasts rank 0's anyway)
     model = VisionMamba(img_size=img, patch_size=patch, stride=patch, embed_dim=embed, depth=depth, dec_embed_dim=dec,
                         rms_norm=True, residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True,
@@ -525,7 +533,7 @@ def run_pretrain(args, rank, world, dev, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         cpu_trainable = [n for n, p in model.named_parameters() if p.requires_grad]
-    secondary = north = None
+    secondary = None
     if args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
         # second half of BASELINE.json's metric ("MAE pretrain images/sec + report-gen decode tokens/sec"): the report
         # decoder of configs[3], measured by the same process right after the training steps (replicas on every rank)
@@ -534,9 +542,6 @@ def run_pretrain(args, rank, world, dev, dist):
         secondary = measure_decode("decode_llama7b_128", 5, args.secondary_warmup, rank, world, dev, dist)
         if secondary is not None and world == 1 and not args.no_cpu_baseline:
             secondary["cpu_baseline"] = cpu_baseline_decode("decode_llama7b_128")
-        # north_star's one numeric kernel target (BASELINE.json: ">= 40 % of MI355X HBM roofline on the selective-scan kernel at L=4096,
-        # D=1536"): the forward scan alone at B8 x L4096 x D1536 x N16 fp32, ~0.1 s, so that the driver's own line carries it
-        north = measure_scan("scan_fwd_target", 200, 20, rank, world, dev, dist, no_cpu_baseline=True)
     if rank != 0:
         return
     stats = {}
