@@ -646,6 +646,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(cons
     // (measured and removed, profiles/r06_scan_fwd_exp_ab.txt: two states per trip through ONE interleaved DPP block, scan16_x2, instead of
     // two scan16_x1 blocks with their s_nops -- 171 VGPRs, the third workgroup per CU is lost: 318.9 vs 259.9 us; with the B / C tile
     // by LDS-DMA to win the registers back, 167 VGPRs: 275.2 us; the tile by LDS-DMA alone: 271.4 us)
+    // (unroll 4: the same instruction count per state, 157 VGPRs; the whole loop unrolled: 256 VGPRs + 1 KB of scratch)
 #pragma unroll 2
     for (int n = 0; n < n_states; ++n) {
       float a[T], bb[T], cv[T], P, hl, x;
