@@ -277,7 +277,10 @@ def test_bias_gradient_from_add_ln_column_sums_and_cached_weight_casts():
     outs = []
     for cache in (True, False):
         m = make()
-        eng = PretrainEngine(m, lr=1e-3, device=DEV)
+        # (use_scaler=False: with the reference's GradScaler -- the default -- the 2^16-scaled backward keeps bf16 gradients that are
+        # mathematically zero, e.g. the key bias of a softmax attention, from flushing to exact zeros, and AdamW turns that rounding
+        # noise into +-lr per step for the whole tensor: two runs of the SAME engine then differ there, cache or no cache)
+        eng = PretrainEngine(m, lr=1e-3, device=DEV, use_scaler=False)
         if not cache:
             eng._cast_params = []
         l = [float(eng.step(imgs)) for _ in range(3)]
