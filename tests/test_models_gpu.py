@@ -254,52 +254,58 @@ def test_bias_gradient_from_add_ln_column_sums_and_cached_weight_casts():
                            residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True, bimamba_type="None").to(DEV)
 
     imgs = torch.randn(4, 3, 128, 128, device=DEV)
-    grads = []
-    for use in (True, False):
-        m = make()
-        real = ssi.bias_grad
-        hits0 = ssi.COLSUM_HITS
-        if not use:
-            ssi.bias_grad = lambda dy, d2, bdt, dim=0: d2.sum(dim, dtype=torch.float32).to(bdt)
-        try:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                m(imgs).mean().backward()
-        finally:
-            ssi.bias_grad = real
-        if use:
-            assert ssi.COLSUM_HITS > hits0, "the w3 bias gradients must have come from the add+LN kernel's column sums"
-        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if n.endswith("w3.bias")})
-    assert grads[0] and grads[0].keys() == grads[1].keys()
-    for n in grads[0]:
-        assert_close(grads[0][n], grads[1][n], 1e-6 * float(grads[1][n].abs().max()) + 1e-9, 1e-5, n)
+    # (1) inside ONE backward pass (two passes of the same model do not repeat bit for bit: fp32 atomics in the scan backward move bf16
+    # roundings -- the two-run form of this check failed 3 times in 6 on the round-5 code as well): every bias gradient the add+LN
+    # column sums deliver is compared, where it is produced, with the plain sum of the same rounded gradient rows
+    m = make()
+    real = ssi.bias_grad
+    hits0 = ssi.COLSUM_HITS
+    seen = []
 
-    # (2) cached casts: two engine steps, with and without the refresh
-    outs = []
-    for cache in (True, False):
-        m = make()
-        # (use_scaler=False: with the reference's GradScaler -- the default -- the 2^16-scaled backward keeps bf16 gradients that are
-        # mathematically zero, e.g. the key bias of a softmax attention, from flushing to exact zeros, and AdamW turns that rounding
-        # noise into +-lr per step for the whole tensor: two runs of the SAME engine then differ there, cache or no cache)
-        eng = PretrainEngine(m, lr=1e-3, device=DEV, use_scaler=False)
-        if not cache:
-            eng._cast_params = []
-        l = [float(eng.step(imgs)) for _ in range(3)]
-        if cache:
-            p = next(q for q in m.parameters() if q.ndim >= 2 and q.requires_grad)
-            assert getattr(p, "_mxvl_lp", None) is not None and p._mxvl_lp[0] == (p._version, p.data_ptr(), p.device)
-        outs.append((l, {n: q.detach().clone() for n, q in m.named_parameters()}))
-    # (dB / dC of the scan backward leave as fp32 atomics: two runs of the same step differ in the last bits, cache or no cache)
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (outs[0][0], outs[1][0])
-    # ... and AdamW turns a gradient element that is ~0 with either sign into +-lr per step: isolated elements may sit up to 2 lr x 3 steps
-    # apart (1 of 174 592 did, at 4.3e-4, once the reference's GradScaler kept the tiniest bf16 gradients from flushing): the bound is
-    # the tight one for all but 1e-4 of a tensor's elements and 2 lr x steps for every element
-    for n in outs[0][1]:
-        a, b = outs[0][1][n].float(), outs[1][1][n].float()
-        err = (a - b).abs()
-        tight = err <= 2e-3 * float(b.abs().max()) + 1e-6 + 1e-2 * b.abs()
-        assert float((~tight).float().mean()) <= 1e-4, f"{n}: {int((~tight).sum())} / {tight.numel()} elements beyond the tight bound"
-        assert float(err.max()) <= 2 * 1e-3 * 3 + 1e-6, f"{n}: max |difference| {float(err.max()):.3e} exceeds 2 lr x steps"
+    def both(dy, d2, bdt, dim=0):
+        r = real(dy, d2, bdt, dim)
+        plain = d2.sum(dim, dtype=torch.float32).to(bdt)
+        seen.append((float((r.float() - plain.float()).abs().max()), float(plain.float().abs().max())))
+        return r
+
+    ssi.bias_grad = both
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m(imgs).mean().backward()
+    finally:
+        ssi.bias_grad = real
+    assert ssi.COLSUM_HITS > hits0, "the w3 bias gradients must have come from the add+LN kernel's column sums"
+    assert len(seen) >= 12
+    for err, scale in seen:
+        assert err <= 1e-5 * scale + 1e-9, (err, scale)
+
+    # (2) cached casts: after an optimizer step the engine holds low-precision copies of every weight; from the SAME weights, a
+    # forward + backward that reads the copies equals one that casts per call -- the forward bit for bit up to the library GEMMs' own
+    # repeatability, the gradients up to the backward's (compared in L2; AdamW-updated weights are no yardstick: it turns a gradient
+    # element that is ~0 with either sign into +-lr)
+    m = make()
+    eng = PretrainEngine(m, lr=1e-3, device=DEV, use_scaler=False)
+    eng.step(imgs)
+    p = next(q for q in m.parameters() if q.ndim >= 2 and q.requires_grad)
+    assert getattr(p, "_mxvl_lp", None) is not None and p._mxvl_lp[0] == (p._version, p.data_ptr(), p.device)
+
+    def fwd_bwd():
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = m(imgs).mean()
+        loss.backward()
+        return float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None}
+
+    l_cached, g_cached = fwd_bwd()
+    l_again, g_again = fwd_bwd()                      # the same thing twice: the repeatability floor
+    eng.drop_casts()
+    assert not hasattr(p, "_mxvl_lp")
+    l_plain, g_plain = fwd_bwd()
+    assert abs(l_cached - l_plain) <= max(1e-6 * abs(l_plain), 2.0 * abs(l_cached - l_again)), (l_cached, l_again, l_plain)
+    num = sum(float((g_cached[n] - g_plain[n]).square().sum()) for n in g_plain)
+    floor = sum(float((g_cached[n] - g_again[n]).square().sum()) for n in g_plain)
+    den = sum(float(g_plain[n].square().sum()) for n in g_plain)
+    assert (num / den) ** 0.5 <= max(2e-2, 4.0 * (floor / den) ** 0.5), ((num / den) ** 0.5, (floor / den) ** 0.5)
 
 
 def test_bias_column_sums_are_dropped_when_the_branch_has_a_second_consumer():
