@@ -28,6 +28,7 @@
 namespace mxvl {
 
 constexpr int kWave = 64;
+typedef float v2f __attribute__((ext_vector_type(2)));   // an aligned VGPR pair: operands of v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
 constexpr float kLog2e = 1.4426950408889634f;
 
 // ---- io element <-> fp32 ---------------------------------------------------------------------
@@ -81,12 +82,6 @@ __device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline float softplus(float x) {
   const float w = fast_exp(x);
   const float s = 1.0f + w;
-#if MXVL_EXP & 1
-  const float den0 = s - 1.0f;
-  const float l0 = fast_log2(s) * 0.6931471805599453f;
-  const float r0 = (den0 == 0.0f) ? w : l0 * w * fast_rcp(den0);
-  return x > 20.0f ? x : r0;
-#endif
   const float den = s - 1.0f;
   const float l = fast_log2(s) * 0.6931471805599453f;
   const float r = fmaf(w - den, fmaxf(1.0f - den, 0.0f), l);

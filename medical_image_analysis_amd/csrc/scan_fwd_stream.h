@@ -55,7 +55,6 @@ __device__ inline void scan8_x1(float& h0, float& P0, float& x0) {
 // B / C tile is stored pair-interleaved -- tile row p holds states (2p, 2p + 1): [4 blocks of 2 steps][LPR lanes][step s, state] so that
 // one ds_read_b128 yields (B_n[i], B_n+1[i], B_n[i+1], B_n+1[i+1]) -- and A * log2(e) and the running state live in two separate
 // [rows][N + 2] arrays (an (n, n + 1) pair is one aligned ds_read_b64 / ds_write_b64).
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <typename io_t, int NWAVES, bool VEC, int MINW, int T = 8, int NS = 0, bool FOLD = false, bool PK = false>
 __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_stream_kernel(const ScanArgs p) {

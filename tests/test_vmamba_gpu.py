@@ -25,7 +25,10 @@ def test_cross_scan_merge_bit_exact_golden():
         assert torch.equal(vm.CrossMerge.apply(ys).float().cpu(), g[ky])
 
 
-@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 7, 33, 65), (1, 5, 1, 70), (2, 4, 31, 1), (1, 2, 128, 96)])
+# planes held in the LDS (flat kernels: several planes per workgroup, a ragged last group, V = 4 and V = 1) and planes that only
+# the 32 x 32 tiles can take (128 x 96 in fp32)
+@pytest.mark.parametrize("shape", [(2, 96, 56, 56), (3, 7, 33, 65), (1, 5, 1, 70), (2, 4, 31, 1), (1, 2, 128, 96),
+                                   (3, 70, 14, 14), (2, 37, 7, 7), (2, 19, 28, 28), (1, 3, 12, 20), (1, 1030, 14, 14)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_cross_scan_merge_bit_exact_vs_oracle(shape, dtype):
     vm = _vm()

@@ -93,6 +93,11 @@ def ab(rounds, libs, what):
                     o = scan_fwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, want_ckpt=(dt != torch.float32))[0]
                     ref_out = o.clone() if ref_out is None else ref_out
                     print(f"      {os.path.basename(l)}: max |out - product out| = {float((o.float() - ref_out.float()).abs().max()):.3e}")
+                if what == "bwd" and r == 0:       # every arm's gradients against the product library's (relative L2)
+                    o = [t.float().clone() for t in scan_bwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, ckpt, dout) if t is not None]
+                    ref_out = o if ref_out is None else ref_out
+                    rel = [float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(o, ref_out)]
+                    print(f"      {os.path.basename(l)}: rel L2 vs product (du ddelta dA dB dC dD dz dbias) = " + " ".join(f"{x:.1e}" for x in rel))
                 if what == "bwd":
                     f = lambda: scan_bwd_raw(u, delta, A, Bm, Cm, Dv, z, bias, True, ckpt, dout, dB=dB, dC=dC)
                 else:
