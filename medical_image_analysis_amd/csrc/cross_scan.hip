@@ -207,7 +207,7 @@ template <typename io_t>
 static int launch_cross(bool merge, const void* in, void* out, int B, int C, int H, int W, hipStream_t s) {
   const int L = H * W;
   const int P = cross_planes_per_wg(merge, B, C, L, (int)sizeof(io_t));
-  if (P > 0 && B <= 65535 && (long)P * L * L < (1l << 32) && !(MXVL_EXP & 1)) {
+  if (P > 0 && B <= 65535 && (long)P * L * L < (1l << 32)) {
     const bool v4 = L % 4 == 0 && ((uintptr_t)in) % 16 == 0 && ((uintptr_t)out) % 16 == 0;
     CrossGeom g;
     g.C = C; g.H = H; g.W = W; g.L = L; g.P = P; g.LV = v4 ? L / 4 : L;

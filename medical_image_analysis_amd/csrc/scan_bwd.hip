@@ -883,6 +883,8 @@ extern "C" int mxvl_scan_bwd_variant(void);   // scan_fwd.hip: bits 8..15 of mxv
 
 }  // namespace mxvl
 #include "scan_n1_bwd.h"
+#define MXVL_N1_SHORT_BWD
+#include "scan_n1_short.h"
 namespace mxvl {
 
 // dstate 1 without z (VMamba's SS2D): the pass-major kernel of scan_n1_bwd.h.  u / delta / B / C rows need T-element alignment (T = 8
@@ -942,6 +944,40 @@ static int try_n1_bwd(const ScanBwdArgs& a, hipStream_t stream, bool& taken) {
   return MXVL_OK;
 }
 
+// rows of at most 128 steps that scan_n1_bwd.h cannot take (L % 4 != 0 or unaligned rows): a lane per row (scan_n1_short.h).  Dense
+// (batch, dim, L) u / delta / dout / du / ddelta, 64 | dim / n_groups.
+template <typename io_t>
+static int try_n1_short_bwd(const ScanBwdArgs& a, hipStream_t stream, bool& taken) {
+  taken = false;
+  if (a.N != 1 || a.z || a.fold_magic || mxvl_scan_bwd_variant() == 3) return MXVL_OK;
+  const int dpg = a.dim / a.G;
+  const int64_t DL = (int64_t)a.dim * a.L;
+  if (a.L < 1 || a.L > 128 || dpg % 64 != 0 || a.dl_ratio > 1) return MXVL_OK;
+  if (a.u_ds != a.L || a.u_bs != DL || a.dl_ds != a.L || a.dl_bs != DL || a.do_ds != a.L || a.do_bs != DL ||
+      a.du_ds != a.L || a.du_bs != DL || a.dd_ds != a.L || a.dd_bs != DL) return MXVL_OK;
+  for (const void* q : {a.u, a.delta, a.dout, (const void*)a.du, (const void*)a.ddelta})
+    if (((uintptr_t)q) % 16 != 0) return MXVL_OK;
+  constexpr int esz = (int)sizeof(io_t);
+  const int gesz = a.out_f32 ? 4 : esz;
+  const size_t per_wave = (size_t)64 * a.L * (2 * esz + gesz + sizeof(float)) + (size_t)2 * ((a.L + 3) & ~3) * sizeof(float);
+  if (per_wave > 64 * 1024) return MXVL_OK;
+  const int64_t waves = (int64_t)a.batch * a.dim / 64;
+  const bool two = 2 * per_wave <= 64 * 1024;
+  const dim3 grid((unsigned)(two ? (waves + 1) / 2 : waves)), block(two ? 128 : 64);
+  const size_t lds = per_wave * (two ? 2 : 1);
+  if (a.out_f32 && esz == 2) {
+    if (two) hipLaunchKernelGGL((scan_n1_short_bwd_kernel<io_t, 2, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((scan_n1_short_bwd_kernel<io_t, 1, true>), grid, block, lds, stream, a);
+  } else {
+    if (two) hipLaunchKernelGGL((scan_n1_short_bwd_kernel<io_t, 2, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((scan_n1_short_bwd_kernel<io_t, 1, false>), grid, block, lds, stream, a);
+  }
+  taken = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_bwd_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
 template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false, bool DMAR = false>
 static int launch_bwd1(const ScanBwdArgs& a, hipStream_t stream) {
   constexpr int DT = NWAVES * 4, CH = 128, NT = NWAVES * 64;
@@ -988,7 +1024,9 @@ template <typename io_t>
 static int dispatch_bwd(const ScanBwdArgs& a, hipStream_t stream) {
   {
     bool taken = false;
-    const int rc = try_n1_bwd<io_t>(a, stream, taken);
+    int rc = try_n1_bwd<io_t>(a, stream, taken);
+    if (rc != MXVL_OK || taken) return rc;
+    rc = try_n1_short_bwd<io_t>(a, stream, taken);
     if (rc != MXVL_OK || taken) return rc;
   }
   if (a.fold_magic) {   // batch folded into the sequence (MXVL_SCAN_FOLD_BATCH): aligned rows, dstate 16, io-dtype dout

@@ -23,6 +23,7 @@
 //
 // Algorithmic HBM bytes per launch: elt*(4*B*D*L + 2*B*G*N*L) + 4*(D*N + 2*D).
 #include "mxvl_common.h"
+#include <type_traits>
 
 namespace mxvl {
 
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(NWAVES * 64, MINW) void scan_fwd_kernel(const ScanA
 }  // namespace mxvl
 #include "scan_fwd_stream.h"
 #include "scan_n1.h"
+#include "scan_n1_short.h"
 namespace mxvl {
 
 // ---------------------------------------------------------------------------------------------
@@ -467,11 +469,47 @@ static int try_n1_fwd(const ScanArgs& a, hipStream_t stream, bool& taken) {
   return MXVL_OK;
 }
 
+// dstate 1, rows of at most 128 steps that scan_n1.h cannot take (L % 4 != 0 -- VMamba's 7 x 7 stage -- or unaligned rows): a lane per
+// row (scan_n1_short.h).  u / delta / out must be dense (batch, dim, L) arrays, 64 | dim / n_groups.
+template <typename io_t>
+static int try_n1_short_fwd(const ScanArgs& a, hipStream_t stream, bool& taken) {
+  taken = false;
+  if (a.N != 1 || a.z || a.fold_magic || (g_variant & 0xff) == 30) return MXVL_OK;
+  const int dpg = a.dim / a.G;
+  const int64_t DL = (int64_t)a.dim * a.L;
+  if (a.L < 1 || a.L > 128 || dpg % 64 != 0 || a.dl_ratio > 1) return MXVL_OK;
+  if (a.u_ds != a.L || a.u_bs != DL || a.dl_ds != a.L || a.dl_bs != DL || a.o_ds != a.L || a.o_bs != DL) return MXVL_OK;
+  for (const void* q : {a.u, a.delta, (const void*)a.out})
+    if (((uintptr_t)q) % 16 != 0) return MXVL_OK;
+  constexpr int esz = (int)sizeof(io_t);
+  const int oesz = a.out_f32 ? 4 : esz;
+  const size_t per_wave = (size_t)64 * a.L * (2 * esz + oesz) + (size_t)2 * ((a.L + 3) & ~3) * sizeof(float);
+  if (per_wave > 64 * 1024) return MXVL_OK;
+  const int64_t waves = (int64_t)a.batch * a.dim / 64;
+  const bool two = 2 * per_wave <= 64 * 1024;
+  const dim3 grid((unsigned)(two ? (waves + 1) / 2 : waves)), block(two ? 128 : 64);
+  const size_t lds = per_wave * (two ? 2 : 1);
+  if (a.out_f32 && esz == 2) {
+    if (two) hipLaunchKernelGGL((scan_n1_short_fwd_kernel<io_t, 2, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((scan_n1_short_fwd_kernel<io_t, 1, true>), grid, block, lds, stream, a);
+  } else {
+    if (two) hipLaunchKernelGGL((scan_n1_short_fwd_kernel<io_t, 2, false>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((scan_n1_short_fwd_kernel<io_t, 1, false>), grid, block, lds, stream, a);
+  }
+  g_last_kernel = "scan_n1_short_fwd";
+  taken = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { g_last_hip_error = (int)e; return MXVL_ERR_LAUNCH; }
+  return MXVL_OK;
+}
+
 template <typename io_t>
 static int dispatch_fwd(const ScanArgs& a, hipStream_t stream) {
   {
     bool taken = false;
-    const int rc = try_n1_fwd<io_t>(a, stream, taken);
+    int rc = try_n1_fwd<io_t>(a, stream, taken);
+    if (rc != MXVL_OK || taken) return rc;
+    rc = try_n1_short_fwd<io_t>(a, stream, taken);
     if (rc != MXVL_OK || taken) return rc;
   }
   if (a.fold_magic) {   // batch folded into the sequence: aligned rows, dstate 16 (the caller asked with MXVL_SCAN_FOLD_BATCH)

@@ -911,6 +911,79 @@ def test_scan_n1_full_size_vmamba_stage_roundtrip():
     assert_close(o1, og, 2e-5 * max(1.0, float(og.abs().max())), 1e-5, "flat-row kernel vs the general kernels, full size")
 
 
+# rows of at most 128 steps that the flat-row kernels cannot take (L % 4 != 0: VMamba's 7 x 7 stage): a lane per row (csrc/scan_n1_short.h)
+N1_SHORT_CASES = [
+    # B, D,   L,  G, dtype,          out_f32
+    (2, 128, 49, 2, torch.bfloat16, True),       # the 7 x 7 stage as the model calls it: bf16 rows, fp32 out / dout (oflex i16o32)
+    (1, 64, 7, 1, torch.float32, False),
+    (3, 192, 81, 1, torch.float16, False),       # 192 channels per group: three waves per batch element
+    (2, 128, 127, 2, torch.bfloat16, False),     # the longest odd row of one chunk
+    (5, 64, 50, 1, torch.float32, False),        # L % 4 == 2; the second workgroup's second wave has no rows
+]
+
+
+@pytest.mark.parametrize("case", N1_SHORT_CASES)
+def test_scan_n1_short_rows_forward_and_backward(case):
+    """Forward (out, last_state) against the C oracle and the general kernels (variant 30); backward (du, ddelta, dA, dB, dC, dD,
+    ddelta_bias) against the oracle's gradients and the general backward kernel (variant 3) on the same inputs."""
+    from oracle import oracle as orc
+    from medical_image_analysis_amd import _abi
+    from medical_image_analysis_amd import selective_scan_interface as ssi
+    B, D, L, G, dtype, of32 = case
+    cpu = scan_inputs(B, D, L, 1, G, False, True, True, seed=91, dtype=dtype)
+    gen = torch.Generator().manual_seed(92)
+    dout = torch.randn(B, D, L, generator=gen)
+    if not of32:
+        dout = dout.to(dtype)
+    f = lambda t: t.float()
+    ref, ref_last = orc.selective_scan_ref(f(cpu["u"]), f(cpu["delta"]), cpu["A"], f(cpu["B"]), f(cpu["C"]), cpu["D"], None, cpu["delta_bias"],
+                                           True, return_last_state=True)
+    gref = orc.selective_scan_ref_bwd(f(cpu["u"]), f(cpu["delta"]), cpu["A"], f(cpu["B"]), f(cpu["C"]), cpu["D"], None, cpu["delta_bias"], True, f(dout))
+    dev = _dev()
+    x = _to(cpu, dev)
+    Bm = x["B"] if G > 1 else x["B"].unsqueeze(1)
+    Cm = x["C"] if G > 1 else x["C"].unsqueeze(1)
+    lib = _abi.load()
+    fw, bw = {}, {}
+    try:
+        for v in (0, 30):
+            lib.mxvl_set_scan_variant(v)
+            fw[v] = ssi.scan_fwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], None, x["delta_bias"], True, want_last_state=True,
+                                     want_ckpt=True, out_f32=of32) + (lib.mxvl_last_scan_kernel().decode(),)
+        for v in (0, 3):
+            lib.mxvl_set_scan_variant(v << 8)
+            bw[v] = ssi.scan_bwd_raw(x["u"], x["delta"], x["A"], Bm, Cm, x["D"], None, x["delta_bias"], True, None, dout.to(dev), dout_f32=of32)
+        torch.cuda.synchronize()
+    finally:
+        lib.mxvl_set_scan_variant(0)
+    out, last, ckpt, name = fw[0]
+    assert name == "scan_n1_short_fwd", name
+    assert not fw[30][3].startswith("scan_n1"), fw[30][3]
+    assert ckpt is None and out.dtype == (torch.float32 if (of32 or dtype == torch.float32) else dtype)
+    if dtype == torch.float32 or of32:
+        assert_close(out, ref, _atol(ref), 1e-5, "out")
+    else:
+        rtol, atol = (3e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 5e-3)
+        assert_close(out, ref, atol, rtol, "out")
+    assert_close(last, ref_last, _atol(ref_last), 1e-5, "last_state")
+    assert_close(last, fw[30][1], 1e-5 * max(1.0, float(ref_last.abs().max())), 1e-5, "last_state vs the general kernels")
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "dz", "ddelta_bias")
+    got, gen_k = dict(zip(names, bw[0])), dict(zip(names, bw[3]))
+    want = dict(gref)
+    want["dB"], want["dC"] = gref["dB"].reshape(Bm.shape), gref["dC"].reshape(Cm.shape)
+    for k in ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"):
+        r = want[k]
+        scale = max(1.0, float(r.abs().max()))
+        if dtype == torch.float32:
+            assert_close(got[k], r, 2e-5 * scale, 1e-4, f"{k} vs the oracle")
+            assert_close(got[k], gen_k[k], 2e-5 * scale, 1e-4, f"{k} vs the general kernel")
+        else:
+            rtol, atol = ((3e-2, 5e-2) if dtype == torch.bfloat16 else (3e-3, 5e-3)) if k in ("du", "ddelta") else (1e-3, 2e-4 * scale)
+            assert_close(got[k].float(), r, atol * (scale if k in ("du", "ddelta") else 1.0), rtol, f"{k} vs the oracle")
+            assert_close(got[k].float(), gen_k[k].float(), atol * (scale if k in ("du", "ddelta") else 1.0), rtol, f"{k} vs the general kernel")
+    assert got["du"].dtype == dtype and got["dB"].dtype == torch.float32
+
+
 @pytest.mark.parametrize("case", N1_CASES + [(2, 32, 1100, 4, 1, torch.float32, False), (2, 64, 520, 2, 2, torch.bfloat16, True)])
 def test_scan_n1_backward_pass_major(case):
     """scan_n1_bwd_kernel (csrc/scan_n1_bwd.h) against the C oracle's gradients (on the delta expanded to all channels) and against
