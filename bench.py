@@ -953,6 +953,9 @@ def main():
                          "two-kernel backward (unfused: the default for bf16 autocast, the reference's training dtype)")
     ap.add_argument("--llm-shadows", choices=["on", "off"], default=None,
                     help="A/B switch of the fine-tuning steps: cached autocast-dtype copies of the frozen LLM's weights (default) or per-call casts")
+    ap.add_argument("--llm-ops", choices=["on", "off"], default=None,
+                    help="A/B switch of the fine-tuning steps: rotary embedding + RMSNorm of the frozen LLM's layers as csrc/llm_ops.hip kernels (default) "
+                         "or as the torch expressions of hybrid_decoder_layer.py")
     ap.add_argument("--decode-gemm", choices=["wide", "ksplit", "wide_pf3", "wide_nw4", "wide_mt3", "wide1"], default=None,
                     help="A/B switch of the 17..80-row decode projections: waves split N + LDS-shared activations (wide, default), the round-4 K-split "
                          "kernels at every row count (ksplit), the wide kernel as first measured (wide_pf3: 33..80 rows, >= 160 workgroups, 3-stage ring, "
@@ -1008,6 +1011,9 @@ def main():
     if args.llm_shadows:
         from medical_image_analysis_amd.report_decoder import ReportDecoder
         ReportDecoder.autocast_shadows = args.llm_shadows == "on"
+    if args.llm_ops:
+        from medical_image_analysis_amd import fused_ops
+        fused_ops.LLM_OPS = args.llm_ops == "on"
     if args.decode_gemm:
         _abi.load().mxvl_set_decode_gemm_wide({"wide": 1, "ksplit": 0, "wide_pf3": 3, "wide_nw4": 4, "wide_mt3": 5, "wide1": 6}[args.decode_gemm])
     if args.decode_norm:

@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 9
+#define MXVL_ABI_VERSION 10
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -533,6 +533,47 @@ int mxvl_swiglu_bwd(const void *ab, const void *dy, void *dab, int rows, int hid
 int mxvl_swiglu_partials(int rows, int hidden);
 int mxvl_swiglu_bwd_colsum(const void *ab, const void *dy, void *dab, void *partial, int n_partials, int rows, int hidden,
                            int io_dtype, void *hip_stream);
+
+/* ---- ABI v10: the element-wise work of a decoder layer in the TRAINING step of the report-generation stages (csrc/llm_ops.hip) ----------
+ * The stage-3 / R2GenCSR step runs a frozen fp16-loaded LLM under bf16 autocast, forward and activation-gradient backward
+ * (CXPMRG_Bench_MambaXray_VL/models/MambaXrayVL_DownStream.py:195-241, R2GenCSR/models/R2GenCSR.py:309-474).
+ *
+ * mxvl_rope: rotary position embedding of q and k in one launch -- apply_rotary_pos_emb / rotate_half
+ * (EMRRG/models/hybrid_decoder_layer.py:290-323; HF's Llama classes carry the same text) followed by the cast back to the projections'
+ * dtype:  y1 = x1 c1 - x2 s1,  y2 = x2 c2 + x1 s2  over the halves (x1 | x2) of every head, every product and the sum rounded to
+ * promote(io_dtype, cs_dtype) (fp32 unless both are the same 16-bit type), the result to io_dtype: bit-identical to the torch
+ * expression.  backward != 0: q / k carry the gradients of the outputs and q_out / k_out receive the gradients of the inputs, with
+ * autograd's rounding points (csrc/llm_ops.hip header).  Any batch / token / head strides with a contiguous head_dim; head_dim % 16 == 0
+ * (16-bit) / % 8 == 0 (fp32); strides multiples of 8 / 4 elements; 16-byte aligned bases.  cos / sin: (batch, seqlen, head_dim) rows,
+ * cs_bs = 0 shares one table over the batch. */
+typedef struct mxvl_rope_desc {
+  int32_t batch, seqlen, n_q_heads, n_k_heads, head_dim;
+  int32_t io_dtype, cs_dtype, backward;
+  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs;           /* element strides of q / k */
+  int64_t qo_bs, qo_ts, qo_hs, ko_bs, ko_ts, ko_hs;     /* of q_out / k_out */
+  int64_t cs_bs, cs_ts;                                  /* of cos / sin */
+  const void *q, *k, *cos, *sin;
+  void *q_out, *k_out;
+} mxvl_rope_desc;
+int mxvl_rope(const mxvl_rope_desc *desc, void *hip_stream);
+/* mxvl_rmsnorm_train_fwd / _bwd: Qwen2RMSNorm / LlamaRMSNorm (EMRRG/models/hybrid_decoder_layer.py:185-199) over (rows, cols)
+ * activations, forward and INPUT gradient (no weight gradient: a trainable norm weight keeps the torch expression).
+ *   fwd: y = y_dtype( P( weight * x_dtype( x * rsqrt(mean(x^2) + eps) ) ) ),  P = promote(w_dtype, x_dtype), fp32 statistics; rstd (rows)
+ *        fp32 is written for the backward (optional).
+ *   bwd: y receives dx (x_dtype) = rstd * (gh - xhat * mean(gh * xhat)),  gh = x_dtype(P(grad * weight)),  xhat = x * rstd;  grad has
+ *        y_dtype.
+ * cols % 8 == 0, contiguous rows, 16-byte aligned bases. */
+typedef struct mxvl_rms_train_desc {
+  int32_t rows, cols;
+  int32_t x_dtype, w_dtype, y_dtype;
+  float eps;
+  const void *x, *weight;
+  const void *grad;          /* bwd only: (rows, cols) y_dtype */
+  void *y;                   /* fwd: (rows, cols) y_dtype;  bwd: dx (rows, cols) x_dtype */
+  void *rstd;                /* (rows) fp32: written by fwd (optional), read by bwd */
+} mxvl_rms_train_desc;
+int mxvl_rmsnorm_train_fwd(const mxvl_rms_train_desc *desc, void *hip_stream);
+int mxvl_rmsnorm_train_bwd(const mxvl_rms_train_desc *desc, void *hip_stream);
 
 /* VMamba SS2D 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67, CrossScan / CrossMerge).
  * mxvl_cross_scan : x (batch,channels,height,width) -> xs (batch,4,channels,height*width): row-major, column-major

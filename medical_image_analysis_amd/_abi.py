@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -39,6 +39,7 @@ SYMBOLS = [
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
+    "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd",
 ]
 
 
@@ -120,6 +121,22 @@ class GemvDesc(ctypes.Structure):
 class RmsNormDesc(ctypes.Structure):
     _fields_ = [("rows", c_int32), ("K", c_int32), ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("y", c_void_p),
                 ("acc", c_void_p), ("residual", c_void_p), ("x_out", c_void_p), ("dtype", c_int32), ("acc_splits", c_int32)]
+
+
+class RopeDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("seqlen", c_int32), ("n_q_heads", c_int32), ("n_k_heads", c_int32), ("head_dim", c_int32),
+        ("io_dtype", c_int32), ("cs_dtype", c_int32), ("backward", c_int32),
+        ("q_bs", c_int64), ("q_ts", c_int64), ("q_hs", c_int64), ("k_bs", c_int64), ("k_ts", c_int64), ("k_hs", c_int64),
+        ("qo_bs", c_int64), ("qo_ts", c_int64), ("qo_hs", c_int64), ("ko_bs", c_int64), ("ko_ts", c_int64), ("ko_hs", c_int64),
+        ("cs_bs", c_int64), ("cs_ts", c_int64),
+        ("q", c_void_p), ("k", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("q_out", c_void_p), ("k_out", c_void_p),
+    ]
+
+
+class RmsTrainDesc(ctypes.Structure):
+    _fields_ = [("rows", c_int32), ("cols", c_int32), ("x_dtype", c_int32), ("w_dtype", c_int32), ("y_dtype", c_int32),
+                ("eps", ctypes.c_float), ("x", c_void_p), ("weight", c_void_p), ("grad", c_void_p), ("y", c_void_p), ("rstd", c_void_p)]
 
 
 class DecodeAttnDesc(ctypes.Structure):
@@ -262,6 +279,9 @@ def load() -> ctypes.CDLL:
     lib.mxvl_beam_step.restype = c_int
     lib.mxvl_beam_step.argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_decode_prologue", "mxvl_decode_rmsnorm"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    for name in ("mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):

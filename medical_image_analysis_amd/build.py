@@ -28,6 +28,13 @@ def sources():
 
 
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
+# per-source additions (behind FLAGS: the later flag wins).  llm_ops.hip restates torch expressions whose products and sums are separate
+# rounding steps: under -ffp-contract=fast the backend fuses them (v_fma_f16 / v_fma_mixlo_f16) whatever the source says
+FILE_FLAGS = {"llm_ops.hip": ["-ffp-contract=off"]}
+
+
+def flags_for(src: str) -> list:
+    return FLAGS + FILE_FLAGS.get(os.path.basename(src), [])
 OBJ_DIR = os.path.join(PKG, "build", "obj")
 LAST_BUILD = {"state": "not run", "compiled": []}
 
@@ -68,7 +75,7 @@ def local_includes(src: str) -> list:
 
 def source_digest() -> str:
     """sha256 over every .hip, every header and the compile line: the identity of a libmxvl.so build."""
-    return _digest(sources() + headers(), FLAGS)
+    return _digest(sources() + headers(), FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(FILE_FLAGS.items())])
 
 
 def _read(path):
@@ -102,10 +109,10 @@ def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> s
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
-        want = _digest([src] + local_includes(src), FLAGS)
+        want = _digest([src] + local_includes(src), flags_for(src))
         if not force and os.path.exists(obj) and _read(obj + ".sha256") == want:
             continue
-        cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc] + flags_for(src) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, obj, want, subprocess.Popen(cmd)))
@@ -137,7 +144,7 @@ def build_exp(exp: int, files=("scan_fwd.hip", "scan_bwd.hip"), verbose: bool = 
         base = os.path.basename(src)
         if base in files:
             obj = os.path.join(out_dir, base.replace(".hip", ".o"))
-            cmd = [hipcc] + FLAGS + [f"-DMXVL_EXP={exp}", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc] + flags_for(src) + [f"-DMXVL_EXP={exp}", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

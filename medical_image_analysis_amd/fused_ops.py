@@ -333,3 +333,129 @@ def swiglu(ab):
     """ab (..., 2H) = [a | b] -> silu(a) * b (..., H)."""
     _abi.require_gpu(ab)
     return _SwiGLU.apply(ab)
+
+
+# ---- decoder-layer element-wise ops of the report-generation training step (csrc/llm_ops.hip) ---------------------------------------
+_LLM_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+LLM_OPS = True        # bench.py --llm-ops off: the A/B switch (the torch expressions of hybrid_decoder_layer.py instead of csrc/llm_ops.hip)
+
+
+def rope_supported(q, k, cos, sin) -> bool:
+    """q (B, T, Hq, D), k (B, T, Hk, D) views with a contiguous head_dim, cos / sin (B or 1, T, D): what mxvl_rope takes."""
+    if not (LLM_OPS and q.is_cuda and q.dim() == 4 and k.dim() == 4 and cos.dim() == 3 and cos.shape == sin.shape):
+        return False
+    if q.dtype != k.dtype or q.dtype not in _LLM_DTYPES or cos.dtype not in _LLM_DTYPES or cos.dtype != sin.dtype:
+        return False
+    D = q.shape[-1]
+    V = 16 // q.element_size()
+    if D % (2 * V) != 0 or cos.shape[-1] != D or cos.shape[1] != q.shape[1] or cos.shape[0] not in (1, q.shape[0]):
+        return False
+    for t in (q, k):
+        if t.stride(-1) != 1 or any(s_ % V for s_ in t.stride()[:-1]) or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def _rope_launch(q, k, cos, sin, backward):
+    lib = _abi.load()
+    B, T, Hq, D = q.shape
+    Hk = k.shape[2]
+    qo = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
+    ko = torch.empty((B, T, Hk, D), dtype=k.dtype, device=k.device)
+    cos, sin = cos.contiguous(), sin.contiguous()
+    d = _abi.RopeDesc()
+    d.batch, d.seqlen, d.n_q_heads, d.n_k_heads, d.head_dim = B, T, Hq, Hk, D
+    d.io_dtype, d.cs_dtype, d.backward = _abi.dtype_code(q.dtype), _abi.dtype_code(cos.dtype), int(backward)
+    d.q_bs, d.q_ts, d.q_hs = q.stride(0), q.stride(1), q.stride(2)
+    d.k_bs, d.k_ts, d.k_hs = k.stride(0), k.stride(1), k.stride(2)
+    d.qo_bs, d.qo_ts, d.qo_hs = qo.stride(0), qo.stride(1), qo.stride(2)
+    d.ko_bs, d.ko_ts, d.ko_hs = ko.stride(0), ko.stride(1), ko.stride(2)
+    d.cs_bs, d.cs_ts = (0 if cos.shape[0] == 1 else cos.stride(0)), cos.stride(1)
+    d.q, d.k, d.cos, d.sin, d.q_out, d.k_out = q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), qo.data_ptr(), ko.data_ptr()
+    with torch.cuda.device(q.device):
+        _abi.check(lib.mxvl_rope(ctypes.byref(d), _abi.stream_ptr(q.device)), "mxvl_rope")
+    return qo, ko
+
+
+class _RopeQK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        return _rope_launch(q, k, cos, sin, False)
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        cos, sin = ctx.saved_tensors
+
+        def prep(g):          # (B, T, H, D) with a contiguous head_dim and aligned strides, as the kernel reads it
+            V = 16 // g.element_size()
+            if g.stride(-1) != 1 or any(s_ % V for s_ in g.stride()[:-1]) or g.data_ptr() % 16:
+                g = g.contiguous()
+            return g
+        gq, gk = _rope_launch(prep(dq), prep(dk), cos, sin, True)
+        return gq, gk, None, None
+
+
+def rope_qk(q, k, cos, sin):
+    """apply_rotary_pos_emb(q, k, cos, sin) + the cast back to q's dtype (hybrid_decoder_layer.py) on token-major tensors:
+    q (B, T, Hq, D), k (B, T, Hk, D) -> the rotated (B, T, H, D) tensors, one kernel each way; cos / sin carry no gradient."""
+    return _RopeQK.apply(q, k, cos.detach(), sin.detach())
+
+
+def rms_norm_supported(x, weight) -> bool:
+    return (LLM_OPS and x.is_cuda and x.dtype in _LLM_DTYPES and weight.dtype in _LLM_DTYPES and x.shape[-1] % 8 == 0 and weight.dim() == 1
+            and weight.shape[0] == x.shape[-1] and not weight.requires_grad)
+
+
+class _RmsNormFrozen(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps, out_dtype):
+        lib = _abi.load()
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous() or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        w = weight.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, C), dtype=out_dtype, device=x.device)
+        need = ctx.needs_input_grad[0]
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need else None
+        d = _abi.RmsTrainDesc()
+        d.rows, d.cols, d.eps = rows, C, eps
+        d.x_dtype, d.w_dtype, d.y_dtype = _abi.dtype_code(x2.dtype), _abi.dtype_code(w.dtype), _abi.dtype_code(out_dtype)
+        d.x, d.weight, d.grad, d.y, d.rstd = x2.data_ptr(), w.data_ptr(), None, y.data_ptr(), _abi.ptr(rstd)
+        with torch.cuda.device(x.device):
+            _abi.check(lib.mxvl_rmsnorm_train_fwd(ctypes.byref(d), _abi.stream_ptr(x.device)), "mxvl_rmsnorm_train_fwd")
+        if need:
+            ctx.save_for_backward(x2, w, rstd)
+            ctx.meta = (x.shape, eps, out_dtype)
+        return y.view(*x.shape[:-1], C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rstd = ctx.saved_tensors
+        shape, eps, out_dtype = ctx.meta
+        lib = _abi.load()
+        rows, C = x2.shape
+        g = dy.reshape(rows, C)
+        if g.dtype != out_dtype or not g.is_contiguous() or g.data_ptr() % 16:
+            g = g.to(out_dtype).contiguous()
+        dx = torch.empty_like(x2)
+        d = _abi.RmsTrainDesc()
+        d.rows, d.cols, d.eps = rows, C, eps
+        d.x_dtype, d.w_dtype, d.y_dtype = _abi.dtype_code(x2.dtype), _abi.dtype_code(w.dtype), _abi.dtype_code(out_dtype)
+        d.x, d.weight, d.grad, d.y, d.rstd = x2.data_ptr(), w.data_ptr(), g.data_ptr(), dx.data_ptr(), rstd.data_ptr()
+        with torch.cuda.device(x2.device):
+            _abi.check(lib.mxvl_rmsnorm_train_bwd(ctypes.byref(d), _abi.stream_ptr(x2.device)), "mxvl_rmsnorm_train_bwd")
+        return dx.view(shape), None, None, None
+
+
+def rms_norm_frozen(x, weight, eps):
+    """Qwen2RMSNorm / LlamaRMSNorm with a weight that takes no gradient: `weight * rms_norm(x.float()).to(x.dtype)`, one kernel each
+    way.  The result has the dtype the consumer reads: the autocast dtype under autocast (the nn.Linear behind the norm casts the
+    torch expression's promoted result to it -- the same values), else promote(weight.dtype, x.dtype)."""
+    if torch.is_autocast_enabled("cuda"):
+        out_dtype = torch.get_autocast_dtype("cuda")
+    else:
+        out_dtype = torch.promote_types(weight.dtype, x.dtype)
+    return _RmsNormFrozen.apply(x, weight, float(eps), out_dtype)

@@ -29,6 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import flash_attention as flash
+from . import fused_ops
 
 
 class Qwen2RMSNorm(nn.Module):
@@ -39,6 +40,11 @@ class Qwen2RMSNorm(nn.Module):
 
     def forward(self, hidden_states):
         # one fused kernel; same arithmetic as the reference (:193-198): fp32 statistics, result cast back, then * weight
+        if hidden_states.requires_grad and torch.is_grad_enabled() and fused_ops.rms_norm_supported(hidden_states, self.weight):
+            # activations that carry a gradient through a weight that takes none -- the frozen LLM of the stage-3 / R2GenCSR training
+            # step: csrc/llm_ops.hip, one kernel each way, the result already in the dtype the projection behind the norm reads.
+            # (Generation keeps the expression below: its fp32 sum order is part of what the HF token goldens pin.)
+            return fused_ops.rms_norm_frozen(hidden_states, self.weight, self.variance_epsilon)
         dt = hidden_states.dtype
         h = F.rms_norm(hidden_states.to(torch.float32), (hidden_states.shape[-1],), None, self.variance_epsilon)
         return self.weight * h.to(dt)
@@ -256,7 +262,13 @@ class Qwen2HybridAttention(nn.Module):
             cos, sin = self.rotary_emb(v, position_ids)
         else:
             cos, sin = position_embeddings
-        q, k = apply_rotary_pos_emb(q, k, cos, sin)
+        qt, kt = q.transpose(1, 2), k.transpose(1, 2)            # (B, T, H, D): the projections' own layout
+        if q.dtype == v.dtype and fused_ops.rope_supported(qt, kt, cos, sin):
+            # one kernel for q and k (csrc/llm_ops.hip): the products, their promotion and the cast back, bit for bit
+            qt, kt = fused_ops.rope_qk(qt, kt, cos, sin)
+            q, k = qt.transpose(1, 2), kt.transpose(1, 2)
+        else:
+            q, k = apply_rotary_pos_emb(q, k, cos, sin)
         if q.dtype != v.dtype:
             # an fp16-loaded LLM under bf16 autocast (the reference's training_step: torch_dtype=torch.float16 weights,
             # MambaXrayVL_DownStream.py:72-92, under Lightning's bf16-mixed precision, configs/config.py:67): the projections come out

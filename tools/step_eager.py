@@ -1,5 +1,5 @@
 """Dev tool (GPU): the eager-torch launches of one headline training step, by aten op, input shapes and the package source line that
-issued them (torch.profiler with_stack).  usage: python tools/step_eager.py [batch] [workload: pretrain|vmamba|mae]"""
+issued them (torch.profiler with_stack).  usage: python tools/step_eager.py [batch] [workload: pretrain|vmamba|finetune|r2gencsr]"""
 import os
 import sys
 from collections import defaultdict
@@ -34,6 +34,38 @@ elif what == "vmamba":
     model = PooledLoss(vssm1_base_0229(drop_path_rate=0.0)).to(dev)
     x = torch.randn(B, 3, 224, 224, device=dev)
     eng = PretrainEngine(model, device=dev)
+elif what in ("finetune", "r2gencsr"):     # the report-generation training steps of bench.py run_finetune (frozen fp16 Llama-2-7B, bf16 autocast)
+    import bench
+    from medical_image_analysis_amd import mambaxray_vl as mx
+    tok = bench._SyntheticTokenizer(32000)
+    with torch.device(dev):
+        llm = mx.build_report_decoder("llama2-7b")
+    words = ["heart", "size", "is", "normal", "lungs", "are", "clear", "no", "acute", "cardiopulmonary", "process", "pleural", "effusion", "."]
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 and int(sys.argv[1]) > 0 else (6 if what == "finetune" else 36)
+    texts = [" ".join(words[int(i)] for i in torch.randint(0, len(words), (int(n),), generator=g)) for n in torch.randint(40, 99, (B,), generator=g)]
+    if what == "finetune":
+        a = mx.default_args(vision_model="Large-None", type="large", freeze_vm=False, max_length=100)
+        model = mx.MambaXrayVLDownStream(a, tokenizer=tok, llm=llm).to(dev)
+    else:
+        from medical_image_analysis_amd.r2gencsr import R2GenCSR
+        a = mx.default_args(vision_model="None", freeze_vm=False, max_length=100, context_pair=3, chosen="vmamba", proj="linear", llm="llama2",
+                            positive="Note: <Img><ImageHere></Img> with desease. ", negative="Note: <Img><ImageHere></Img> normal. ",
+                            use_feature_mean=True)
+        model = R2GenCSR(a, tokenizer=tok, llm=llm).to(dev)
+        model.set_context_samples(torch.randn(3, 3, 224, 224, generator=g).to(dev), torch.randn(3, 3, 224, 224, generator=g).to(dev))
+    model.llama_model.to(torch.float16)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+    x = {"id": [f"s{i}" for i in range(B)], "image": [torch.randn(B, 3, 224, 224, generator=g).to(dev)], "input_text": texts}
+
+    class _Eng:
+        def step(self, batch):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = model(batch)["loss"]
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    eng = _Eng()
 else:
     raise SystemExit("workload")
 for _ in range(2):
