@@ -574,6 +574,11 @@ typedef struct mxvl_rms_train_desc {
 } mxvl_rms_train_desc;
 int mxvl_rmsnorm_train_fwd(const mxvl_rms_train_desc *desc, void *hip_stream);
 int mxvl_rmsnorm_train_bwd(const mxvl_rms_train_desc *desc, void *hip_stream);
+/* mxvl_silu_mul: the gate of Qwen2MLP / LlamaMLP, `act_fn(gate_proj(x)) * up_proj(x)` (EMRRG/models/hybrid_decoder_layer.py:326-338), over
+ * n contiguous elements of one dtype, with the two roundings of the two torch kernels:  y = io(io(silu(a)) * b).  With dy != NULL it is the
+ * backward of that expression as autograd runs it: y receives da = io(ds * sig(a) (1 + a (1 - sig(a)))), ds = io(dy * b), and db receives
+ * io(dy * io(silu(a))).  n % 8 == 0, 16-byte aligned bases. */
+int mxvl_silu_mul(const void *a, const void *b, const void *dy, void *y, void *db, int64_t n, int io_dtype, void *hip_stream);
 
 /* VMamba SS2D 4-direction orderings (R2GenCSR/VMamba/classification/models/vmamba.py:25-67, CrossScan / CrossMerge).
  * mxvl_cross_scan : x (batch,channels,height,width) -> xs (batch,4,channels,height*width): row-major, column-major

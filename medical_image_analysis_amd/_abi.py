@@ -39,7 +39,7 @@ SYMBOLS = [
     "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
-    "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd",
+    "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd", "mxvl_silu_mul",
 ]
 
 
@@ -284,6 +284,8 @@ def load() -> ctypes.CDLL:
     for name in ("mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    lib.mxvl_silu_mul.restype = c_int
+    lib.mxvl_silu_mul.argtypes = [c_void_p] * 5 + [c_int64, c_int, c_void_p]
     for name in ("mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]

@@ -202,6 +202,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const RmsArgs p) {
   }
 }
 
+// silu(a) * b of the gated MLP (Qwen2MLP / LlamaMLP: act_fn(gate_proj(x)) * up_proj(x)) with the two roundings of the two torch kernels;
+// backward: autograd's sequence -- db = io(dy * s), ds = io(dy * b), da = io(ds * sig (1 + a (1 - sig))) -- from a, b, dy alone (s = io(silu(a))
+// is recomputed: the same arithmetic, the same bits)
+template <typename io_t>
+__global__ __launch_bounds__(256) void silu_mul_kernel(const io_t* __restrict__ a, const io_t* __restrict__ b, const io_t* __restrict__ dy,
+                                                        io_t* __restrict__ y, io_t* __restrict__ db, int64_t n8) {
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n8; v += (int64_t)gridDim.x * 256) {
+    float av[8], bv[8], o[8];
+    ld8<io_t>(a + v * 8, av);
+    ld8<io_t>(b + v * 8, bv);
+    if (dy == nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s = rnd_to<io_t>(av[e] / (1.0f + expf(-av[e])));
+        o[e] = s * bv[e];
+      }
+      st8<io_t>(y + v * 8, o);
+    } else {
+      float gv[8], ob[8];
+      ld8<io_t>(dy + v * 8, gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sig = 1.0f / (1.0f + expf(-av[e]));
+        const float s = rnd_to<io_t>(av[e] / (1.0f + expf(-av[e])));
+        ob[e] = gv[e] * s;
+        const float ds = rnd_to<io_t>(gv[e] * bv[e]);
+        o[e] = ds * sig * (1.0f + av[e] * (1.0f - sig));
+      }
+      st8<io_t>(y + v * 8, o);         // da
+      st8<io_t>(db + v * 8, ob);
+    }
+  }
+}
+
 template <typename io_t>
 static int rope_launch_cs(const RopeArgs& a, int cs_dtype, hipStream_t s) {
   const int V = 16 / (int)sizeof(io_t);
@@ -290,3 +324,21 @@ static int rms_common(const mxvl_rms_train_desc* d, bool bwd, void* hip_stream) 
 }
 extern "C" int mxvl_rmsnorm_train_fwd(const mxvl_rms_train_desc* d, void* hip_stream) { return rms_common(d, false, hip_stream); }
 extern "C" int mxvl_rmsnorm_train_bwd(const mxvl_rms_train_desc* d, void* hip_stream) { return rms_common(d, true, hip_stream); }
+
+extern "C" int mxvl_silu_mul(const void* a, const void* b, const void* dy, void* y, void* db, int64_t n, int io_dtype, void* hip_stream) {
+  if (!a || !b || !y || (dy && !db)) return MXVL_ERR_NULL;
+  if (n <= 0) return MXVL_ERR_SHAPE;
+  if (!dtype_ok(io_dtype)) return MXVL_ERR_DTYPE;
+  if (n % 8 != 0) return MXVL_ERR_UNSUPPORTED;
+  for (const void* q : {a, b, dy, (const void*)y, (const void*)db})
+    if (q && ((uintptr_t)q) % 16 != 0) return MXVL_ERR_UNSUPPORTED;
+  const int64_t n8 = n / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 < 65536 * 8 ? (n8 + 255) / 256 : 65536 * 8);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32: hipLaunchKernelGGL(silu_mul_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)b, (const float*)dy, (float*)y, (float*)db, n8); break;
+    case MXVL_BF16: hipLaunchKernelGGL(silu_mul_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)dy, (bf16_t*)y, (bf16_t*)db, n8); break;
+    default: hipLaunchKernelGGL(silu_mul_kernel<f16_t>, dim3(grid), dim3(256), 0, s, (const f16_t*)a, (const f16_t*)b, (const f16_t*)dy, (f16_t*)y, (f16_t*)db, n8); break;
+  }
+  return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
+}

@@ -459,3 +459,36 @@ def rms_norm_frozen(x, weight, eps):
     else:
         out_dtype = torch.promote_types(weight.dtype, x.dtype)
     return _RmsNormFrozen.apply(x, weight, float(eps), out_dtype)
+
+
+def silu_mul_supported(a, b) -> bool:
+    return (LLM_OPS and a.is_cuda and a.dtype in _LLM_DTYPES and b.dtype == a.dtype and a.shape == b.shape and a.numel() % 8 == 0
+            and a.is_contiguous() and b.is_contiguous() and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+class _SiluMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _abi.load()
+        y = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _abi.check(lib.mxvl_silu_mul(a.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, a.numel(), _abi.dtype_code(a.dtype),
+                                         _abi.stream_ptr(a.device)), "mxvl_silu_mul")
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        lib = _abi.load()
+        g = dy.to(a.dtype).contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        with torch.cuda.device(a.device):
+            _abi.check(lib.mxvl_silu_mul(a.data_ptr(), b.data_ptr(), g.data_ptr(), da.data_ptr(), db.data_ptr(), a.numel(),
+                                         _abi.dtype_code(a.dtype), _abi.stream_ptr(a.device)), "mxvl_silu_mul")
+        return da, db
+
+
+def silu_mul(a, b):
+    """silu(a) * b with the roundings of the two torch kernels (Qwen2MLP / LlamaMLP), one kernel each way (csrc/llm_ops.hip)."""
+    return _SiluMul.apply(a, b)

@@ -105,7 +105,10 @@ class Qwen2MLP(nn.Module):
         self.act_fn = nn.SiLU()
 
     def forward(self, hidden_state):
-        return self.down_proj(self.act_fn(self.gate_proj(hidden_state)) * self.up_proj(hidden_state))
+        g, u = self.gate_proj(hidden_state), self.up_proj(hidden_state)
+        if g.requires_grad and torch.is_grad_enabled() and fused_ops.silu_mul_supported(g, u):
+            return self.down_proj(fused_ops.silu_mul(g, u))      # training steps: one kernel each way (csrc/llm_ops.hip)
+        return self.down_proj(self.act_fn(g) * u)
 
 
 def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:

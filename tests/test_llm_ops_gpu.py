@@ -101,6 +101,29 @@ def test_rms_norm_frozen_matches_the_module_expression(xdt, wdt, ac, shape):
     assert float((ga - gb).abs().max()) <= (4 * gx_ulp + 1e-6) * scale, float((ga - gb).abs().max()) / scale
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_silu_mul_matches_the_two_torch_kernels(dt):
+    """act_fn(gate) * up forward and backward against autograd through the torch expression: equal except where the fp32 sigmoid of the
+    two implementations rounds differently (a handful of elements per million, one ulp of the io dtype)."""
+    from medical_image_analysis_amd import fused_ops
+    g = torch.Generator().manual_seed(5)
+    a0 = (torch.randn(7, 61, 1376, generator=g) * 2).to(DEV, dt)
+    b0 = torch.randn(7, 61, 1376, generator=g).to(DEV, dt)
+    dy = torch.randn(7, 61, 1376, generator=g).to(DEV, dt)
+    res = []
+    for fused in (True, False):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = fused_ops.silu_mul(a, b) if fused else torch.nn.functional.silu(a) * b
+        y.backward(dy)
+        res.append((y.detach().float(), a.grad.float(), b.grad.float()))
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 2.0 ** -19}[dt]     # fp32: the two exp implementations
+    for name, u, v in zip(("y", "da", "db"), *res):
+        d = (u - v).abs()
+        assert float((d / v.abs().clamp_min(1e-2)).max()) <= 2.1 * ulp, name
+        if dt != torch.float32:
+            assert float((d > 0).float().mean()) < 2e-3, name
+
+
 def test_decoder_layer_training_step_fused_vs_unfused_small_llm():
     """A 2-layer fp16 ReportDecoder, frozen, under bf16 autocast (the stage-3 configuration in small): logits and the gradient that
     reaches the input embeddings with the kernels of llm_ops.hip against the same modules with the kernels switched off."""
