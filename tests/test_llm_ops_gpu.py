@@ -119,8 +119,10 @@ def test_silu_mul_matches_the_two_torch_kernels(dt):
     ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 2.0 ** -19}[dt]     # fp32: the two exp implementations
     for name, u, v in zip(("y", "da", "db"), *res):
         d = (u - v).abs()
-        assert float((d / v.abs().clamp_min(1e-2)).max()) <= 2.1 * ulp, name
-        if dt != torch.float32:
+        if dt == torch.float32:          # nothing is rounded below fp32: the last bits of the two exp / divide implementations show
+            assert float((d / (v.abs() + 1.0)).max()) <= 2e-6, name
+        else:
+            assert float((d / v.abs().clamp_min(1e-2)).max()) <= 2.1 * ulp, name
             assert float((d > 0).float().mean()) < 2e-3, name
 
 
