@@ -154,6 +154,7 @@ template <typename io_t, int NWAVES, bool VEC, int NS, bool FOLD = false, bool D
 __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdArgs p) {
   constexpr int T = 8, LPR = 16, RPW = 4, DT = NWAVES * RPW, CH = 128, NT = NWAVES * 64;
   constexpr int FG = 4;                    // states per dB/dC flush group
+  constexpr bool PKB = FOLD;               // the packed state body (below): the instantiations it was measured faster on
   static_assert(CH == kCkptLenB, "one checkpoint per chunk");
   static_assert(NS % FG == 0, "compile-time dstate is a whole number of flush groups");
   using io = Io<io_t>;
@@ -682,6 +683,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       f_off = (int64_t)sb * p.dB_bs + (tf - sb * SL);          // dB and dC share their strides (checked by the launcher)
     }
 
+    // pair views of the per-chunk arrays for the packed body (PKB)
+    v2f dl2[4], du2[4], dy2[4], y2[4], sgB2[4], sAh2[4];
+    if constexpr (PKB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dl2[q] = v2f{dl[2 * q], dl[2 * q + 1]};
+        du2[q] = v2f{du[2 * q], du[2 * q + 1]};
+        dy2[q] = v2f{dy[2 * q], dy[2 * q + 1]};
+        y2[q] = sgB2[q] = sAh2[q] = v2f{0.0f, 0.0f};
+      }
+    }
     auto flush_load = [&](int grp, float (&part)[FK * NWAVES]) {
       const float* src = sAcc + (grp & 1) * GBUF;
 #pragma unroll
@@ -721,82 +733,192 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       for (int k = 0; k < FG; ++k) {
         const int n = ng * FG + k;
         if (NS > 0 || n < N) {
-          const float A2 = ac[n].x;
-          const float hin = ac_in[n].y;
-          const float gin = gq_in[n];
-          const float dA_old = dA_w[n];
-          float a[T], bb[T], cv[T], h[T];
-          {
-            const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
-            const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
-            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-            cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
-          }
-          // ---- forward recompute -----------------------------------------------------------------------
-#pragma unroll
-          for (int i = 0; i < T; ++i) a[i] = dl[i] * A2;
-          float P = A2 * dsum;
-          if constexpr (FOLD) {
-            a[0] += rbias;
-            P += rbias;
-          }
-          asm volatile(
-              "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
-              "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
-              : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(P));
-          float hl = du[0] * bb[0];
-#pragma unroll
-          for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, du[i] * bb[i]);
-          // ---- adjoint fold: g_i = C_i dy_i + a_{i+1} g_{i+1} ----------------------------------------------
-          float ql = cv[T - 1] * dy[T - 1];
-#pragma unroll
-          for (int i = T - 2; i >= 0; --i) ql = fmaf(a[i + 1], ql, cv[i] * dy[i]);
-          ql *= a[0];                      // what this lane hands to its left neighbour for gamma_in = 0
-          float Pf = P, x = hin, Pr = P, gx = gin;
-          hl = fmaf(P, hin, hl);
-          ql = fmaf(P, gin, ql);
-          scan16_fwd_rev(hl, Pf, x, ql, Pr, gx);   // x = state entering this lane's steps, gx = a_{next} g_{next} entering from the right
-          {
-            float hh = x;
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-              hh = fmaf(a[i], hh, du[i] * bb[i]);
-              h[i] = hh;
-              y[i] = fmaf(cv[i], hh, y[i]);
+          if constexpr (PKB) {
+            // Steps (2k, 2k + 1) of the state in the halves of an aligned register pair: every element-wise product / FMA of the
+            // recompute and of the adjoint pass is ONE v_pk_*_f32 over the pair (12 of the 16 operations per step; the four
+            // recurrences -- fold, states, adjoint fold, adjoints -- stay scalar chains over the halves).  The adjoint itself is
+            // carried, g_i = a_{i+1} g_{i+1} + C_i dy_i, so a_i g_i is element-wise too; h_{i-1} next to h_i takes one pair move per
+            // two steps.  690 instead of 811 instructions per four states.  Measured per instantiation, interleaved in one process
+            // (profiles/r06_scan_bwd_pk_ab.txt): the batch-folded walk 799 -> 751 us (B64 x D4096 x L200, the 4-direction encoders),
+            // fp32 rows 1306 -> 1289 -- but the row-DMA kernel of the pre-training shape 1003 -> 1036 (the instruction mix is not what
+            // bounds it: 4.3), so only the folded instantiations take this body.  Gradients equal to rounding (<= 2e-5 relative L2 in
+            // bf16 outputs, <= 3e-7 in the fp32 accumulators).
+            const float A2 = ac[n].x;
+            const float hin = ac_in[n].y;
+            const float gin = gq_in[n];
+            const float dA_old = dA_w[n];
+            v2f a2[4], b2[4], c2[4], h2[4], g2[4];
+            {
+              const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
+              const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
+              b2[0] = v2f{b0.x, b0.y}; b2[1] = v2f{b0.z, b0.w}; b2[2] = v2f{b1.x, b1.y}; b2[3] = v2f{b1.z, b1.w};
+              c2[0] = v2f{c0.x, c0.y}; c2[1] = v2f{c0.z, c0.w}; c2[2] = v2f{c1.x, c1.y}; c2[3] = v2f{c1.z, c1.w};
             }
-          }
-          gq_w[n] = ql;                    // lane 0: leaves the chunk towards chunk c-1
-          float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
-          float dA_part = 0.0f;
-          float vB[T], vC[T];
+            float P = A2 * dsum;
+            {
+              v2f t[4];
 #pragma unroll
-          for (int i = T - 1; i >= 0; --i) {
-            const float gi = fmaf(cv[i], dy[i], gg);          // g_i
-            const float hprev = (i == 0) ? x : h[i - 1];
-            const float ga = gi * a[i];                       // a_i g_i
-            const float gha = ga * hprev;                     // g_i h_{i-1} a_i
-            vC[i] = dy[i] * h[i];   // dC_{n,t} share of this row
-            vB[i] = gi * du[i];     // dB_{n,t} share of this row
-            sgB[i] = fmaf(gi, bb[i], sgB[i]);
-            sAh[i] = fmaf(gha, A2, sAh[i]);
-            dA_part = fmaf(gha, dl[i], dA_part);
-            gg = ga;
-          }
-          dA_part = row_sum_to_lane15(dA_part);
-          dA_w[n] = dA_old + dA_part;      // lane 15: dA of (row, n) over the chunks
-          {
-            // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
-            // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
-            // steps {i, i+1, i+4, i+5}
-            float sr[8];
-            lane32_swap_x8(vB, vC);
+              for (int q = 0; q < 4; ++q) t[q] = dl2[q] * A2;
+              if constexpr (FOLD) {
+                t[0].x += rbias;
+                P += rbias;
+              }
+              float e0, e1, e2, e3, e4, e5, e6, e7, e8;       // outputs not tied to the inputs (scan_fwd_stream.h, PK)
+              asm volatile(
+                  "v_exp_f32 %0, %9\n v_exp_f32 %1, %10\n v_exp_f32 %2, %11\n v_exp_f32 %3, %12\n v_exp_f32 %4, %13\n"
+                  "v_exp_f32 %5, %14\n v_exp_f32 %6, %15\n v_exp_f32 %7, %16\n v_exp_f32 %8, %17\n"
+                  : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7), "=&v"(e8)
+                  : "v"(t[0].x), "v"(t[0].y), "v"(t[1].x), "v"(t[1].y), "v"(t[2].x), "v"(t[2].y), "v"(t[3].x), "v"(t[3].y), "v"(P));
+              a2[0] = v2f{e0, e1}; a2[1] = v2f{e2, e3}; a2[2] = v2f{e4, e5}; a2[3] = v2f{e6, e7};
+              P = e8;
+            }
+            v2f ub[4], cd[4];                     // delta_i u_i B_i and C_i dy_i
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
-            lane16_swap_x4(sr);
-            float* w0 = wg0 + k * (NWAVES * 2 * CH);
-            float* w2 = wg2 + k * (NWAVES * 2 * CH);
-            w0[0] = sr[0] + sr[1]; w2[0] = sr[2] + sr[3];
-            w0[CH] = sr[4] + sr[5]; w2[CH] = sr[6] + sr[7];
+            for (int q = 0; q < 4; ++q) {
+              ub[q] = du2[q] * b2[q];
+              cd[q] = c2[q] * dy2[q];
+            }
+            float hl = ub[0].x;
+            hl = fmaf(a2[0].y, hl, ub[0].y);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+              hl = fmaf(a2[q].x, hl, ub[q].x);
+              hl = fmaf(a2[q].y, hl, ub[q].y);
+            }
+            float ql = cd[3].y;
+            ql = fmaf(a2[3].y, ql, cd[3].x);
+#pragma unroll
+            for (int q = 2; q >= 0; --q) {
+              ql = fmaf(a2[q + 1].x, ql, cd[q].y);
+              ql = fmaf(a2[q].y, ql, cd[q].x);
+            }
+            ql *= a2[0].x;                   // what this lane hands to its left neighbour for gamma_in = 0
+            float Pf = P, x = hin, Pr = P, gx = gin;
+            hl = fmaf(P, hin, hl);
+            ql = fmaf(P, gin, ql);
+            scan16_fwd_rev(hl, Pf, x, ql, Pr, gx);   // x = state entering this lane's steps, gx = a_{next} g_{next} entering from the right
+            gq_w[n] = ql;                    // lane 0: leaves the chunk towards chunk c-1
+            {
+              float hh = x;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                hh = fmaf(a2[q].x, hh, ub[q].x); h2[q].x = hh;
+                hh = fmaf(a2[q].y, hh, ub[q].y); h2[q].y = hh;
+              }
+              float gg = cd[3].y + gx;
+              g2[3].y = gg;
+              gg = fmaf(a2[3].y, gg, cd[3].x); g2[3].x = gg;
+#pragma unroll
+              for (int q = 2; q >= 0; --q) {
+                gg = fmaf(a2[q + 1].x, gg, cd[q].y); g2[q].y = gg;
+                gg = fmaf(a2[q].y, gg, cd[q].x); g2[q].x = gg;
+              }
+            }
+            v2f vB2[4], vC2[4], dA2 = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const v2f hp = (q == 0) ? v2f{x, h2[0].x} : __builtin_shufflevector(h2[q > 0 ? q - 1 : 0], h2[q], 1, 2);   // (h_{i-1}, h_i)
+              const v2f gha = g2[q] * a2[q] * hp;                      // g_i a_i h_{i-1}
+              y2[q] = __builtin_elementwise_fma(c2[q], h2[q], y2[q]);
+              vC2[q] = dy2[q] * h2[q];     // dC_{n,t} share of this row
+              vB2[q] = g2[q] * du2[q];     // dB_{n,t} share of this row
+              sgB2[q] = __builtin_elementwise_fma(g2[q], b2[q], sgB2[q]);
+              sAh2[q] = __builtin_elementwise_fma(gha, v2f{A2, A2}, sAh2[q]);
+              dA2 = __builtin_elementwise_fma(gha, dl2[q], dA2);
+            }
+            const float dA_part = row_sum_to_lane15(dA2.x + dA2.y);
+            dA_w[n] = dA_old + dA_part;      // lane 15: dA of (row, n) over the chunks
+            {
+              float vB[8] = {vB2[0].x, vB2[0].y, vB2[1].x, vB2[1].y, vB2[2].x, vB2[2].y, vB2[3].x, vB2[3].y};
+              float vC[8] = {vC2[0].x, vC2[0].y, vC2[1].x, vC2[1].y, vC2[2].x, vC2[2].y, vC2[3].x, vC2[3].y};
+              lane32_swap_x8(vB, vC);          // (see the unpacked body below)
+              const v2f s01 = v2f{vB[0], vB[1]} + v2f{vB[4], vB[5]}, s23 = v2f{vB[2], vB[3]} + v2f{vB[6], vB[7]};
+              const v2f s45 = v2f{vC[0], vC[1]} + v2f{vC[4], vC[5]}, s67 = v2f{vC[2], vC[3]} + v2f{vC[6], vC[7]};
+              float sr[8] = {s01.x, s01.y, s23.x, s23.y, s45.x, s45.y, s67.x, s67.y};
+              lane16_swap_x4(sr);
+              float* w0 = wg0 + k * (NWAVES * 2 * CH);
+              float* w2 = wg2 + k * (NWAVES * 2 * CH);
+              w0[0] = sr[0] + sr[1]; w2[0] = sr[2] + sr[3];
+              w0[CH] = sr[4] + sr[5]; w2[CH] = sr[6] + sr[7];
+            }
+          } else {
+            const float A2 = ac[n].x;
+            const float hin = ac_in[n].y;
+            const float gin = gq_in[n];
+            const float dA_old = dA_w[n];
+            float a[T], bb[T], cv[T], h[T];
+            {
+              const float4 b0 = *(const float4*)(cB + n * CH), b1 = *(const float4*)(cB + n * CH + q1);
+              const float4 c0 = *(const float4*)(cC + n * CH), c1 = *(const float4*)(cC + n * CH + q1);
+              bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+              cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+            }
+            // ---- forward recompute -----------------------------------------------------------------------
+  #pragma unroll
+            for (int i = 0; i < T; ++i) a[i] = dl[i] * A2;
+            float P = A2 * dsum;
+            if constexpr (FOLD) {
+              a[0] += rbias;
+              P += rbias;
+            }
+            asm volatile(
+                "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n"
+                "v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n v_exp_f32 %8, %8\n"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(P));
+            float hl = du[0] * bb[0];
+  #pragma unroll
+            for (int i = 1; i < T; ++i) hl = fmaf(a[i], hl, du[i] * bb[i]);
+            // ---- adjoint fold: g_i = C_i dy_i + a_{i+1} g_{i+1} ----------------------------------------------
+            float ql = cv[T - 1] * dy[T - 1];
+  #pragma unroll
+            for (int i = T - 2; i >= 0; --i) ql = fmaf(a[i + 1], ql, cv[i] * dy[i]);
+            ql *= a[0];                      // what this lane hands to its left neighbour for gamma_in = 0
+            float Pf = P, x = hin, Pr = P, gx = gin;
+            hl = fmaf(P, hin, hl);
+            ql = fmaf(P, gin, ql);
+            scan16_fwd_rev(hl, Pf, x, ql, Pr, gx);   // x = state entering this lane's steps, gx = a_{next} g_{next} entering from the right
+            {
+              float hh = x;
+  #pragma unroll
+              for (int i = 0; i < T; ++i) {
+                hh = fmaf(a[i], hh, du[i] * bb[i]);
+                h[i] = hh;
+                y[i] = fmaf(cv[i], hh, y[i]);
+              }
+            }
+            gq_w[n] = ql;                    // lane 0: leaves the chunk towards chunk c-1
+            float gg = gx;                   // = a_{i+1} g_{i+1} for i = T-1
+            float dA_part = 0.0f;
+            float vB[T], vC[T];
+  #pragma unroll
+            for (int i = T - 1; i >= 0; --i) {
+              const float gi = fmaf(cv[i], dy[i], gg);          // g_i
+              const float hprev = (i == 0) ? x : h[i - 1];
+              const float ga = gi * a[i];                       // a_i g_i
+              const float gha = ga * hprev;                     // g_i h_{i-1} a_i
+              vC[i] = dy[i] * h[i];   // dC_{n,t} share of this row
+              vB[i] = gi * du[i];     // dB_{n,t} share of this row
+              sgB[i] = fmaf(gi, bb[i], sgB[i]);
+              sAh[i] = fmaf(gha, A2, sAh[i]);
+              dA_part = fmaf(gha, dl[i], dA_part);
+              gg = ga;
+            }
+            dA_part = row_sum_to_lane15(dA_part);
+            dA_w[n] = dA_old + dA_part;      // lane 15: dA of (row, n) over the chunks
+            {
+              // rows r and r+2 (lanes l, l+32): register pair (v[i], v[i+4]) -> one register holding v[i] summed in lanes 0-31 and
+              // v[i+4] summed in lanes 32-63; then rows r and r+1: pair (s[i], s[i+1]) -> 16-lane rows holding the 4-row sums of
+              // steps {i, i+1, i+4, i+5}
+              float sr[8];
+              lane32_swap_x8(vB, vC);
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) { sr[i] = vB[i] + vB[i + 4]; sr[4 + i] = vC[i] + vC[i + 4]; }
+              lane16_swap_x4(sr);
+              float* w0 = wg0 + k * (NWAVES * 2 * CH);
+              float* w2 = wg2 + k * (NWAVES * 2 * CH);
+              w0[0] = sr[0] + sr[1]; w2[0] = sr[2] + sr[3];
+              w0[CH] = sr[4] + sr[5]; w2[CH] = sr[6] + sr[7];
+            }
           }
           if (k == 0 && ng > 0) flush_add(ng - 1, fpart);
           if (k == FG - 1 || n == N - 1) __syncthreads();
@@ -804,6 +926,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void scan_bwd_kernel(const ScanBwdA
       }
     }
 
+    if constexpr (PKB) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y[2 * q] = y2[q].x; y[2 * q + 1] = y2[q].y;
+        sgB[2 * q] = sgB2[q].x; sgB[2 * q + 1] = sgB2[q].y;
+        sAh[2 * q] = sAh2[q].x; sAh[2 * q + 1] = sAh2[q].y;
+      }
+    }
     if constexpr (DMAR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next chunk's tiles, requested before the state loop
     {
       {     // the last group's shares
