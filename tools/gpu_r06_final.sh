@@ -11,7 +11,7 @@ O=$R/gpurun_out
 TAG=${1:-r06}
 mkdir -p $O
 cd $R
-(timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -15) > $O/${TAG}_pytest_gpu_tail.log
+(timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -15) > $O/${TAG}_pytest_gpu_tail.log
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3) > $O/${TAG}_smoke.log
 cd /tmp && export TMPDIR=/tmp
 P=/tmp/prof_$TAG; mkdir -p $P
@@ -60,5 +60,7 @@ if [ $PARTS = all ]; then
 (timeout 300 python tools/scan_r03_bench.py n1 3 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_scan_n1_final.txt
 (timeout 300 python tools/step_eager.py 16 pretrain 2>&1 | grep -v "amdgpu.ids\|arn") > $O/${TAG}_step_eager_pretrain.txt
 (timeout 300 python tools/step_eager.py 32 vmamba 2>&1 | grep -v "amdgpu.ids\|arn") > $O/${TAG}_step_eager_vmamba.txt
+(timeout 300 python tools/cross_bench.py 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_cross_dwconv_bench.txt
+(timeout 600 python tools/step_eager.py 0 r2gencsr 2>&1 | grep -v "amdgpu.ids\|arn" | cut -c1-150 | head -60) > $O/${TAG}_step_eager_r2gencsr_after.txt
 fi
 cat $O/${TAG}_pytest_gpu_tail.log $O/${TAG}_smoke.log $O/${TAG}_pmc_traffic.log; for f in $O/${TAG}_bench_*.json; do echo "== $f"; cut -c1-330 $f; done
