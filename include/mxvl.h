@@ -37,7 +37,9 @@
  * (forward) / pass-major per wave (backward), wave-wide DPP scans, no LDS tiles.  Taken when seqlen % 4 == 0 and the rows of u,
  * delta, B, C start on 4-element boundaries (8 elements for 16-bit rows with seqlen % 8 == 0: 16-byte accesses); the backward also
  * needs dim / n_groups % 4 == 0.  Same descriptors, same checkpoint layout (the state entering every 128-step chunk), same
- * tolerances: nothing about the call changes, and either direction may run on the general kernels while the other does not.
+ * tolerances: nothing about the call changes, and either direction may run on the general kernels while the other does not.  Rows of
+ * at most 128 steps that miss those alignments (seqlen % 4 != 0: the 7 x 7 stage) take a lane-per-row kernel pair (csrc/scan_n1_short.h)
+ * when u / delta / out (and dout / du / ddelta) are dense (batch, dim, seqlen) arrays and 64 | dim / n_groups.
  *
  * Deviations from SURVEY.md section 8-b, recorded here because this header is the boundary:
  *   * `mxvl_mamba_inner_fwd / mxvl_mamba_inner_bwd` (one fused entry for mamba_inner_fn, CXPMRG_Bench_MambaXray_VL/pretrain/
