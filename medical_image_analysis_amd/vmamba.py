@@ -309,10 +309,25 @@ class PatchMerging2D(nn.Module):
         return self.reduction(self.norm(x))
 
 
+LINEAR_LP = True      # tools/vmamba_ab.py: the A/B switch of LinearLP
+
+
+class LinearLP(nn.Linear):
+    """nn.Linear of the channel-last VSS blocks (in_proj / out_proj / the MLP; same parameters and state_dict keys).  On a GPU it runs
+    as selective_scan_interface.linear_splitk: the weight comes from the engine's low-precision copy of the step (ONE multi-tensor cast
+    for all parameters, pretrain_engine._refresh_casts) instead of an autocast cast launch per weight and forward, and the weight
+    gradient is the package's token-sliced GEMM."""
+
+    def forward(self, x):
+        if LINEAR_LP and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16):
+            return ssi.linear_splitk(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0, channels_first=False):
         super().__init__()
-        Linear = Linear2d if channels_first else nn.Linear
+        Linear = Linear2d if channels_first else LinearLP
         self.fc1 = Linear(in_features, hidden_features or in_features)
         self.act = act_layer()
         self.fc2 = Linear(hidden_features or in_features, out_features or in_features)
@@ -327,7 +342,7 @@ class gMlp(nn.Module):
         super().__init__()
         self.channel_first = channels_first
         hidden_features = hidden_features or in_features
-        Linear = Linear2d if channels_first else nn.Linear
+        Linear = Linear2d if channels_first else LinearLP
         self.fc1 = Linear(in_features, 2 * hidden_features)
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features or in_features)
@@ -364,7 +379,7 @@ class SS2D(nn.Module):
         d_inner = int(ssm_ratio * d_model)
         dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
         self.d_conv, self.channel_first = d_conv, channel_first
-        Linear = Linear2d if channel_first else nn.Linear
+        Linear = Linear2d if channel_first else LinearLP
         self.disable_force32, forward_type = _strip("no32", forward_type)
         self.disable_z, forward_type = _strip("noz", forward_type)
         self.disable_z_act, forward_type = _strip("nozact", forward_type)
