@@ -1,5 +1,5 @@
 """Dev tool (GPU): the eager-torch launches of one headline training step, by aten op, input shapes and the package source line that
-issued them (torch.profiler with_stack).  usage: python tools/step_eager.py [batch] [workload: pretrain|vmamba|finetune|r2gencsr]"""
+issued them (torch.profiler with_stack).  usage: python tools/step_eager.py [batch] [workload: pretrain|vmamba|mae|finetune|r2gencsr]"""
 import os
 import sys
 from collections import defaultdict
@@ -34,6 +34,22 @@ elif what == "vmamba":
     model = PooledLoss(vssm1_base_0229(drop_path_rate=0.0)).to(dev)
     x = torch.randn(B, 3, 224, 224, device=dev)
     eng = PretrainEngine(model, device=dev)
+elif what == "mae":         # bench.py run_mae: ViT-MAE large, 1280 x 1280 one-channel images, fp16 autocast + GradScaler
+    import torch.nn as nn
+    from medical_image_analysis_amd.mae import mae_vit_large_patch16
+
+    class MaeLoss(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+
+        def forward(self, imgs):
+            loss, mask = self.net(imgs, 1, 0.85, 0.95)
+            return ((loss * mask).sum() / mask.sum()).reshape(1)
+    B = B if len(sys.argv) > 1 and int(sys.argv[1]) > 0 else 256
+    model = MaeLoss(mae_vit_large_patch16()).to(dev)
+    x = torch.randn(B, 1, 1280, 1280, device=dev)
+    eng = PretrainEngine(model, device=dev, amp_dtype=torch.float16)
 elif what in ("finetune", "r2gencsr"):     # the report-generation training steps of bench.py run_finetune (frozen fp16 Llama-2-7B, bf16 autocast)
     import bench
     from medical_image_analysis_amd import mambaxray_vl as mx
