@@ -46,8 +46,25 @@ struct RopeArgs {
   void *qo, *ko;
 };
 
+// V consecutive cos / sin values as vector loads (8, 16 or 2 x 16 bytes; the launcher checks the alignment and passes CSV = false otherwise)
+template <typename cs_t, int V, bool CSV>
+__device__ __forceinline__ void rope_ld_cs(const cs_t* q, float (&v)[V]) {
+  if constexpr (!CSV) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = Io<cs_t>::ld(q + e);
+  } else {
+    cs_t t[V];
+    constexpr int BYTES = V * (int)sizeof(cs_t);
+    if constexpr (BYTES == 8) *(uint2*)t = *(const uint2*)q;
+    else if constexpr (BYTES == 16) *(uint4*)t = *(const uint4*)q;
+    else { *(uint4*)t = *(const uint4*)q; *((uint4*)t + 1) = *((const uint4*)q + 1); }
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = Io<cs_t>::ld(t + e);
+  }
+}
+
 // one thread: V elements of the first half of a head and the V matching elements of the second half
-template <typename io_t, typename cs_t>
+template <typename io_t, typename cs_t, bool CSV>
 __global__ __launch_bounds__(256) void rope_kernel(const RopeArgs p) {
   constexpr int V = 16 / (int)sizeof(io_t);                 // 8 (16-bit) / 4 (fp32) elements = 16 bytes
   constexpr bool R16 = std::is_same<io_t, cs_t>::value && sizeof(io_t) == 2;   // no promotion: intermediates live in the io dtype
@@ -70,11 +87,15 @@ __global__ __launch_bounds__(256) void rope_kernel(const RopeArgs p) {
     *(uint4*)x1 = *(const uint4*)(x + i0);
     *(uint4*)x2 = *(const uint4*)(x + half + i0);
     auto rr = [](float v) { return R16 ? rnd_to<io_t>(v) : v; };
+    float cv1[V], cv2[V], sv1[V], sv2[V];
+    rope_ld_cs<cs_t, V, CSV>(c + i0, cv1);
+    rope_ld_cs<cs_t, V, CSV>(c + half + i0, cv2);
+    rope_ld_cs<cs_t, V, CSV>(s + i0, sv1);
+    rope_ld_cs<cs_t, V, CSV>(s + half + i0, sv2);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const float a1 = Io<io_t>::ld(x1 + e), a2 = Io<io_t>::ld(x2 + e);
-      const float c1 = Io<cs_t>::ld(c + i0 + e), c2 = Io<cs_t>::ld(c + half + i0 + e);
-      const float s1 = Io<cs_t>::ld(s + i0 + e), s2 = Io<cs_t>::ld(s + half + i0 + e);
+      const float c1 = cv1[e], c2 = cv2[e], s1 = sv1[e], s2 = sv2[e];
       if (!p.backward) {
         Io<io_t>::st(o1 + e, rr(rr(a1 * c1) + rr(-a2 * s1)));
         Io<io_t>::st(o2 + e, rr(rr(a2 * c2) + rr(a1 * s2)));
@@ -241,11 +262,21 @@ static int rope_launch_cs(const RopeArgs& a, int cs_dtype, hipStream_t s) {
   const int V = 16 / (int)sizeof(io_t);
   const int64_t total = (int64_t)a.B * a.T * (a.Hq + a.Hk) * (a.D / 2 / V);
   const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 16 ? (total + 255) / 256 : 65536 * 16);
+  // cos / sin rows as vectors when every (batch, token) row and both half-head offsets are aligned to the vector
+  const int csz = cs_dtype == MXVL_F32 ? 4 : 2, bytes = V * csz, al = bytes > 16 ? 16 : bytes;
+  const bool csv = ((uintptr_t)a.cos) % al == 0 && ((uintptr_t)a.sin) % al == 0 && (a.cs_bs * csz) % al == 0 && (a.cs_ts * csz) % al == 0 &&
+                   ((int64_t)(a.D / 2) * csz) % al == 0;
+#define MXVL_ROPE_GO(CS)                                                                              \
+  do {                                                                                                \
+    if (csv) hipLaunchKernelGGL((rope_kernel<io_t, CS, true>), dim3(grid), dim3(256), 0, s, a);       \
+    else hipLaunchKernelGGL((rope_kernel<io_t, CS, false>), dim3(grid), dim3(256), 0, s, a);          \
+  } while (0)
   switch (cs_dtype) {
-    case MXVL_F32: hipLaunchKernelGGL((rope_kernel<io_t, float>), dim3(grid), dim3(256), 0, s, a); break;
-    case MXVL_BF16: hipLaunchKernelGGL((rope_kernel<io_t, bf16_t>), dim3(grid), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((rope_kernel<io_t, f16_t>), dim3(grid), dim3(256), 0, s, a); break;
+    case MXVL_F32: MXVL_ROPE_GO(float); break;
+    case MXVL_BF16: MXVL_ROPE_GO(bf16_t); break;
+    default: MXVL_ROPE_GO(f16_t); break;
   }
+#undef MXVL_ROPE_GO
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
 
