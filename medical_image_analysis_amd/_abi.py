@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -40,6 +40,7 @@ SYMBOLS = [
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
     "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd", "mxvl_silu_mul",
+    "mxvl_mamba_inner_fwd", "mxvl_mamba_inner_bwd", "mxvl_mamba_inner_workspace_bytes", "mxvl_mamba_inner_bwd_workspace_bytes",
 ]
 
 
@@ -67,6 +68,26 @@ class ScanBwdDesc(ctypes.Structure):
         ("dC_bs", c_int64), ("dC_gs", c_int64), ("dC_ns", c_int64),
         ("dout", c_void_p), ("du", c_void_p), ("ddelta", c_void_p), ("dz", c_void_p),
         ("dA", c_void_p), ("dB", c_void_p), ("dC", c_void_p), ("dD", c_void_p), ("ddelta_bias", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
+    ]
+
+
+class MambaInnerDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32), ("dim", c_int32), ("seqlen", c_int32), ("dstate", c_int32), ("dt_rank", c_int32), ("width", c_int32),
+        ("d_model", c_int32), ("io_dtype", c_int32), ("flags", c_uint32), ("reserved0", c_int32),
+        ("xz", c_void_p), ("conv_weight", c_void_p), ("conv_bias", c_void_p), ("x_proj_weight", c_void_p), ("dt_proj_weight", c_void_p),
+        ("out_proj_weight", c_void_p), ("out_proj_bias", c_void_p), ("A", c_void_p), ("D", c_void_p), ("delta_bias", c_void_p),
+        ("out", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
+    ]
+
+
+class MambaInnerBwdDesc(ctypes.Structure):
+    _fields_ = [
+        ("fwd", MambaInnerDesc),
+        ("dout", c_void_p), ("dxz", c_void_p), ("dconv_weight", c_void_p), ("dconv_bias", c_void_p),
+        ("dx_proj_weight", c_void_p), ("ddt_proj_weight", c_void_p), ("dout_proj_weight", c_void_p), ("dout_proj_bias", c_void_p),
+        ("dA", c_void_p), ("dD", c_void_p), ("ddelta_bias", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
@@ -269,6 +290,12 @@ def load() -> ctypes.CDLL:
                  "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_nt"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    for name in ("mxvl_mamba_inner_fwd", "mxvl_mamba_inner_bwd"):
+        getattr(lib, name).restype = c_int
+        getattr(lib, name).argtypes = [c_void_p, c_void_p]
+    for name in ("mxvl_mamba_inner_workspace_bytes", "mxvl_mamba_inner_bwd_workspace_bytes"):
+        getattr(lib, name).restype = c_int64
+        getattr(lib, name).argtypes = [c_void_p]
     lib.mxvl_conv1d_update.restype = c_int
     lib.mxvl_conv1d_update.argtypes = [c_void_p] * 5 + [c_int] * 5 + [c_void_p]
     lib.mxvl_state_update.restype = c_int

@@ -703,6 +703,96 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     return proj_out(y, out_proj_weight, out_proj_bias)
 
 
+class _MambaInnerNativeFn(torch.autograd.Function):
+    """mamba_inner_fn[_no_out_proj] through the ONE native entry mxvl_mamba_inner_fwd / _bwd (include/mxvl.h, ABI v11: this
+    library's conv1d / scan kernels + rocBLAS GEMMs composed behind the C-ABI, every intermediate in a caller-owned workspace)."""
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_w, out_b, A, D, delta_bias, delta_softplus):
+        from .causal_conv1d import _w2
+        _abi.require_gpu(xz, conv_w, x_proj_w, dt_proj_w, A)
+        lib = _abi.load()
+        batch, two_d, L = xz.shape
+        d = two_d // 2
+        io = xz.dtype
+        xz = xz.contiguous()
+        w32 = _w2(conv_w).detach().float().contiguous()
+        b32 = conv_b.detach().float().contiguous() if conv_b is not None else None
+        wx, wdt = x_proj_w.detach().to(io).contiguous(), dt_proj_w.detach().to(io).contiguous()
+        wo = out_w.detach().to(io).contiguous() if out_w is not None else None
+        bo = out_b.detach().to(io).contiguous() if out_b is not None else None
+        A32 = A.detach().float().contiguous()
+        D32 = D.detach().float().contiguous() if D is not None else None
+        db32 = delta_bias.detach().float().contiguous() if delta_bias is not None else None
+        desc = _abi.MambaInnerDesc()
+        desc.batch, desc.dim, desc.seqlen, desc.dstate, desc.dt_rank, desc.width = batch, d, L, A.shape[1], dt_proj_w.shape[1], w32.shape[1]
+        desc.d_model = wo.shape[0] if wo is not None else 0
+        desc.io_dtype, desc.flags = _abi.dtype_code(io), (_abi.SCAN_DELTA_SOFTPLUS if delta_softplus else 0)
+        desc.xz, desc.conv_weight, desc.conv_bias = xz.data_ptr(), w32.data_ptr(), _abi.ptr(b32)
+        desc.x_proj_weight, desc.dt_proj_weight = wx.data_ptr(), wdt.data_ptr()
+        desc.out_proj_weight, desc.out_proj_bias = _abi.ptr(wo), _abi.ptr(bo)
+        desc.A, desc.D, desc.delta_bias = A32.data_ptr(), _abi.ptr(D32), _abi.ptr(db32)
+        nbytes = lib.mxvl_mamba_inner_workspace_bytes(ctypes.byref(desc))
+        if nbytes < 0:
+            raise RuntimeError("mxvl_mamba_inner_workspace_bytes: invalid descriptor")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xz.device)
+        out = torch.empty((batch, L, desc.d_model) if wo is not None else (batch, d, L), dtype=io, device=xz.device)
+        desc.out, desc.workspace, desc.workspace_bytes = out.data_ptr(), ws.data_ptr(), nbytes
+        with torch.cuda.device(xz.device):
+            _abi.check(lib.mxvl_mamba_inner_fwd(ctypes.byref(desc), _abi.stream_ptr(xz.device)), "mxvl_mamba_inner_fwd")
+        ctx.save_for_backward(xz, w32, b32, wx, wdt, wo, bo, A32, D32, db32, ws)
+        ctx.meta = (delta_softplus, conv_w.shape, conv_w.dtype, None if conv_b is None else conv_b.dtype, x_proj_w.dtype, dt_proj_w.dtype,
+                    None if out_w is None else out_w.dtype, None if out_b is None else out_b.dtype, A.dtype,
+                    None if D is None else D.dtype, None if delta_bias is None else delta_bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xz, w32, b32, wx, wdt, wo, bo, A32, D32, db32, ws = ctx.saved_tensors
+        softplus, cw_shape, cw_dt, cb_dt, wx_dt, wdt_dt, wo_dt, bo_dt, A_dt, D_dt, bias_dt = ctx.meta
+        lib = _abi.load()
+        batch, two_d, L = xz.shape
+        d = two_d // 2
+        io, dev = xz.dtype, xz.device
+        b = _abi.MambaInnerBwdDesc()
+        f = b.fwd
+        f.batch, f.dim, f.seqlen, f.dstate, f.dt_rank, f.width = batch, d, L, A32.shape[1], wdt.shape[1], w32.shape[1]
+        f.d_model = wo.shape[0] if wo is not None else 0
+        f.io_dtype, f.flags = _abi.dtype_code(io), (_abi.SCAN_DELTA_SOFTPLUS if softplus else 0)
+        f.xz, f.conv_weight, f.conv_bias = xz.data_ptr(), w32.data_ptr(), _abi.ptr(b32)
+        f.x_proj_weight, f.dt_proj_weight, f.out_proj_weight, f.out_proj_bias = wx.data_ptr(), wdt.data_ptr(), _abi.ptr(wo), _abi.ptr(bo)
+        f.A, f.D, f.delta_bias = A32.data_ptr(), _abi.ptr(D32), _abi.ptr(db32)
+        f.workspace, f.workspace_bytes = ws.data_ptr(), ws.numel()
+        dout = dout.to(io).contiguous()
+        dxz = torch.empty_like(xz)
+        z32 = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev) if t is not None else None
+        dcw, dcb, dwx, dwdt, dwo, dbo, dA, dD, ddb = (z32(t) for t in (w32, b32, wx, wdt, wo, bo, A32, D32, db32))
+        nbytes = lib.mxvl_mamba_inner_bwd_workspace_bytes(ctypes.byref(f))
+        bws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b.dout, b.dxz = dout.data_ptr(), dxz.data_ptr()
+        b.dconv_weight, b.dconv_bias, b.dx_proj_weight, b.ddt_proj_weight = dcw.data_ptr(), _abi.ptr(dcb), dwx.data_ptr(), dwdt.data_ptr()
+        b.dout_proj_weight, b.dout_proj_bias = _abi.ptr(dwo), _abi.ptr(dbo)
+        b.dA, b.dD, b.ddelta_bias = dA.data_ptr(), _abi.ptr(dD), _abi.ptr(ddb)
+        b.workspace, b.workspace_bytes = bws.data_ptr(), nbytes
+        with torch.cuda.device(dev):
+            _abi.check(lib.mxvl_mamba_inner_bwd(ctypes.byref(b), _abi.stream_ptr(dev)), "mxvl_mamba_inner_bwd")
+        to = lambda t, dt: t.to(dt) if t is not None else None
+        return (dxz, dcw.reshape(cw_shape).to(cw_dt), to(dcb, cb_dt), dwx.to(wx_dt), dwdt.to(wdt_dt), to(dwo, wo_dt), to(dbo, bo_dt),
+                dA.to(A_dt), to(dD, D_dt), to(ddb, bias_dt), None)
+
+
+def mamba_inner_fn_native(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
+                          A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
+    """mamba_inner_fn's signature (out_proj_weight=None: mamba_inner_fn_no_out_proj's result, (batch, d_inner, seqlen)) served by the
+    single C-ABI entry mxvl_mamba_inner_fwd / _bwd -- what a non-torch host of libmxvl.so calls.  The projections run in xz's dtype."""
+    if B is not None or C is not None or B_proj_bias is not None or C_proj_bias is not None:
+        raise NotImplementedError("mamba_inner_fn_native: input-dependent B / C without projection biases (what the reference passes)")
+    if xz.dim() != 3 or xz.shape[1] % 2 != 0:
+        raise RuntimeError("mamba_inner_fn: xz must be (batch, 2*d_inner, seqlen)")
+    return autograd_util.apply(_MambaInnerNativeFn, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                               out_proj_bias, A, D, delta_bias, delta_softplus)
+
+
 def bimamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight, out_proj_bias,
                      A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None, C_proj_bias=None, delta_softplus=True):
     """bimamba_type "v1" (call site arm/Finetuning/mamba_simple.py:429-444).  The function itself lives in the patched

@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
                                               ("mxvl_dir_perm_desc", _abi.DirPermDesc), ("mxvl_beam_desc", _abi.BeamDesc),
                                               ("mxvl_add_ln_desc", _abi.AddLnDesc), ("mxvl_add_ln_bwd_desc", _abi.AddLnBwdDesc),
                                               ("mxvl_image_desc", _abi.ImageDesc), ("mxvl_gemm_swiglu_desc", _abi.GemmSwigluDesc),
-                                              ("mxvl_decode_prologue_desc", _abi.DecodePrologueDesc)])
+                                              ("mxvl_decode_prologue_desc", _abi.DecodePrologueDesc),
+                                              ("mxvl_mamba_inner_desc", _abi.MambaInnerDesc), ("mxvl_mamba_inner_bwd_desc", _abi.MambaInnerBwdDesc)])
 def test_ctypes_struct_mirrors_header(cstruct, pystruct):
     m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
@@ -39,7 +40,7 @@ def test_ctypes_struct_mirrors_header(cstruct, pystruct):
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|int8_t|uint8_t|int16_t|uint64_t|mxvl_scan_desc|mxvl_conv1d_desc|mxvl_add_ln_desc)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|int8_t|uint8_t|int16_t|uint64_t|mxvl_scan_desc|mxvl_conv1d_desc|mxvl_add_ln_desc|mxvl_mamba_inner_desc)\s*", "", decl)
         names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
     assert names == [f[0] for f in pystruct._fields_]
 
@@ -61,6 +62,36 @@ def test_scan_descriptor_validation_without_gpu():
     assert lib.mxvl_scan_fwd(ctypes.byref(d), None) == -5  # MXVL_ERR_STRIDE
     assert lib.mxvl_scan_chunk_len(4096, 16) > 0
     assert lib.mxvl_scan_n_chunks(4097, 16) == -(-4097 // lib.mxvl_scan_chunk_len(4097, 16))
+
+
+def test_mamba_inner_descriptor_validation_and_workspace_without_gpu():
+    """mxvl_mamba_inner_*: argument checks and the workspace arithmetic run without a GPU (nothing is launched)."""
+    lib = _abi.load()
+    d = _abi.MambaInnerDesc()
+    assert lib.mxvl_mamba_inner_fwd(ctypes.byref(d), None) == -1       # MXVL_ERR_NULL
+    assert lib.mxvl_mamba_inner_workspace_bytes(ctypes.byref(d)) == -1
+    d.xz = d.conv_weight = d.x_proj_weight = d.dt_proj_weight = d.A = 64   # fake non-null pointers, never dereferenced
+    d.io_dtype = 5
+    assert lib.mxvl_mamba_inner_fwd(ctypes.byref(d), None) == -2       # MXVL_ERR_DTYPE
+    d.io_dtype = _abi.MXVL_BF16
+    assert lib.mxvl_mamba_inner_fwd(ctypes.byref(d), None) == -3       # MXVL_ERR_SHAPE: zero sizes
+    d.batch, d.dim, d.seqlen, d.dstate, d.dt_rank, d.width = 16, 1024, 4080, 16, 64, 4
+    assert lib.mxvl_mamba_inner_fwd(ctypes.byref(d), None) == -1       # no out / workspace
+    al = lambda b: (b + 255) // 256 * 256
+    BDL, M = 16 * 1024 * 4080, 64 + 32
+    n_ckpt = lib.mxvl_scan_n_chunks(4080, 16)
+    want = 2 * al(BDL * 2) + al(16 * M * 4080 * 2) + al(16 * 1024 * n_ckpt * 16 * 4)
+    assert lib.mxvl_mamba_inner_workspace_bytes(ctypes.byref(d)) == want
+    assert lib.mxvl_mamba_inner_bwd_workspace_bytes(ctypes.byref(d)) == 2 * al(BDL * 2) + al(16 * 32 * 4080 * 4) + al(16 * M * 4080 * 2)
+    d.out_proj_weight, d.d_model = 64, 1024                              # with out_proj: y (forward) and dy (backward) are kept too
+    assert lib.mxvl_mamba_inner_workspace_bytes(ctypes.byref(d)) == want + al(BDL * 2)
+    d.d_model = 0
+    assert lib.mxvl_mamba_inner_workspace_bytes(ctypes.byref(d)) == -1
+    d.dstate, d.d_model = 300, 1024
+    d.out = d.workspace = 64
+    assert lib.mxvl_mamba_inner_fwd(ctypes.byref(d), None) == -4       # MXVL_ERR_DSTATE
+    b = _abi.MambaInnerBwdDesc()
+    assert lib.mxvl_mamba_inner_bwd(ctypes.byref(b), None) == -1
 
 
 def test_ops_refuse_cpu_tensors():

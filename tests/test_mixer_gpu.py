@@ -78,6 +78,105 @@ def test_mamba_inner_fn_equals_reference_slow_path(name):
         assert_close(P[k].grad, ref, 5e-5 * scale, 1e-3, "grad " + k)
 
 
+@pytest.mark.parametrize("name", golden_names("mamba_slow_"))
+def test_mamba_inner_native_entry_equals_reference_slow_path(name):
+    """The same goldens through the ONE C-ABI entry mxvl_mamba_inner_fwd / _bwd (conv1d + scan kernels + rocBLAS GEMMs composed in
+    csrc/mamba_inner.hip): out and every gradient of the reference mixer's slow path."""
+    from medical_image_analysis_amd.selective_scan_interface import mamba_inner_fn_native
+    g = load_golden(name)
+    P = {k[2:]: v.to(DEV).requires_grad_(True) for k, v in g.items() if k.startswith("p_")}
+    hidden = g["hidden"].to(DEV).requires_grad_(True)
+    xz = torch.matmul(P["in_proj.weight"], hidden.transpose(1, 2))
+    A = -torch.exp(P["A_log"].float())
+    out = mamba_inner_fn_native(xz, P["conv1d.weight"], P["conv1d.bias"], P["x_proj.weight"], P["dt_proj.weight"],
+                                P["out_proj.weight"], None, A, None, None, P["D"].float(),
+                                delta_bias=P["dt_proj.bias"].float(), delta_softplus=True)
+    assert_close(out, g["out"], 2e-5, 1e-4, "out")
+    out.backward(g["dout"].to(DEV))
+    assert_close(hidden.grad, g["dhidden"], 2e-5, 1e-3, "dhidden")
+    for k in ("in_proj.weight", "conv1d.weight", "conv1d.bias", "x_proj.weight", "dt_proj.weight", "dt_proj.bias",
+              "A_log", "D", "out_proj.weight"):
+        ref = g["g_" + k]
+        scale = max(1.0, float(ref.abs().max()))
+        assert_close(P[k].grad, ref, 5e-5 * scale, 1e-3, "grad " + k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("out_proj", [False, True])
+def test_mamba_inner_native_entry_equals_the_autograd_node(dtype, out_proj):
+    """mxvl_mamba_inner_fwd / _bwd against the package's own mixer node (_MambaInnerFn: the same conv / scan kernels, torch's GEMMs)
+    at a pre-training-like shape: aligned 16-bit rows (the vector / LDS-DMA kernels), several chunks, out_proj with a bias."""
+    from medical_image_analysis_amd.selective_scan_interface import mamba_inner_fn, mamba_inner_fn_native, mamba_inner_fn_no_out_proj
+    B, D, L, N, R, dm = 3, 256, 392, 16, 16, 128
+    gen = torch.Generator().manual_seed(3)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, generator=gen) * scale)
+    base = dict(xz=rn(B, 2 * D, L).to(dtype), cw=rn(D, 1, 4, scale=0.5), cb=rn(D, scale=0.1), wx=rn(R + 2 * N, D, scale=D ** -0.5).to(dtype),
+                wdt=rn(D, R, scale=R ** -0.5).to(dtype), wo=rn(dm, D, scale=D ** -0.5).to(dtype), bo=rn(dm, scale=0.1).to(dtype),
+                A=-torch.rand(D, N, generator=gen) - 0.1, Dv=rn(D), db=torch.rand(D, generator=gen) * 0.5 - 2.0)
+    dout = rn(B, L, dm).to(dtype) if out_proj else rn(B, D, L).to(dtype)
+    res = []
+    for fn in ("node", "native"):
+        t = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+        if fn == "native":
+            out = mamba_inner_fn_native(t["xz"], t["cw"], t["cb"], t["wx"], t["wdt"], t["wo"] if out_proj else None, t["bo"] if out_proj else None,
+                                        t["A"], None, None, t["Dv"], delta_bias=t["db"], delta_softplus=True)
+        elif out_proj:
+            out = mamba_inner_fn(t["xz"], t["cw"], t["cb"], t["wx"], t["wdt"], t["wo"], t["bo"], t["A"], None, None, t["Dv"], delta_bias=t["db"],
+                                 delta_softplus=True)
+        else:
+            out = mamba_inner_fn_no_out_proj(t["xz"], t["cw"], t["cb"], t["wx"], t["wdt"], t["A"], None, None, t["Dv"], delta_bias=t["db"],
+                                             delta_softplus=True)
+        out.backward(dout.to(DEV))
+        res.append((out.detach().float(), {k: v.grad.float() for k, v in t.items() if v.grad is not None}))
+    (o0, g0), (o1, g1) = res
+    assert o0.shape == o1.shape
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    scale = lambda r: max(1.0, float(r.abs().max()))
+    assert_close(o1, o0, tol * scale(o0), tol, "out")
+    assert set(g1) == set(g0) - (set() if out_proj else {"wo", "bo"})
+    for k in g1:
+        # 16-bit: the two paths round the same tensors at the same points but sum their GEMMs in different orders; weight gradients
+        # are sums over B * L tokens of products of rounded factors -- judged on the tensor's own scale
+        assert_close(g1[k], g0[k], (5e-5 if dtype == torch.float32 else 3e-2) * scale(g0[k]), tol, "grad " + k)
+
+
+def test_mamba_inner_from_a_plain_c_host(tmp_path):
+    """tests/c_host/mamba_inner_host.c: a C program with no torch in the process (gcc + the HIP runtime; rocBLAS reaches it through the
+    entry's own dlopen) runs mxvl_mamba_inner_fwd / _bwd on tensors handed over in a file; its outputs equal the autograd node's."""
+    import os
+    import subprocess
+    import numpy as np
+    from conftest import ROOT
+    from medical_image_analysis_amd.selective_scan_interface import mamba_inner_fn
+    pkg = os.path.join(ROOT, "medical_image_analysis_amd")
+    exe = str(tmp_path / "mamba_inner_host")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "c_host", "mamba_inner_host.c"), "-o", exe, "-L", pkg, "-l:libmxvl.so",
+                           "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"])
+    B, D, L, N, R, dm = 2, 64, 200, 16, 4, 48
+    gen = torch.Generator().manual_seed(11)
+    rn = lambda *s, scale=1.0: torch.randn(*s, generator=gen) * scale
+    t = [rn(B, 2 * D, L), rn(D, 4, scale=0.5), rn(D, scale=0.1), rn(R + 2 * N, D, scale=D ** -0.5), rn(D, R, scale=R ** -0.5),
+         rn(dm, D, scale=D ** -0.5), rn(dm, scale=0.1), -torch.rand(D, N, generator=gen) - 0.1, rn(D), torch.rand(D, generator=gen) * 0.5 - 2.0,
+         rn(B, L, dm)]
+    np.concatenate([x.numpy().ravel() for x in t]).astype(np.float32).tofile(tmp_path / "in.bin")
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), *map(str, (B, D, L, N, R, dm))], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    xz, cw, cb, wx, wdt, wo, bo, A, Dv, db, dout = [x.to(DEV).requires_grad_(True) for x in t]
+    out = mamba_inner_fn(xz, cw.unsqueeze(1), cb, wx, wdt, wo, bo, A, None, None, Dv, delta_bias=db, delta_softplus=True)
+    out.backward(dout.detach())
+    o = 0
+    for name, ref in (("out", out), ("dxz", xz.grad), ("dconv_w", cw.grad), ("dconv_b", cb.grad), ("dx_proj_w", wx.grad), ("ddt_proj_w", wdt.grad),
+                      ("dout_proj_w", wo.grad), ("dout_proj_b", bo.grad), ("dA", A.grad), ("dD", Dv.grad), ("ddelta_bias", db.grad)):
+        n = ref.numel()
+        piece = torch.from_numpy(got[o:o + n].copy()).view(ref.shape)
+        o += n
+        assert_close(piece, ref.detach(), 5e-5 * max(1.0, float(ref.detach().abs().max())), 1e-4, name)
+    assert o == got.size
+
+
 def test_decode_step_kernels_golden():
     """conv1d_update + selective_state_update reproduce the reference Mamba.step recurrence."""
     from medical_image_analysis_amd.causal_conv1d import causal_conv1d_update
