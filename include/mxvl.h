@@ -53,12 +53,11 @@
  *     the C oracle itself needs that scaling against the reference's fp32 torch loop); bf16 / fp16 io -- the reference test's own
  *     rtol / atol (test_selective_scan.py: 3e-2 / 5e-2 bf16, 3e-3 / 5e-3 fp16).  Index / ordering entries (mxvl_row_gather,
  *     mxvl_cross_scan / _merge, mxvl_dir_gather, mxvl_patch_cols, mxvl_image_preprocess, mxvl_beam_step's choices) are bit-exact.
- *   * mxvl_add_layernorm_fwd / _bwd serve row widths cols = 256 * k, k in {1, 2, 3, 4, 6, 8} (256 .. 2048: every width of the
- *     reference's ARM / VisionMamba / ViT-MAE factories) and, since round 6, the narrow rows 64, 128, 192, 384 (four / two rows per
- *     wave: VMamba's first stage and patch embedding, the constructors' default embed_dim = 192).  The Python mirror
- *     (fused_ops.add_layer_norm_supported) still routes any OTHER width to torch.nn.functional.layer_norm, a library path and not a
- *     HIP kernel of this library: a documented exception to "no fallback"; no reference configuration and no constructor default
- *     reaches it any more.
+ *   * mxvl_add_layernorm_fwd / _bwd serve EVERY row width: cols = 256 * k, k in {1, 2, 3, 4, 6, 8} (256 .. 2048: every width of the
+ *     reference's ARM / VisionMamba / ViT-MAE factories) a row per wave in registers, the narrow rows 64, 128, 192, 384 four / two rows
+ *     per wave (VMamba's first stage and patch embedding, the constructors' default embed_dim = 192), and since ABI v11 any other
+ *     width on a wave-per-row element-wise kernel pair (same arithmetic and rounding points, several times slower): the Python mirror
+ *     no longer routes any width of a HIP tensor to torch.nn.functional.layer_norm.
  */
 #ifndef MXVL_H_
 #define MXVL_H_

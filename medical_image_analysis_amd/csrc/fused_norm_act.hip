@@ -212,6 +212,78 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
   }
 }
 
+// ---- any other row width: a 64-thread workgroup (ONE wave) per row, element accesses, the row walked three times (it stays in the
+// vector cache: a row of this path is at most a few kilobytes).  Same arithmetic and rounding points as the kernels above -- fp32 two-pass
+// statistics, the residual stream normalised as stored -- so a model whose width is not one of the built instantiations runs the same
+// function, only slower: the package has no library LayerNorm to fall back to (include/mxvl.h).
+template <typename res_t, typename br_t, typename out_t>
+__global__ __launch_bounds__(64) void add_ln_fwd_any_kernel(const NormArgs p) {
+  const int lane = threadIdx.x, C = p.C;
+  for (int row = blockIdx.x; row < p.rows; row += gridDim.x) {
+    const res_t* xr = (const res_t*)p.x + (size_t)row * C;
+    const res_t* src = xr;
+    float s = 0.0f;
+    if (p.br) {
+      const br_t* br = (const br_t*)p.br + (size_t)row * C;
+      res_t* hr = (res_t*)p.h + (size_t)row * C;
+      for (int c = lane; c < C; c += 64) {
+        const float v = ln_round_trip<res_t>(Io<res_t>::ld(xr + c) + Io<br_t>::ld(br + c));
+        Io<res_t>::st(hr + c, v);                       // (read back below by the lane that wrote it)
+        s += v;
+      }
+      src = hr;
+    } else {
+      for (int c = lane; c < C; c += 64) s += Io<res_t>::ld(xr + c);
+    }
+    const float mean = wsum<64>(s) / (float)C;
+    float q = 0.0f;
+    for (int c = lane; c < C; c += 64) { const float d = Io<res_t>::ld(src + c) - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(wsum<64>(q) / (float)C + p.eps);
+    out_t* nr = (out_t*)p.n + (size_t)row * C;
+    for (int c = lane; c < C; c += 64)
+      Io<out_t>::st(nr + c, fmaf((Io<res_t>::ld(src + c) - mean) * rstd, p.gamma[c], p.beta ? p.beta[c] : 0.0f));
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+  }
+}
+
+// backward: workgroup w = partial row w of dgamma | dbeta | d-branch sums, which it owns alone (column c always meets the same lane): the
+// first row it walks stores, the following ones add -- plain read-modify-writes, no zero fill, no atomics
+template <typename res_t, typename br_t, typename out_t>
+__global__ __launch_bounds__(64) void add_ln_bwd_any_kernel(const NormBwdArgs p) {
+  const int lane = threadIdx.x, C = p.C;
+  float* pg = p.pgamma + (size_t)blockIdx.x * C;
+  float* pb = p.pbeta + (size_t)blockIdx.x * C;
+  float* pd = p.pdbr ? p.pdbr + (size_t)blockIdx.x * C : nullptr;
+  bool first = true;
+  for (int row = blockIdx.x; row < p.rows; row += gridDim.x, first = false) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    const res_t* hr = (const res_t*)p.h + (size_t)row * C;
+    const out_t* dr = (const out_t*)p.dn + (size_t)row * C;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (Io<res_t>::ld(hr + c) - mean) * rstd, dy = Io<out_t>::ld(dr + c);
+      pg[c] = first ? dy * xh : fmaf(dy, xh, pg[c]);
+      pb[c] = first ? dy : pb[c] + dy;
+      const float dg = dy * p.gamma[c];
+      s1 += dg;
+      s2 = fmaf(dg, xh, s2);
+    }
+    const float m1 = wsum<64>(s1) / (float)C, m2 = wsum<64>(s2) / (float)C;
+    res_t* dxr = (res_t*)p.dx + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (Io<res_t>::ld(hr + c) - mean) * rstd, dg = Io<out_t>::ld(dr + c) * p.gamma[c];
+      float o = rstd * (dg - m1 - xh * m2);
+      if (p.dh) o += Io<res_t>::ld((const res_t*)p.dh + (size_t)row * C + c);
+      Io<res_t>::st(dxr + c, o);
+      if (p.dbr) Io<br_t>::st((br_t*)p.dbr + (size_t)row * C + c, o);
+      if (pd) {
+        const float r = p.dbr ? ln_round_trip<br_t>(o) : ln_round_trip<res_t>(o);
+        pd[c] = first ? r : pd[c] + r;
+      }
+    }
+  }
+}
+
 // ---- SwiGLU gate: ab (rows, 2H) -> y (rows, H) = silu(ab[:, :H]) * ab[:, H:] ------------------------------------------
 // H need not be a multiple of 8 (2730 for ARM-large): rows are only 4-byte aligned in bf16.  A wave walks a row in
 // 512-column tiles; a lane owns the column PAIRS lane*2 + k*128 (k = 0..3), so every load instruction of the wave is
@@ -490,6 +562,12 @@ static void launch_ln(bool bwd, const void* args, int rows, hipStream_t s) {
   if (bwd) hipLaunchKernelGGL((add_ln_bwd_kernel<R, B, O, K, LPR>), dim3(wgs), dim3(256), 0, s, *(const NormBwdArgs*)args);
   else hipLaunchKernelGGL((add_ln_fwd_kernel<R, B, O, K, LPR>), dim3(wgs), dim3(256), 0, s, *(const NormArgs*)args);
 }
+// any other width: one wave per row (the backward's grid is still the caller's n_partials: a workgroup owns a partial row)
+template <typename R, typename B, typename O>
+static void launch_ln_any(bool bwd, const void* args, int rows, hipStream_t s) {
+  if (bwd) hipLaunchKernelGGL((add_ln_bwd_any_kernel<R, B, O>), dim3(std::min((rows + 3) / 4, kLnBwdPartials)), dim3(64), 0, s, *(const NormBwdArgs*)args);
+  else hipLaunchKernelGGL((add_ln_fwd_any_kernel<R, B, O>), dim3(std::min(rows, 8192)), dim3(64), 0, s, *(const NormArgs*)args);
+}
 template <typename R, typename B, typename O>
 static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s) {
   if (C % 256 != 0) {       // narrow rows: 128 k (two rows per wave) or 64 k (four rows per wave), k in {1, 3}
@@ -498,7 +576,7 @@ static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s
       case 384: launch_ln<R, B, O, 3, 32>(bwd, args, rows, s); break;
       case 64: launch_ln<R, B, O, 1, 16>(bwd, args, rows, s); break;
       case 192: launch_ln<R, B, O, 3, 16>(bwd, args, rows, s); break;
-      default: return MXVL_ERR_UNSUPPORTED;
+      default: launch_ln_any<R, B, O>(bwd, args, rows, s); break;
     }
     return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
   }
@@ -509,12 +587,11 @@ static int dispatch_k(bool bwd, const void* args, int rows, int C, hipStream_t s
     case 4: launch_ln<R, B, O, 4>(bwd, args, rows, s); break;
     case 6: launch_ln<R, B, O, 6>(bwd, args, rows, s); break;
     case 8: launch_ln<R, B, O, 8>(bwd, args, rows, s); break;
-    default: return MXVL_ERR_UNSUPPORTED;
+    default: launch_ln_any<R, B, O>(bwd, args, rows, s); break;
   }
   return hipGetLastError() == hipSuccess ? MXVL_OK : MXVL_ERR_LAUNCH;
 }
 static int dispatch_ln(bool bwd, const void* args, int rows, int C, int res_dt, int br_dt, int out_dt, hipStream_t s) {
-  if (C % 64 != 0) return MXVL_ERR_UNSUPPORTED;
   if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_F32) return dispatch_k<float, float, float>(bwd, args, rows, C, s);
   if (res_dt == MXVL_F32 && br_dt == MXVL_BF16 && out_dt == MXVL_BF16) return dispatch_k<float, bf16_t, bf16_t>(bwd, args, rows, C, s);
   if (res_dt == MXVL_F32 && br_dt == MXVL_F32 && out_dt == MXVL_BF16) return dispatch_k<float, float, bf16_t>(bwd, args, rows, C, s);

@@ -13,7 +13,8 @@ def _ref_add_ln(x, br, w, b, eps):
     return h, F.layer_norm(h, (h.shape[-1],), w.float(), b.float() if b is not None else None, eps)
 
 
-@pytest.mark.parametrize("C", [64, 128, 192, 384, 256, 512, 768, 1024, 1536, 2048])   # 64 .. 384: four / two rows per wave (round 6)
+@pytest.mark.parametrize("C", [64, 128, 192, 384, 256, 512, 768, 1024, 1536, 2048,     # 64 .. 384: four / two rows per wave (round 6)
+                               7, 96, 100, 1000, 1280, 2304])                          # any other width: the wave-per-row kernels
 @pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
                                     (torch.bfloat16, torch.bfloat16, torch.bfloat16), (torch.float32, None, torch.bfloat16),
                                     (torch.float32, torch.float16, torch.float16), (torch.float32, None, torch.float16)])   # fp16 autocast (ViT-MAE)
