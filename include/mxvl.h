@@ -652,6 +652,14 @@ typedef struct mxvl_attn_desc {
   void *lse;
   const void *key_mask;
   const void *bias;
+  /* ABI v11: attention dropout (training): probability (query i, key j) of head (b, h) is zeroed with probability dropout_p and
+   * the kept ones scaled by 1 / (1 - dropout_p), AFTER the softmax normalisation, as nn.Dropout on the attention matrix does
+   * (models_pretrain.py:62,80 attn_drop; hybrid_decoder_layer.py attention_dropout; Blip2 Q-Former attention_probs_dropout_prob).
+   * The keep bit is a pure function of (dropout_seed, b * n_heads + h, i, j) -- csrc/attn.hip attn_drop_hash, restated on the host by
+   * flash_attention.dropout_keep_mask -- so mxvl_attn_bwd reproduces the forward's mask from the same two fields.  0 = no dropout
+   * (and the only value the 64-queries-per-wave / LDS-DMA kernels serve: a call with dropout runs on the general kernels). */
+  float dropout_p;
+  uint32_t dropout_seed;
 } mxvl_attn_desc;
 typedef struct mxvl_attn_bwd_desc {
   mxvl_attn_desc fwd;   /* fwd.out and fwd.lse as the forward call left them */

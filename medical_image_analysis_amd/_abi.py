@@ -99,7 +99,7 @@ class AttnDesc(ctypes.Structure):
         ("q_bs", c_int64), ("q_hs", c_int64), ("q_ts", c_int64), ("k_bs", c_int64), ("k_hs", c_int64), ("k_ts", c_int64),
         ("v_bs", c_int64), ("v_hs", c_int64), ("v_ts", c_int64), ("o_bs", c_int64), ("o_hs", c_int64), ("o_ts", c_int64),
         ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p), ("key_mask", c_void_p),
-        ("bias", c_void_p),
+        ("bias", c_void_p), ("dropout_p", ctypes.c_float), ("dropout_seed", c_uint32),
     ]
 
 

@@ -47,7 +47,22 @@ struct AttnArgs {
   float *lse, *delta;          // (batch, H, Lq)
   const uint8_t* kmask;        // (batch, Lk), nonzero = attend
   const float* bias;           // (Lq, Lk) additive, broadcast over batch and heads
+  // attention dropout (training-time nn.Dropout on the probabilities: models_pretrain.py:62 attn_drop, hybrid_decoder_layer.py
+  // attention_dropout, Blip2 Q-Former attention_probs_dropout_prob): probability (query i, key j) of head (b, h) is kept iff
+  // attn_drop_hash(seed, b * H + h, i, j) >= drop_thresh and scaled by drop_scale = 1 / (1 - p).  0 = off.
+  uint32_t drop_thresh, drop_seed;
+  float drop_scale;
 };
+
+// counter-based: a pure function of (seed, head, query, key), so the forward, the dQ pass and the dK / dV pass -- which meet an element
+// in different tiles and lanes -- draw the same bit, and a test can rebuild the whole mask on the host (flash_attention.dropout_keep_mask)
+__device__ __forceinline__ uint32_t attn_drop_hash(uint32_t seed, uint32_t bh, uint32_t q, uint32_t k) {
+  uint32_t x = seed ^ (bh * 0x9E3779B1u);
+  x = (x ^ (q * 0x85EBCA77u)) * 0xC2B2AE3Du;
+  x ^= k * 0x27D4EB2Fu;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;     // murmur3's finaliser
+  return x;
+}
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 constexpr float kNegInf = -__builtin_inff();
@@ -419,9 +434,15 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = fast_exp2(s[h2][r] - mu);
+          float pv = fast_exp2(s[h2][r] - mu);
+          rs += pv;                                          // the normaliser sums the probabilities BEFORE dropout
+          if constexpr (EXTRA) {
+            if (p.drop_thresh) {
+              const uint32_t key = (uint32_t)(k0 + 32 * h2 + crow(r, hi));
+              pv = attn_drop_hash(p.drop_seed, (uint32_t)blockIdx.x, (uint32_t)qrow, key) >= p.drop_thresh ? pv * p.drop_scale : 0.f;
+            }
+          }
           s[h2][r] = pv;
-          rs += pv;
         }
       rs = pair_sum(rs);
       l = fmaf(l, alpha, rs);
@@ -453,7 +474,14 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = fast_exp2(s[h2][r] - lse);     // masked: exp2(-inf) = 0; rows without keys: lse = +inf
-          s[h2][r] = pv * (dp[r] - delta);
+          float dpr = dp[r];
+          if constexpr (EXTRA) {
+            if (p.drop_thresh) {                           // d(dropped P) -> dP: the kept elements' scale, zero elsewhere
+              const uint32_t key = (uint32_t)(k0 + 32 * h2 + crow(r, hi));
+              dpr = attn_drop_hash(p.drop_seed, (uint32_t)blockIdx.x, (uint32_t)qrow, key) >= p.drop_thresh ? dpr * p.drop_scale : 0.f;
+            }
+          }
+          s[h2][r] = pv * (dpr - delta);
         }
 #pragma unroll
         for (int ks = 0; ks < NKR; ++ks) {
@@ -1109,8 +1137,17 @@ __global__ __launch_bounds__(NW * 64, (D >= 128 || sizeof(E) == 4) ? 1 : 2) void
         }
         const bool on = key_on && krow < rk[r];
         const float pv = on ? fast_exp2(x - rl[r]) : 0.f;
-        s[r] = pv;
-        dp[r] = pv * (dp[r] - rd[r]);
+        float pd = pv, dpr = dp[r];
+        if constexpr (EXTRA) {
+          if (p.drop_thresh) {
+            const int hq = hk * grp + it / per_head;
+            const bool keep = attn_drop_hash(p.drop_seed, (uint32_t)(b * p.H + hq), (uint32_t)(q0 + 32 * h2 + crow(r, hi)), (uint32_t)krow) >= p.drop_thresh;
+            pd = keep ? pv * p.drop_scale : 0.f;           // dV sees the dropped probabilities, dS the undropped ones
+            dpr = keep ? dpr * p.drop_scale : 0.f;
+          }
+        }
+        s[r] = pd;
+        dp[r] = pv * (dpr - rd[r]);
       }
 #pragma unroll
       for (int ks = 0; ks < NKR; ++ks) {
@@ -1190,9 +1227,9 @@ static int launch_q(const AttnArgs& a, hipStream_t s) {
     // 16-byte aligned rows (the DMA moves 16-byte units) and no key mask / bias: the 64-queries-per-wave kernels
     const bool aligned = a.k_ts % 8 == 0 && a.v_ts % 8 == 0 && a.k_hs % 8 == 0 && a.v_hs % 8 == 0 && a.k_bs % 8 == 0 && a.v_bs % 8 == 0 &&
                          ((uintptr_t)a.k % 16) == 0 && ((uintptr_t)a.v % 16) == 0;
-    if (!a.kmask && !a.bias && aligned && a.Lk > 0) return launch_fwd64<E, DQ>(a, s);
+    if (!a.kmask && !a.bias && !a.drop_thresh && aligned && a.Lk > 0) return launch_fwd64<E, DQ>(a, s);
   }
-  return (a.kmask || a.bias) ? launch_q1<E, D, DQ, true>(a, s) : launch_q1<E, D, DQ, false>(a, s);
+  return (a.kmask || a.bias || a.drop_thresh) ? launch_q1<E, D, DQ, true>(a, s) : launch_q1<E, D, DQ, false>(a, s);
 }
 
 template <typename E, int D, bool EXTRA, bool DMAQ = false>
@@ -1202,9 +1239,9 @@ static int launch_dkv(const AttnArgs& a, hipStream_t s) {
   if constexpr (D == 64 && sizeof(E) == 2) {      // Q / dO tiles by LDS-DMA: 16-byte aligned rows, 32-bit in-tile offsets
     const bool aligned = a.q_ts % 8 == 0 && a.do_ts % 8 == 0 && a.q_hs % 8 == 0 && a.do_hs % 8 == 0 && a.q_bs % 8 == 0 && a.do_bs % 8 == 0 &&
                          ((uintptr_t)a.q % 16) == 0 && ((uintptr_t)a.dout % 16) == 0 && a.q_ts < (1 << 24) && a.do_ts < (1 << 24);
-    if (!a.kmask && !a.bias && aligned && a.Lq > 0) return launch_dkv1<E, D, false, true>(a, s);
+    if (!a.kmask && !a.bias && !a.drop_thresh && aligned && a.Lq > 0) return launch_dkv1<E, D, false, true>(a, s);
   }
-  return (a.kmask || a.bias) ? launch_dkv1<E, D, true>(a, s) : launch_dkv1<E, D, false>(a, s);
+  return (a.kmask || a.bias || a.drop_thresh) ? launch_dkv1<E, D, true>(a, s) : launch_dkv1<E, D, false>(a, s);
 }
 template <typename E, int D, bool EXTRA, bool DMAQ>
 static int launch_dkv1(const AttnArgs& a, hipStream_t s) {
@@ -1252,6 +1289,13 @@ static int fill_args(const mxvl_attn_desc* d, AttnArgs& a) {
   a.v_bs = d->v_bs; a.v_hs = d->v_hs; a.v_ts = d->v_ts; a.o_bs = d->o_bs; a.o_hs = d->o_hs; a.o_ts = d->o_ts;
   a.q = d->q; a.k = d->k; a.v = d->v; a.out = d->out; a.o = d->out; a.lse = (float*)d->lse;
   a.kmask = (const uint8_t*)d->key_mask; a.bias = (const float*)d->bias;
+  a.drop_thresh = 0; a.drop_seed = d->dropout_seed; a.drop_scale = 1.0f;
+  if (d->dropout_p != 0.0f) {
+    if (!(d->dropout_p > 0.0f && d->dropout_p < 1.0f)) return MXVL_ERR_SHAPE;
+    const double t = (double)d->dropout_p * 4294967296.0;
+    a.drop_thresh = t < 1.0 ? 1u : (t > 4294967295.0 ? 4294967295u : (uint32_t)t);
+    a.drop_scale = 1.0f / (1.0f - d->dropout_p);
+  }
   a.dout = nullptr; a.dq = a.dk = a.dv = nullptr; a.delta = nullptr;
   a.do_bs = a.do_hs = a.do_ts = a.dq_bs = a.dq_hs = a.dq_ts = a.dk_bs = a.dk_hs = a.dk_ts = a.dv_bs = a.dv_hs = a.dv_ts = 0;
   return MXVL_OK;

@@ -1,6 +1,6 @@
 """Fused multi-head attention on the MI355X matrix cores: autograd binding of mxvl_attn_fwd / mxvl_attn_bwd (csrc/attn.hip).
 
-    out = attention(q, k, v, scale=None, mask="none" | "causal" | "block_causal", cluster=16, key_mask=None, bias=None)
+    out = attention(q, k, v, scale=None, mask="none" | "causal" | "block_causal", cluster=16, key_mask=None, bias=None, dropout_p=0.0)
 
 q (B, H, Lq, D), k / v (B, Hkv, Lk, D) in any batch / head / token strides with D contiguous -- the (B, L, H, D) layout a
 `Linear(...).reshape(B, L, H, D).transpose(1, 2)` produces is consumed in place.  The result is returned as a (B, H, Lq, D)
@@ -36,7 +36,7 @@ def _token_major(B, H, L, D, like):
     return torch.empty(B, L, H, D, dtype=like.dtype, device=like.device).transpose(1, 2)
 
 
-def _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias):
+def _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias, drop=(0.0, 0)):
     B, H, Lq, D = q.shape
     desc.batch, desc.n_heads, desc.n_kv_heads, desc.seqlen_q, desc.seqlen_k, desc.head_dim = B, H, k.shape[1], Lq, k.shape[2], D
     desc.io_dtype = _abi.dtype_code(q.dtype)
@@ -47,9 +47,10 @@ def _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias):
     desc.o_bs, desc.o_hs, desc.o_ts = out.stride(0), out.stride(1), out.stride(2)
     desc.q, desc.k, desc.v, desc.out, desc.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _abi.ptr(lse)
     desc.key_mask, desc.bias = _abi.ptr(key_mask), _abi.ptr(bias)
+    desc.dropout_p, desc.dropout_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
 
 
-def attn_fwd_raw(q, k, v, scale, mask_mode=0, cluster=16, key_mask=None, bias=None, want_lse=True):
+def attn_fwd_raw(q, k, v, scale, mask_mode=0, cluster=16, key_mask=None, bias=None, want_lse=True, drop=(0.0, 0)):
     lib = _abi.load()
     _abi.require_gpu(q, k, v)
     B, H, Lq, D = q.shape
@@ -69,13 +70,13 @@ def attn_fwd_raw(q, k, v, scale, mask_mode=0, cluster=16, key_mask=None, bias=No
     out = _token_major(B, H, Lq, D, q)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device) if want_lse else None
     desc = _abi.AttnDesc()
-    _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias)
+    _fill(desc, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias, drop)
     with torch.cuda.device(q.device):
         _abi.check(lib.mxvl_attn_fwd(ctypes.byref(desc), _abi.stream_ptr(q.device)), "mxvl_attn_fwd")
     return out, lse, (q, k, v, key_mask, bias)
 
 
-def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=None, dv=None):
+def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=None, dv=None, drop=(0.0, 0)):
     lib = _abi.load()
     q, k, v, key_mask, bias = saved
     B, H, Lq, D = q.shape
@@ -85,7 +86,7 @@ def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=N
     dv = _token_major(B, k.shape[1], k.shape[2], D, q) if dv is None else dv
     delta = torch.empty_like(lse)
     desc = _abi.AttnBwdDesc()
-    _fill(desc.fwd, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias)
+    _fill(desc.fwd, q, k, v, out, lse, scale, mask_mode, cluster, key_mask, bias, drop)
     desc.dout_bs, desc.dout_hs, desc.dout_ts = dout.stride(0), dout.stride(1), dout.stride(2)
     desc.dq_bs, desc.dq_hs, desc.dq_ts = dq.stride(0), dq.stride(1), dq.stride(2)
     desc.dk_bs, desc.dk_hs, desc.dk_ts = dk.stride(0), dk.stride(1), dk.stride(2)
@@ -98,25 +99,25 @@ def attn_bwd_raw(saved, out, lse, dout, scale, mask_mode, cluster, dq=None, dk=N
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, scale, mask_mode, cluster, key_mask, bias):
+    def forward(ctx, q, k, v, scale, mask_mode, cluster, key_mask, bias, drop=(0.0, 0)):
         need = any(ctx.needs_input_grad[:3])
-        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, key_mask, bias, want_lse=need)
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, key_mask, bias, want_lse=need, drop=drop)
         if need:
             ctx.save_for_backward(saved[0], saved[1], saved[2], out, lse,
                                   *( [saved[3]] if saved[3] is not None else []), *([saved[4]] if saved[4] is not None else []))
-            ctx.cfg = (scale, mask_mode, cluster, saved[3] is not None, saved[4] is not None)
+            ctx.cfg = (scale, mask_mode, cluster, saved[3] is not None, saved[4] is not None, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        scale, mask_mode, cluster, has_km, has_bias = ctx.cfg
+        scale, mask_mode, cluster, has_km, has_bias, drop = ctx.cfg
         t = list(ctx.saved_tensors)
         q, k, v, out, lse = t[:5]
         rest = t[5:]
         km = rest.pop(0) if has_km else None
         bias = rest.pop(0) if has_bias else None
-        dq, dk, dv = attn_bwd_raw((q, k, v, km, bias), out, lse, dout, scale, mask_mode, cluster)
-        return dq, dk, dv, None, None, None, None, None
+        dq, dk, dv = attn_bwd_raw((q, k, v, km, bias), out, lse, dout, scale, mask_mode, cluster, drop=drop)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 class _AttentionKVPacked(torch.autograd.Function):
@@ -124,24 +125,24 @@ class _AttentionKVPacked(torch.autograd.Function):
     back as one tensor of the same layout -- autograd's select-backward would zero-fill and copy two full-size tensors."""
 
     @staticmethod
-    def forward(ctx, q, kv, scale, mask_mode, cluster):
+    def forward(ctx, q, kv, scale, mask_mode, cluster, drop=(0.0, 0)):
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need)
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need, drop=drop)
         if need:
             ctx.save_for_backward(saved[0], kv, out, lse)
-            ctx.cfg = (scale, mask_mode, cluster)
+            ctx.cfg = (scale, mask_mode, cluster, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, kv, out, lse = ctx.saved_tensors
-        scale, mask_mode, cluster = ctx.cfg
+        scale, mask_mode, cluster, drop = ctx.cfg
         k, v = _prep(kv[:, :, 0].transpose(1, 2)), _prep(kv[:, :, 1].transpose(1, 2))
         dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)
         dq, _, _ = attn_bwd_raw((q, k, v, None, None), out, lse, dout, scale, mask_mode, cluster,
-                                dk=dkv[:, :, 0].transpose(1, 2), dv=dkv[:, :, 1].transpose(1, 2))
-        return dq, dkv, None, None, None
+                                dk=dkv[:, :, 0].transpose(1, 2), dv=dkv[:, :, 1].transpose(1, 2), drop=drop)
+        return dq, dkv, None, None, None, None
 
 
 class _AttentionQKVPacked(torch.autograd.Function):
@@ -149,24 +150,24 @@ class _AttentionQKVPacked(torch.autograd.Function):
     the gradient is written into one tensor of the same layout."""
 
     @staticmethod
-    def forward(ctx, qkv, scale, mask_mode, cluster):
+    def forward(ctx, qkv, scale, mask_mode, cluster, drop=(0.0, 0)):
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         need = ctx.needs_input_grad[0]
-        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need)
+        out, lse, saved = attn_fwd_raw(q, k, v, scale, mask_mode, cluster, None, None, want_lse=need, drop=drop)
         if need:
             ctx.save_for_backward(qkv, out, lse)
-            ctx.cfg = (scale, mask_mode, cluster)
+            ctx.cfg = (scale, mask_mode, cluster, drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        scale, mask_mode, cluster = ctx.cfg
+        scale, mask_mode, cluster, drop = ctx.cfg
         q, k, v = (_prep(qkv[:, :, i].transpose(1, 2)) for i in range(3))
         dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)
         attn_bwd_raw((q, k, v, None, None), out, lse, dout, scale, mask_mode, cluster, dq=dqkv[:, :, 0].transpose(1, 2),
-                     dk=dqkv[:, :, 1].transpose(1, 2), dv=dqkv[:, :, 2].transpose(1, 2))
-        return dqkv, None, None, None
+                     dk=dqkv[:, :, 1].transpose(1, 2), dv=dqkv[:, :, 2].transpose(1, 2), drop=drop)
+        return dqkv, None, None, None, None
 
 
 def _pad_head_dim(D: int) -> int:
@@ -188,29 +189,61 @@ def _padded(q, k, v):
     return pad(q), pad(k), pad(v), D
 
 
-def attention(q, k, v, scale=None, mask="none", cluster=16, key_mask=None, bias=None):
+def _draw(dropout_p):
+    """(p, seed) of one attention call.  The seed comes from torch's CPU generator (torch.manual_seed makes a run repeatable, no device
+    sync); the kernels turn (seed, head, query, key) into the keep bit (csrc/attn.hip attn_drop_hash, dropout_keep_mask below)."""
+    p = float(dropout_p)
+    if p == 0.0:
+        return (0.0, 0)
+    if not 0.0 < p < 1.0:
+        raise ValueError(f"attention dropout probability must be in [0, 1), got {p}")
+    return (p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+
+
+def dropout_keep_mask(seed, B, H, Lq, Lk, p, device="cpu"):
+    """The (B, H, Lq, Lk) bool keep mask the kernels apply for (p, seed): attn_drop_hash of csrc/attn.hip restated in int64 arithmetic
+    (tests build the reference attention with it; nothing on the product path calls this)."""
+    M = 0xFFFFFFFF
+    bh = torch.arange(B * H, dtype=torch.int64, device=device).view(B, H, 1, 1)
+    q = torch.arange(Lq, dtype=torch.int64, device=device).view(1, 1, Lq, 1)
+    k = torch.arange(Lk, dtype=torch.int64, device=device).view(1, 1, 1, Lk)
+    x = (int(seed) & M) ^ ((bh * 0x9E3779B1) & M)
+    x = ((x ^ ((q * 0x85EBCA77) & M)) * 0xC2B2AE3D) & M
+    x = x ^ ((k * 0x27D4EB2F) & M)
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & M
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & M
+    x = x ^ (x >> 16)
+    t = float(p) * 4294967296.0
+    thresh = 1 if t < 1.0 else min(int(t), M)
+    return x >= thresh
+
+
+def attention(q, k, v, scale=None, mask="none", cluster=16, key_mask=None, bias=None, dropout_p=0.0, _drop=None):
     """softmax(q k^T * scale + mask) v.  mask: "none", "causal" (key j <= query i + Lk - Lq) or "block_causal" (key cluster <=
-    query cluster, cluster tokens each); key_mask (B, Lk) bool: True = may be attended; bias (Lq, Lk) additive fp32."""
+    query cluster, cluster tokens each); key_mask (B, Lk) bool: True = may be attended; bias (Lq, Lk) additive fp32; dropout_p:
+    nn.Dropout on the probabilities (training), drawn inside the kernels (_drop = (p, seed): a fixed draw, for tests)."""
     scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
     q, k, v, D = _padded(q, k, v)
-    out = _Attention.apply(q, k, v, scale, MASKS[mask], int(cluster), key_mask, bias)
+    out = _Attention.apply(q, k, v, scale, MASKS[mask], int(cluster), key_mask, bias, _drop if _drop is not None else _draw(dropout_p))
     return out if out.shape[-1] == D else out[..., :D]
 
 
-def attention_kvpacked(q, kv, scale=None, mask="none", cluster=16):
+def attention_kvpacked(q, kv, scale=None, mask="none", cluster=16, dropout_p=0.0):
     """q (B, H, Lq, D) view, kv (B, Lk, 2, Hkv, D)."""
     scale = float(q.shape[-1] ** -0.5 if scale is None else scale)
     if q.shape[-1] not in HEAD_DIMS:
-        return attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale, mask, cluster)
-    return _AttentionKVPacked.apply(q, kv, scale, MASKS[mask], int(cluster))
+        return attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale, mask, cluster, dropout_p=dropout_p)
+    return _AttentionKVPacked.apply(q, kv, scale, MASKS[mask], int(cluster), _draw(dropout_p))
 
 
-def attention_qkvpacked(qkv, scale=None, mask="none", cluster=16):
+def attention_qkvpacked(qkv, scale=None, mask="none", cluster=16, dropout_p=0.0):
     """qkv (B, L, 3, H, D) -> (B, H, L, D) view of a (B, L, H, D) buffer."""
     scale = float(qkv.shape[-1] ** -0.5 if scale is None else scale)
     if qkv.shape[-1] not in HEAD_DIMS:
-        return attention(*(qkv[:, :, i].transpose(1, 2) for i in range(3)), scale, mask, cluster)
-    return _AttentionQKVPacked.apply(qkv, scale, MASKS[mask], int(cluster))
+        return attention(*(qkv[:, :, i].transpose(1, 2) for i in range(3)), scale, mask, cluster, dropout_p=dropout_p)
+    return _AttentionQKVPacked.apply(qkv, scale, MASKS[mask], int(cluster), _draw(dropout_p))
 
 
 def is_block_causal_mask(mask: torch.Tensor, cluster: int = 16) -> bool:
@@ -249,14 +282,10 @@ def require(q, what: str, dropout_p: float = 0.0, *others) -> bool:
     caller evaluates its torch reference expression (host-side tests, golden generation).  A HIP tensor the kernels cannot
     serve RAISES -- there is no library attention fallback on the GPU.  `others` = the k / v tensors of the call: head_dim 256 is
     forward-only, and a call where only k / v need gradients must be refused HERE, not inside backward.
-    Restriction (documented, deliberate): attention dropout > 0 raises on a HIP device.  Every configuration the reference ships
-    trains with attn_drop = 0 / attention_dropout = 0.0 (models_pretrain.py CrossAttention default, Qwen2 / Llama configs); a config
-    that sets it needs the dropout mask inside the kernel, which is not built -- an eager softmax-dropout path would be a second,
-    silent attention implementation."""
+    Attention dropout (training) is drawn inside the kernels (mxvl_attn_desc.dropout_p / dropout_seed): the caller passes its
+    probability on to attention(..., dropout_p=p); head_dim 256 (forward-only prefill) has no dropout."""
     if not q.is_cuda:
         return False
-    if dropout_p != 0.0:
-        raise RuntimeError(f"{what}: attention dropout is not implemented by the HIP kernels (the reference trains with attn_drop = 0)")
     if not supported(q, *others):
         raise RuntimeError(f"{what}: head_dim {q.shape[-1]} / dtype {q.dtype} has no HIP attention kernel (head_dim <= 128 for "
                            "fp32 / bf16 / fp16 forward + backward; 256: bf16 / fp16 forward only)")

@@ -137,7 +137,7 @@ class ScaleDotProductCrossAttention(nn.Module):
             if attn_mask is not None:
                 raise RuntimeError("ScaleDotProductCrossAttention: a query-dependent (B, Lq, Lk) mask has no HIP kernel; both "
                                    "cross-attention variants of the reference pass a per-key mask (key_mask)")
-            o = flash.attention(q, k, v, scale=self.softmax_scale, key_mask=key_mask)
+            o = flash.attention(q, k, v, scale=self.softmax_scale, key_mask=key_mask, dropout_p=p)
             B, H, L, D = o.shape
             return o.transpose(1, 2).reshape(B, L, H * D)
         # CPU tensors only (host-side tests, golden comparison): the reference expression
@@ -288,7 +288,7 @@ class Qwen2HybridAttention(nn.Module):
             if attention_mask is not None and attention_mask.dim() != 2:
                 raise RuntimeError("Qwen2HybridAttention: pass the (B, kv_len) padding mask; an additive 4-D mask has no HIP kernel")
             km = None if attention_mask is None else attention_mask[:, :kv_len].bool()
-            attn = flash.attention(q, k, v, mask="causal", key_mask=km)
+            attn = flash.attention(q, k, v, mask="causal", key_mask=km, dropout_p=p_drop)
             attn_output = attn.transpose(1, 2).reshape(bsz, q_len, self.hidden_size)
             return self._finish(attn_output, q, visual_hidden_states, token_type, text2visual_attention_mask, past_key_value)
         # CPU tensors only (host-side tests): the reference expression

@@ -96,7 +96,7 @@ class Attention(nn.Module):
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         p = self.attn_drop.p if self.training else 0.0
         if flash.require(qkv, "mae.Attention", p):
-            x = flash.attention_qkvpacked(qkv, scale=self.scale)      # MFMA flash attention over the packed projection
+            x = flash.attention_qkvpacked(qkv, scale=self.scale, dropout_p=p)      # MFMA flash attention over the packed projection
         else:   # CPU tensors only (host-side tests): the reference expression
             qkv = qkv.permute(2, 0, 3, 1, 4)
             x = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p, scale=self.scale)

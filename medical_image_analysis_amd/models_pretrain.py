@@ -95,9 +95,9 @@ class CrossAttention(nn.Module):
             # hand-written MFMA flash attention (csrc/attn.hip): the block-lower-triangular mask of mask_generate is a kernel
             # mode that never visits the tiles above the diagonal; any other mask tensor goes in as an additive bias
             if flash.is_block_causal_mask(mask, 16):
-                x = flash.attention_kvpacked(q, kv, scale=self.scale, mask="block_causal", cluster=16)
+                x = flash.attention_kvpacked(q, kv, scale=self.scale, mask="block_causal", cluster=16, dropout_p=p)
             else:
-                x = flash.attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale=self.scale, bias=mask)
+                x = flash.attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), scale=self.scale, bias=mask, dropout_p=p)
         else:   # CPU tensors only (host-side tests, golden comparison): the reference expression (models_pretrain.py:69-83)
             kvp = kv.permute(2, 0, 3, 1, 4)
             x = F.scaled_dot_product_attention(q, kvp[0], kvp[1], attn_mask=mask.to(q.dtype), dropout_p=p, scale=self.scale)

@@ -36,17 +36,11 @@ class _Attention(nn.Module):
         split = lambda t: t.view(B, t.shape[1], self.heads, H // self.heads).transpose(1, 2)
         p = self.dropout if self.training else 0.0
         q, k, v = split(self.query(x)), split(self.key(kv)), split(self.value(kv))
-        if p > 0.0 and q.is_cuda:
-            # training with HF's attention_probs_dropout_prob (0.1 by default): dropout acts on the probabilities, which the fused
-            # kernel never materialises.  64 queries x <= 64 keys: HF's eager expression (Blip2QFormerMultiHeadAttention.forward)
-            scores = torch.matmul(q, k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
-            if mask is not None:
-                scores = scores + mask
-            out = torch.matmul(F.dropout(torch.softmax(scores, dim=-1), p, True), v)
-        elif flash.require(q, "Blip2 Q-Former attention", p):
-            # HF's additive (B, 1, 1, Lk) mask (0 / dtype-min) is a per-key keep mask
+        if flash.require(q, "Blip2 Q-Former attention", p):
+            # HF's additive (B, 1, 1, Lk) mask (0 / dtype-min) is a per-key keep mask; training with HF's attention_probs_dropout_prob
+            # (0.1 by default): the dropout on the probabilities is drawn inside the kernel
             km = None if mask is None else (mask.reshape(B, -1, mask.shape[-1])[:, 0] == 0)
-            out = flash.attention(q, k, v, key_mask=km)
+            out = flash.attention(q, k, v, key_mask=km, dropout_p=p)
         else:     # CPU tensors only (host-side tests): the reference expression
             out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=p)
         return out.transpose(1, 2).reshape(B, Lq, H)

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def ref_attention(q, k, v, scale, mask="none", cluster=16, key_mask=None, bias=None):
-    """fp64 masked softmax (B, H, Lq, D)."""
+def ref_attention(q, k, v, scale, mask="none", cluster=16, key_mask=None, bias=None, keep=None, keep_scale=1.0):
+    """fp64 masked softmax (B, H, Lq, D); keep (B, H, Lq, Lk) bool: nn.Dropout's mask on the probabilities, kept ones times keep_scale."""
     q, k, v = q.double(), k.double(), v.double()
     B, H, Lq, D = q.shape
     Hkv, Lk = k.shape[1], k.shape[2]
@@ -34,7 +34,10 @@ def ref_attention(q, k, v, scale, mask="none", cluster=16, key_mask=None, bias=N
         s = s + bias.double()
     if key_mask is not None:
         s = s.masked_fill(~key_mask.bool()[:, None, None, :], float("-inf"))
-    return torch.softmax(s, dim=-1) @ v
+    pr = torch.softmax(s, dim=-1)
+    if keep is not None:
+        pr = torch.where(keep, pr * keep_scale, torch.zeros_like(pr))
+    return pr @ v
 
 
 def _mk(B, H, Hkv, Lq, Lk, D, dtype, seed, layout="bhld"):
@@ -167,9 +170,57 @@ def test_attention_block_causal_equals_mask_generate_semantics_at_full_size():
         assert_close(got, want, 6e-2 * sc, 5e-2, name + " 4080 tokens")
 
 
+DROP_CASES = [
+    # B, H, Hkv, Lq,  Lk,  D,  mask,          key mask, p
+    (2, 4, 4, 150, 150, 64, "none", False, 0.1),            # head_dim 64 leaves the 64-queries-per-wave kernels for the general ones
+    (1, 4, 2, 77, 205, 64, "causal", True, 0.25),           # GQA + causal offset + a key mask
+    (2, 3, 3, 401, 401, 32, "none", False, 0.1),            # MAE decoder geometry
+    (1, 4, 2, 130, 197, 128, "none", True, 0.5),            # head_dim 128, text x image keys
+    (1, 2, 2, 96, 96, 64, "block_causal", False, 0.1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", DROP_CASES)
+def test_attention_dropout_forward_backward_against_the_host_mask(case, dtype):
+    """Attention dropout inside the kernels (mxvl_attn_desc.dropout_p / dropout_seed): with the keep mask rebuilt on the host from the
+    same (seed, head, query, key) hash, the forward and all three gradients equal nn.Dropout-on-the-probabilities in fp64; the kept
+    fraction is 1 - p; the three kernels (forward, dQ, dK / dV) meet every element with the same bit."""
+    from medical_image_analysis_amd import flash_attention as flash
+    B, H, Hkv, Lq, Lk, D, mask, use_km, p = case
+    q, k, v = _mk(B, H, Hkv, Lq, Lk, D, dtype, 17)
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+    km = None
+    if use_km:
+        km = torch.rand(B, Lk, generator=torch.Generator().manual_seed(3)) > 0.2
+        km[:, 0] = True
+        km = km.to(DEV)
+    seed = 123456789 + Lq
+    scale = D ** -0.5
+    out = flash.attention(q, k, v, scale=scale, mask=mask, key_mask=km, _drop=(p, seed))
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV, dtype)
+    out.backward(g)
+    keep = flash.dropout_keep_mask(seed, B, H, Lq, Lk, p, device=DEV)
+    assert abs(float(keep.float().mean()) - (1.0 - p)) < 0.02
+    qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = ref_attention(qr, kr, vr, scale, mask, 16, km, None, keep=keep, keep_scale=1.0 / (1.0 - p))
+    ref.backward(g.double())
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    sc = lambda t: max(1.0, float(t.detach().abs().max()))
+    assert_close(out.float(), ref.float(), tol * sc(ref), tol, "out")
+    for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert_close(a.float(), b.float(), tol * sc(b), tol, name)
+    # the same seed repeats the draw bit for bit; p = 0 is the undropped kernel
+    out2 = flash.attention(q.detach(), k.detach(), v.detach(), scale=scale, mask=mask, key_mask=km, _drop=(p, seed))
+    assert torch.equal(out2, out.detach())
+    plain = flash.attention(q.detach(), k.detach(), v.detach(), scale=scale, mask=mask, key_mask=km)
+    assert not torch.equal(plain, out2)
+
+
 def test_gpu_attention_has_no_library_fallback():
-    """Every attention call site dispatches through flash.require: HIP tensors take the MFMA kernels or RAISE (attention
-    dropout, head_dim without a kernel, query-dependent masks); only CPU tensors evaluate the torch reference expression."""
+    """Every attention call site dispatches through flash.require: HIP tensors take the MFMA kernels or RAISE (head_dim without a
+    kernel, query-dependent masks); only CPU tensors evaluate the torch reference expression.  Attention dropout is drawn inside the
+    kernels: a training-mode module with attn_drop > 0 runs on them too."""
     import torch.nn.functional as F
     from medical_image_analysis_amd import flash_attention as flash
     from medical_image_analysis_amd.hybrid_decoder_layer import ScaleDotProductCrossAttention
@@ -180,13 +231,10 @@ def test_gpu_attention_has_no_library_fallback():
     with pytest.raises(RuntimeError, match="head_dim 256"):       # 256 is forward-only, 16-bit
         flash.require(torch.randn(1, 2, 8, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True), "test")
     assert flash.require(torch.randn(1, 2, 8, 256, device=DEV, dtype=torch.bfloat16), "test") is True
-    with pytest.raises(RuntimeError, match="dropout"):
-        flash.require(torch.randn(1, 2, 8, 64, device=DEV), "test", 0.1)
+    assert flash.require(torch.randn(1, 2, 8, 64, device=DEV), "test", 0.1) is True
     assert flash.require(torch.randn(1, 2, 8, 128, device=DEV, requires_grad=True), "test") is True
     assert flash.require(torch.randn(1, 2, 8, 64), "test") is False           # CPU: host-side reference path
     m = Attention(128, num_heads=2, qkv_bias=True, attn_drop=0.1).to(DEV).train()
-    with pytest.raises(RuntimeError, match="dropout"):
-        m(torch.randn(2, 9, 128, device=DEV))
     ca = ScaleDotProductCrossAttention(0)
     qq, kk = torch.randn(1, 2, 4, 64, device=DEV), torch.randn(1, 2, 6, 64, device=DEV)
     with pytest.raises(RuntimeError, match="query-dependent"):
@@ -195,7 +243,13 @@ def test_gpu_attention_has_no_library_fallback():
     orig = F.scaled_dot_product_attention
     try:
         F.scaled_dot_product_attention = lambda *a, **k: calls.append(1) or orig(*a, **k)
-        m.eval()(torch.randn(2, 9, 128, device=DEV))
+        xin = torch.randn(2, 9, 128, device=DEV)
+        torch.manual_seed(5)
+        y1 = m(xin)
+        torch.manual_seed(5)
+        y2 = m(xin)
+        assert torch.equal(y1, y2) and not torch.equal(y1, m(xin))            # dropout: repeatable under the seed, a fresh draw otherwise
+        assert not torch.equal(y1, m.eval()(xin))
         ca(qq, kk, kk, key_mask=torch.ones(1, 6, dtype=torch.bool, device=DEV))
     finally:
         F.scaled_dot_product_attention = orig
