@@ -28,6 +28,7 @@ fi
 prof dg_fetch --kernel-trace --pmc FETCH_SIZE -d $P/dg_fetch -o r -- $DG
 prof dg_write --kernel-trace --pmc WRITE_SIZE -d $P/dg_write -o r -- $DG
 prof dg_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -d $P/dg_sq -o r -- $DG
+[ $PARTS = all ] && prof pretrain_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $P/pretrain_mfma -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 [ $PARTS = all ] && prof pretrain_stats --kernel-trace --stats -d $P/pretrain_stats -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 prof dec1 --kernel-trace --stats -d $P/dec1 -o r -- python $R/bench.py --workload decode_llama7b_128 --steps 1 --warmup 1 --no-cpu-baseline
 prof dec18 --kernel-trace --stats -d $P/dec18 -o r -- python $R/bench.py --workload decode_llama7b_b6x3 --steps 1 --warmup 1 --no-cpu-baseline
@@ -38,6 +39,7 @@ for n in bwd_fetch bwd_write fwd_fetch fwd_write dg_fetch dg_write dg_sq pretrai
   [ -f $P/$n/r_results.db ] || continue
   python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -70 | cut -c1-170 > $O/prof_${TAG}_$n.txt
 done
+[ -f $P/pretrain_mfma/r_results.db ] && python tools/mfma_busy.py $P/pretrain_mfma/r_results.db 30 2>&1 | cut -c1-170 > $O/${TAG}_pretrain_mfma_busy.txt
 python tools/decode_timeline.py $P/dec1/r_results.db 40 2>&1 | cut -c1-150 > $O/${TAG}_decode_timeline_decode_llama7b_128.txt
 python tools/decode_timeline.py $P/dec18/r_results.db 40 2>&1 | cut -c1-150 > $O/${TAG}_decode_timeline_decode_llama7b_b6x3.txt
 python tools/decode_timeline.py $P/dec80/r_results.db 40 2>&1 | cut -c1-150 > $O/${TAG}_decode_timeline_decode_llama7b_b16x5.txt
