@@ -474,6 +474,14 @@ int mxvl_patch_loss(const void *img, const void *pred, const void *dloss, void *
  * dtype for an fp32 image: the autocast cast of the GEMM input).  patch in {4, 8, 16, 32, 64}, 16-byte aligned pointers. */
 int mxvl_patch_cols(const void *img, void *cols, int batch, int channels, int h, int w, int patch, int in_dtype, int out_dtype,
                     void *hip_stream);
+/* ABI v11: window rows of a CHANNELS-LAST feature map with the activation in front of them fused -- the `F.relu(conv1(x))` -> `conv2`
+ * hand-off of SmallPatchEmbed (HD_Xray_Pretrain_MAE/pretrain/patch_embed.py:21-41: kernel == stride convolutions as GEMMs):
+ *   forward  (backward = 0): cols[n][i * gw + j][(di * k + dj) * C + c] = act(x[n][i * k + di][j * k + dj][c]),  x (N, H, W, C), act = ReLU iff relu
+ *   backward (backward = 1): out = dx (N, H, W, C) = dcols gathered back, zeroed where the PRE-activation x <= 0 (x may be NULL without relu)
+ * one io dtype, C % (16 bytes) == 0, 16-byte aligned buffers.  One pass each way instead of ReLU + strided copy (+ their two backward
+ * passes) over a (256, 80, 80, 1024) map. */
+int mxvl_window_cols(const void *x, const void *dcols, void *out, int N, int H, int W, int C, int k, int relu, int backward, int io_dtype,
+                     void *hip_stream);
 
 /*
  * mxvl_gemm_swiglu_fwd (ABI v4): the SwiGLU input projection of the block MLP as ONE MFMA GEMM with the gate in its epilogue --

@@ -40,7 +40,7 @@ SYMBOLS = [
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
     "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd", "mxvl_silu_mul",
-    "mxvl_mamba_inner_fwd", "mxvl_mamba_inner_bwd", "mxvl_mamba_inner_workspace_bytes", "mxvl_mamba_inner_bwd_workspace_bytes",
+    "mxvl_window_cols", "mxvl_mamba_inner_fwd", "mxvl_mamba_inner_bwd", "mxvl_mamba_inner_workspace_bytes", "mxvl_mamba_inner_bwd_workspace_bytes",
 ]
 
 
@@ -353,6 +353,8 @@ def load() -> ctypes.CDLL:
     lib.mxvl_patch_loss.argtypes = [c_void_p] * 5 + [c_int] * 6 + [c_void_p]
     lib.mxvl_beam_workspace_bytes.restype = c_int64
     lib.mxvl_beam_workspace_bytes.argtypes = [c_int] * 3
+    lib.mxvl_window_cols.restype = c_int
+    lib.mxvl_window_cols.argtypes = [c_void_p] * 3 + [c_int] * 8 + [c_void_p]
     lib.mxvl_patch_cols.restype = c_int
     lib.mxvl_patch_cols.argtypes = [c_void_p] * 2 + [c_int] * 7 + [c_void_p]
     lib.mxvl_scan_chunk_len.restype = c_int

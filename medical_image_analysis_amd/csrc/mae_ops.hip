@@ -18,6 +18,8 @@
 //                        statistics), never materialising the (N, L, p*p) target; the backward recomputes the target the same
 //                        way and writes d pred = dloss * 2 (pred - tgt) / (p*p).
 // HBM-bound: algorithmic bytes = read + write of every row once (gather), image + pred (+ dpred) once (loss).
+#include <algorithm>
+
 #include "mxvl_common.h"
 
 namespace mxvl {
@@ -230,6 +232,75 @@ extern "C" int mxvl_patch_loss(const void* img, const void* pred, const void* dl
     default: MXVL_PL(f16_t); break;
   }
 #undef MXVL_PL
+  return mae_check();
+}
+
+// ---- window rows of a CHANNELS-LAST feature map, the activation in front of it fused (ABI v11) ---------------------------------------
+// SmallPatchEmbed's second convolution (HD_Xray_Pretrain_MAE/pretrain/patch_embed.py:21-41: conv 16x16/s16 -> ReLU -> conv 4x4/s4 -> ReLU
+// -> conv 1x1) reads the ReLU of the first one's output, a (256, 80, 80, 1024) map at the reference's 1280 x 1280 input: as torch
+// expressions that was a ReLU pass, a strided copy into window rows, and in backward the inverse copy and threshold_backward -- four
+// passes over a 3.3 GB tensor.  Here: cols[n][(i, j)][(di, dj, c)] = act(x[n][i k + di][j k + dj][c]) in one pass (16-byte units along the
+// channel axis: a window row is k runs of k C contiguous elements), and the backward dx = dcols (inverse placement) * act'(x) in one pass
+// from the PRE-activation map, which is the only tensor kept (the post-ReLU map never exists).
+struct WindowArgs {
+  int N, H, W, C, k, relu, backward;
+  const void *x, *g;     // forward: x; backward: x (pre-activation, may be null without relu) and g = dcols
+  void* out;             // forward: cols; backward: dx
+};
+template <typename io_t>
+__global__ __launch_bounds__(256) void window_cols_kernel(const WindowArgs p) {
+  constexpr int V = 16 / (int)sizeof(io_t);
+  const int cv = p.C / V, gw = p.W / p.k;
+  const int64_t total = (int64_t)p.N * p.H * p.W * cv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    // idx walks the map (n, h, w, c-vector): reads of x (and stores of dx) are fully coalesced; the window side moves k C-element runs
+    const int c8 = (int)(idx % cv);
+    int64_t t = idx / cv;
+    const int w = (int)(t % p.W);
+    t /= p.W;
+    const int h = (int)(t % p.H), n = (int)(t / p.H);
+    const int i = h / p.k, di = h - i * p.k, j = w / p.k, dj = w - j * p.k;
+    const int64_t col = ((((int64_t)n * (p.H / p.k) + i) * gw + j) * (p.k * p.k) + di * p.k + dj) * p.C + (int64_t)c8 * V;
+    const int64_t src = idx * V;
+    io_t v[V];
+    if (!p.backward) {
+      *(uint4*)v = *(const uint4*)((const io_t*)p.x + src);
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) Io<io_t>::st(v + e, fmaxf(Io<io_t>::ld(v + e), 0.0f));
+      }
+      *(uint4*)((io_t*)p.out + col) = *(const uint4*)v;
+    } else {
+      *(uint4*)v = *(const uint4*)((const io_t*)p.g + col);
+      if (p.relu) {
+        io_t xv[V];
+        *(uint4*)xv = *(const uint4*)((const io_t*)p.x + src);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (!(Io<io_t>::ld(xv + e) > 0.0f)) Io<io_t>::st(v + e, 0.0f);      // threshold_backward: the gradient passes where x > 0
+      }
+      *(uint4*)((io_t*)p.out + src) = *(const uint4*)v;
+    }
+  }
+}
+
+extern "C" int mxvl_window_cols(const void* x, const void* dcols, void* out, int N, int H, int W, int C, int k, int relu, int backward,
+                                int io_dtype, void* hip_stream) {
+  if (!out || (backward ? (!dcols || (relu && !x)) : !x)) return MXVL_ERR_NULL;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H % k != 0 || W % k != 0) return MXVL_ERR_SHAPE;
+  if (io_dtype != MXVL_F32 && io_dtype != MXVL_BF16 && io_dtype != MXVL_F16) return MXVL_ERR_DTYPE;
+  const int V = io_dtype == MXVL_F32 ? 4 : 8;
+  if (C % V != 0 || (uintptr_t)out % 16 != 0 || (x && (uintptr_t)x % 16 != 0) || (dcols && (uintptr_t)dcols % 16 != 0)) return MXVL_ERR_UNSUPPORTED;
+  WindowArgs a;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.k = k; a.relu = relu ? 1 : 0; a.backward = backward ? 1 : 0; a.x = x; a.g = dcols; a.out = out;
+  const int64_t total = (int64_t)N * H * W * (C / V);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
+  hipStream_t s = (hipStream_t)hip_stream;
+  switch (io_dtype) {
+    case MXVL_F32: hipLaunchKernelGGL(window_cols_kernel<float>, dim3(grid), dim3(256), 0, s, a); break;
+    case MXVL_BF16: hipLaunchKernelGGL(window_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(window_cols_kernel<f16_t>, dim3(grid), dim3(256), 0, s, a); break;
+  }
   return mae_check();
 }
 

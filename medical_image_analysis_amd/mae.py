@@ -39,13 +39,19 @@ def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
     return emb
 
 
-def _patch_gemm(x, conv: nn.Conv2d):
-    """Conv2d with kernel == stride, no padding, as a GEMM: (B, C, H, W) -> (B, O, H/k, W/k)."""
+def _patch_gemm(x, conv: nn.Conv2d, relu_in=False):
+    """Conv2d with kernel == stride, no padding, as a GEMM: (B, C, H, W) -> (B, O, H/k, W/k).  relu_in: the convolution reads relu(x)
+    (SmallPatchEmbed's hand-offs): on a HIP channels-last map the ReLU rides in the window-row kernel (mae_ops.window_cols)."""
     k = conv.kernel_size[0]
     B, C, H, W = x.shape
     gh, gw = H // k, W // k
     w = conv.weight
-    if k == 1:
+    if relu_in and not (k > 1 and C > 1 and x.permute(0, 2, 3, 1).is_contiguous() and mae_ops.window_cols_supported(x.permute(0, 2, 3, 1), k)):
+        x, relu_in = F.relu(x), False
+    if relu_in:
+        cols = mae_ops.window_cols(x.permute(0, 2, 3, 1), k, relu=True)
+        w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    elif k == 1:
         cols = x.permute(0, 2, 3, 1).reshape(B, gh * gw, C)
         w2 = w.reshape(w.shape[0], -1)
     elif C > 1 and x.permute(0, 2, 3, 1).is_contiguous():
@@ -144,9 +150,9 @@ class SmallPatchEmbed(nn.Module):
         self.patch_size = (64, 64)
 
     def forward(self, x):
-        x = F.relu(_patch_gemm(x, self.conv1))
-        x = F.relu(_patch_gemm(x, self.conv2))
-        x = _patch_gemm(x, self.proj)
+        x = _patch_gemm(x, self.conv1)
+        x = _patch_gemm(x, self.conv2, relu_in=True)         # relu(conv1(x)) as the window-row kernel's activation
+        x = _patch_gemm(x, self.proj, relu_in=True)
         return x.flatten(2).transpose(1, 2)
 
 

@@ -146,6 +146,48 @@ class _PatchCols(torch.autograd.Function):
         return d.to(dt), None, None
 
 
+class _WindowCols(torch.autograd.Function):
+    """csrc/mae_ops.hip window_cols_kernel: the window rows of a channels-last map with the ReLU in front of them fused, forward and
+    backward one pass each; the pre-activation map is the only tensor kept."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, k, relu):
+        lib = _abi.load()
+        N, H, W, C = x_nhwc.shape
+        cols = torch.empty((N, (H // k) * (W // k), k * k * C), dtype=x_nhwc.dtype, device=x_nhwc.device)
+        with torch.cuda.device(x_nhwc.device):
+            _abi.check(lib.mxvl_window_cols(x_nhwc.data_ptr(), None, cols.data_ptr(), N, H, W, C, k, int(relu), 0, _abi.dtype_code(x_nhwc.dtype),
+                                            _abi.stream_ptr(x_nhwc.device)), "mxvl_window_cols")
+        if relu:
+            ctx.save_for_backward(x_nhwc)
+        ctx.meta = (x_nhwc.shape, k, relu)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        (N, H, W, C), k, relu = ctx.meta
+        lib = _abi.load()
+        x = ctx.saved_tensors[0] if relu else None
+        dcols = dcols.contiguous()
+        dx = torch.empty((N, H, W, C), dtype=dcols.dtype, device=dcols.device)
+        with torch.cuda.device(dcols.device):
+            _abi.check(lib.mxvl_window_cols(_abi.ptr(x), dcols.data_ptr(), dx.data_ptr(), N, H, W, C, k, int(relu), 1, _abi.dtype_code(dcols.dtype),
+                                            _abi.stream_ptr(dcols.device)), "mxvl_window_cols (backward)")
+        return dx, None, None
+
+
+def window_cols_supported(x_nhwc, k):
+    return (x_nhwc.is_cuda and x_nhwc.dim() == 4 and x_nhwc.is_contiguous() and x_nhwc.dtype in (torch.float32, torch.float16, torch.bfloat16)
+            and x_nhwc.shape[1] % k == 0 and x_nhwc.shape[2] % k == 0 and (x_nhwc.shape[3] * x_nhwc.element_size()) % 16 == 0
+            and x_nhwc.data_ptr() % 16 == 0)
+
+
+def window_cols(x_nhwc, k, relu=False):
+    """(N, H, W, C) contiguous -> (N, (H/k)(W/k), k k C): rows = the k x k windows in (di, dj, c) order, of relu(x) when `relu`."""
+    _abi.require_gpu(x_nhwc)
+    return _WindowCols.apply(x_nhwc, int(k), bool(relu))
+
+
 def patch_cols_supported(img, patch):
     return (img.is_cuda and img.dim() == 4 and img.is_contiguous() and img.dtype in (torch.float32, torch.float16, torch.bfloat16)
             and patch % 4 == 0 and 256 % patch == 0 and img.shape[2] % patch == 0 and img.shape[3] % patch == 0
