@@ -230,3 +230,28 @@ def test_decode_descriptors_refuse_dtypes_the_kernels_do_not_have():
             setattr(a, f, 64)
         a.rows, a.n_heads, a.n_kv_heads, a.head_dim, a.max_len, a.dtype = 3, 32, 32, 128, 512, bad
         assert lib.mxvl_decode_attn(ctypes.byref(a), None) == -2
+
+
+def test_attention_dropout_host_mask_and_seed_draw():
+    """flash_attention.dropout_keep_mask (the host restatement of csrc/attn.hip attn_drop_hash, what the GPU tests rebuild the kernels'
+    mask with) is a pure function of (seed, head, query, key) with the requested keep rate, and the seed of a call is drawn from torch's
+    CPU generator: torch.manual_seed repeats it."""
+    import torch
+    from medical_image_analysis_amd import flash_attention as flash
+    a = flash.dropout_keep_mask(1234, 2, 3, 50, 70, 0.25)
+    assert a.shape == (2, 3, 50, 70) and a.dtype == torch.bool
+    assert torch.equal(a, flash.dropout_keep_mask(1234, 2, 3, 50, 70, 0.25))
+    assert not torch.equal(a, flash.dropout_keep_mask(1235, 2, 3, 50, 70, 0.25))
+    assert abs(float(a.float().mean()) - 0.75) < 0.02
+    assert not torch.equal(a[0, 0], a[0, 1]) and not torch.equal(a[0, 0], a[1, 0])        # heads and batch elements draw differently
+    big = flash.dropout_keep_mask(7, 1, 1, 400, 400, 0.1)
+    assert abs(float(big.float().mean()) - 0.9) < 0.01
+    assert abs(float(big.float().mean(0).std()) - (0.9 * 0.1 / 400) ** 0.5) < 0.01          # columns: binomial spread, no stripes
+    # a sub-block of a larger call is the same draw: the bit depends on the indices, not on the launch geometry
+    assert torch.equal(flash.dropout_keep_mask(7, 1, 1, 400, 400, 0.1)[..., :64, :32], flash.dropout_keep_mask(7, 1, 1, 64, 32, 0.1))
+    torch.manual_seed(99)
+    d1 = flash._draw(0.1)
+    torch.manual_seed(99)
+    assert flash._draw(0.1) == d1 and d1[0] == 0.1 and flash._draw(0.0) == (0.0, 0)
+    with pytest.raises(ValueError):
+        flash._draw(1.0)
