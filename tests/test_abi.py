@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
                                               ("mxvl_add_ln_desc", _abi.AddLnDesc), ("mxvl_add_ln_bwd_desc", _abi.AddLnBwdDesc),
                                               ("mxvl_image_desc", _abi.ImageDesc), ("mxvl_gemm_swiglu_desc", _abi.GemmSwigluDesc),
                                               ("mxvl_decode_prologue_desc", _abi.DecodePrologueDesc),
-                                              ("mxvl_mamba_inner_desc", _abi.MambaInnerDesc), ("mxvl_mamba_inner_bwd_desc", _abi.MambaInnerBwdDesc)])
+                                              ("mxvl_mamba_inner_desc", _abi.MambaInnerDesc), ("mxvl_mamba_inner_bwd_desc", _abi.MambaInnerBwdDesc),
+                                              ("mxvl_attn_desc", _abi.AttnDesc), ("mxvl_attn_bwd_desc", _abi.AttnBwdDesc)])
 def test_ctypes_struct_mirrors_header(cstruct, pystruct):
     m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
@@ -40,7 +41,7 @@ def test_ctypes_struct_mirrors_header(cstruct, pystruct):
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|int8_t|uint8_t|int16_t|uint64_t|mxvl_scan_desc|mxvl_conv1d_desc|mxvl_add_ln_desc|mxvl_mamba_inner_desc)\s*", "", decl)
+        decl = re.sub(r"^(const\s+)?(void|int32_t|uint32_t|int64_t|float|int8_t|uint8_t|int16_t|uint64_t|mxvl_scan_desc|mxvl_conv1d_desc|mxvl_add_ln_desc|mxvl_mamba_inner_desc|mxvl_attn_desc)\s*", "", decl)
         names += [n.strip().lstrip("*").strip() for n in decl.split(",")]
     assert names == [f[0] for f in pystruct._fields_]
 
