@@ -483,6 +483,50 @@ def cpu_baseline_vssm(sd, depths, budget_s=15.0):
                       f"oracle/mxvl_oracle.c; the GPU value is a training step: forward + backward + AdamW), threads = {cores}; {elapsed:.1f} s of CPU work"}
 
 
+def _graph_kw(args, world):
+    if not getattr(args, "graph", False):
+        return {}
+    if world > 1:
+        raise SystemExit("--graph: single-process steps only")
+    return {"use_graph": True}
+
+
+def _timed_steps(eng, batches, steps, warmup, ssi, dist):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize pairs.  Eager engine: the scan launches of the timed steps
+    are bracketed by HIP events (ssi.KERNEL_TIMERS) for the roofline object.  Graph engine: the timed steps are graph launches (nothing in
+    Python to bracket), the kernel events come from two more EAGER steps behind the timed region."""
+    graph = getattr(eng, "use_graph", False)
+    if graph:
+        warmup = max(warmup, eng.graph_warmup + 2)          # the capture and the first replay belong to the warm-up
+    for i in range(warmup):
+        eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timers = []
+    if not graph:
+        ssi.KERNEL_TIMERS = timers
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = eng.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ssi.KERNEL_TIMERS = None
+    loss = loss.clone()
+    if graph:
+        ssi.KERNEL_TIMERS = timers
+        for i in range(2):
+            eng._eager_step(batches[i % 2])
+        torch.cuda.synchronize()
+        ssi.KERNEL_TIMERS = None
+    eng.timer_steps = 2 if graph else steps               # how many steps the kernel events cover
+    return loss, wall, timers, warmup
+
+
 def run_pretrain(args, rank, world, dev, dist):
     """Stage-1 pre-training step: VisionMamba forward+backward+clip+AdamW, bf16 autocast, DDP gradient all-reduce."""
     import medical_image_analysis_amd.selective_scan_interface as ssi
@@ -504,26 +548,12 @@ def run_pretrain(args, rank, world, dev, dist):
                         rms_norm=True, residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True,
                         bimamba_type="None").to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    eng = PretrainEngine(model, device=dev)
+    eng = PretrainEngine(model, device=dev, **_graph_kw(args, world))
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     batches = [torch.randn(B, 3, img, img, generator=g).to(dev) for _ in range(2)]
-    steps, warmup = args.steps, args.warmup
-    for i in range(warmup):
-        eng.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ssi.KERNEL_TIMERS = timers = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = eng.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ssi.KERNEL_TIMERS = None
+    steps = args.steps
+    loss, wall, timers, warmup = _timed_steps(eng, batches, steps, args.warmup, ssi, dist)
+    timer_steps = eng.timer_steps
     if dist is not None:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -563,12 +593,13 @@ def run_pretrain(args, rank, world, dev, dist):
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world,
                    "seq_len": L, "params": n_params, "parallelism": _dp_label(world),
                    "final_loss": final_loss,
-                   "timed_step": "forward + backward (DDP bucketed grad all-reduce overlapped) + loss all-reduce + clip + fused AdamW"},
+                   "timed_step": "forward + backward (DDP bucketed grad all-reduce overlapped) + loss all-reduce + clip + fused AdamW",
+                   "launch": "one hipGraph launch per step (PretrainEngine use_graph)" if getattr(args, "graph", False) else "eager launches"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kind,
                      "kernel_ms": tot_ms / calls, "launches_timed": calls,
                      "algorithmic_bytes_per_launch": tot_bytes // calls,
-                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()},
+                     "step_share": {k: round(v[0] / timer_steps / (wall / steps * 1e3), 4) for k, v in stats.items()},
                      "limited_by": "VALU issue rate of the fp32 recurrence (5 VALU + 1 v_exp per step and state), not HBM traffic (DESIGN.md 4.1 / 4.3); the HBM fraction is what the contract asks for"},
     }
     attach_traffic(out["roofline"], "scan_bwd_pretrain" if (kind == "scan_bwd" and args.workload == DEFAULT_WORKLOAD and B == 16)
@@ -812,26 +843,12 @@ def run_vmamba(args, rank, world, dev, dist):
     else:
         model = PooledLoss(vssm1_base_0229(drop_path_rate=0.0)).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    eng = PretrainEngine(model, device=dev)
+    eng = PretrainEngine(model, device=dev, **_graph_kw(args, world))
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     batches = [torch.randn(B, 3, 224, 224, generator=g).to(dev) for _ in range(2)]
-    steps, warmup = args.steps, args.warmup
-    for i in range(warmup):
-        eng.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ssi.KERNEL_TIMERS = timers = []
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = eng.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ssi.KERNEL_TIMERS = None
+    steps = args.steps
+    loss, wall, timers, warmup = _timed_steps(eng, batches, steps, args.warmup, ssi, dist)
+    timer_steps = eng.timer_steps
     if dist is not None:
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -856,12 +873,13 @@ def run_vmamba(args, rank, world, dev, dist):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic N(0,1) images (seed 1000+rank), random-init weights (seed 0)",
         "config": {"workload": f"{args.workload}: {desc}", "per_gpu_batch": B, "global_batch": B * world, "params": n_params,
-                   "parallelism": _dp_label(world), "final_loss": float(loss.mean())},
+                   "parallelism": _dp_label(world), "final_loss": float(loss.mean()),
+                   "launch": "one hipGraph launch per step (PretrainEngine use_graph)" if getattr(args, "graph", False) else "eager launches"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "kernel": kind + (" (4 directions stacked: one launch, n_groups 4, L = 197)" if args.workload.startswith("arm_")
                                                          else " (all SS2D stages: L = 3136 / 784 / 196 / 49, 4 direction groups, d_state 1)"),
                      "kernel_ms": tot_ms / calls, "launches_timed": calls, "algorithmic_bytes_per_launch": tot_bytes // calls,
-                     "step_share": {k: round(v[0] / (wall * 1e3), 4) for k, v in stats.items()}}}))
+                     "step_share": {k: round(v[0] / timer_steps / (wall / steps * 1e3), 4) for k, v in stats.items()}}}))
 
 
 def measure_scan(workload, steps, warmup, rank, world, dev, dist, no_cpu_baseline=False, one_gpu=False):
@@ -944,6 +962,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override for the pre-training workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the decode tokens/sec leg of the default workload")
+    ap.add_argument("--graph", action="store_true", help="training-step workloads, one process: the whole step captured once into a hipGraph and "
+                    "replayed (PretrainEngine(use_graph=True)); the launch-bound small-image steps gain, the 1024 x 1024 headline step is "
+                    "GPU-bound either way -- off by default so that the N = 1 line is the same program as the N > 1 lines")
     ap.add_argument("--secondary-warmup", type=int, default=8,
                     help="untimed generate() calls of the decode leg: it starts on a chip the training leg has just driven at its power limit, and "
                          "the first ~3 s of (memory-bound) decoding run 3 %% below the standalone decode line until the clocks recover -- "
@@ -966,6 +987,8 @@ def main():
                     help="A/B switch of the decode step: RMSNorm fused into the consuming projection (default) or the round-4 path "
                          "(K-split o_proj / down_proj folded by explicit norm launches)")
     args = ap.parse_args()
+    if args.graph and (args.gpus > 1 or not (args.workload in PRETRAIN_WORKLOADS or args.workload in VMAMBA_WORKLOADS)):
+        raise SystemExit("--graph: one process, a VisionMamba / ARM / VMamba training-step workload")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: launch the N ranks ourselves, exactly the way the driver does
