@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
-for w in vmamba_base_224 arm_encoder_large_224 arm_pretrain_base_192; do
+for w in ${WORKLOADS:-vmamba_base_224 arm_encoder_large_224 arm_pretrain_base_192}; do
   rm -rf /tmp/hb_$w
-  timeout 600 rocprofv3 --kernel-trace -d /tmp/hb_$w -o r -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > /tmp/hb_$w.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace -d /tmp/hb_$w -o r -- python $GRAFT_REPO_ROOT/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline ${EXTRA:-} > /tmp/hb_$w.log 2>&1
   python - <<PY
 import sqlite3, glob, json
 db = glob.glob('/tmp/hb_$w/**/*.db', recursive=True)[0]
