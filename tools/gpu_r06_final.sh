@@ -55,6 +55,9 @@ fi
 for w in ${WORKLOADS:-scan_bwd_pretrain scan_fwd_target scan_fwd_cfg2 scan_fwd_target_bf16 decode_llama7b_128 decode_llama7b_128_fp16 decode_llama7b_b6x3 decode_llama7b_b6x3_fp16 decode_llama7b_b8x3 decode_llama7b_b16x3 decode_llama7b_b16x5 decode_qwen1p8b_b16x5 decode_qwen1p8b_b1x5 finetune_stage3_llama7b r2gencsr_step mae_vit_large_1280 arm_encoder_large_224 vmamba_base_224 arm_pretrain_base_192}; do
   (timeout 600 python bench.py --workload $w 2>&1 | tail -1) > $O/${TAG}_bench_$w.json
 done
+for w in ${GRAPH_WORKLOADS:-arm_pretrain_base_192 vmamba_base_224}; do
+  (timeout 600 python bench.py --workload $w --graph 2>&1 | tail -1) > $O/${TAG}_bench_${w}_graph.json
+done
 (timeout 300 python tools/decode_gemm_bench.py 3 18 24 48 80 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_decode_gemm_bench.txt
 if [ $PARTS = all ]; then
 (timeout 300 python tools/gemm_swiglu_bwd_bench.py 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_gemm_swiglu_bwd_bench.txt
