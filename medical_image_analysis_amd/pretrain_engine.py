@@ -296,6 +296,10 @@ class PretrainEngine:
         """misc.load_model (misc.py:323-340): model, then optimizer + epoch + scaler when the file has them."""
         self.raw_model.load_state_dict(state["model"])
         self.drop_casts()
+        # a captured step reads the optimizer / scaler state tensors it was captured with: loading replaces them, so the next steps run
+        # eagerly again and the step is re-captured behind them
+        self._graph = self._graph_in = self._graph_out = self._graph_local = None
+        self._eager_steps = 0
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
         if "epoch" in state:

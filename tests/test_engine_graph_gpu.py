@@ -53,3 +53,26 @@ def test_graph_engine_refuses_what_it_cannot_capture():
         PretrainEngine(m, device=None, amp_dtype=None, use_graph=True)
     with pytest.raises(ValueError, match="accum_iter"):
         PretrainEngine(m.to(DEV), device=DEV, use_graph=True, accum_iter=2)
+
+
+def test_graph_engine_recaptures_after_loading_a_checkpoint():
+    """load_checkpoint_state replaces the optimizer / scaler tensors the captured step reads: the engine drops the graph, runs its warm-up
+    steps eagerly again and re-captures; training continues from the loaded state exactly as the eager engine does."""
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.randn(4, 3, 128, 128, generator=g).to(DEV) for _ in range(2)]
+    ma, ea = _build(use_graph=True, graph_warmup=1)
+    for i in range(4):
+        ea.step(batches[i % 2])
+    assert ea._graph is not None
+    state = ea.checkpoint_state()
+    state = {k: (v if not isinstance(v, dict) else __import__("copy").deepcopy(v)) for k, v in state.items()}
+    mb, eb = _build(use_graph=True, graph_warmup=1)
+    eb.step(batches[0]); eb.step(batches[1])
+    assert eb._graph is not None
+    eb.load_checkpoint_state(state)
+    assert eb._graph is None
+    la = [float(ea.step(batches[i % 2])) for i in range(4)]
+    lb = [float(eb.step(batches[i % 2])) for i in range(4)]
+    assert eb._graph is not None
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (la, lb)
