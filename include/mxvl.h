@@ -68,7 +68,7 @@
 extern "C" {
 #endif
 
-#define MXVL_ABI_VERSION 11
+#define MXVL_ABI_VERSION 12
 
 typedef enum mxvl_status {
   MXVL_OK = 0,
@@ -529,6 +529,24 @@ typedef struct mxvl_gemm_nt_desc {
   void *c;
 } mxvl_gemm_nt_desc;
 int mxvl_gemm_nt(const mxvl_gemm_nt_desc *desc, void *hip_stream);
+/* ABI v12: the weight-gradient GEMM, c (M, N) fp32 (+)= a^T b for TOKEN-MAJOR operands a (K, M), b (K, N) -- autograd's
+ * `grad_weight = dy^T x` of every nn.Linear of the blocks (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/mamba_simple.py:76,91 in_proj /
+ * out_proj, models_mamba.py:59-83 w1 | w2 | w3; K = the step's tokens).  One MFMA kernel (csrc/gemm_tn.hip): operands through
+ * LDS-DMA and the gfx950 transpose read, the token axis split over the XCDs, partial tiles added into c by fp32 atomics (so the
+ * low bits of c depend on the arrival order, like the dB / dC of mxvl_scan_bwd).  accumulate == 0: c is zeroed on the stream first.
+ * K % 64 == 0, K >= 512, M % 8 == 0, N % 8 == 0, 16-byte aligned a / b rows, bf16 / fp16 operands, fp32 accumulation and output.
+ * slices_per_xcd: 0 = chosen from the shape (1..4 token slices per XCD), q / -q = forced with / without the split of the last round
+ * (measurement). */
+typedef struct mxvl_gemm_tn_desc {
+  int32_t M, N, K;
+  int32_t io_dtype;
+  int32_t accumulate;
+  int32_t slices_per_xcd;
+  int64_t a_rs, b_rs, c_rs;            /* row strides in elements */
+  const void *a, *b;
+  void *c;
+} mxvl_gemm_tn_desc;
+int mxvl_gemm_tn(const mxvl_gemm_tn_desc *desc, void *hip_stream);
 int mxvl_gemm_swiglu_bwd_partials(int M);
 /* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */

@@ -15,7 +15,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmxvl.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 MXVL_F32, MXVL_BF16, MXVL_F16 = 0, 1, 2
 SCAN_DELTA_SOFTPLUS = 1
@@ -36,7 +36,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_gemm_tn", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
     "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd", "mxvl_silu_mul",
@@ -218,6 +218,14 @@ class GemmNtDesc(ctypes.Structure):
     ]
 
 
+class GemmTnDesc(ctypes.Structure):
+    _fields_ = [
+        ("M", c_int32), ("N", c_int32), ("K", c_int32), ("io_dtype", c_int32), ("accumulate", c_int32), ("slices_per_xcd", c_int32),
+        ("a_rs", c_int64), ("b_rs", c_int64), ("c_rs", c_int64),
+        ("a", c_void_p), ("b", c_void_p), ("c", c_void_p),
+    ]
+
+
 class GemmSwigluBwdDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_int32), ("K", c_int32), ("H", c_int32), ("io_dtype", c_int32),
@@ -287,7 +295,7 @@ def load() -> ctypes.CDLL:
     lib.mxvl_last_scan_kernel.restype = ctypes.c_char_p
     lib.mxvl_scan_bwd_workspace_bytes.restype = c_int64
     for name in ("mxvl_scan_fwd", "mxvl_scan_bwd", "mxvl_conv1d_fwd", "mxvl_conv1d_bwd", "mxvl_decode_gemv", "mxvl_decode_attn",
-                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_nt"):
+                 "mxvl_decode_cross_attn", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_nt", "mxvl_gemm_tn"):
         getattr(lib, name).restype = c_int
         getattr(lib, name).argtypes = [c_void_p, c_void_p]
     for name in ("mxvl_mamba_inner_fwd", "mxvl_mamba_inner_bwd"):

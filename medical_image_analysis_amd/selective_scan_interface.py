@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import ctypes
 
+import os
+
 import torch
 
 from . import _abi, autograd_util
@@ -351,8 +353,47 @@ def wgrad_splits(K, M, N):
     return S
 
 
+def gemm_tn(a_km, b_kn, out=None, slices_per_xcd=0):
+    """c (M, N) fp32 = a_km^T @ b_kn through mxvl_gemm_tn (csrc/gemm_tn.hip); `out`: an fp32 (M, N) tensor to ADD into."""
+    import ctypes
+    from . import _abi
+    K, M = a_km.shape
+    N = b_kn.shape[1]
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a_km.device)
+    d = _abi.GemmTnDesc()
+    d.M, d.N, d.K, d.io_dtype = M, N, K, _abi.dtype_code(a_km.dtype)
+    d.accumulate, d.slices_per_xcd = (1 if out is not None else 0), slices_per_xcd
+    d.a_rs, d.b_rs, d.c_rs = a_km.stride(0), b_kn.stride(0), c.stride(0)
+    d.a, d.b, d.c = a_km.data_ptr(), b_kn.data_ptr(), c.data_ptr()
+    _abi.check(_abi.load().mxvl_gemm_tn(ctypes.byref(d), _abi.stream_ptr(a_km.device)), "mxvl_gemm_tn")
+    return c
+
+
+# MXVL_WGRAD_TN=0: the round-2..5 form (batched library GEMM + plane sum) for A/B runs
+_WGRAD_TN = os.environ.get("MXVL_WGRAD_TN", "1") != "0"
+
+
+def gemm_tn_takes(a_km, b_kn):
+    """Shapes / layouts mxvl_gemm_tn accepts AND wins on (tools/wgrad_tn_bench.py): 16-bit token-major operands with unit column
+    stride, whole 64-token K steps, 16-byte aligned rows."""
+    if not (_WGRAD_TN and a_km.is_cuda and a_km.dtype in (torch.bfloat16, torch.float16) and b_kn.dtype == a_km.dtype):
+        return False
+    K, M = a_km.shape
+    N = b_kn.shape[1]
+    return (K % 64 == 0 and K >= 4096 and M % 8 == 0 and N % 8 == 0 and M >= 256 and N >= 256
+            and a_km.stride(1) == 1 and b_kn.stride(1) == 1 and a_km.stride(0) % 8 == 0 and b_kn.stride(0) % 8 == 0
+            and a_km.data_ptr() % 16 == 0 and b_kn.data_ptr() % 16 == 0)
+
+
 def splitk_wgrad(a_km, b_kn, out_dtype):
     """dW (M, N) = a_km^T @ b_kn for token-major operands a (K, M), b (K, N) (any strides torch.bmm accepts)."""
+    if gemm_tn_takes(a_km, b_kn):
+        return gemm_tn(a_km, b_kn).to(out_dtype)
+    return splitk_wgrad_library(a_km, b_kn, out_dtype)
+
+
+def splitk_wgrad_library(a_km, b_kn, out_dtype):
+    """The same product as one batched library GEMM over token slices + a sum over the fp32 planes."""
     K, M = a_km.shape
     N = b_kn.shape[1]
     S = wgrad_splits(K, M, N)

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
                                               ("mxvl_image_desc", _abi.ImageDesc), ("mxvl_gemm_swiglu_desc", _abi.GemmSwigluDesc),
                                               ("mxvl_decode_prologue_desc", _abi.DecodePrologueDesc),
                                               ("mxvl_mamba_inner_desc", _abi.MambaInnerDesc), ("mxvl_mamba_inner_bwd_desc", _abi.MambaInnerBwdDesc),
-                                              ("mxvl_attn_desc", _abi.AttnDesc), ("mxvl_attn_bwd_desc", _abi.AttnBwdDesc)])
+                                              ("mxvl_attn_desc", _abi.AttnDesc), ("mxvl_attn_bwd_desc", _abi.AttnBwdDesc),
+                                              ("mxvl_gemm_nt_desc", _abi.GemmNtDesc), ("mxvl_gemm_tn_desc", _abi.GemmTnDesc)])
 def test_ctypes_struct_mirrors_header(cstruct, pystruct):
     m = re.search(r"typedef struct " + cstruct + r" \{(.*?)\} " + cstruct + ";", _header(), re.S)
     body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)

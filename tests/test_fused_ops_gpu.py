@@ -256,3 +256,52 @@ def test_gemm_nt_kernel_vs_fp32_torch(M, K, N, dtype, bias):
     err = (c.float() - ref).abs()
     assert bool(torch.isfinite(c).all())
     assert float((err - ulp * ref.abs()).max()) <= 1e-3 * ulp * float(ref.abs().max()) + 1e-6, float(err.max())
+
+
+@pytest.mark.parametrize("K,M,N,dtype,q,strided", [(512, 256, 256, torch.bfloat16, 0, False), (4096, 264, 520, torch.bfloat16, 0, False),
+                                                   (8192, 5504, 1024, torch.bfloat16, 0, False), (4160, 1024, 2752, torch.float16, 0, False),
+                                                   (2048, 8, 776, torch.bfloat16, 3, True), (16320, 2048, 1024, torch.bfloat16, 4, True),
+                                                   (1024, 1000, 40, torch.float16, 1, False)])
+def test_gemm_tn_kernel_vs_fp64_torch(K, M, N, dtype, q, strided):
+    """mxvl_gemm_tn (csrc/gemm_tn.hip: K-major x K-major MFMA kernel through LDS-DMA + transpose reads, token axis split over the XCDs,
+    fp32 atomic epilogue), c = a^T b, against float64 torch on the same 16-bit operands.  The kernel sums 16-bit products exactly in
+    fp32 accumulators and adds <= 32 partial tiles: bound = fp32 rounding of a K-term sum, scaled by sum |a||b|.  Ragged tiles (M, N not
+    multiples of 256), every slice count, row-strided operands (a column block of a wider tensor), accumulation into an existing c."""
+    from medical_image_analysis_amd.selective_scan_interface import gemm_tn
+    g = torch.Generator().manual_seed(K + M + N)
+    wa, wb = (M + 64, N + 24) if strided else (M, N)
+    a = torch.randn(K, wa, generator=g).to(DEV, dtype)[:, wa - M:]
+    b = torch.randn(K, wb, generator=g).to(DEV, dtype)[:, :N]
+    if strided:
+        a, b = a[:, :M], b                       # a starts 64 columns (128 bytes) into its rows
+    ref = a.double().t() @ b.double()
+    mag = a.double().abs().t() @ b.double().abs()
+    c = gemm_tn(a, b, slices_per_xcd=q)
+    torch.cuda.synchronize()
+    assert c.dtype == torch.float32 and c.shape == (M, N) and bool(torch.isfinite(c).all())
+    bound = 2.0 ** -22 * (K ** 0.5 + 40) * mag + 1e-6
+    assert bool(((c.double() - ref).abs() <= bound).all()), float(((c.double() - ref).abs() / bound).max())
+    c0 = torch.randn(M, N, generator=g).to(DEV)
+    c1 = gemm_tn(a, b, out=c0.clone(), slices_per_xcd=q)
+    assert bool(((c1.double() - c0.double() - ref).abs() <= bound + 2.0 ** -23 * c0.abs().double()).all())
+
+
+def test_gemm_tn_refusals():
+    import ctypes
+    from medical_image_analysis_amd import _abi
+    lib = _abi.load()
+    a = torch.zeros(1024, 256, dtype=torch.bfloat16, device=DEV)
+    c = torch.zeros(256, 256, device=DEV)
+
+    def call(**kw):
+        d = _abi.GemmTnDesc()
+        d.M, d.N, d.K, d.io_dtype = 256, 256, 1024, _abi.dtype_code(torch.bfloat16)
+        d.a_rs, d.b_rs, d.c_rs = 256, 256, 256
+        d.a, d.b, d.c = a.data_ptr(), a.data_ptr(), c.data_ptr()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.mxvl_gemm_tn(ctypes.byref(d), _abi.stream_ptr(torch.device(DEV)))
+    assert call() == 0
+    assert call(K=1000) != 0 and call(K=256) != 0 and call(M=252) != 0 and call(N=100) != 0       # K steps / 8-column units
+    assert call(io_dtype=_abi.dtype_code(torch.float32)) != 0
+    assert call(a_rs=252) != 0 and call(c_rs=128) != 0 and call(a=a.data_ptr() + 2) != 0 and call(c=None) != 0
