@@ -25,7 +25,8 @@
 // [LOAD 12 ds_read_b64_tr_b16] barrier [COMPUTE 8 MFMA] barrier with the two waves of every SIMD one segment apart (the schedule of
 // gemm_swiglu.hip).  Measured and dropped (profiles/r06_wgrad_tn_bench.txt): requesting the fragments of sub-step s + 1 at the top of
 // the COMPUTE segment of sub-step s (two register sets, 218 VGPRs) -- 17-20 % SLOWER at every shape: the reads then compete with the
-// partner wave's LOAD segment for the LDS instead of filling the gap the partner's MFMAs leave.
+// partner wave's LOAD segment for the LDS instead of filling the gap the partner's MFMAs leave; ONE segment pair per K step (24 reads,
+// 16 MFMAs, half the barriers) -- 4-6 % slower.
 // Split over K.  M x N <= 5504 x 1024 gives 16..88 tiles for 256 CUs, so the token axis is cut into 8 q slices: XCD x takes the
 // slices x, x + 8, ... and its 32 persistent workgroups walk (slice, tile) units in step -- the workgroups resident on one XCD
 // read the SAME k range of different tiles, i.e. they share the A / B slices through that XCD's L2 (a tile's operands are
