@@ -281,35 +281,82 @@ class _MlpSwiGLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from .selective_scan_interface import bias_grad, splitk_wgrad
         x2, w, ab, h, w3c = ctx.saved_tensors
         shape, xdt, w12dt, b12dt, w3dt, b3dt = ctx.meta
-        lib = _abi.load()
-        rows, H = ab.shape[0], ab.shape[1] // 2
-        d2 = dy.reshape(-1, dy.shape[-1]).to(w3c.dtype)
-        if not d2.is_contiguous():
-            d2 = d2.contiguous()
-        db12 = None
-        fused = _MlpSwiGLU.FUSED_BWD if _MlpSwiGLU.FUSED_BWD is not None else ab.dtype == torch.float16
-        if fused:
-            dab, colsum = gemm_swiglu_bwd_raw(d2, w3c.t().contiguous(), ab, want_colsum=b12dt is not None)
-            if colsum is not None:
-                db12 = colsum.to(b12dt)
-        else:
-            dh = torch.matmul(d2, w3c)
-            dab = torch.empty_like(ab)
-            n_part = lib.mxvl_swiglu_partials(rows, H) if b12dt is not None else 0
-            partial = torch.empty((max(n_part, 1), 2 * H), dtype=torch.float32, device=ab.device)
-            with torch.cuda.device(ab.device):
-                _abi.check(lib.mxvl_swiglu_bwd_colsum(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), partial.data_ptr(), n_part, rows, H,
-                                                      _abi.dtype_code(ab.dtype), _abi.stream_ptr(ab.device)), "mxvl_swiglu_bwd_colsum")
-            if b12dt is not None:
-                db12 = partial.sum(0).to(b12dt)
-        dw3 = splitk_wgrad(d2, h, w3dt)
-        db3 = bias_grad(dy, d2, b3dt) if b3dt is not None else None
-        dx = torch.matmul(dab, w).view(shape).to(xdt)
-        dw12 = splitk_wgrad(dab, x2, w12dt)
-        return dx, dw12, db12, dw3, db3
+        dx, dw12, db12, dw3, db3 = _mlp_swiglu_bwd(x2, w, ab, h, w3c, dy, b12dt is not None, b3dt is not None)
+        return (dx.view(shape).to(xdt), dw12.to(w12dt), None if db12 is None else db12.to(b12dt), dw3.to(w3dt),
+                None if db3 is None else db3.to(b3dt))
+
+
+def _mlp_swiglu_bwd(x2, w, ab, h, w3c, dy, want_b12, want_b3):
+    """Backward of the MLP node from its saved tensors: dx (rows, K) in the compute dtype, dw12 (2H, K) / dw3 (out, H) fp32 where the
+    wgrad kernel ran (else the library's dtype), db12 (2H) fp32, db3 fp32."""
+    from .selective_scan_interface import bias_grad, splitk_wgrad
+    lib = _abi.load()
+    rows, H = ab.shape[0], ab.shape[1] // 2
+    d2 = dy.reshape(-1, dy.shape[-1]).to(w3c.dtype)
+    if not d2.is_contiguous():
+        d2 = d2.contiguous()
+    db12 = None
+    fused = _MlpSwiGLU.FUSED_BWD if _MlpSwiGLU.FUSED_BWD is not None else ab.dtype == torch.float16
+    if fused:
+        dab, colsum = gemm_swiglu_bwd_raw(d2, w3c.t().contiguous(), ab, want_colsum=want_b12)
+        db12 = colsum
+    else:
+        dh = torch.matmul(d2, w3c)
+        dab = torch.empty_like(ab)
+        n_part = lib.mxvl_swiglu_partials(rows, H) if want_b12 else 0
+        partial = torch.empty((max(n_part, 1), 2 * H), dtype=torch.float32, device=ab.device)
+        with torch.cuda.device(ab.device):
+            _abi.check(lib.mxvl_swiglu_bwd_colsum(ab.data_ptr(), dh.data_ptr(), dab.data_ptr(), partial.data_ptr(), n_part, rows, H,
+                                                  _abi.dtype_code(ab.dtype), _abi.stream_ptr(ab.device)), "mxvl_swiglu_bwd_colsum")
+        if want_b12:
+            db12 = partial.sum(0)
+    dw3 = splitk_wgrad(d2, h, torch.float32)
+    db3 = bias_grad(dy, d2, torch.float32) if want_b3 else None
+    dx = torch.matmul(dab, w)
+    dw12 = splitk_wgrad(dab, x2, torch.float32)
+    return dx, dw12, db12, dw3, db3
+
+
+class _MlpSwiGLUParams(torch.autograd.Function):
+    """_MlpSwiGLU over the module's OWN parameters (w1, w2, w3 and their biases) and a per-module cache of what the kernels read: the
+    hidden-axis-padded [w1; 0; w2; 0] and [w3 | 0] in the compute dtype, [b1 | 0 | b2 | 0] in fp32 (models_mamba.SwiGLU._fused_params,
+    rebuilt when a parameter changed).  Rounds 3-5 concatenated the fp32 parameters in every forward (three `cat`s and two casts per
+    layer, 1.6 ms of the 213 ms headline step) and autograd cut the merged gradients apart again; here the gradients of w1 / w2 / b1 /
+    b2 are row ranges of the merged fp32 gradient (views: autograd adopts them as they are)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, w12c, b12c, w3c, H):
+        from .selective_scan_interface import _compute_dtype
+        cd = _compute_dtype(x)
+        x2 = x.reshape(-1, x.shape[-1]).to(cd)
+        needs_grad = autograd_util.wants_grad(ctx, 7)
+        h, ab = gemm_swiglu_fwd_raw(x2, w12c, b12c, want_ab=needs_grad)
+        y = torch.nn.functional.linear(h, w3c, None if b3 is None else autograd_util.cast_param(b3, cd))
+        if needs_grad:
+            ctx.save_for_backward(x2, w12c, ab, h, w3c)
+        ctx.meta = (x.shape, x.dtype, H, w1.dtype, None if b1 is None else b1.dtype, w3.dtype, None if b3 is None else b3.dtype)
+        return y.view(*x.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, ab, h, w3c = ctx.saved_tensors
+        shape, xdt, H, wdt, bdt, w3dt, b3dt = ctx.meta
+        Hp = ab.shape[1] // 2
+        dx, dw12, db12, dw3, db3 = _mlp_swiglu_bwd(x2, w, ab, h, w3c, dy, bdt is not None, b3dt is not None)
+        dw1, dw2 = dw12[:H].to(wdt), dw12[Hp:Hp + H].to(wdt)
+        db1 = db2 = None
+        if db12 is not None:
+            db1, db2 = db12[:H].to(bdt), db12[Hp:Hp + H].to(bdt)
+        return (dx.view(shape).to(xdt), dw1, db1, dw2, db2, dw3[:, :H].to(w3dt), None if db3 is None else db3.to(b3dt),
+                None, None, None, None)
+
+
+def mlp_swiglu_params(x, w1, b1, w2, b2, w3, b3, w12c, b12c, w3c):
+    """w3(silu(x w1^T + b1) * (x w2^T + b2)) from the parameters and their cached kernel-side forms (see _MlpSwiGLUParams)."""
+    _abi.require_gpu(x, w12c, b12c, w3c)
+    return autograd_util.apply(_MlpSwiGLUParams, x, w1, b1, w2, b2, w3, b3, w12c, b12c, w3c, w1.shape[0])
 
 
 def mlp_swiglu_supported(x, w12, w3):

@@ -111,6 +111,35 @@ class SwiGLU(nn.Module):
             self._zpad[shape] = torch.zeros(shape, device=w.device, dtype=w.dtype)
         return self._zpad[shape]
 
+    def _fused_params(self, cd):
+        """What the MLP kernels read, cached per module: [w1; 0; w2; 0] (2 Hp, K) and [w3 | 0] (out, Hp) in the compute dtype, the
+        merged bias in fp32, the hidden axis zero-padded to whole 64-column tiles (see forward).  The stamp is the five parameters'
+        (autograd version, storage address) -- in-place optimizer updates and load_state_dict bump the version, `.to()` / `p.data = `
+        change the address; a write THROUGH p.data into the same storage is invisible, as for autograd_util.cast_param
+        (PretrainEngine.drop_casts clears this cache too).  Never a parameter or a buffer: not in the state dict."""
+        ps = (self.w1.weight, self.w1.bias, self.w2.weight, self.w2.bias, self.w3.weight)
+        stamp = (cd,) + tuple((p._version, p.data_ptr()) for p in ps)
+        c = self.__dict__.get("_mxvl_fused")
+        if c is not None and c[0] == stamp:
+            return c[1]
+        H, K = self.w1.weight.shape
+        Hp = H + (-H % _HIDDEN_TILE)
+        dev = self.w1.weight.device
+        with torch.no_grad():
+            if c is not None and c[1][0].shape == (2 * Hp, K) and c[1][0].dtype == cd and c[1][0].device == dev:
+                w12c, b12c, w3c = c[1]            # same buffers: the zero pads are still in place
+            else:
+                w12c = torch.zeros((2 * Hp, K), dtype=cd, device=dev)
+                b12c = torch.zeros((2 * Hp,), dtype=torch.float32, device=dev)
+                w3c = torch.zeros((self.w3.weight.shape[0], Hp), dtype=cd, device=dev)
+            w12c[:H].copy_(self.w1.weight)
+            w12c[Hp:Hp + H].copy_(self.w2.weight)
+            b12c[:H].copy_(self.w1.bias)
+            b12c[Hp:Hp + H].copy_(self.w2.bias)
+            w3c[:, :H].copy_(self.w3.weight)
+        self.__dict__["_mxvl_fused"] = (stamp, (w12c, b12c, w3c))
+        return w12c, b12c, w3c
+
     def forward(self, x):
         if x.is_cuda and isinstance(self.act, nn.SiLU) and isinstance(self.ffn_ln, nn.Identity):
             # [w1 x | w2 x] from ONE GEMM with the gate in its epilogue (csrc/gemm_swiglu.hip) or as one HIP kernel behind the
@@ -121,6 +150,13 @@ class SwiGLU(nn.Module):
             # tokens (profiles/r03_pad_gemm_bench.txt) and every row becomes 16-byte aligned.  Parameters keep the reference shapes.
             H, K = self.w1.weight.shape
             pad = -H % _HIDDEN_TILE
+            from .selective_scan_interface import _compute_dtype
+            cd = _compute_dtype(x)
+            if (cd in (torch.bfloat16, torch.float16) and self.w1.bias is not None and K % 64 == 0 and K <= 1024
+                    and self.w3.weight.shape[0] % 64 == 0):
+                w12c, b12c, w3c = self._fused_params(cd)
+                return self.drop(fused_ops.mlp_swiglu_params(x, self.w1.weight, self.w1.bias, self.w2.weight, self.w2.bias, self.w3.weight,
+                                                             self.w3.bias, w12c, b12c, w3c))
             if pad:
                 zw, zb = self._zeros(pad, K), self._zeros(pad)
                 w = torch.cat([self.w1.weight, zw, self.w2.weight, zw], dim=0)

@@ -187,6 +187,8 @@ class PretrainEngine:
         for p in self._cast_params:
             if hasattr(p, "_mxvl_lp"):
                 del p._mxvl_lp
+        for m in self.raw_model.modules():
+            m.__dict__.pop("_mxvl_fused", None)          # models_mamba.SwiGLU._fused_params
 
     def start_epoch(self):
         """engine_pretrain.py:31 `optimizer.zero_grad()` + the iteration counter the schedule and the accumulation window read."""

@@ -305,3 +305,47 @@ def test_gemm_tn_refusals():
     assert call(K=1000) != 0 and call(K=256) != 0 and call(M=252) != 0 and call(N=100) != 0       # K steps / 8-column units
     assert call(io_dtype=_abi.dtype_code(torch.float32)) != 0
     assert call(a_rs=252) != 0 and call(c_rs=128) != 0 and call(a=a.data_ptr() + 2) != 0 and call(c=None) != 0
+
+
+@pytest.mark.parametrize("K,H,dtype", [(128, 90, torch.bfloat16), (256, 128, torch.float16), (1024, 2730, torch.bfloat16)])
+def test_swiglu_module_cached_params_path(K, H, dtype):
+    """models_mamba.SwiGLU under 16-bit autocast: the per-module cache of the kernel-side parameter forms ([w1; 0; w2; 0], [w3 | 0],
+    merged bias) and the params-level autograd node against the reference composition w3(silu(w1 x) * (w2 x))
+    (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:59-83) in fp32 on the same 16-bit-rounded operands; the gradients of
+    w1 / w2 / b1 / b2 are views of the merged gradient, and the cache follows in-place parameter updates (the optimizer's)."""
+    from medical_image_analysis_amd.models_mamba import SwiGLU
+    torch.manual_seed(K + H)
+    m = SwiGLU(K, H).to(DEV)
+    rows = 4096 + 40                                   # >= 4096 tokens: the weight gradients take mxvl_gemm_tn
+    x = torch.randn(rows, K, device=DEV).requires_grad_(True)
+    dy = torch.randn(rows, K, device=DEV)
+    with torch.autocast("cuda", dtype=dtype):
+        y = m(x)
+    assert "_mxvl_fused" in m.__dict__ and y.dtype == dtype
+    y.float().backward(dy)
+    r = lambda t: t.detach().to(dtype).float()          # noqa: E731
+    xr = r(x).requires_grad_(True)
+    w1, w2, w3 = (r(p).requires_grad_(True) for p in (m.w1.weight, m.w2.weight, m.w3.weight))
+    b1, b2 = (p.detach().clone().requires_grad_(True) for p in (m.w1.bias, m.w2.bias))
+    b3 = r(m.w3.bias).requires_grad_(True)                               # added in the compute dtype (autocast's F.linear)
+    h = (F.silu(F.linear(xr, w1, b1)) * F.linear(xr, w2, b2))
+    yr = F.linear(h, w3, b3)
+    yr.backward(r(dy))
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float((y.float() - yr).abs().max()) <= 6 * ulp * float(yr.abs().max())
+    for name, got, ref in (("dx", x.grad, xr.grad), ("dw1", m.w1.weight.grad, w1.grad), ("dw2", m.w2.weight.grad, w2.grad),
+                           ("dw3", m.w3.weight.grad, w3.grad), ("db1", m.w1.bias.grad, b1.grad), ("db2", m.w2.bias.grad, b2.grad),
+                           ("db3", m.w3.bias.grad, b3.grad)):
+        assert got.shape == ref.shape and got.dtype == torch.float32, name
+        assert float((got - ref).abs().max()) <= 8 * ulp * float(ref.abs().max()) + 1e-6, (name, float((got - ref).abs().max()), float(ref.abs().max()))
+    # the cache follows the parameters: an in-place update (what the optimizer does) changes the next forward
+    stamp = m.__dict__["_mxvl_fused"][0]
+    with torch.autocast("cuda", dtype=dtype), torch.no_grad():
+        y1 = m(x)
+        assert m.__dict__["_mxvl_fused"][0] == stamp          # unchanged parameters: served from the cache
+        m.w3.weight.mul_(2.0)
+        m.w3.bias.mul_(2.0)
+        y2 = m(x)
+    assert m.__dict__["_mxvl_fused"][0] != stamp
+    assert float((y2.float() - 2.0 * y1.float()).abs().max()) <= 2 * ulp * float(y2.float().abs().max())
+    assert "_mxvl_fused" not in m.state_dict() and len(m.state_dict()) == 6
