@@ -27,6 +27,7 @@ from . import flash_attention as flash
 from . import mae_ops
 from . import fused_ops
 from .models_mamba import DropPath, run_blocks, to_2tuple, trunc_normal_
+from .selective_scan_interface import linear_module
 from .models_pretrain import get_2d_sincos_pos_embed as _sincos_no_cls
 import numpy as np
 
@@ -84,7 +85,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(linear_module(self.fc2, self.drop(self.act(linear_module(self.fc1, x)))))
 
 
 class Attention(nn.Module):
@@ -99,14 +100,14 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv = linear_module(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         p = self.attn_drop.p if self.training else 0.0
         if flash.require(qkv, "mae.Attention", p):
             x = flash.attention_qkvpacked(qkv, scale=self.scale, dropout_p=p)      # MFMA flash attention over the packed projection
         else:   # CPU tensors only (host-side tests): the reference expression
             qkv = qkv.permute(2, 0, 3, 1, 4)
             x = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=p, scale=self.scale)
-        return self.proj_drop(self.proj(x.transpose(1, 2).reshape(B, N, C)))
+        return self.proj_drop(linear_module(self.proj, x.transpose(1, 2).reshape(B, N, C)))
 
 
 class Block(nn.Module):

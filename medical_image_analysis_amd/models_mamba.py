@@ -112,15 +112,17 @@ class SwiGLU(nn.Module):
         return self._zpad[shape]
 
     def _fused_params(self, cd):
-        """What the MLP kernels read, cached per module: [w1; 0; w2; 0] (2 Hp, K) and [w3 | 0] (out, Hp) in the compute dtype, the
-        merged bias in fp32, the hidden axis zero-padded to whole 64-column tiles (see forward).  The stamp is the five parameters'
-        (autograd version, storage address) -- in-place optimizer updates and load_state_dict bump the version, `.to()` / `p.data = `
-        change the address; a write THROUGH p.data into the same storage is invisible, as for autograd_util.cast_param
-        (PretrainEngine.drop_casts clears this cache too).  Never a parameter or a buffer: not in the state dict."""
+        """What the MLP kernels read: [w1; 0; w2; 0] (2 Hp, K) and [w3 | 0] (out, Hp) in the compute dtype, the merged bias in fp32, the
+        hidden axis zero-padded to whole 64-column tiles (see forward), in per-module buffers (never parameters or buffers of the
+        module: not in the state dict).  They are REBUILT IN EVERY FORWARD (five small copies) unless a training engine vouches for
+        the parameters: PretrainEngine stamps the module with its optimizer-step count after every step (`_mxvl_epoch`), and only
+        then is an unchanged stamp -- the count plus the parameters' (autograd version, storage address) -- served from the cache.
+        Nothing else can tell: fused optimizers update the parameters in place WITHOUT bumping the autograd version."""
         ps = (self.w1.weight, self.w1.bias, self.w2.weight, self.w2.bias, self.w3.weight)
-        stamp = (cd,) + tuple((p._version, p.data_ptr()) for p in ps)
+        epoch = self.__dict__.get("_mxvl_epoch")
+        stamp = (cd, epoch) + tuple((p._version, p.data_ptr()) for p in ps)
         c = self.__dict__.get("_mxvl_fused")
-        if c is not None and c[0] == stamp:
+        if epoch is not None and c is not None and c[0] == stamp:
             return c[1]
         H, K = self.w1.weight.shape
         Hp = H + (-H % _HIDDEN_TILE)

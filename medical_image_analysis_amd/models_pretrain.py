@@ -26,6 +26,7 @@ from . import fused_ops
 from .models_mamba import Block as _FtBlock  # noqa: F401  (same Block arithmetic; kept for isinstance checks)
 from .models_mamba import DropPath, PatchEmbed, SwiGLU, _init_weights, run_blocks, segm_init_weights, trunc_normal_
 from .mamba_simple import Mamba
+from .selective_scan_interface import linear_module
 
 
 def get_2d_sincos_pos_embed(embed_dim: int, grid_size: int, cls_token: bool = False) -> np.ndarray:
@@ -67,7 +68,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(linear_module(self.fc2, self.drop(self.act(linear_module(self.fc1, x)))))
 
 
 class CrossAttention(nn.Module):
@@ -89,8 +90,8 @@ class CrossAttention(nn.Module):
         B, N, C = q.shape
         H = self.num_heads
         p = self.attn_drop.p if self.training else 0.0
-        q = self.q(q).reshape(B, N, H, C // H).transpose(1, 2)                 # (B, H, N, dh) view, no copy
-        kv = self.kv(kv).reshape(B, N, 2, H, C // H)                           # packed (B, N, 2, H, dh)
+        q = linear_module(self.q, q).reshape(B, N, H, C // H).transpose(1, 2)  # (B, H, N, dh) view, no copy
+        kv = linear_module(self.kv, kv).reshape(B, N, 2, H, C // H)            # packed (B, N, 2, H, dh)
         if flash.require(q, "pre-training CrossAttention", p, kv):
             # hand-written MFMA flash attention (csrc/attn.hip): the block-lower-triangular mask of mask_generate is a kernel
             # mode that never visits the tiles above the diagonal; any other mask tensor goes in as an additive bias
@@ -102,7 +103,7 @@ class CrossAttention(nn.Module):
             kvp = kv.permute(2, 0, 3, 1, 4)
             x = F.scaled_dot_product_attention(q, kvp[0], kvp[1], attn_mask=mask.to(q.dtype), dropout_p=p, scale=self.scale)
         x = x.transpose(1, 2).reshape(B, N, C)
-        return self.proj_drop(self.proj(x))
+        return self.proj_drop(linear_module(self.proj, x))
 
 
 class DecoderBlock(nn.Module):

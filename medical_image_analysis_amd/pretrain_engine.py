@@ -172,7 +172,13 @@ class PretrainEngine:
     @torch.no_grad()
     def _refresh_casts(self):
         """Low-precision copies of every parameter (the GEMM weights and the biases added to their outputs) in ONE multi-tensor launch, right after the optimizer
-        step; the projections pick them up through autograd_util.cast_param (one cast kernel per weight and forward before)."""
+        step; the projections pick them up through autograd_util.cast_param (one cast kernel per weight and forward before).
+        Modules that keep their own kernel-side parameter forms (models_mamba.SwiGLU._fused_params) get the optimizer-step count as
+        their stamp: their next forward rebuilds, later forwards of the same step (accumulation, evaluation) are served."""
+        self._param_epoch = getattr(self, "_param_epoch", 0) + 1
+        for m in self.raw_model.modules():
+            if hasattr(m, "_fused_params"):
+                m.__dict__["_mxvl_epoch"] = self._param_epoch
         if self.amp_dtype not in (torch.bfloat16, torch.float16) or not self._cast_params:
             return
         if self._cast_shadow is None:
@@ -189,6 +195,7 @@ class PretrainEngine:
                 del p._mxvl_lp
         for m in self.raw_model.modules():
             m.__dict__.pop("_mxvl_fused", None)          # models_mamba.SwiGLU._fused_params
+            m.__dict__.pop("_mxvl_epoch", None)
 
     def start_epoch(self):
         """engine_pretrain.py:31 `optimizer.zero_grad()` + the iteration counter the schedule and the accumulation window read."""

@@ -456,6 +456,23 @@ def linear_splitk(x, weight, bias=None):
     return _LinearSplitK.apply(x, weight, bias)
 
 
+# MXVL_LINEAR_TN=0: the transformer blocks' nn.Linear layers stay on autograd's own matmul backward (A/B runs)
+_LINEAR_TN = os.environ.get("MXVL_LINEAR_TN", "1") != "0"
+
+
+def linear_module(mod, x):
+    """`mod(x)` for an nn.Linear of a transformer block (ViT-MAE blocks, the pre-training decoder): on a HIP device under 16-bit
+    autocast with enough tokens for the weight-gradient kernel it is the _LinearSplitK node -- the same forward GEMM on the same
+    low-precision operands, grad_weight = dy^T x through mxvl_gemm_tn (fp32, instead of autograd's K-major x K-major library GEMM
+    in the autocast dtype), grad_bias from fp32 column sums.  Anything else (CPU, fp32, LoRA-wrapped or hooked modules, short
+    sequences) is the module call."""
+    if (_LINEAR_TN and type(mod) is torch.nn.Linear and x.is_cuda and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and x.numel() // x.shape[-1] >= 4096
+            and not mod._forward_hooks and not mod._forward_pre_hooks and not mod._backward_hooks):
+        return linear_splitk(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 class _ProjIn(torch.autograd.Function):
     """tokens (B, L, K) -> (B, M, L) channel-major: Y2 = W @ X2^T, one GEMM; backward dX2 = dY2^T @ W."""
 

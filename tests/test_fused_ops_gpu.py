@@ -338,14 +338,26 @@ def test_swiglu_module_cached_params_path(K, H, dtype):
                            ("db3", m.w3.bias.grad, b3.grad)):
         assert got.shape == ref.shape and got.dtype == torch.float32, name
         assert float((got - ref).abs().max()) <= 8 * ulp * float(ref.abs().max()) + 1e-6, (name, float((got - ref).abs().max()), float(ref.abs().max()))
-    # the cache follows the parameters: an in-place update (what the optimizer does) changes the next forward
-    stamp = m.__dict__["_mxvl_fused"][0]
+    # without an engine's stamp the kernel-side forms are rebuilt in every forward: even a write that bumps no autograd version (what a
+    # fused optimizer does) is seen
     with torch.autocast("cuda", dtype=dtype), torch.no_grad():
         y1 = m(x)
-        assert m.__dict__["_mxvl_fused"][0] == stamp          # unchanged parameters: served from the cache
-        m.w3.weight.mul_(2.0)
-        m.w3.bias.mul_(2.0)
+        v = m.w3.weight._version
+        m.w3.weight.data.mul_(2.0)
+        m.w3.bias.data.mul_(2.0)
+        assert m.w3.weight._version == v
         y2 = m(x)
-    assert m.__dict__["_mxvl_fused"][0] != stamp
-    assert float((y2.float() - 2.0 * y1.float()).abs().max()) <= 2 * ulp * float(y2.float().abs().max())
+        assert float((y2.float() - 2.0 * y1.float()).abs().max()) <= 2 * ulp * float(y2.float().abs().max())
+        # with the stamp PretrainEngine leaves after an optimizer step, an unchanged stamp is served from the cache and the next stamp rebuilds
+        m.__dict__["_mxvl_epoch"] = 7
+        y3 = m(x)
+        built = m.__dict__["_mxvl_fused"][1][0].clone()
+        m.w1.weight.data.mul_(0.5)                         # invisible until the engine stamps the next step
+        y4 = m(x)
+        assert torch.equal(y3, y4) and torch.equal(m.__dict__["_mxvl_fused"][1][0], built)
+        m.__dict__["_mxvl_epoch"] = 8
+        y5 = m(x)
+        assert not torch.equal(y5, y4) and not torch.equal(m.__dict__["_mxvl_fused"][1][0], built)
+        m.w2.weight.mul_(1.5)                              # an ordinary in-place update bumps the version: seen at once
+        assert not torch.equal(m(x), y5)
     assert "_mxvl_fused" not in m.state_dict() and len(m.state_dict()) == 6

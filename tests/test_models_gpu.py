@@ -344,3 +344,34 @@ def test_bias_column_sums_are_dropped_when_the_branch_has_a_second_consumer():
         assert_close(b.grad, want, 0.02 * scale, 0.02, f"bias gradient, second consumer = {second}")
         if not second:
             assert ssi.COLSUM_HITS > hits0, "single consumer: the column sums of the add+LN backward were used"
+
+
+def test_engine_steps_with_cached_swiglu_forms_equal_steps_that_rebuild_them():
+    """PretrainEngine's fused AdamW updates the parameters in place WITHOUT bumping their autograd version, so the SwiGLU modules'
+    cached kernel-side parameter forms (models_mamba.SwiGLU._fused_params) are valid only through the engine's own stamp.  Twelve
+    steps with the stamp (cache served within a step, rebuilt after each optimizer step) against twelve steps of the same model with
+    the stamp removed after every step (rebuilt in every forward): the same loss curve up to the backward's atomics -- a cache that
+    missed ONE optimizer step is off by 7e-3 at the second step at this learning rate."""
+    from medical_image_analysis_amd.models_pretrain import VisionMamba
+    from medical_image_analysis_amd.pretrain_engine import PretrainEngine
+
+    def run(cache):
+        torch.manual_seed(0)
+        m = VisionMamba(img_size=128, patch_size=16, stride=16, embed_dim=256, depth=12, dec_embed_dim=256, rms_norm=True,
+                        residual_in_fp32=True, fused_add_norm=True, if_abs_pos_embed=True, bimamba_type="None").to(DEV)
+        eng = PretrainEngine(m, lr=1e-3, device=DEV)
+        imgs = torch.randn(8, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+        out = []
+        for _ in range(12):
+            out.append(float(eng.step(imgs)))
+            served = [mod for mod in m.modules() if "_mxvl_epoch" in mod.__dict__]
+            assert len(served) == 12                                   # one SwiGLU per block carries the engine's stamp
+            if not cache:
+                for mod in served:
+                    del mod.__dict__["_mxvl_epoch"]
+        return out
+
+    a, b = run(True), run(False)
+    assert a[-1] < a[0] - 0.05                                         # it trains
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert abs(x - y) <= 2e-3 * abs(y), (i, a, b)
