@@ -27,7 +27,7 @@ from . import flash_attention as flash
 from . import mae_ops
 from . import fused_ops
 from .models_mamba import DropPath, run_blocks, to_2tuple, trunc_normal_
-from .selective_scan_interface import linear_module
+from .selective_scan_interface import linear_module, linear_tokens
 from .models_pretrain import get_2d_sincos_pos_embed as _sincos_no_cls
 import numpy as np
 
@@ -70,7 +70,7 @@ def _patch_gemm(x, conv: nn.Conv2d, relu_in=False):
     else:
         cols = x.reshape(B, C, gh, k, gw, k).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * k * k)
         w2 = w.reshape(w.shape[0], -1)
-    y = F.linear(cols, w2, conv.bias)
+    y = linear_tokens(cols, w2, conv.bias)
     return y.reshape(B, gh, gw, -1).permute(0, 3, 1, 2)
 
 

@@ -460,6 +460,15 @@ def linear_splitk(x, weight, bias=None):
 _LINEAR_TN = os.environ.get("MXVL_LINEAR_TN", "1") != "0"
 
 
+def linear_tokens(x, weight, bias=None):
+    """F.linear(x, weight, bias) for token-major x and any weight tensor (a reshaped convolution kernel: mae._patch_gemm); the
+    _LinearSplitK node on a HIP device under 16-bit autocast with enough tokens, else F.linear."""
+    if (_LINEAR_TN and x.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+            and x.numel() // x.shape[-1] >= 4096):
+        return linear_splitk(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def linear_module(mod, x):
     """`mod(x)` for an nn.Linear of a transformer block (ViT-MAE blocks, the pre-training decoder): on a HIP device under 16-bit
     autocast with enough tokens for the weight-gradient kernel it is the _LinearSplitK node -- the same forward GEMM on the same
