@@ -39,6 +39,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md)
 
 
+MFMA_KINDS = ("gemm_tn",)      # timed kernels whose work figure is FLOPs (selective_scan_interface.gemm_tn); the others report bytes
+
+
+def _kernel_stats(timers):
+    stats = {}
+    for kind, e0, e1, work in timers:
+        d = stats.setdefault(kind, [0.0, 0, 0])
+        d[0] += e0.elapsed_time(e1)
+        d[1] += 1
+        d[2] += work
+    return stats
+
+
+def _mfma_kernel_object(stats, timer_steps, step_ms):
+    """The weight-gradient MFMA kernel's own roofline object (an extra to the contract's `roofline`, which is the dominant kernel's)."""
+    if "gemm_tn" not in stats:
+        return None
+    ms, calls, flops = stats["gemm_tn"]
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_tn_kernel (weight gradients dW = dy^T x of the blocks' token-major linears, csrc/gemm_tn.hip)", "bound": "mfma",
+            "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel_ms": ms / calls, "launches_timed": calls, "algorithmic_flops_per_launch": flops // calls,
+            "step_share": round(ms / timer_steps / step_ms, 4)}
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch of the workload's dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
     written by tools/gpu_round.sh: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command, KB units,
@@ -574,14 +599,13 @@ def run_pretrain(args, rank, world, dev, dist):
             secondary["cpu_baseline"] = cpu_baseline_decode("decode_llama7b_128")
     if rank != 0:
         return
-    stats = {}
-    for kind, e0, e1, nbytes in timers:
-        d = stats.setdefault(kind, [0.0, 0, 0])
-        d[0] += e0.elapsed_time(e1)
-        d[1] += 1
-        d[2] += nbytes
-    # dominant hand-written kernel of the step = the one with the largest total time
-    kind = max(stats, key=lambda k: stats[k][0])
+    stats = _kernel_stats(timers)
+    mfma_obj = _mfma_kernel_object(stats, timer_steps, wall / steps * 1e3)
+    # dominant hand-written kernel of the step = the timed kernel with the largest total time.  At this shape the weight-gradient MFMA
+    # kernel (priced against the matrix cores) and the scan backward (priced against HBM, as the contract asks) are within a few
+    # per cent of each other: whichever leads on this box is `roofline`, the other one is reported beside it (`mfma_kernel` / `hbm_kernel`)
+    dominant = max(stats, key=lambda k: stats[k][0])
+    kind = max((k for k in stats if k not in MFMA_KINDS), key=lambda k: stats[k][0])
     tot_ms, calls, tot_bytes = stats[kind]
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
     L = (img // patch) ** 2 - 16
@@ -607,6 +631,14 @@ def run_pretrain(args, rank, world, dev, dist):
     if secondary is not None:
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                       "dtype", "config", "roofline", "cpu_baseline") if k in secondary}
+    if mfma_obj is not None and dominant in MFMA_KINDS:
+        hbm_obj = out["roofline"]
+        out["roofline"] = dict(mfma_obj, step_share=hbm_obj["step_share"],
+                               limited_by="matrix-core issue behind LDS transpose reads and barriers: MFMA busy 0.41 of the peak-clock cycles "
+                                          "(profiles/r06_wgrad_tn_bench.txt); the same structure as the guide's best plain-HIP GEMMs (0.53-0.62)")
+        out["hbm_kernel"] = hbm_obj
+    elif mfma_obj is not None:
+        out["mfma_kernel"] = mfma_obj
     if north is not None:
         out["north_star_kernel"] = {k: north[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline")}
     if cpu_sd is not None:
@@ -855,11 +887,9 @@ def run_vmamba(args, rank, world, dev, dist):
         wall = float(t[0])
     if rank != 0:
         return
-    stats = {}
-    for kind, e0, e1, nbytes in timers:
-        d = stats.setdefault(kind, [0.0, 0, 0])
-        d[0] += e0.elapsed_time(e1); d[1] += 1; d[2] += nbytes
-    kind = max(stats, key=lambda k: stats[k][0])
+    stats = _kernel_stats(timers)
+    mfma_obj = _mfma_kernel_object(stats, timer_steps, wall / steps * 1e3)
+    kind = max((k for k in stats if k not in MFMA_KINDS), key=lambda k: stats[k][0])
     tot_ms, calls, tot_bytes = stats[kind]
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
     cpu_b = None
@@ -868,6 +898,7 @@ def run_vmamba(args, rank, world, dev, dist):
         cpu_b = cpu_baseline_vssm(sd, [2, 2, 15, 2])
     print(json.dumps({
         **({"cpu_baseline": cpu_b} if cpu_b is not None else {}),
+        **({"mfma_kernel": mfma_obj} if mfma_obj is not None else {}),
         "metric": "encoder training images/sec (forward + backward + grad-clip + AdamW)", "value": B * world * steps / wall,
         "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

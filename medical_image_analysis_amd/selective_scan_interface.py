@@ -365,7 +365,16 @@ def gemm_tn(a_km, b_kn, out=None, slices_per_xcd=0):
     d.accumulate, d.slices_per_xcd = (1 if out is not None else 0), slices_per_xcd
     d.a_rs, d.b_rs, d.c_rs = a_km.stride(0), b_kn.stride(0), c.stride(0)
     d.a, d.b, d.c = a_km.data_ptr(), b_kn.data_ptr(), c.data_ptr()
-    _abi.check(_abi.load().mxvl_gemm_tn(ctypes.byref(d), _abi.stream_ptr(a_km.device)), "mxvl_gemm_tn")
+    timers = KERNEL_TIMERS
+    with torch.cuda.device(a_km.device):
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = _abi.load().mxvl_gemm_tn(ctypes.byref(d), _abi.stream_ptr(a_km.device))
+        if timers is not None:
+            e1.record()
+            timers.append(("gemm_tn", e0, e1, 2 * K * M * N))          # MFMA-bound: the work figure is FLOPs, not bytes
+    _abi.check(rc, "mxvl_gemm_tn")
     return c
 
 
