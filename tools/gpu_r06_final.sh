@@ -61,6 +61,7 @@ done
 (timeout 300 python tools/decode_gemm_bench.py 3 18 24 48 80 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_decode_gemm_bench.txt
 if [ $PARTS = all ]; then
 (timeout 300 python tools/gemm_swiglu_bwd_bench.py 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_gemm_swiglu_bwd_bench.txt
+(timeout 300 python tools/wgrad_tn_bench.py --tuned 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_wgrad_tn_bench_final.txt
 (timeout 300 python tools/scan_r03_bench.py all 2 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_scan_variants.txt
 (timeout 300 python tools/scan_r03_bench.py n1 3 2>&1 | grep -v amdgpu.ids) > $O/${TAG}_scan_n1_final.txt
 (timeout 300 python tools/step_eager.py 16 pretrain 2>&1 | grep -v "amdgpu.ids\|arn") > $O/${TAG}_step_eager_pretrain.txt
