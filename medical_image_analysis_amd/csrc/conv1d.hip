@@ -92,9 +92,14 @@ __global__ __launch_bounds__(256) void conv1d_fwd_vec_kernel(const ConvArgs p) {
     const float bias = p.bias ? p.bias[d] : 0.0f;
     float xv[12];   // x[t0-4 .. t0+8)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 h = t0 > 0 ? ld4<io_t>(xr + t0 - 4) : z4;
+    // every load is issued, from an in-range address, and the halo is zeroed by a select afterwards: as `cond ? load : 0` each
+    // guarded load sat in its own basic block behind an `s_waitcnt vmcnt(0)` -- three serialised memory round trips per thread
+    // (read off the ISA, round 6)
+    const bool has_h = t0 > 0, has_1 = t0 + 4 < p.L;
+    const float4 h_r = ld4<io_t>(xr + (has_h ? t0 - 4 : t0));
     const float4 a0 = ld4<io_t>(xr + t0);                       // L % 4 == 0 on this path: [t0, t0+4) is in range
-    const float4 a1 = (t0 + 4 < p.L) ? ld4<io_t>(xr + t0 + 4) : z4;
+    const float4 a1_r = ld4<io_t>(xr + (has_1 ? t0 + 4 : t0));
+    const float4 h = has_h ? h_r : z4, a1 = has_1 ? a1_r : z4;
     xv[0] = h.x; xv[1] = h.y; xv[2] = h.z; xv[3] = h.w;
     xv[4] = a0.x; xv[5] = a0.y; xv[6] = a0.z; xv[7] = a0.w;
     xv[8] = a1.x; xv[9] = a1.y; xv[10] = a1.z; xv[11] = a1.w;
@@ -122,9 +127,12 @@ __device__ __forceinline__ void conv_bwd_vec_body(const io_t* xr, const io_t* gr
                                                   float bias, int silu_on, float (&dw_acc)[WT], float& db_acc) {
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float xv[16], g[12];   // x[t0-4 .. t0+12), dy[t0 .. t0+12)
-  const float4 x0 = t0 > 0 ? ld4<io_t>(xr + t0 - 4) : z4, x1 = ld4<io_t>(xr + t0);
-  const float4 x2 = t0 + 4 < L ? ld4<io_t>(xr + t0 + 4) : z4, x3 = t0 + 8 < L ? ld4<io_t>(xr + t0 + 8) : z4;
-  const float4 g0 = ld4<io_t>(gr + t0), g1 = t0 + 4 < L ? ld4<io_t>(gr + t0 + 4) : z4, g2 = t0 + 8 < L ? ld4<io_t>(gr + t0 + 8) : z4;
+  // all seven loads issued from in-range addresses, the halo zeroed by selects afterwards (guarded loads serialise: see the forward)
+  const bool has_h = t0 > 0, has_1 = t0 + 4 < L, has_2 = t0 + 8 < L;
+  const int o1 = has_1 ? t0 + 4 : t0, o2 = has_2 ? t0 + 8 : t0;
+  const float4 x0r = ld4<io_t>(xr + (has_h ? t0 - 4 : t0)), x1 = ld4<io_t>(xr + t0), x2r = ld4<io_t>(xr + o1), x3r = ld4<io_t>(xr + o2);
+  const float4 g0 = ld4<io_t>(gr + t0), g1r = ld4<io_t>(gr + o1), g2r = ld4<io_t>(gr + o2);
+  const float4 x0 = has_h ? x0r : z4, x2 = has_1 ? x2r : z4, x3 = has_2 ? x3r : z4, g1 = has_1 ? g1r : z4, g2 = has_2 ? g2r : z4;
   xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
   xv[8] = x2.x; xv[9] = x2.y; xv[10] = x2.z; xv[11] = x2.w; xv[12] = x3.x; xv[13] = x3.y; xv[14] = x3.z; xv[15] = x3.w;
   g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;

@@ -79,18 +79,25 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const NormArgs p) {
     if (p.br) {
       const br_t* br = (const br_t*)p.br + (size_t)row * C;
       res_t* hr = (res_t*)p.h + (size_t)row * C;
+      // ALL branch loads first, then the stores of the new stream: interleaved (load k, store k, load k + 1, ...) the compiler must
+      // order each load behind the store in front of it (the pointers may alias) and waits for both -- K serialised memory round trips
+      // per row, stores included (read off the ISA, round 6)
+      float b[K][4];
+#pragma unroll
+      for (int k = 0; k < K; ++k) ld4v<br_t>(br + (k * LPR + sl) * 4, b[k]);
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        float b[4];
-        ld4v<br_t>(br + (k * LPR + sl) * 4, b);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[k][j] += b[j];
+          v[k][j] += b[k][j];
           if constexpr (sizeof(res_t) == 2) {  // the stream itself is half precision: normalise what is stored
             res_t t; Io<res_t>::st(&t, v[k][j]); v[k][j] = Io<res_t>::ld(&t);
           }
         }
-        if (live) st4v<res_t>(hr + (k * LPR + sl) * 4, v[k]);
+      }
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) st4v<res_t>(hr + (k * LPR + sl) * 4, v[k]);
       }
     }
     float s = 0.0f;
@@ -159,19 +166,25 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const NormBwdArgs p) {
         s2 = fmaf(dy[k][j], xh[k][j], s2);
       }
     }
+    // the incoming residual gradient is requested BEFORE the row reduction (it depends on nothing computed here): one memory round
+    // trip per row instead of two
+    float rin[K][4];
+    if (p.dh) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) ld4v<res_t>((const res_t*)p.dh + (size_t)row * C + (k * LPR + sl) * 4, rin[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rin[k][j] = 0.0f;
+    }
     const float m1 = wsum<LPR>(s1) / (float)C, m2 = wsum<LPR>(s2) / (float)C;
     res_t* dxr = (res_t*)p.dx + (size_t)row * C;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       float o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = rstd * (dy[k][j] - m1 - xh[k][j] * m2);
-      if (p.dh) {
-        float r[4];
-        ld4v<res_t>((const res_t*)p.dh + (size_t)row * C + (k * LPR + sl) * 4, r);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += r[j];
-      }
+      for (int j = 0; j < 4; ++j) o[j] = rstd * (dy[k][j] - m1 - xh[k][j] * m2) + rin[k][j];
       if (live) {
         st4v<res_t>(dxr + (k * LPR + sl) * 4, o);
         if (p.dbr) st4v<br_t>((br_t*)p.dbr + (size_t)row * C + (k * LPR + sl) * 4, o);

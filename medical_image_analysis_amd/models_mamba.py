@@ -128,8 +128,11 @@ class SwiGLU(nn.Module):
         Hp = H + (-H % _HIDDEN_TILE)
         dev = self.w1.weight.device
         with torch.no_grad():
-            if c is not None and c[1][0].shape == (2 * Hp, K) and c[1][0].dtype == cd and c[1][0].device == dev:
-                w12c, b12c, w3c = c[1]            # same buffers: the zero pads are still in place
+            if epoch is not None and c is not None and c[1][0].shape == (2 * Hp, K) and c[1][0].dtype == cd and c[1][0].device == dev:
+                # under the engine's stamp the forms change once per optimizer step, behind the backward that read them: rebuilt in
+                # place (the zero pads stay).  Without it a second forward may come BEFORE the backward of the first (the CLIP step
+                # encodes twice): autograd saved these tensors, so every rebuild gets buffers of its own
+                w12c, b12c, w3c = c[1]
             else:
                 w12c = torch.zeros((2 * Hp, K), dtype=cd, device=dev)
                 b12c = torch.zeros((2 * Hp,), dtype=torch.float32, device=dev)

@@ -338,6 +338,11 @@ def test_swiglu_module_cached_params_path(K, H, dtype):
                            ("db3", m.w3.bias.grad, b3.grad)):
         assert got.shape == ref.shape and got.dtype == torch.float32, name
         assert float((got - ref).abs().max()) <= 8 * ulp * float(ref.abs().max()) + 1e-6, (name, float((got - ref).abs().max()), float(ref.abs().max()))
+    # two forwards BEFORE one backward (the CLIP step encodes twice): without the stamp every forward owns its buffers, so autograd's
+    # saved tensors are not overwritten
+    with torch.autocast("cuda", dtype=dtype):
+        ya, yb = m(x), m(x.detach() * 0.5)
+    (ya.float().sum() + yb.float().sum()).backward()
     # without an engine's stamp the kernel-side forms are rebuilt in every forward: even a write that bumps no autograd version (what a
     # fused optimizer does) is seen
     with torch.autocast("cuda", dtype=dtype), torch.no_grad():
