@@ -562,10 +562,10 @@ static int dispatch_swiglu(const void* ab, const void* dy, void* out, int rows, 
   }
 }
 
-// backward workgroups = partial rows of dgamma | dbeta | d-branch sums the caller reduces: 1024 = one round of 4 workgroups per CU
-// (32 KB of LDS each).  With 2048 the three (2048, C) partial tensors cost a 41 us reduce_kernel per add+LN backward (2 ms of the
-// ARM-large step) on top of a kernel that is bandwidth-bound either way.
-constexpr int kLnBwdPartials = 1024;
+// backward workgroups = partial rows of dgamma | dbeta | d-branch sums the caller reduces: 768 = ONE round of 3 workgroups per CU --
+// the 1024-wide instantiation holds 152-162 VGPRs, i.e. three waves per SIMD, so of the 1024 workgroups of rounds 4-6 a quarter ran as
+// a second, mostly idle round.  (With 2048 the three (2048, C) partial tensors cost a 41 us reduce_kernel per add+LN backward.)
+constexpr int kLnBwdPartials = 768;
 
 template <typename R, typename B, typename O, int K, int LPR = 64>
 static void launch_ln(bool bwd, const void* args, int rows, hipStream_t s) {
