@@ -17,6 +17,10 @@ for f in sorted(glob.glob(os.path.join(root, "profiles", f"{tag}_bench_*.json"))
     roof = f"{r.get('frac', 0):.3f} of {r.get('bound', '?')}"
     if r.get("traffic"):
         roof += f", traffic {r['traffic'] / 1e6:.0f} MB"
+    for extra in ("hbm_kernel", "mfma_kernel"):
+        if extra in d:
+            e = d[extra]
+            roof += f"; {extra} {e.get('kernel', '?')[:24]} {e.get('frac', 0):.3f} of {e.get('bound', '?')}"
     cpu = f"{c['value']:.3g} {c['unit']}" if c else "—"
     print(f"| `{name}` | **{d['value']:.4g} {d['unit']}** | {d['ms_per_step']:.4g} ms | {d.get('dtype')} | {roof} | {cpu} |")
     for k in ("north_star_kernel", "secondary"):
