@@ -547,6 +547,11 @@ typedef struct mxvl_gemm_tn_desc {
   void *c;
 } mxvl_gemm_tn_desc;
 int mxvl_gemm_tn(const mxvl_gemm_tn_desc *desc, void *hip_stream);
+/* ABI v12: the bias gradient beside it, autograd's `grad_bias = dy.sum(0)` over the token axis of a token-major (rows, cols) bf16 / fp16
+ * tensor: partial (mxvl_colsum_partials(rows, cols), cols) fp32 receives one partial sum per row group (every element written); the
+ * caller adds the rows.  cols % 8 == 0, 16-byte aligned rows (row_stride in elements). */
+int mxvl_colsum_partials(int rows, int cols);
+int mxvl_colsum(const void *x, void *partial, int rows, int cols, int64_t row_stride, int n_partials, int io_dtype, void *hip_stream);
 int mxvl_gemm_swiglu_bwd_partials(int M);
 /* SwiGLU gate of the block MLP (models_mamba.py:59-83 `act(w1 x) * w2 x`): ab (rows, 2*hidden) = [w1 x | w2 x] from ONE
  * GEMM -> y (rows, hidden) = silu(a) * b; backward writes dab (rows, 2*hidden).  Contiguous, one io dtype. */

@@ -36,7 +36,7 @@ SYMBOLS = [
     "mxvl_decode_cross_attn", "mxvl_decode_prologue", "mxvl_decode_rmsnorm",
     "mxvl_cross_scan", "mxvl_cross_merge",
     "mxvl_add_layernorm_fwd", "mxvl_add_layernorm_bwd", "mxvl_add_layernorm_partials", "mxvl_swiglu_fwd", "mxvl_swiglu_bwd",
-    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_gemm_tn", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
+    "mxvl_swiglu_partials", "mxvl_swiglu_bwd_colsum", "mxvl_gemm_swiglu_fwd", "mxvl_gemm_swiglu_bwd", "mxvl_gemm_swiglu_bwd_partials", "mxvl_set_decode_gemm_wide", "mxvl_decode_gemm_plan", "mxvl_gemm_nt", "mxvl_gemm_tn", "mxvl_colsum", "mxvl_colsum_partials", "mxvl_row_gather", "mxvl_patch_loss", "mxvl_patch_cols", "mxvl_beam_workspace_bytes",
     "mxvl_dwconv2d_fwd", "mxvl_dwconv2d_bwd", "mxvl_beam_step", "mxvl_dir_gather", "mxvl_dir_merge",
     "mxvl_resample_ksize", "mxvl_resample_coeffs", "mxvl_image_preprocess", "mxvl_attn_fwd", "mxvl_attn_bwd", "mxvl_clip_loss",
     "mxvl_rope", "mxvl_rmsnorm_train_fwd", "mxvl_rmsnorm_train_bwd", "mxvl_silu_mul",
@@ -338,6 +338,10 @@ def load() -> ctypes.CDLL:
     lib.mxvl_swiglu_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     lib.mxvl_swiglu_partials.restype = c_int
     lib.mxvl_swiglu_partials.argtypes = [c_int, c_int]
+    lib.mxvl_colsum_partials.restype = c_int
+    lib.mxvl_colsum_partials.argtypes = [c_int, c_int]
+    lib.mxvl_colsum.restype = c_int
+    lib.mxvl_colsum.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]
     lib.mxvl_swiglu_bwd_colsum.restype = c_int
     lib.mxvl_swiglu_bwd_colsum.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.mxvl_dwconv2d_fwd.restype = c_int

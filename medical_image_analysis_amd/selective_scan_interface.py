@@ -389,9 +389,21 @@ def gemm_tn_takes(a_km, b_kn):
         return False
     K, M = a_km.shape
     N = b_kn.shape[1]
-    return (K % 64 == 0 and K >= 4096 and M % 8 == 0 and N % 8 == 0 and M >= 256 and N >= 256
+    return (K % 64 == 0 and gemm_tn_wins(K, M, N) and M % 8 == 0 and N % 8 == 0
             and a_km.stride(1) == 1 and b_kn.stride(1) == 1 and a_km.stride(0) % 8 == 0 and b_kn.stride(0) % 8 == 0
             and a_km.data_ptr() % 16 == 0 and b_kn.data_ptr() % 16 == 0)
+
+
+def gemm_tn_wins(K, M, N):
+    """Where the kernel beats the library's batched split-K GEMM + plane sum (tools/wgrad_tn_bench.py, profiles/r06_wgrad_tn_bench.txt):
+    a token axis of >= 32 000 (x1.09-1.39 at 65 280, x1.16 at 32 640; x0.95 at 25 856, x0.83 at 16 384, x0.63 at 8 192: a unit's K range
+    must amortise its atomic epilogue) AND a tile count that fills the 32 workgroups of an XCD with at most 4 token slices per XCD
+    (12 tiles -- 1536 x 512 -- x0.85, 4 tiles x0.91; 16 / 44 / 48 / 64 / 88 tiles x1.09-1.39)."""
+    if K < 32000 or M < 256 or N < 256:
+        return False
+    tiles = -(-M // 256) * -(-N // 256)
+    fill = max(q * tiles / (32 * -(-q * tiles // 32)) for q in (1, 2, 3, 4))
+    return fill >= 0.85
 
 
 def splitk_wgrad(a_km, b_kn, out_dtype):
@@ -434,7 +446,26 @@ def bias_grad(dy, d2, bdt, dim=0):
     if stamp is not None and stamp[0] == dy._version and dim == 0 and stamp[1].numel() == d2.shape[1] and dy.dtype == d2.dtype:
         COLSUM_HITS += 1
         return stamp[1].to(bdt)
+    if dim == 0 and colsum_takes(d2):
+        return colsum(d2).to(bdt)
     return d2.sum(dim, dtype=torch.float32).to(bdt)
+
+
+def colsum_takes(d2):
+    return (_WGRAD_TN and d2.is_cuda and d2.ndim == 2 and d2.dtype in (torch.bfloat16, torch.float16) and d2.shape[0] >= 4096
+            and d2.shape[1] % 8 == 0 and d2.stride(1) == 1 and d2.stride(0) % 8 == 0 and d2.data_ptr() % 16 == 0)
+
+
+def colsum(d2):
+    """fp32 column sums of a token-major 16-bit (rows, C) tensor through mxvl_colsum (csrc/gemm_tn.hip) + a sum over its few partial rows."""
+    lib = _abi.load()
+    rows, C = d2.shape
+    n = lib.mxvl_colsum_partials(rows, C)
+    partial = torch.empty((n, C), dtype=torch.float32, device=d2.device)
+    with torch.cuda.device(d2.device):
+        _abi.check(lib.mxvl_colsum(d2.data_ptr(), partial.data_ptr(), rows, C, d2.stride(0), n, _abi.dtype_code(d2.dtype),
+                                   _abi.stream_ptr(d2.device)), "mxvl_colsum")
+    return partial.sum(0) if n > 1 else partial[0]
 
 
 class _LinearSplitK(torch.autograd.Function):

@@ -316,7 +316,7 @@ def test_swiglu_module_cached_params_path(K, H, dtype):
     from medical_image_analysis_amd.models_mamba import SwiGLU
     torch.manual_seed(K + H)
     m = SwiGLU(K, H).to(DEV)
-    rows = 4096 + 40                                   # >= 4096 tokens: the weight gradients take mxvl_gemm_tn
+    rows = 32768 + 64 if K == 1024 else 4096 + 40      # the ARM-large case: a token axis long enough for mxvl_gemm_tn (gemm_tn_wins)
     x = torch.randn(rows, K, device=DEV).requires_grad_(True)
     dy = torch.randn(rows, K, device=DEV)
     with torch.autocast("cuda", dtype=dtype):
@@ -366,3 +366,21 @@ def test_swiglu_module_cached_params_path(K, H, dtype):
         m.w2.weight.mul_(1.5)                              # an ordinary in-place update bumps the version: seen at once
         assert not torch.equal(m(x), y5)
     assert "_mxvl_fused" not in m.state_dict() and len(m.state_dict()) == 6
+
+
+@pytest.mark.parametrize("rows,C,dtype,strided", [(4096, 8, torch.bfloat16, False), (65280, 512, torch.bfloat16, False), (5000, 2752, torch.float16, False),
+                                                   (40000, 1000, torch.bfloat16, True), (4100, 4096, torch.float16, True)])
+def test_colsum_kernel_vs_fp64(rows, C, dtype, strided):
+    """mxvl_colsum (csrc/gemm_tn.hip): the bias gradient dy.sum(0) of a token-major 16-bit tensor in fp32, against float64 on the same values;
+    ragged column tiles (C not a multiple of 512), row-strided input, every row-group count."""
+    from medical_image_analysis_amd.selective_scan_interface import bias_grad, colsum, colsum_takes
+    g = torch.Generator().manual_seed(rows + C)
+    full = torch.randn(rows, C + (24 if strided else 0), generator=g).to(DEV, dtype)
+    x = full[:, 8:8 + C] if strided else full
+    assert colsum_takes(x)
+    got = colsum(x)
+    ref = x.double().sum(0)
+    mag = x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert bool(((got.double() - ref).abs() <= 2.0 ** -21 * mag + 1e-6).all()), float(((got.double() - ref).abs() / (mag + 1e-9)).max())
+    assert torch.equal(bias_grad(x, x, torch.float32), got)                       # what the linear nodes call

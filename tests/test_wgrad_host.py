@@ -21,6 +21,15 @@ def test_gemm_tn_is_exported_and_routing_refuses_cpu_tensors():
     assert float((dw - ref).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
 
 
+def test_gemm_tn_routing_rule():
+    """the measured win region (profiles/r06_wgrad_tn_bench.txt): long token axes and tile counts that fill an XCD's 32 workgroups"""
+    w = ssi.gemm_tn_wins
+    assert w(65280, 5504, 1024) and w(65280, 1024, 2752) and w(65280, 2048, 512) and w(32640, 5504, 1024) and w(102656, 512, 2048)
+    assert not w(25856, 4096, 1024) and not w(8192, 4096, 1024)            # short token axis: the library's batched split-K wins
+    assert not w(102656, 1536, 512) and not w(65280, 512, 512)             # 12 / 4 tiles: a quarter / half of the workgroups idle
+    assert not w(65280, 128, 1024)
+
+
 def test_wgrad_splits_rule():
     assert ssi.wgrad_splits(1024, 4096, 4096) == 1                                  # short token axis: one GEMM
     assert ssi.wgrad_splits(65280, 5504, 1024) == 16                                # the measured exception

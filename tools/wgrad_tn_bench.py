@@ -32,11 +32,17 @@ def main():
     K = 65280
     shapes = [("w1|w2", 5504, 1024), ("w3", 1024, 2752), ("in_proj", 4096, 1024), ("in_proj half", 2048, 1024), ("out_proj", 1024, 2048),
               ("square 1024", 1024, 1024), ("decoder fc1", 2048, 512), ("w1|w2 base", 4096, 768), ("K 32640 w1|w2", 5504, 1024)]
+    dt = torch.float16 if "--fp16" in sys.argv else torch.bfloat16
+    if "--mae" in sys.argv:        # mae_vit_large_1280 at per-GPU batch 256: 101 visible tokens per image, 401 in the decoder
+        shapes = [("enc qkv", 3072, 1024, 25856), ("enc proj", 1024, 1024, 25856), ("enc fc1", 4096, 1024, 25856), ("enc fc2", 1024, 4096, 25856),
+                  ("dec qkv", 1536, 512, 102656), ("dec proj", 512, 512, 102656), ("dec fc1", 2048, 512, 102656), ("dec fc2", 512, 2048, 102656),
+                  ("K 16384 fc1", 4096, 1024, 16384), ("K 8192 fc1", 4096, 1024, 8192), ("K 131072 fc1", 4096, 1024, 131072)]
     g = torch.Generator().manual_seed(0)
-    for name, M, N in shapes:
-        k = 32640 if name.startswith("K 32640") else K
-        a = torch.randn(k, M, generator=g).to(dev, torch.bfloat16)
-        b = torch.randn(k, N, generator=g).to(dev, torch.bfloat16)
+    for shp in shapes:
+        name, M, N = shp[:3]
+        k = shp[3] if len(shp) > 3 else (32640 if name.startswith("K 32640") else K)
+        a = torch.randn(k, M, generator=g).to(dev, dt)
+        b = torch.randn(k, N, generator=g).to(dev, dt)
         ref = torch.matmul(a[:4096].double().t(), b[:4096].double())
         got = ssi.gemm_tn(a[:4096], b[:4096])
         err = float((got.double() - ref).abs().max()) / float(ref.abs().max())
