@@ -58,6 +58,11 @@
  *     per wave (VMamba's first stage and patch embedding, the constructors' default embed_dim = 192), and since ABI v11 any other
  *     width on a wave-per-row element-wise kernel pair (same arithmetic and rounding points, several times slower): the Python mirror
  *     no longer routes any width of a HIP tensor to torch.nn.functional.layer_norm.
+ *   * GEMMs: the token-major forward / data-gradient products of the blocks' linears stay on the vendor library (hipBLASLt through
+ *     torch / rocBLAS: 0.95-1.48 PFLOP/s at the step's shapes, where the hand-written NT kernel mxvl_gemm_nt measured slower on 7 of
+ *     8 shapes); the WEIGHT gradients dW = dy^T x -- two K-major operands, the layout the library is weak on -- are mxvl_gemm_tn
+ *     (ABI v12) wherever it was measured to win (token axis >= 32 000, a tile count that fills an XCD's workgroups:
+ *     selective_scan_interface.gemm_tn_wins), the library's batched split-K form elsewhere.
  */
 #ifndef MXVL_H_
 #define MXVL_H_
