@@ -2,10 +2,13 @@
 //
 //     C (M, N) fp32  (+)=  A^T B        A (K, M), B (K, N) token-major bf16 / fp16, K = tokens (65 280 per GPU at the headline shape)
 //
-// Replaces, for every `nn.Linear` of the ARM / VisionMamba blocks (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/mamba_simple.py:76,91
-// in_proj / out_proj; models_mamba.py:59-83 w1 | w2 | w3), what autograd's `grad_weight = dy^T x` was in the round-2..5 step: a
-// batched library GEMM over S token slices into S fp32 planes plus an `aten::sum` over the planes (235 reduce launches and
-// 4.7 ms of the 213 ms step, profiles/r06_step_eager_pretrain.txt; the batched GEMMs themselves ran 0.84-1.09 PFLOP/s).
+// Replaces, for the TOKEN-MAJOR `nn.Linear` layers of the step (CXPMRG_Bench_MambaXray_VL/arm/Finetuning/models_mamba.py:59-83 SwiGLU
+// w1 | w2 | w3; pretrain/models_pretrain.py:45-83 the decoder's q / kv / proj / fc1 / fc2; the ViT-MAE blocks), what autograd's
+// `grad_weight = dy^T x` was in the round-2..5 step: a batched library GEMM over S token slices into S fp32 planes plus an `aten::sum`
+// over the planes (235 reduce launches and 4.7 ms of the 213 ms step, profiles/r06_step_eager_pretrain.txt; the batched GEMMs
+// themselves ran 0.84-1.09 PFLOP/s).  in_proj / out_proj / x_proj / dt_proj (mamba_simple.py:76,91) hold one operand channel-major
+// (K-contiguous): the library runs those at 0.95-1.13 PFLOP/s and keeps them.  Where the kernel wins is a measured rule on the host
+// side (selective_scan_interface.gemm_tn_wins: token axis >= 32 000, a tile count that fills an XCD's workgroups).
 //
 // Both operands are K-major (the reduction axis is the SLOW one), which is the layout the NT kernel of gemm_swiglu.hip cannot
 // take: an MFMA lane needs 8 consecutive k of ONE output row.  gfx950's transpose read does that on the way out of the LDS:
