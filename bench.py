@@ -87,7 +87,7 @@ def _dp_label(world):
     return f"dp{world} (DDP, RCCL all-reduce of fp32 grads, 256 MiB buckets)"
 
 
-def attach_traffic(roofline, workload):
+def attach_traffic(roofline, workload, command=None):
     """roofline.traffic = HBM bytes per launch of the dominant kernel.  It is NOT re-measured by this process (PMC needs
     rocprofv3 around the command): the number is read from the committed PMC record of the same command and labelled so."""
     pmc = pmc_traffic(workload)
@@ -96,7 +96,7 @@ def attach_traffic(roofline, workload):
     roofline["traffic"] = pmc["bytes"]
     roofline["traffic_from_profile"] = (f"profiles/{pmc['source']} ({pmc.get('kernel')}): FETCH_SIZE {pmc['fetch_kb']} KB x2 (gfx950 "
                                         f"correction) + WRITE_SIZE {pmc['write_kb']} KB per launch, separate rocprofv3 --pmc passes of "
-                                        f"`bench.py --workload {workload}`; copied from the profile, not re-measured in this run")
+                                        f"`{command or 'bench.py --workload ' + workload}`; copied from the profile, not re-measured in this run")
 
 WORKLOADS = {
     # name: (B, D, L, N, torch dtype name, description)
@@ -631,6 +631,12 @@ def run_pretrain(args, rank, world, dev, dist):
     if secondary is not None:
         out["secondary"] = {k: secondary[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                       "dtype", "config", "roofline", "cpu_baseline") if k in secondary}
+    if mfma_obj is not None and args.workload == DEFAULT_WORKLOAD and B == 16:
+        # the weight-gradient kernel's HBM bytes per launch, averaged over its launches of THIS step (PMC passes of the step itself)
+        attach_traffic(mfma_obj, "gemm_tn_pretrain", "bench.py --workload arm_pretrain_large_1024 --steps 2 --warmup 1")
+        mfma_obj["algorithmic_bytes_per_launch"] = ("2 K (M + N) + 4 M N: 874 / 504 MB for the two SwiGLU gradients (5504 x 1024, 1024 x 2752 at K = 65 280), "
+                                                    "610 MB averaged over the step's 60 launches; the counters also see the split-K atomics "
+                                                    "(8-16 partial tiles of 4 M N bytes added into the output, fetched and written by the memory-side atomic unit)")
     if mfma_obj is not None and dominant in MFMA_KINDS:
         hbm_obj = out["roofline"]
         out["roofline"] = dict(mfma_obj, step_share=hbm_obj["step_share"],

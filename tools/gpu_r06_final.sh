@@ -29,15 +29,22 @@ prof dg_fetch --kernel-trace --pmc FETCH_SIZE -d $P/dg_fetch -o r -- $DG
 prof dg_write --kernel-trace --pmc WRITE_SIZE -d $P/dg_write -o r -- $DG
 prof dg_sq --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY -d $P/dg_sq -o r -- $DG
 [ $PARTS = all ] && prof pretrain_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $P/pretrain_mfma -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+if [ $PARTS = all ]; then
+prof tn_fetch --kernel-trace --pmc FETCH_SIZE -d $P/tn_fetch -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+prof tn_write --kernel-trace --pmc WRITE_SIZE -d $P/tn_write -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
+fi
 [ $PARTS = all ] && prof pretrain_stats --kernel-trace --stats -d $P/pretrain_stats -o r -- python $R/bench.py --workload arm_pretrain_large_1024 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary
 prof dec1 --kernel-trace --stats -d $P/dec1 -o r -- python $R/bench.py --workload decode_llama7b_128 --steps 1 --warmup 1 --no-cpu-baseline
 prof dec18 --kernel-trace --stats -d $P/dec18 -o r -- python $R/bench.py --workload decode_llama7b_b6x3 --steps 1 --warmup 1 --no-cpu-baseline
 prof dec80 --kernel-trace --stats -d $P/dec80 -o r -- python $R/bench.py --workload decode_llama7b_b16x5 --steps 1 --warmup 1 --no-cpu-baseline
 prof decq --kernel-trace --stats -d $P/decq -o r -- python $R/bench.py --workload decode_qwen1p8b_b16x5 --steps 1 --warmup 1 --no-cpu-baseline
 cd $R
-for n in bwd_fetch bwd_write fwd_fetch fwd_write dg_fetch dg_write dg_sq pretrain_stats; do
+for n in bwd_fetch bwd_write fwd_fetch fwd_write dg_fetch dg_write dg_sq pretrain_stats tn_fetch tn_write; do
   [ -f $P/$n/r_results.db ] || continue
-  python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -70 | cut -c1-170 > $O/prof_${TAG}_$n.txt
+  case $n in
+    tn_*) python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | grep -E "^==|^kernel|gemm_tn" | cut -c1-170 > $O/prof_${TAG}_$n.txt ;;   # a whole step: keep this kernel's rows
+    *) python tools/rocpd_summary.py $P/$n/r_results.db 2>&1 | head -70 | cut -c1-170 > $O/prof_${TAG}_$n.txt ;;
+  esac
 done
 [ -f $P/pretrain_mfma/r_results.db ] && python tools/mfma_busy.py $P/pretrain_mfma/r_results.db 30 2>&1 | cut -c1-170 > $O/${TAG}_pretrain_mfma_busy.txt
 python tools/decode_timeline.py $P/dec1/r_results.db 40 2>&1 | cut -c1-150 > $O/${TAG}_decode_timeline_decode_llama7b_128.txt
@@ -48,6 +55,7 @@ if [ $PARTS = all ]; then
 rm -f $O/${TAG}_pmc_traffic.json
 python tools/pmc_traffic.py scan_bwd_pretrain scan_bwd_kernel $O/prof_${TAG}_bwd_fetch.txt $O/prof_${TAG}_bwd_write.txt $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
 python tools/pmc_traffic.py scan_fwd_target scan_fwd_stream_kernel $O/prof_${TAG}_fwd_fetch.txt $O/prof_${TAG}_fwd_write.txt $O/${TAG}_pmc_traffic.json >> $O/${TAG}_pmc_traffic.log 2>&1
+python tools/pmc_traffic.py gemm_tn_pretrain gemm_tn_kernel $O/prof_${TAG}_tn_fetch.txt $O/prof_${TAG}_tn_write.txt $O/${TAG}_pmc_traffic.json >> $O/${TAG}_pmc_traffic.log 2>&1
 cp $O/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json     # bench.py reads the record from profiles/
 (timeout 900 python bench.py 2>&1 | tail -1) > $O/${TAG}_bench_default.json
 fi
