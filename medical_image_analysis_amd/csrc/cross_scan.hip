@@ -167,9 +167,15 @@ __global__ __launch_bounds__(256) void cross_merge_flat_kernel(const io_t* __res
   const int L = g.L, LV = g.LV, H = g.H, W = g.W, nvec = Pn * LV, PL = Pn * L;
   const size_t dir = (size_t)g.C * L;
   const io_t* src = ys + ((size_t)b * 4 * g.C + c0) * L;
+  // the four direction planes of a vector position are requested together, then written to the LDS: direction by direction every
+  // load sat behind its own wait (one memory round trip per direction, read off the ISA)
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    vec_t r[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    for (int v = threadIdx.x; v < nvec; v += 256) *(vec_t*)(s + k * PL + (size_t)v * V) = *(const vec_t*)(src + k * dir + (size_t)v * V);
+    for (int k = 0; k < 4; ++k) r[k] = *(const vec_t*)(src + k * dir + (size_t)v * V);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(vec_t*)(s + k * PL + (size_t)v * V) = r[k];
+  }
   __syncthreads();
   io_t* dst = y + ((size_t)b * g.C + c0) * L;
   for (int v = threadIdx.x; v < nvec; v += 256) {
